@@ -1,0 +1,123 @@
+/*
+ * wise_hip.h — C ABI of libwise_hip.so: the MI355X (gfx950) hot paths of WISE.
+ *
+ * The reference (ox-vgg/wise) has no FFI of its own: its hot paths disappear into three Python
+ * packages (open_clip, msclap, faiss).  Each entry point below replaces ONE such call and names the
+ * reference call site it stands behind.  Everything is plain pointers + sizes: device pointers are
+ * raw HBM addresses (any allocator: hipMalloc, torch), `stream` is a hipStream_t passed as void*.
+ * No call allocates, frees or synchronises; all scratch comes from the caller's workspace, so every
+ * entry point is hipGraph-capturable.
+ *
+ * Return value: 0 on success, otherwise a WISE_E_* code (<0) or a hipError_t (>0).
+ * wise_last_error() returns a thread-local human-readable message for the last failure.
+ */
+#ifndef WISE_HIP_H
+#define WISE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WISE_OK 0
+#define WISE_E_INVALID (-1)   /* bad argument (shape, alignment, null pointer)          */
+#define WISE_E_WORKSPACE (-2) /* workspace smaller than *_workspace_bytes() asks for    */
+#define WISE_E_UNSUPPORTED (-3)
+
+const char* wise_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int wise_abi_version(void);
+/* 1 when a HIP device of arch gfx950 is visible to the calling process, else 0. */
+int wise_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * HP-2  brute-force inner-product top-k  (replaces faiss IndexIDMap{IndexFlatIP}::search,
+ *       reference call sites src/index/feature_search_index.py:113 and api/routes.py:1407)
+ *
+ * X   [N,d]  fp32 row-major database rows resident in HBM (what faiss stores: :47-52,:81)
+ * Q   [nq,d] fp32 queries (device)
+ * ids [N]    int64 external ids (IndexIDMap, :52,:81) or NULL => id = id_base + row
+ * outD [nq,k] fp32 descending; outI [nq,k] int64; tail padded with (-3.4028235e38, -1) when N < k
+ *            (faiss semantics relied on by search.py:142-143, routes.py:1411)
+ * Ties: the row with the lower position wins (faiss leaves tie order unspecified).
+ * Limits: d % 4 == 0, 4 <= d <= 2048, 1 <= k <= 2048, 1 <= nq <= 1024, X 16-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+size_t wise_ip_topk_workspace_bytes(int64_t N, int d, int nq, int k);
+int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, int k,
+                     const int64_t* ids, int64_t id_base, float* outD, int64_t* outI,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same scan, but leaves the per-shard result as sortable 64-bit keys plus positions so that shards
+ * living on different GPUs can be merged after an all-gather.  outD/outI as above with
+ * outI = id (ids!=NULL) or id_base+row. Provided for symmetry: wise_ip_topk_f32 already returns the
+ * (score,id) pairs that are all-gathered. */
+
+/* Merge `parts` partial top-k lists (e.g. one per GPU after the RCCL all-gather) into one.
+ * inD [parts,nq,k] fp32, inI [parts,nq,k] int64 (entries with id -1 are padding) -> outD/outI [nq,k].
+ * Ties: lower part index first, then the order within the part.  k <= 2048, parts*k <= 65536. */
+int wise_topk_merge(const float* inD, const int64_t* inI, int parts, int nq, int k, float* outD,
+                    int64_t* outI, void* stream);
+
+/* IndexIDMap::reconstruct_batch (api/routes.py:1078): out[i,:] = X[row_of(ids_query[i]),:].
+ * ids==NULL => row = id - id_base.  With ids given, a linear search kernel maps id -> row
+ * (faiss does the same without a direct map).  Missing ids give a row of NaN. */
+int wise_reconstruct_batch(const float* X, int64_t N, int d, const int64_t* ids, int64_t id_base,
+                           const int64_t* query_ids, int n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * HP-1  OpenCLIP VisionTransformer image tower (replaces model.encode_image + L2 normalise,
+ *       reference call site src/feature/mlfoundation_openclip.py:99-100)
+ *
+ * Weights are two caller-owned device blobs in the fixed layout wise_vit_layout() reports:
+ *   wb  bf16 : conv1 [W, Kp] (K = 3*P*P zero-padded to Kp = roundup(K,64)), then per layer
+ *              in_proj [3W,W], out_proj [W,W], c_fc [F,W], c_proj [W,F], then proj^T [D,W]
+ *   pf  fp32 : class_embedding [W], positional_embedding [T,W], ln_pre w,b [W],[W], then per layer
+ *              ln_1 w,b, in_proj_bias [3W], out_proj bias [W], ln_2 w,b, c_fc bias [F], c_proj bias [W],
+ *              then ln_post w,b
+ * (names are open_clip 2.24.0 state-dict keys under `visual.`; see wise_amd/feature/vit_weights.py)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct wise_vit_config {
+    int32_t image_size; /* S: 224 */
+    int32_t patch;      /* P: 32 (ViT-B/32), 14 (ViT-L/14), 16 */
+    int32_t width;      /* W: 768 / 1024 ; multiple of 128, head dim must be 64 */
+    int32_t layers;     /* L */
+    int32_t heads;      /* H = W/64 */
+    int32_t mlp;        /* F: 4W */
+    int32_t embed_dim;  /* D: 512 / 768 */
+    int32_t act;        /* 0 = QuickGELU x*sigmoid(1.702x) (openai tags), 1 = erf GELU */
+} wise_vit_config;
+
+#define WISE_VIT_IN_F32 0  /* images [B,3,S,S] fp32, already normalised (preprocess_image output) */
+#define WISE_VIT_IN_U8 1   /* images [B,3,S,S] uint8 0..255; (x/255-mean)/std fused in the patch gather */
+
+/* element counts of the two blobs and the byte offset table (for packers); returns 0 or WISE_E_* */
+int wise_vit_layout(const wise_vit_config* cfg, int64_t* wb_elems, int64_t* pf_elems);
+size_t wise_vit_workspace_bytes(const wise_vit_config* cfg, int batch);
+/* out [B,D] fp32, rows L2-normalised without epsilon (mlfoundation_openclip.py:100). */
+int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, const float* pf,
+                     const void* images, int in_kind, int batch, float* out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* Debug/parity tap: copy the residual stream x [B*T, W] fp32 as it stands after `after_layer`
+ * blocks (0 = after ln_pre) from the workspace of the LAST forward into dst. */
+int wise_vit_tap_residual(const wise_vit_config* cfg, int batch, const void* workspace, float* dst,
+                          void* stream);
+
+/* Building blocks, exported so the parity tests can pin each kernel separately. */
+/* C[M,N] = epilogue(A[M,K] bf16 @ Wt[N,K]^T bf16 + bias[N]) ; M%128==0 rows must be readable
+ * (callers pad), N%128==0, K%64==0.
+ * mode: 0 -> out_bf16 = acc+bias ; 1 -> out_bf16 = quickgelu(acc+bias) ; 2 -> out_bf16 = gelu(acc+bias)
+ *       3 -> resid_f32 += acc+bias (in place, fp32 residual stream) ; 4 -> out_f32 = acc+bias */
+int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K,
+                   int mode, void* out, void* stream);
+/* y_bf16[r,:] = (x[r,:]-mean)/sqrt(var+eps)*w+b over W for r < rows. */
+int wise_layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows, int W,
+                            float eps, uint16_t* y, void* stream);
+/* qkv [B*T, 3*H*64] bf16 (q|k|v packed like in_proj) -> o [B*T, H*64] bf16 ; softmax(QK^T/8)V */
+int wise_attention_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WISE_HIP_H */

@@ -1,0 +1,131 @@
+"""-m gpu: HP-2 parity — HIP scan+top-k (through the C ABI) against the CPU oracle and golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ip_topk_ref
+from wise_amd.index.flat_ip import FlatIPIndex
+
+pytestmark = pytest.mark.gpu
+
+
+def unit_rows(n, d, seed):
+    x = np.random.default_rng(seed).standard_normal((n, d), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def check_against_oracle(X, Q, k, ids, D, I, tol=2e-5):
+    Dr, Ir = ip_topk_ref.ip_topk(X, Q, k, ids=ids)
+    assert D.shape == Dr.shape and I.shape == Ir.shape and I.dtype == np.int64 and D.dtype == np.float32
+    # padding is exact
+    assert np.array_equal(I == -1, Ir == -1)
+    assert np.all(D[I == -1] == ip_topk_ref.NEG)
+    valid = Ir != -1
+    assert np.allclose(D[valid], Dr[valid], atol=tol, rtol=0), np.abs(D[valid] - Dr[valid]).max()
+    # descending
+    assert np.all(np.diff(D, axis=1) <= 0)
+    # ids: identical wherever the oracle's neighbouring scores are separated by more than fp noise
+    S = (Q @ X.T).astype(np.float32) if X.shape[0] else None
+    for q in range(Q.shape[0]):
+        for j in range(k):
+            if Ir[q, j] < 0 or I[q, j] == Ir[q, j]:
+                continue
+            # a swap is only acceptable between near-tied scores
+            row = int(np.where(ids == I[q, j])[0][0]) if ids is not None else int(I[q, j])
+            assert abs(S[q, row] - Dr[q, j]) <= tol, (q, j, I[q, j], Ir[q, j])
+    assert ip_topk_ref.recall_at_k(I, Ir) >= 0.99
+
+
+def test_golden_vectors(golden_dir):
+    g = np.load(golden_dir / "ip_topk.npz")
+    X = unit_rows(4096, 512, 2)
+    Q = unit_rows(8, 512, 3)
+    ids = np.arange(4096, dtype=np.int64) + 1
+    idx = FlatIPIndex(512)
+    for s in range(0, 4096, 512):  # batches of 512 like feature_search_index.py:80-82
+        idx.add_with_ids(X[s:s + 512], ids[s:s + 512])
+    assert idx.ntotal == 4096 and idx.d == 512
+    for k in (1, 10, 100):
+        D, I = idx.search(Q, k)
+        assert np.array_equal(I, g[f"I{k}"])
+        assert np.allclose(D, g[f"D{k}"], atol=2e-6, rtol=0)
+    # tie case: identical rows, lower row first
+    Xt = X[:1024].copy()
+    Xt[[5, 17, 900]] = Q[0]
+    it = FlatIPIndex(512)
+    it.add_with_ids(Xt, ids[:1024])
+    D, I = it.search(Q[:2], 5)
+    assert np.array_equal(I, g["Itie"])
+    assert list(I[0, :3]) == [6, 18, 901]
+    # N < k: faiss padding
+    ish = FlatIPIndex(512)
+    ish.add_with_ids(X[:7], ids[:7])
+    D, I = ish.search(Q[:2], 10)
+    assert np.array_equal(I, g["Ishort"]) and np.all(I[:, 7:] == -1)
+    assert np.all(D[:, 7:] == ip_topk_ref.NEG)
+    assert np.allclose(D[:, :7], g["Dshort"][:, :7], atol=2e-6)
+
+
+@pytest.mark.parametrize("N,d,nq,k", [
+    (1, 512, 1, 1), (3, 512, 2, 10), (4097, 512, 1, 10), (5000, 768, 3, 10), (5000, 1024, 5, 100),
+    (20000, 512, 8, 1000), (3001, 100, 2, 7), (2000, 4, 1, 3), (777, 2048, 2, 10), (70000, 512, 1, 2048),
+    (50000, 64, 9, 33),
+])
+def test_shapes_against_oracle(N, d, nq, k):
+    X = unit_rows(N, d, 100 + N % 97)
+    Q = unit_rows(nq, d, 7)
+    ids = (np.arange(N, dtype=np.int64) * 3 + 11)
+    idx = FlatIPIndex(d)
+    idx.add_with_ids(X, ids)
+    D, I = idx.search(Q, k)
+    check_against_oracle(X, Q, k, ids, D, I)
+
+
+def test_empty_index_and_all_ties():
+    idx = FlatIPIndex(512)
+    D, I = idx.search(unit_rows(2, 512, 1), 5)
+    assert np.all(I == -1) and np.all(D == ip_topk_ref.NEG)
+    # every row identical (8 black frames give 8 identical embeddings): ids come back in row order
+    row = unit_rows(1, 512, 9)
+    X = np.repeat(row, 300, axis=0)
+    idx = FlatIPIndex(512)
+    idx.add_with_ids(X, np.arange(300, dtype=np.int64) + 1)
+    D, I = idx.search(row, 10)
+    assert list(I[0]) == list(range(1, 11))
+
+
+def test_adopt_without_ids_and_reconstruct():
+    X = unit_rows(1000, 512, 4)
+    Xd = torch.from_numpy(X).cuda()
+    idx = FlatIPIndex(512).adopt(Xd, None, id_base=1)
+    D, I = idx.search(X[123:124], 3)
+    assert I[0, 0] == 124 and abs(D[0, 0] - 1.0) < 1e-5
+    rec = idx.reconstruct_batch([124, 1, 1000])
+    assert np.array_equal(rec, X[[123, 0, 999]])
+    idx2 = FlatIPIndex(512)
+    idx2.add_with_ids(X, np.arange(1000, dtype=np.int64) * 2 + 5)
+    rec = idx2.reconstruct_batch([5, 2003])
+    assert np.array_equal(rec, X[[0, 999]])
+
+
+def test_full_size_properties():
+    """BASELINE cfg-3 shape (10M x 512) is too big for the oracle: check size-independent properties."""
+    N, d = 2_000_000, 512
+    g = torch.Generator(device="cuda").manual_seed(2)
+    X = torch.randn(N, d, generator=g, device="cuda")
+    X /= X.norm(dim=1, keepdim=True)
+    idx = FlatIPIndex(d).adopt(X, None, id_base=1)
+    # planted neighbours: query = a database row => that row is rank 1 with score 1
+    rows = torch.tensor([0, 1, 999_999, N - 1, 123_457], device="cuda")
+    D, I = idx.search_device(X[rows], 10)
+    assert torch.equal(I[:, 0].cpu(), rows.cpu() + 1)
+    assert torch.allclose(D[:, 0], torch.ones(5, device="cuda"), atol=1e-5)
+    assert bool((D[:, :-1] >= D[:, 1:]).all())
+    # against torch's own matmul+topk on the device (fp32)
+    Dt, It = torch.topk(X[rows] @ X.T, 10, dim=1)
+    assert torch.allclose(D, Dt, atol=2e-5)
+    assert (I == It + 1).float().mean().item() >= 0.99
+    # linearity: scores for 2q are 2x, same ids
+    D2, I2 = idx.search_device(2.0 * X[rows], 10)
+    assert torch.equal(I2, I) and torch.allclose(D2, 2 * D, atol=1e-5)

@@ -1,0 +1,172 @@
+"""-m gpu: HP-1 parity — HIP ViT kernels (through the C ABI) against the fp32 CPU oracle and the
+committed golden vectors.  Tolerance (BASELINE.json north_star): cosine within 1e-3 of the fp32 path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_ref
+from wise_amd import _lib
+from wise_amd.feature.vit import VitEngine, VitSpec, random_state_dict, spec_for
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-3
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def cosine(a, b):
+    a = a.double(); b = b.double()
+    return ((a * b).sum(-1) / (a.norm(dim=-1) * b.norm(dim=-1))).min().item()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (12800, 768, 768), (1280, 2304, 768),
+                                    (640, 768, 3072), (12544, 768, 3072)])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_gemm_modes(M, N, K, mode):
+    if M > 2000 and mode not in (0, 3):
+        pytest.skip("large shapes: bf16-out and residual modes only")
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(M + N + K + mode)
+    A = bf16_round(torch.randn(M, K, generator=g))
+    W = bf16_round(torch.randn(N, K, generator=g) * K ** -0.5)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    Ad, Wd, bd = A.to(torch.bfloat16).cuda(), W.to(torch.bfloat16).cuda(), bias.cuda()
+    if mode == 3:
+        resid = torch.randn(M, N, generator=g)
+        out = resid.clone().cuda()
+        ref = ref + resid.double()
+    elif mode == 4:
+        out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    else:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        if mode == 1:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        elif mode == 2:
+            ref = 0.5 * ref * (1 + torch.erf(ref / 2 ** 0.5))
+    _lib.check(lib.wise_gemm_bf16(Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), M, N, K, mode, out.data_ptr(),
+                                  _lib.stream_ptr()), "gemm")
+    torch.cuda.synchronize()
+    got = out.float().cpu().double()
+    err = (got - ref).abs().max().item()
+    tol = 2e-3 if mode in (3, 4) else 3e-2  # fp32 out: accumulation order only; bf16 out: one bf16 rounding of O(4) values
+    assert err <= tol, (err, tol)
+    if mode in (3, 4):
+        assert torch.allclose(got, ref, atol=2e-3, rtol=1e-5)
+
+
+def test_gemm_identity_asymmetric():
+    """A = I (padded) against an asymmetric W: catches a transposed C-write or a bad swizzle."""
+    lib = _lib.lib()
+    M = N = 128; K = 128
+    A = torch.eye(M, K)
+    W = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) - 125  # exact in bf16 (|v| <= 125)
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    _lib.check(lib.wise_gemm_bf16(A.to(torch.bfloat16).cuda().data_ptr(), W.to(torch.bfloat16).cuda().data_ptr(), 0,
+                                  M, N, K, 4, out.data_ptr(), _lib.stream_ptr()), "gemm")
+    assert torch.equal(out.cpu(), W.t().contiguous()[:M, :N])
+
+
+@pytest.mark.parametrize("rows,W", [(1, 768), (50, 768), (12800, 768), (257, 1024), (5, 96), (7, 3072), (3, 4096)])
+def test_layernorm(rows, W):
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(rows + W)
+    x = torch.randn(rows, W, generator=g) * 3 + 0.5
+    w = 1 + 0.1 * torch.randn(W, generator=g)
+    b = 0.1 * torch.randn(W, generator=g)
+    y = torch.empty(rows, W, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.wise_layernorm_f32_bf16(x.cuda().data_ptr(), w.cuda().data_ptr(), b.cuda().data_ptr(), rows, W,
+                                           1e-5, y.data_ptr(), _lib.stream_ptr()), "ln")
+    ref = vit_ref.layer_norm(x, w, b)
+    assert torch.equal(y.cpu(), ref.to(torch.bfloat16)) or (y.float().cpu() - ref).abs().max() <= 2 ** -7 * ref.abs().max()
+    # at most 1 bf16 ulp from the fp32 oracle rounded to bf16
+    assert (y.float().cpu() - bf16_round(ref)).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 1, 2), (3, 50, 12), (2, 257, 16), (2, 64, 2), (1, 65, 2), (5, 197, 12)])
+def test_attention(B, T, H):
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(B * 1000 + T + H)
+    W = H * 64
+    qkv = torch.randn(B * T, 3 * W, generator=g)
+    qkv[:, : 2 * W] *= 2.0  # peaky softmax
+    qkv = bf16_round(qkv)
+    o = torch.full((B * T, W), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.wise_attention_bf16(qkv.to(torch.bfloat16).cuda().data_ptr(), B, T, H, o.data_ptr(),
+                                       _lib.stream_ptr()), "attn")
+    ref = vit_ref.attention_ref(qkv, B, T, H)
+    got = o.float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 3e-2
+    assert cosine(got, ref) >= 1 - 1e-4
+
+
+def load_golden(golden_dir, name):
+    g = np.load(golden_dir / name)
+    s = [int(v) for v in g["spec"]]
+    spec = VitSpec(name, s[0], s[1], s[2], s[3], s[4], s[5], s[6], "quick_gelu" if s[7] == 0 else "gelu")
+    frames = np.random.default_rng(int(g["frame_seed"])).integers(0, 256, size=(int(g["n_frames"]), 3, s[0], s[0]),
+                                                                  dtype=np.uint8)
+    return spec, g, torch.from_numpy(frames)
+
+
+@pytest.mark.parametrize("name", ["vit_tiny.npz", "vit_tiny_gelu.npz", "vit_b32.npz", "vit_l14.npz"])
+def test_vit_golden(golden_dir, name):
+    spec, g, frames = load_golden(golden_dir, name)
+    sd = random_state_dict(spec, int(g["weight_seed"]))
+    eng = VitEngine(spec, sd, max_batch=frames.shape[0])
+    out_u8 = eng.forward(frames).cpu()
+    out_f32 = eng.forward(vit_ref.normalize_u8(frames)).cpu()
+    gold = torch.from_numpy(g["out"])
+    assert out_u8.shape == gold.shape and out_u8.dtype == torch.float32
+    assert torch.allclose(out_u8.norm(dim=1), torch.ones(gold.shape[0]), atol=1e-5)
+    c = cosine(out_f32, gold)
+    assert c >= 1 - COS_TOL, c
+    assert cosine(out_u8, gold) >= 1 - COS_TOL
+    # residual stream after the last block: compare the cls rows with the oracle's last tap
+    taps = torch.from_numpy(g["taps"])
+    x = eng.residual(frames.shape[0]).cpu().reshape(frames.shape[0], spec.tokens, spec.width)
+    last = taps[-1] if taps.dim() == 3 else taps[-1][:, 0, :]
+    assert cosine(x[:, 0, :], last) >= 1 - COS_TOL
+    if taps.dim() == 4:  # tiny models carry every token
+        assert cosine(x.reshape(-1, spec.width), taps[-1].reshape(-1, spec.width)) >= 1 - COS_TOL
+
+
+@pytest.mark.parametrize("layers", [0, 1, 3])
+def test_vit_b32_depth_taps(golden_dir, layers):
+    """Truncated ViT-B/32 against the per-block golden taps: localises an error to a block."""
+    spec, g, frames = load_golden(golden_dir, "vit_b32.npz")
+    sd = random_state_dict(spec, int(g["weight_seed"]))
+    short = VitSpec(spec.name, spec.image_size, spec.patch, spec.width, layers, spec.heads, spec.mlp, spec.embed_dim,
+                    spec.act)
+    sd_short = {k: v for k, v in sd.items()
+                if "resblocks." not in k or int(k.split("resblocks.")[1].split(".")[0]) < layers}
+    eng = VitEngine(short, sd_short, max_batch=4)
+    eng.forward(vit_ref.normalize_u8(frames))
+    x = eng.residual(4).cpu().reshape(4, spec.tokens, spec.width)
+    tap = torch.from_numpy(g["taps"])[layers]
+    assert cosine(x[:, 0, :], tap) >= 1 - 2e-4
+    assert (x[:, 0, :] - tap).abs().max() <= 0.05 * tap.abs().max()
+
+
+def test_vit_b32_batch256_consistency(golden_dir):
+    """BASELINE cfg-2 shape: bs=256.  Frames 0..3 are the golden frames; every row must be unit-norm,
+    the golden rows must match, and the result must not depend on the batch a frame sits in."""
+    spec, g, frames = load_golden(golden_dir, "vit_b32.npz")
+    sd = random_state_dict(spec, int(g["weight_seed"]))
+    eng = VitEngine(spec, sd, max_batch=256)
+    rest = torch.from_numpy(np.random.default_rng(99).integers(0, 256, size=(252, 3, 224, 224), dtype=np.uint8))
+    batch = torch.cat([frames, rest], dim=0)
+    out = eng.forward(batch).cpu()
+    assert out.shape == (256, 512)
+    assert torch.allclose(out.norm(dim=1), torch.ones(256), atol=1e-5)
+    assert cosine(out[:4], torch.from_numpy(g["out"])) >= 1 - COS_TOL
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(0))
+    out_p = eng.forward(batch[perm]).cpu()
+    assert torch.equal(out_p, out[perm])  # deterministic kernels, frames independent
+    # ragged batch (not a multiple of anything)
+    out_r = eng.forward(batch[:37]).cpu()
+    assert torch.equal(out_r, out[:37])

@@ -1,0 +1,91 @@
+"""ctypes binding of libwise_hip.so (the C ABI declared in include/wise_hip.h).
+
+This is the ONLY way the Python host side reaches the kernels; there is no CPU fallback.  Anything
+that needs a kernel calls `lib()` and gets a RuntimeError if the library is missing or no gfx950
+device is visible.  torch is used only to own device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_LIB = None
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libwise_hip.so"
+
+WISE_OK = 0
+WISE_VIT_IN_F32 = 0
+WISE_VIT_IN_U8 = 1
+
+EPI_BF16, EPI_QUICKGELU, EPI_GELU, EPI_RESID, EPI_F32 = range(5)
+
+
+class VitConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("image_size", "patch", "width", "layers", "heads", "mlp", "embed_dim", "act")]
+
+
+# every symbol include/wise_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+SIGNATURES = {
+    "wise_last_error": (C.c_char_p, []),
+    "wise_abi_version": (_i, []),
+    "wise_device_ok": (_i, []),
+    "wise_ip_topk_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
+    "wise_ip_topk_f32": (_i, [_vp, _i64, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "wise_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "wise_reconstruct_batch": (_i, [_vp, _i64, _i, _vp, _i64, _vp, _i, _vp, _vp]),
+    "wise_vit_layout": (_i, [C.POINTER(VitConfig), C.POINTER(_i64), C.POINTER(_i64)]),
+    "wise_vit_workspace_bytes": (_sz, [C.POINTER(VitConfig), _i]),
+    "wise_vit_forward": (_i, [C.POINTER(VitConfig), _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "wise_vit_tap_residual": (_i, [C.POINTER(VitConfig), _i, _vp, _vp, _vp]),
+    "wise_gemm_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "wise_layernorm_f32_bf16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "wise_attention_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+}
+
+
+def load(path: Path | None = None):
+    """dlopen the library and attach prototypes.  No GPU needed for this step."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise RuntimeError(
+            f"{p} is missing: build it with `python -m wise_amd.build` (hipcc --offload-arch=gfx950). "
+            "wise_amd has no CPU fallback.")
+    lib = C.CDLL(str(p))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def lib():
+    """Library handle for compute calls: additionally requires a visible gfx950 device."""
+    import torch
+
+    l = load()
+    if not torch.cuda.is_available():
+        raise RuntimeError("wise_amd: no HIP device visible (torch.cuda.is_available() is False); "
+                           "the HIP path is the only path")
+    return l
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().wise_last_error()
+        raise RuntimeError(f"libwise_hip {what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a torch tensor / None."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

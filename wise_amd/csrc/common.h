@@ -1,0 +1,65 @@
+// Shared host/device helpers for libwise_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/wise_hip.h"
+
+namespace wise {
+
+void set_error(const char* fmt, ...);
+
+#define WISE_CHECK_ARG(cond, ...)          \
+    do {                                   \
+        if (!(cond)) {                     \
+            ::wise::set_error(__VA_ARGS__); \
+            return WISE_E_INVALID;         \
+        }                                  \
+    } while (0)
+
+// kernel launches report through hipGetLastError (no sync: graph-capturable)
+#define WISE_LAUNCH_CHECK(name)                                                     \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            ::wise::set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return (int)e_;                                                         \
+        }                                                                           \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- bf16 bit helpers (device) -------------------------------------------------------------
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// round-to-nearest-even, NaN kept a NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+using short8 = __attribute__((ext_vector_type(8))) short;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// wave64 all-reduce helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace wise

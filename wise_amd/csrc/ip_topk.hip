@@ -1,0 +1,490 @@
+// HP-2: brute-force inner-product scan + top-k for gfx950 (MI355X).
+//
+// Replaces faiss IndexIDMap{IndexFlatIP}::search as called from the reference at
+// src/index/feature_search_index.py:113 and api/routes.py:1407 (semantics: SURVEY.md App. A.3).
+//
+// Roofline: HBM-bound.  Algorithmic bytes per query batch = N*d*4 (every fp32 row read once).
+//
+// Kernel 1 (ip_scan_kernel): every wave streams groups of R rows (16 B per lane per load, rows are
+//   contiguous so a group is one R*d*4-byte burst), keeps the query chunk(s) it needs in VGPRs, and
+//   reduces the R*NQ partial dot products with a butterfly *transpose*-reduce (log-many cross-lane
+//   moves for all R rows together, not 6 per row).  Selection is fused: each (score,row) becomes a
+//   sortable 64-bit key; a wave appends the keys that beat its running threshold to a wave-private
+//   LDS list and re-thresholds (bitonic sort in LDS, wave-synchronous, no block barrier) when the
+//   list fills.  Nothing but the k best keys per block ever goes back to HBM.
+// Kernel 2 (merge_keys_kernel): one block per query folds the per-block lists into the final
+//   top-k with the same threshold lists, then translates row -> external id (IndexIDMap).
+#include "common.h"
+
+namespace wise {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ unsigned f32_order(float f) {
+    unsigned u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float f32_unorder(unsigned o) {
+    unsigned u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+    return __uint_as_float(u);
+}
+// larger key = better: higher score first, then lower row
+__device__ __forceinline__ u64 make_key(float score, unsigned row) {
+    return ((u64)f32_order(score) << 32) | (u64)(0xFFFFFFFFu - row);
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // one wave executes its DS instructions in order; this only stops the compiler reordering them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Sort buf[0..cap) descending by one wave (cap = power of two >= 64).
+__device__ void wave_bitonic_desc(volatile u64* buf, int cap, int lane) {
+    for (int size = 2; size <= cap; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < (cap >> 1); t += 64) {
+                int pos = ((t / stride) * (stride << 1)) + (t % stride);
+                int par = pos + stride;
+                bool desc = ((pos & size) == 0);
+                u64 a = buf[pos], b = buf[par];
+                bool sw = desc ? (a < b) : (a > b);
+                if (sw) { buf[pos] = b; buf[par] = a; }
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
+// A wave-private running top-k list in LDS.
+struct WaveList {
+    volatile u64* buf;  // cap entries
+    int cap, k, cnt;
+    u64 tau;  // keys <= tau cannot enter the top-k any more
+    __device__ void init(u64* b, int cap_, int k_, int lane) {
+        buf = b; cap = cap_; k = k_; cnt = 0; tau = 0;
+        for (int i = lane; i < cap; i += 64) buf[i] = 0;
+        wave_lds_fence();
+    }
+    __device__ void compact(int lane) {
+        for (int i = cnt + lane; i < cap; i += 64) buf[i] = 0;
+        wave_lds_fence();
+        wave_bitonic_desc(buf, cap, lane);
+        if (cnt >= k) { cnt = k; tau = buf[k - 1]; }
+    }
+    // every lane may carry one candidate key (pass=false -> none); wave-uniform control flow
+    __device__ void offer(bool pass, u64 key, int lane, int max_new) {
+        u64 mask = __ballot(pass);
+        if (mask == 0) return;
+        int n = __popcll(mask);
+        if (cnt + n > cap) {
+            compact(lane);
+            // the threshold moved: re-test
+            pass = pass && (key > tau);
+            mask = __ballot(pass);
+            if (mask == 0) return;
+            n = __popcll(mask);
+        }
+        int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+        if (pass) buf[pos] = key;
+        cnt += n;
+        wave_lds_fence();
+        (void)max_new;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// scan kernel: NV = float4 chunks per lane per row (ceil(d/256)), NQ queries, R rows per group
+// ------------------------------------------------------------------------------------------------
+template <int NV, int NQ, int R>
+__global__ __launch_bounds__(256) void ip_scan_kernel(const f32x4* __restrict__ X, long long N, int d4,
+                                                      const float* __restrict__ Q, int k, int cap,
+                                                      u64* __restrict__ part /*[grid][NQ][k]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    u64* lds = reinterpret_cast<u64*>(smem);
+    // wave w, query q -> lds + (w*NQ + q)*cap
+
+    float4 qv[NQ][NV];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int c = v * 64 + lane;
+            qv[q][v] = (c < d4) ? reinterpret_cast<const float4*>(Q)[(long long)q * d4 + c]
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+
+    WaveList wl[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) wl[q].init(lds + (size_t)(wave * NQ + q) * cap, cap, k, lane);
+
+    const long long ngroups = (N + R - 1) / R;
+    const long long gw = (long long)blockIdx.x * 4 + wave;
+    const long long nw = (long long)gridDim.x * 4;
+
+    // which of the R rows this lane ends up holding after the transpose-reduce
+    int myr = 0;
+    {
+        int bit = 5;
+#pragma unroll
+        for (int h = R / 2; h >= 1; h >>= 1, --bit) myr += ((lane >> bit) & 1) * h;
+    }
+    constexpr int LOGR = (R == 8) ? 3 : (R == 4) ? 2 : (R == 2) ? 1 : 0;
+    const bool owner = (lane & ((64 >> LOGR) - 1)) == 0;
+
+    for (long long g = gw; g < ngroups; g += nw) {
+        const long long row0 = g * R;
+        f32x4 x[R][NV];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            long long row = row0 + r;
+            if (row >= N) row = N - 1;  // stay in bounds; masked below
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                int c = v * 64 + lane;
+                if (NV * 64 == d4 || c < d4)
+                    x[r][v] = __builtin_nontemporal_load(&X[row * d4 + c]);
+                else
+                    x[r][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float a[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    s = fmaf(x[r][v][0], qv[q][v].x, s);
+                    s = fmaf(x[r][v][1], qv[q][v].y, s);
+                    s = fmaf(x[r][v][2], qv[q][v].z, s);
+                    s = fmaf(x[r][v][3], qv[q][v].w, s);
+                }
+                a[r] = s;
+            }
+            // transpose-reduce: after step with mask m, a lane keeps half of its values, each summed
+            // with the partner lane's copy
+            int bit = 5;
+#pragma unroll
+            for (int h = R / 2; h >= 1; h >>= 1, --bit) {
+                const int m = 1 << bit;
+                const bool up = (lane >> bit) & 1;
+#pragma unroll
+                for (int i = 0; i < h; ++i) {
+                    float send = up ? a[i] : a[i + h];
+                    float keep = up ? a[i + h] : a[i];
+                    a[i] = keep + __shfl_xor(send, m, 64);
+                }
+            }
+            float s = a[0];
+#pragma unroll
+            for (int m = (32 >> LOGR); m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+
+            const long long row = row0 + myr;
+            const u64 key = make_key(s, (unsigned)row);
+            const bool pass = owner && (row < N) && (key > wl[q].tau);
+            wl[q].offer(pass, key, lane, R);
+        }
+    }
+
+    // fold the block's 4 wave lists into wave 0's list, then publish k keys per query
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) wl[q].compact(lane);
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            for (int w = 1; w < 4; ++w) {
+                const u64* other = lds + (size_t)(w * NQ + q) * cap;
+                for (int i0 = 0; i0 < k; i0 += 64) {
+                    int i = i0 + lane;
+                    u64 key = (i < k) ? other[i] : 0;
+                    bool pass = (key != 0) && (key > wl[q].tau);
+                    wl[q].offer(pass, key, lane, 64);
+                }
+            }
+            wl[q].compact(lane);
+            u64* dst = part + ((size_t)blockIdx.x * NQ + q) * k;
+            for (int i = lane; i < k; i += 64) dst[i] = wl[q].buf[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge kernel: one block per query, NW waves; part [P][nq_stride][k] keys -> outD/outI [nq][k]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void merge_keys_kernel(const u64* __restrict__ part, int P, int qstride,
+                                                          int k, int cap, const long long* __restrict__ ids,
+                                                          long long id_base, float* __restrict__ outD,
+                                                          long long* __restrict__ outI, int q_off) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int q = blockIdx.x;
+    u64* lds = reinterpret_cast<u64*>(smem);
+
+    WaveList wl;
+    wl.init(lds + (size_t)wave * cap, cap, k, lane);
+    // wave w takes lists w, w+nwaves, ...
+    for (int p = wave; p < P; p += nwaves) {
+        const u64* src = part + ((size_t)p * qstride + q) * k;
+        for (int i0 = 0; i0 < k; i0 += 64) {
+            int i = i0 + lane;
+            u64 key = (i < k) ? src[i] : 0;
+            bool pass = (key != 0) && (key > wl.tau);
+            wl.offer(pass, key, lane, 64);
+        }
+    }
+    wl.compact(lane);
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < nwaves; ++w) {
+            const u64* other = lds + (size_t)w * cap;
+            for (int i0 = 0; i0 < k; i0 += 64) {
+                int i = i0 + lane;
+                u64 key = (i < k) ? other[i] : 0;
+                bool pass = (key != 0) && (key > wl.tau);
+                wl.offer(pass, key, lane, 64);
+            }
+        }
+        wl.compact(lane);
+        for (int i = lane; i < k; i += 64) {
+            u64 key = wl.buf[i];
+            float dscore = -3.4028234663852886e38f;
+            long long id = -1;
+            if (key != 0) {
+                unsigned row = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+                dscore = f32_unorder((unsigned)(key >> 32));
+                id = ids ? ids[row] : (id_base + (long long)row);
+            }
+            outD[(size_t)(q_off + q) * k + i] = dscore;
+            outI[(size_t)(q_off + q) * k + i] = id;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge of (score,id) partial lists (multi-GPU all-gather result): one wave per query
+// key = (order(score), ~slot) where slot = part*k + i keeps "lower part first, then list order"
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void merge_pairs_kernel(const float* __restrict__ inD,
+                                                         const long long* __restrict__ inI, int parts, int nq,
+                                                         int k, int cap, float* __restrict__ outD,
+                                                         long long* __restrict__ outI) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int q = blockIdx.x;
+    WaveList wl;
+    wl.init(reinterpret_cast<u64*>(smem), cap, k, lane);
+    for (int p = 0; p < parts; ++p) {
+        const size_t base = ((size_t)p * nq + q) * k;
+        for (int i0 = 0; i0 < k; i0 += 64) {
+            int i = i0 + lane;
+            bool valid = (i < k) && (inI[base + i] >= 0);
+            u64 key = valid ? make_key(inD[base + i], (unsigned)(p * k + i)) : 0;
+            bool pass = valid && (key > wl.tau);
+            wl.offer(pass, key, lane, 64);
+        }
+    }
+    wl.compact(lane);
+    for (int i = lane; i < k; i += 64) {
+        u64 key = wl.buf[i];
+        float dscore = -3.4028234663852886e38f;
+        long long id = -1;
+        if (key != 0) {
+            unsigned slot = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+            int p = slot / k, j = slot % k;
+            size_t src = ((size_t)p * nq + q) * k + j;
+            dscore = inD[src];
+            id = inI[src];
+        }
+        outD[(size_t)q * k + i] = dscore;
+        outI[(size_t)q * k + i] = id;
+    }
+}
+
+__global__ void reconstruct_kernel(const float* __restrict__ X, long long N, int d,
+                                   const long long* __restrict__ ids, long long id_base,
+                                   const long long* __restrict__ qids, int n, float* __restrict__ out) {
+    __shared__ unsigned long long s_row1;  // row + 1, 0 = not found
+    const int i = blockIdx.x;
+    const long long want = qids[i];
+    if (threadIdx.x == 0)
+        s_row1 = ids ? 0ull : ((want >= id_base && want - id_base < N) ? (unsigned long long)(want - id_base + 1) : 0ull);
+    __syncthreads();
+    if (ids) {
+        for (long long r = threadIdx.x; r < N; r += blockDim.x)
+            if (ids[r] == want) atomicMax(&s_row1, (unsigned long long)(r + 1));
+        __syncthreads();
+    }
+    const long long row = (long long)s_row1 - 1;
+    for (int c = threadIdx.x; c < d; c += blockDim.x)
+        out[(size_t)i * d + c] = (row >= 0) ? X[row * d + c] : __builtin_nanf("");
+}
+
+static int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+// a list must be able to take one 64-wide offer on top of k survivors
+static int list_cap(int k) { return next_pow2(k + 64); }
+
+struct ScanPlan {
+    int cap, nq_per_pass, grid, rows;
+    size_t lds;
+};
+
+static ScanPlan plan_scan(long long N, int d, int nq, int k) {
+    ScanPlan p;
+    p.cap = list_cap(k);
+    const int nv = (d / 4 + 63) / 64;
+    // queries per pass: registers (NV*NQ <= 8 keeps the kernel spill-free) and LDS
+    // (4 waves * NQ * cap * 8 B <= 64 KiB so two blocks fit a CU)
+    int nqp = 1;
+    while (nqp * 2 <= nq && nqp * 2 <= 4 && nv * nqp * 2 <= 8 && (size_t)4 * nqp * 2 * p.cap * 8 <= 64 * 1024) nqp <<= 1;
+    p.nq_per_pass = nqp;
+    p.lds = (size_t)4 * nqp * p.cap * 8;
+    p.rows = 4;
+    int blocks_per_cu = (p.lds > 40 * 1024) ? 2 : 4;
+    p.grid = 256 * blocks_per_cu;
+    long long ngroups = (N + p.rows - 1) / p.rows;
+    long long need = (ngroups + 3) / 4;
+    if (need < 1) need = 1;
+    if (p.grid > need) p.grid = (int)need;
+    return p;
+}
+
+template <int NV, int NQ>
+static void launch_scan(const ScanPlan& p, const float* X, long long N, int d, const float* Q, int k, u64* part,
+                        hipStream_t st) {
+    auto kern = ip_scan_kernel<NV, NQ, 4>;
+    if (p.lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)p.lds);
+    hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds, st, reinterpret_cast<const f32x4*>(X), N, d / 4, Q, k,
+                       p.cap, part);
+}
+
+template <int NV>
+static int dispatch_nq(const ScanPlan& p, const float* X, long long N, int d, const float* Q, int k, u64* part,
+                       hipStream_t st) {
+    switch (p.nq_per_pass) {
+        case 1: launch_scan<NV, 1>(p, X, N, d, Q, k, part, st); return 0;
+        case 2:
+            if constexpr (NV * 2 <= 8) { launch_scan<NV, 2>(p, X, N, d, Q, k, part, st); return 0; }
+            break;
+        case 4:
+            if constexpr (NV * 4 <= 8) { launch_scan<NV, 4>(p, X, N, d, Q, k, part, st); return 0; }
+            break;
+    }
+    return WISE_E_INVALID;
+}
+
+}  // namespace wise
+
+using namespace wise;
+
+extern "C" size_t wise_ip_topk_workspace_bytes(int64_t N, int d, int nq, int k) {
+    if (N < 0 || d < 4 || nq < 1 || k < 1 || k > 2048) return 0;
+    ScanPlan p = plan_scan(N, d, nq, k);
+    // part keys [grid][nq_per_pass][k] + padded query block
+    return align_up((size_t)p.grid * p.nq_per_pass * k * sizeof(u64), 256) +
+           align_up((size_t)p.nq_per_pass * d * sizeof(float), 256) + 256;
+}
+
+extern "C" int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, int k, const int64_t* ids,
+                                int64_t id_base, float* outD, int64_t* outI, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    WISE_CHECK_ARG(d >= 4 && d <= 2048 && d % 4 == 0, "ip_topk: d=%d must be a multiple of 4 in [4,2048]", d);
+    WISE_CHECK_ARG(k >= 1 && k <= 2048, "ip_topk: k=%d out of [1,2048]", k);
+    WISE_CHECK_ARG(nq >= 1 && nq <= 1024, "ip_topk: nq=%d out of [1,1024]", nq);
+    WISE_CHECK_ARG(N >= 0 && N < 0xFFFFFFFFll, "ip_topk: N=%lld out of range", (long long)N);
+    WISE_CHECK_ARG(Q && outD && outI && (X || N == 0), "ip_topk: null pointer");
+    WISE_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Q & 15) == 0, "ip_topk: X and Q must be 16-byte aligned");
+    size_t need = wise_ip_topk_workspace_bytes(N, d, nq, k);
+    if (!workspace || workspace_bytes < need) {
+        set_error("ip_topk: workspace %zu < %zu bytes", workspace_bytes, need);
+        return WISE_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    ScanPlan p = plan_scan(N, d, nq, k);
+    u64* part = reinterpret_cast<u64*>(workspace);
+    float* qpad = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) +
+                                           align_up((size_t)p.grid * p.nq_per_pass * k * sizeof(u64), 256));
+    const int nv = (d / 4 + 63) / 64;
+    // merge geometry
+    int mw = 8192 / p.cap;
+    if (mw < 1) mw = 1;
+    if (mw > 16) mw = 16;
+    const size_t mlds = (size_t)mw * p.cap * 8;
+
+    for (int q0 = 0; q0 < nq; q0 += p.nq_per_pass) {
+        const int nqa = (nq - q0 < p.nq_per_pass) ? nq - q0 : p.nq_per_pass;
+        const float* qptr = Q + (size_t)q0 * d;
+        if (nqa < p.nq_per_pass) {
+            // ragged tail: replicate the last query so the kernel shape stays fixed (results ignored)
+            for (int j = 0; j < p.nq_per_pass; ++j) {
+                int srcq = q0 + (j < nqa ? j : nqa - 1);
+                hipError_t e = hipMemcpyAsync(qpad + (size_t)j * d, Q + (size_t)srcq * d, (size_t)d * sizeof(float),
+                                              hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) { set_error("ip_topk: memcpy: %s", hipGetErrorString(e)); return (int)e; }
+            }
+            qptr = qpad;
+        }
+        if (N > 0) {
+            int rc = 0;
+            switch (nv) {
+                case 1: rc = dispatch_nq<1>(p, X, N, d, qptr, k, part, st); break;
+                case 2: rc = dispatch_nq<2>(p, X, N, d, qptr, k, part, st); break;
+                case 3: rc = dispatch_nq<3>(p, X, N, d, qptr, k, part, st); break;
+                case 4: rc = dispatch_nq<4>(p, X, N, d, qptr, k, part, st); break;
+                case 5: rc = dispatch_nq<5>(p, X, N, d, qptr, k, part, st); break;
+                case 6: rc = dispatch_nq<6>(p, X, N, d, qptr, k, part, st); break;
+                case 7: rc = dispatch_nq<7>(p, X, N, d, qptr, k, part, st); break;
+                case 8: rc = dispatch_nq<8>(p, X, N, d, qptr, k, part, st); break;
+                default: rc = WISE_E_INVALID;
+            }
+            if (rc) { set_error("ip_topk: no kernel for d=%d", d); return rc; }
+            WISE_LAUNCH_CHECK("ip_scan_kernel");
+        }
+        if (mlds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_keys_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds);
+        hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mw * 64), mlds, st, part, N > 0 ? p.grid : 0,
+                           p.nq_per_pass, k, p.cap, reinterpret_cast<const long long*>(ids), (long long)id_base, outD,
+                           reinterpret_cast<long long*>(outI), q0);
+        WISE_LAUNCH_CHECK("merge_keys_kernel");
+    }
+    return WISE_OK;
+}
+
+extern "C" int wise_topk_merge(const float* inD, const int64_t* inI, int parts, int nq, int k, float* outD,
+                               int64_t* outI, void* stream) {
+    WISE_CHECK_ARG(inD && inI && outD && outI, "topk_merge: null pointer");
+    WISE_CHECK_ARG(parts >= 1 && nq >= 1 && k >= 1 && k <= 2048 && (long long)parts * k <= 65536,
+                   "topk_merge: parts=%d nq=%d k=%d out of range", parts, nq, k);
+    const int cap = list_cap(k);
+    const size_t lds = (size_t)cap * 8;
+    hipLaunchKernelGGL(merge_pairs_kernel, dim3(nq), dim3(64), lds, (hipStream_t)stream, inD,
+                       reinterpret_cast<const long long*>(inI), parts, nq, k, cap, outD,
+                       reinterpret_cast<long long*>(outI));
+    WISE_LAUNCH_CHECK("merge_pairs_kernel");
+    return WISE_OK;
+}
+
+extern "C" int wise_reconstruct_batch(const float* X, int64_t N, int d, const int64_t* ids, int64_t id_base,
+                                      const int64_t* query_ids, int n, float* out, void* stream) {
+    WISE_CHECK_ARG(X && query_ids && out && n >= 0 && d >= 1, "reconstruct_batch: bad argument");
+    if (n == 0) return WISE_OK;
+    hipLaunchKernelGGL(reconstruct_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, X, (long long)N, d,
+                       reinterpret_cast<const long long*>(ids), (long long)id_base,
+                       reinterpret_cast<const long long*>(query_ids), n, out);
+    WISE_LAUNCH_CHECK("reconstruct_kernel");
+    return WISE_OK;
+}

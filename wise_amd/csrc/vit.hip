@@ -1,0 +1,562 @@
+// HP-1: OpenCLIP VisionTransformer image tower on gfx950.
+//
+// Replaces `self.model.encode_image(x).float()` + L2 normalise at
+// src/feature/mlfoundation_openclip.py:99-100 (arithmetic: SURVEY.md App. A.1, open_clip 2.24.0
+// VisionTransformer; the same computation as transformers' CLIPVisionModelWithProjection,
+// which is what the oracle is pinned against).
+//
+// Data layout in HBM (workspace, all row-major, rows padded to a multiple of 128 so the GEMM never
+// needs an M edge):
+//   x    fp32 [Mp, W]    residual stream (kept fp32; LN statistics and the residual adds are fp32)
+//   h    bf16 [Mp, W]    LayerNorm output / attention output (GEMM A operand)
+//   qkv  bf16 [Mp, 3W]   in_proj output;       also patch-embed fp32 output [Mpp, W] before layer 0
+//   a    bf16 [Mp, F]    MLP hidden;           also the im2col patches bf16 [Mpp, Kp] before layer 0
+#include "common.h"
+
+namespace wise {
+
+int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out,
+              hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row in registers, exact two-pass statistics in fp32
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, int rows, int W, float eps,
+                                                        bf16_t* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int w4 = W >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * W);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = (c < w4) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < w4) {
+            float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
+    uint2* yr = reinterpret_cast<uint2*>(y + (size_t)row * W);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < w4) {
+            const float4 ww = reinterpret_cast<const float4*>(w)[c];
+            const float4 bb = reinterpret_cast<const float4*>(b)[c];
+            uint2 pk;
+            pk.x = pack_bf16x2((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y);
+            pk.y = pack_bf16x2((v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+            yr[c] = pk;
+        }
+    }
+}
+
+int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows, int W, float eps, bf16_t* y,
+                       hipStream_t st) {
+    WISE_CHECK_ARG(x && w && b && y, "layernorm: null pointer");
+    WISE_CHECK_ARG(rows >= 0 && W >= 4 && W % 4 == 0 && W <= 4096, "layernorm: W=%d must be a multiple of 4, <= 4096", W);
+    if (rows == 0) return WISE_OK;
+    const int nv = (W / 4 + 63) / 64;
+    const dim3 grid((rows + 3) / 4), block(256);
+#define LN_CASE(n) \
+    case n: hipLaunchKernelGGL(layernorm_kernel<n>, grid, block, 0, st, x, w, b, rows, W, eps, y); break;
+    switch (nv) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+        LN_CASE(9) LN_CASE(10) LN_CASE(11) LN_CASE(12) LN_CASE(13) LN_CASE(14) LN_CASE(15) LN_CASE(16)
+    }
+#undef LN_CASE
+    WISE_LAUNCH_CHECK("layernorm_kernel");
+    return WISE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention, head dim 64, no mask: one wave per (image, head, 64-query chunk), flash-style over
+// 64-key blocks.  Computes S^T = K Q^T so that a lane owns whole query columns: the softmax
+// reduction is in-lane plus two cross-lane steps, and the exponentiated accumulators are, as they
+// stand, the B operand of O^T = V^T P^T (MFMA k-slot order permuted consistently on the V^T side).
+// V^T comes from a wave-private LDS image [64 dh][64 keys (+4 pad)].
+// ------------------------------------------------------------------------------------------------
+constexpr int VT_LD = 68;  // bf16 elements per V^T row (64 keys + pad) = 136 B
+
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, int B, int T, int H,
+                                                        bf16_t* __restrict__ o) {
+    __shared__ __attribute__((aligned(16))) bf16_t vt_all[4][64 * VT_LD];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nqc = (T + 63) >> 6;
+    const long long item = (long long)blockIdx.x * 4 + wave;  // (b, h, qc)
+    if (item >= (long long)B * H * nqc) return;
+    const int qc = (int)(item % nqc);
+    const int h = (int)((item / nqc) % H);
+    const int b = (int)(item / ((long long)nqc * H));
+    const int W = H * 64, W3 = 3 * W;
+    const bf16_t* base = qkv + (size_t)b * T * W3;
+    bf16_t* vt = vt_all[wave];
+    const int l15 = lane & 15, g = lane >> 4;
+
+    // Q fragments: B operand, lane holds Q[query = qt*16 + l15][dh = s*32 + 8g .. +7]
+    bf16x8 qf[4][2];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        int t = qc * 64 + qt * 16 + l15;
+        if (t >= T) t = T - 1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            qf[qt][s] = *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + h * 64 + s * 32 + g * 8);
+    }
+
+    f32x4 oacc[4][4];  // [dt][qt]: O^T[dh = dt*16 + g*4 + r][query = qt*16 + l15]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun[4], lrun[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) { mrun[qt] = -INFINITY; lrun[qt] = 0.f; }
+    const float sc = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+
+    const int nkb = (T + 63) >> 6;
+    for (int kb = 0; kb < nkb; ++kb) {
+        // ---- V^T image: 8 passes, lane reads 16 B of V row (key = p*8 + lane/8, dh = (lane&7)*8 ..)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int key = p * 8 + (lane >> 3);
+            int t = kb * 64 + key;
+            const bool valid = t < T;
+            if (!valid) t = T - 1;
+            short8 v = *reinterpret_cast<const short8*>(base + (size_t)t * W3 + 2 * W + h * 64 + (lane & 7) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vt[((lane & 7) * 8 + j) * VT_LD + key] = valid ? (bf16_t)v[j] : (bf16_t)0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- S^T[kt][qt] = K Q^T
+        f32x4 sacc[4][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            int t = kb * 64 + kt * 16 + l15;
+            if (t >= T) t = T - 1;
+            bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + W + h * 64 + g * 8);
+            bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + W + h * 64 + 32 + g * 8);
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[qt][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[qt][1], c, 0, 0, 0);
+                sacc[kt][qt] = c;
+            }
+        }
+        // ---- online softmax per query column (qt, l15); this lane holds keys kt*16 + g*4 + r
+        bf16x8 pf[2][4];  // [ks][qt] B operand of the PV product
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb * 64 + kt * 16 + g * 4 + r;
+                    float s2 = (key < T) ? sacc[kt][qt][r] * sc : -INFINITY;
+                    sacc[kt][qt][r] = s2;
+                    mx = fmaxf(mx, s2);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrun[qt], mx);
+            const float alpha = exp2f(mrun[qt] - mnew);
+            mrun[qt] = mnew;
+            float ps = 0.f;
+            float p[4][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[kt][r] = exp2f(sacc[kt][qt][r] - mnew);
+                    ps += p[kt][r];
+                }
+            lrun[qt] = lrun[qt] * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha;
+                oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f[r] = (__bf16)p[2 * ks][r];
+                    f[4 + r] = (__bf16)p[2 * ks + 1][r];
+                }
+                pf[ks][qt] = f;
+            }
+        }
+        // ---- O^T += V^T P^T ; A operand: V^T[dh = dt*16 + l15][slot 8g + j] with
+        //      slot j<4 -> key ks*32 + g*4 + j ; j>=4 -> key ks*32 + 16 + g*4 + (j-4)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16_t* rowp = vt + (dt * 16 + l15) * VT_LD + ks * 32 + g * 4;
+                const uint2 lo = *reinterpret_cast<const uint2*>(rowp);
+                const uint2 hi = *reinterpret_cast<const uint2*>(rowp + 16);
+                union { uint4 u; bf16x8 f; } cv;
+                cv.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt)
+                    oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cv.f, pf[ks][qt], oacc[dt][qt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- normalise and store O[query][h*64 + dt*16 + g*4 + r]
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        float l = lrun[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.f / l;
+        const int t = qc * 64 + qt * 16 + l15;
+        if (t < T) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 pk;
+                pk.x = pack_bf16x2(oacc[dt][qt][0] * inv, oacc[dt][qt][1] * inv);
+                pk.y = pack_bf16x2(oacc[dt][qt][2] * inv, oacc[dt][qt][3] * inv);
+                *reinterpret_cast<uint2*>(o + ((size_t)b * T + t) * W + h * 64 + dt * 16 + g * 4) = pk;
+            }
+        }
+    }
+}
+
+int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st) {
+    WISE_CHECK_ARG(qkv && o && B > 0 && T > 0 && H > 0, "attention: bad argument");
+    const int nqc = (T + 63) / 64;
+    const long long items = (long long)B * H * nqc;
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, B, T, H, o);
+    WISE_LAUNCH_CHECK("attention_kernel");
+    return WISE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// patch gather (im2col): images [B,3,S,S] fp32 or u8 -> patches bf16 [B*g*g, Kp], k = c*P*P + py*P + px
+// u8 input applies (x/255 - mean)/std of the OpenAI CLIP transform (mlfoundation_openclip.py:81-90)
+// ------------------------------------------------------------------------------------------------
+template <typename TIN>
+__global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ img, int B, int S, int P, int g,
+                                                       int Kp, bf16_t* __restrict__ patches) {
+    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+    const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+    const int prow = blockIdx.x;  // b*g*g + gy*g + gx
+    const int b = prow / (g * g), gy = (prow / g) % g, gx = prow % g;
+    const int K = 3 * P * P;
+    for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
+        float v = 0.f;
+        if (k < K) {
+            const int c = k / (P * P), py = (k / P) % P, px = k % P;
+            const size_t src = (((size_t)b * 3 + c) * S + gy * P + py) * S + gx * P + px;
+            if (sizeof(TIN) == 1)
+                v = ((float)img[src] * (1.f / 255.f) - mean[c]) / stdv[c];
+            else
+                v = (float)img[src];
+        }
+        patches[(size_t)prow * Kp + k] = f32_to_bf16(v);
+    }
+}
+
+// x[b*T + t, :] = ln_pre( (t == 0 ? cls : patch_out[b*g*g + t-1, :]) + pos[t, :] ), one wave per row
+template <int NV>
+__global__ __launch_bounds__(256) void embed_lnpre_kernel(const float* __restrict__ patch_out,
+                                                          const float* __restrict__ cls, const float* __restrict__ pos,
+                                                          const float* __restrict__ w, const float* __restrict__ bb,
+                                                          int rows, int T, int W, float eps, float* __restrict__ x) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / T, t = row % T;
+    const int w4 = W >> 2;
+    const float4* src = (t == 0) ? reinterpret_cast<const float4*>(cls)
+                                 : reinterpret_cast<const float4*>(patch_out + ((size_t)b * (T - 1) + (t - 1)) * W);
+    const float4* pr = reinterpret_cast<const float4*>(pos + (size_t)t * W);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < w4) {
+            float4 a = src[c], p = pr[c];
+            v[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+        } else
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < w4) {
+            float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
+    float4* xr = reinterpret_cast<float4*>(x + (size_t)row * W);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < w4) {
+            const float4 ww = reinterpret_cast<const float4*>(w)[c];
+            const float4 b4 = reinterpret_cast<const float4*>(bb)[c];
+            xr[c] = make_float4((v[i].x - mean) * rstd * ww.x + b4.x, (v[i].y - mean) * rstd * ww.y + b4.y,
+                                (v[i].z - mean) * rstd * ww.z + b4.z, (v[i].w - mean) * rstd * ww.w + b4.w);
+        }
+    }
+}
+
+// out[b,:] = normalize( ln_post(x[b*T, :]) @ proj ), projT bf16 [D, W]; one block (256 thr) per image
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bb, const bf16_t* __restrict__ projT,
+                                                   int T, int W, int D, float eps, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* y = reinterpret_cast<float*>(smem);  // [W] ln_post(cls), then [D] outputs
+    float* e = y + W;
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xr = x + (size_t)blockIdx.x * T * W;
+    float s = 0.f;
+    for (int c = tid; c < W; c += 256) s += xr[c];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)W;
+    __syncthreads();
+    float q = 0.f;
+    for (int c = tid; c < W; c += 256) { float a = xr[c] - mean; q += a * a; }
+    q = wave_sum(q);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)W + eps);
+    for (int c = tid; c < W; c += 256) {
+        y[c] = (xr[c] - mean) * rstd * w[c] + bb[c];
+    }
+    __syncthreads();
+    float sq = 0.f;
+    for (int dcol = wave; dcol < D; dcol += 4) {
+        const bf16_t* pr = projT + (size_t)dcol * W;
+        float acc = 0.f;
+        for (int c = lane * 8; c < W; c += 512) {
+            short8 pv = *reinterpret_cast<const short8*>(pr + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(y[c + j], bf16_to_f32((bf16_t)pv[j]), acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) e[dcol] = acc;
+        sq += acc * acc;  // same in every lane
+    }
+    __syncthreads();
+    if (lane == 0) red[4 + wave] = sq;
+    __syncthreads();
+    const float nrm = sqrtf(red[4] + red[5] + red[6] + red[7]);
+    for (int dcol = tid; dcol < D; dcol += 256) out[(size_t)blockIdx.x * D + dcol] = e[dcol] / nrm;
+}
+
+struct VitDims {
+    int S, P, W, L, H, F, D, g, T, K, Kp;
+};
+static int vit_dims(const wise_vit_config* c, VitDims* d) {
+    WISE_CHECK_ARG(c, "vit: null config");
+    d->S = c->image_size; d->P = c->patch; d->W = c->width; d->L = c->layers; d->H = c->heads;
+    d->F = c->mlp; d->D = c->embed_dim;
+    WISE_CHECK_ARG(d->P > 0 && d->S > 0 && d->S % d->P == 0, "vit: image_size %d not a multiple of patch %d", d->S, d->P);
+    WISE_CHECK_ARG(d->W > 0 && d->W % 128 == 0 && d->H * 64 == d->W, "vit: width %d must be heads*64 and a multiple of 128",
+                   d->W);
+    WISE_CHECK_ARG(d->F > 0 && d->F % 128 == 0, "vit: mlp %d must be a multiple of 128", d->F);
+    WISE_CHECK_ARG(d->D > 0 && d->L >= 0 && d->W <= 4096 && d->W % 8 == 0, "vit: bad dims");
+    WISE_CHECK_ARG(c->act == 0 || c->act == 1, "vit: act must be 0 (quick_gelu) or 1 (gelu)");
+    d->g = d->S / d->P; d->T = d->g * d->g + 1; d->K = 3 * d->P * d->P; d->Kp = (d->K + 63) / 64 * 64;
+    return WISE_OK;
+}
+
+struct VitOffsets {
+    // bf16 blob (elements)
+    size_t conv1, layer0_b, per_layer_b, in_proj, out_proj, c_fc, c_proj, projT, total_b;
+    // fp32 blob (elements)
+    size_t cls, pos, ln_pre_w, ln_pre_b, layer0_f, per_layer_f, ln1_w, ln1_b, in_b, out_b, ln2_w, ln2_b, fc_b, proj_b,
+        ln_post_w, ln_post_b, total_f;
+};
+static VitOffsets vit_offsets(const VitDims& d) {
+    VitOffsets o;
+    const size_t W = d.W, F = d.F;
+    o.conv1 = 0;
+    o.layer0_b = W * d.Kp;
+    o.in_proj = 0; o.out_proj = 3 * W * W; o.c_fc = o.out_proj + W * W; o.c_proj = o.c_fc + F * W;
+    o.per_layer_b = o.c_proj + W * F;
+    o.projT = o.layer0_b + o.per_layer_b * d.L;
+    o.total_b = o.projT + (size_t)d.D * W;
+    o.cls = 0; o.pos = W; o.ln_pre_w = o.pos + (size_t)d.T * W; o.ln_pre_b = o.ln_pre_w + W;
+    o.layer0_f = o.ln_pre_b + W;
+    o.ln1_w = 0; o.ln1_b = W; o.in_b = 2 * W; o.out_b = 5 * W; o.ln2_w = 6 * W; o.ln2_b = 7 * W; o.fc_b = 8 * W;
+    o.proj_b = o.fc_b + F;
+    o.per_layer_f = o.proj_b + W;
+    o.ln_post_w = o.layer0_f + o.per_layer_f * d.L; o.ln_post_b = o.ln_post_w + W;
+    o.total_f = o.ln_post_b + W;
+    return o;
+}
+
+struct VitWs {
+    size_t x, h, qkv, a, total;
+    int M, Mp, Mpatch, Mpp;
+};
+static VitWs vit_ws(const VitDims& d, int B) {
+    VitWs w;
+    w.M = B * d.T; w.Mp = (w.M + 127) / 128 * 128;
+    w.Mpatch = B * d.g * d.g; w.Mpp = (w.Mpatch + 127) / 128 * 128;
+    size_t off = 0;
+    w.x = off; off += align_up((size_t)w.Mp * d.W * 4, 256);
+    w.h = off; off += align_up((size_t)w.Mp * d.W * 2, 256);
+    size_t qkv_b = (size_t)w.Mp * 3 * d.W * 2, po_b = (size_t)w.Mpp * d.W * 4;
+    w.qkv = off; off += align_up(qkv_b > po_b ? qkv_b : po_b, 256);
+    size_t a_b = (size_t)w.Mp * d.F * 2, pa_b = (size_t)w.Mpp * d.Kp * 2;
+    w.a = off; off += align_up(a_b > pa_b ? a_b : pa_b, 256);
+    w.total = off;
+    return w;
+}
+
+template <int NV>
+static void launch_embed(const float* po, const float* cls, const float* pos, const float* w, const float* b, int rows,
+                         int T, int W, float* x, hipStream_t st) {
+    hipLaunchKernelGGL(embed_lnpre_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, st, po, cls, pos, w, b, rows, T, W,
+                       1e-5f, x);
+}
+
+}  // namespace wise
+
+using namespace wise;
+
+extern "C" int wise_vit_layout(const wise_vit_config* cfg, int64_t* wb_elems, int64_t* pf_elems) {
+    VitDims d;
+    int rc = vit_dims(cfg, &d);
+    if (rc) return rc;
+    VitOffsets o = vit_offsets(d);
+    if (wb_elems) *wb_elems = (int64_t)o.total_b;
+    if (pf_elems) *pf_elems = (int64_t)o.total_f;
+    return WISE_OK;
+}
+
+extern "C" size_t wise_vit_workspace_bytes(const wise_vit_config* cfg, int batch) {
+    VitDims d;
+    if (vit_dims(cfg, &d) || batch < 1) return 0;
+    return vit_ws(d, batch).total;
+}
+
+extern "C" int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, const float* pf, const void* images,
+                                int in_kind, int batch, float* out, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    VitDims d;
+    int rc = vit_dims(cfg, &d);
+    if (rc) return rc;
+    WISE_CHECK_ARG(wb && pf && images && out, "vit_forward: null pointer");
+    WISE_CHECK_ARG(batch >= 1, "vit_forward: batch=%d", batch);
+    WISE_CHECK_ARG(in_kind == WISE_VIT_IN_F32 || in_kind == WISE_VIT_IN_U8, "vit_forward: in_kind=%d", in_kind);
+    const VitWs ws = vit_ws(d, batch);
+    if (!workspace || workspace_bytes < ws.total) {
+        set_error("vit_forward: workspace %zu < %zu bytes", workspace_bytes, ws.total);
+        return WISE_E_WORKSPACE;
+    }
+    WISE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wb & 15) == 0 && ((uintptr_t)pf & 15) == 0,
+                   "vit_forward: workspace must be 256-byte and weight blobs 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const VitOffsets o = vit_offsets(d);
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+    float* x = reinterpret_cast<float*>(wsb + ws.x);
+    bf16_t* h = reinterpret_cast<bf16_t*>(wsb + ws.h);
+    bf16_t* qkv = reinterpret_cast<bf16_t*>(wsb + ws.qkv);
+    bf16_t* a = reinterpret_cast<bf16_t*>(wsb + ws.a);
+    float* patch_out = reinterpret_cast<float*>(wsb + ws.qkv);
+    bf16_t* patches = a;
+    const int W = d.W;
+
+    // 1. patch gather + conv1-as-GEMM (no bias)
+    if (in_kind == WISE_VIT_IN_U8)
+        hipLaunchKernelGGL(patchify_kernel<unsigned char>, dim3(ws.Mpatch), dim3(256), 0, st,
+                           reinterpret_cast<const unsigned char*>(images), batch, d.S, d.P, d.g, d.Kp, patches);
+    else
+        hipLaunchKernelGGL(patchify_kernel<float>, dim3(ws.Mpatch), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(images), batch, d.S, d.P, d.g, d.Kp, patches);
+    WISE_LAUNCH_CHECK("patchify_kernel");
+    rc = gemm_bf16(patches, wb + o.conv1, nullptr, ws.Mpp, W, d.Kp, 4, patch_out, st);
+    if (rc) return rc;
+    // 2. cls + pos + ln_pre -> x
+    {
+        const int nv = (W / 4 + 63) / 64;
+        const float* cls = pf + o.cls; const float* pos = pf + o.pos;
+        const float* lw = pf + o.ln_pre_w; const float* lb = pf + o.ln_pre_b;
+        switch (nv) {
+            case 1: launch_embed<1>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
+            case 2: launch_embed<2>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
+            case 3: launch_embed<3>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
+            case 4: launch_embed<4>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
+            case 5: launch_embed<5>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
+            case 6: launch_embed<6>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
+            case 7: launch_embed<7>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
+            case 8: launch_embed<8>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
+            default: set_error("vit_forward: width %d too large", W); return WISE_E_UNSUPPORTED;
+        }
+        WISE_LAUNCH_CHECK("embed_lnpre_kernel");
+    }
+    // 3. transformer blocks
+    for (int l = 0; l < d.L; ++l) {
+        const bf16_t* lwb = wb + o.layer0_b + o.per_layer_b * l;
+        const float* lpf = pf + o.layer0_f + o.per_layer_f * l;
+        if ((rc = layernorm_f32_bf16(x, lpf + o.ln1_w, lpf + o.ln1_b, ws.M, W, 1e-5f, h, st))) return rc;
+        if ((rc = gemm_bf16(h, lwb + o.in_proj, lpf + o.in_b, ws.Mp, 3 * W, W, 0, qkv, st))) return rc;
+        if ((rc = attention_bf16(qkv, batch, d.T, d.H, h, st))) return rc;
+        if ((rc = gemm_bf16(h, lwb + o.out_proj, lpf + o.out_b, ws.Mp, W, W, 3, x, st))) return rc;
+        if ((rc = layernorm_f32_bf16(x, lpf + o.ln2_w, lpf + o.ln2_b, ws.M, W, 1e-5f, h, st))) return rc;
+        if ((rc = gemm_bf16(h, lwb + o.c_fc, lpf + o.fc_b, ws.Mp, d.F, W, cfg->act == 0 ? 1 : 2, a, st))) return rc;
+        if ((rc = gemm_bf16(a, lwb + o.c_proj, lpf + o.proj_b, ws.Mp, W, d.F, 3, x, st))) return rc;
+    }
+    // 4. ln_post(cls) @ proj, L2 normalise
+    hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(256), (size_t)(W + d.D) * 4, st, x, pf + o.ln_post_w,
+                       pf + o.ln_post_b, wb + o.projT, d.T, W, d.D, 1e-5f, out);
+    WISE_LAUNCH_CHECK("head_kernel");
+    return WISE_OK;
+}
+
+extern "C" int wise_vit_tap_residual(const wise_vit_config* cfg, int batch, const void* workspace, float* dst,
+                                     void* stream) {
+    VitDims d;
+    int rc = vit_dims(cfg, &d);
+    if (rc) return rc;
+    WISE_CHECK_ARG(workspace && dst && batch >= 1, "vit_tap_residual: bad argument");
+    const VitWs ws = vit_ws(d, batch);
+    hipError_t e = hipMemcpyAsync(dst, reinterpret_cast<const unsigned char*>(workspace) + ws.x,
+                                  (size_t)ws.M * d.W * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("vit_tap_residual: %s", hipGetErrorString(e)); return (int)e; }
+    return WISE_OK;
+}
+
+extern "C" int wise_layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows, int W, float eps,
+                                       uint16_t* y, void* stream) {
+    return layernorm_f32_bf16(x, w, b, rows, W, eps, y, (hipStream_t)stream);
+}
+
+extern "C" int wise_attention_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream) {
+    return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream);
+}

@@ -1,0 +1,205 @@
+"""Host side of the OpenCLIP image tower: model table, weight packing, and the engine that drives
+`wise_vit_forward` (include/wise_hip.h).
+
+Weights are addressed by open_clip 2.24.0 state-dict keys (the names the reference's
+`open_clip.create_model_and_transforms` produces, src/feature/mlfoundation_openclip.py:38), so a
+real checkpoint is a pure data problem: `pack_weights(spec, state_dict)`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict
+
+import torch
+
+from .. import _lib
+
+
+@dataclass(frozen=True)
+class VitSpec:
+    name: str
+    image_size: int
+    patch: int
+    width: int
+    layers: int
+    heads: int
+    mlp: int
+    embed_dim: int
+    act: str = "quick_gelu"  # 'quick_gelu' (openai tags) | 'gelu' (laion tags)
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch
+
+    @property
+    def tokens(self) -> int:
+        return self.grid * self.grid + 1
+
+    @property
+    def kdim(self) -> int:
+        return 3 * self.patch * self.patch
+
+    @property
+    def kpad(self) -> int:
+        return (self.kdim + 63) // 64 * 64
+
+    def flops_per_frame(self) -> int:
+        """2*MAC of the contractions only."""
+        g2, T, W, F, D = self.grid ** 2, self.tokens, self.width, self.mlp, self.embed_dim
+        per_layer = T * W * 3 * W * 2 + 2 * self.heads * T * T * 64 * 2 + T * W * W * 2 + 2 * T * W * F * 2
+        return g2 * self.kdim * W * 2 + self.layers * per_layer + W * D * 2
+
+    def c_config(self) -> _lib.VitConfig:
+        return _lib.VitConfig(self.image_size, self.patch, self.width, self.layers, self.heads, self.mlp,
+                              self.embed_dim, 0 if self.act == "quick_gelu" else 1)
+
+
+# open_clip model names WISE passes as id token [2]
+SPECS: Dict[str, VitSpec] = {
+    "ViT-B-32": VitSpec("ViT-B-32", 224, 32, 768, 12, 12, 3072, 512),
+    "ViT-B-16": VitSpec("ViT-B-16", 224, 16, 768, 12, 12, 3072, 512),
+    "ViT-L-14": VitSpec("ViT-L-14", 224, 14, 1024, 24, 16, 4096, 768),
+}
+
+
+def spec_for(model_name: str, pretrained: str = "openai") -> VitSpec:
+    base = model_name.replace("-quickgelu", "")
+    if base not in SPECS:
+        raise ValueError(f"Model ({model_name}, {pretrained}) not available")
+    s = SPECS[base]
+    quick = model_name.endswith("-quickgelu") or pretrained == "openai"
+    return VitSpec(**{**s.__dict__, "name": model_name, "act": "quick_gelu" if quick else "gelu"})
+
+
+def state_dict_keys(spec: VitSpec):
+    """(key, shape) in the order the seeded initialiser draws them."""
+    W, F, D, T, P = spec.width, spec.mlp, spec.embed_dim, spec.tokens, spec.patch
+    keys = [("visual.conv1.weight", (W, 3, P, P)), ("visual.class_embedding", (W,)),
+            ("visual.positional_embedding", (T, W)), ("visual.ln_pre.weight", (W,)), ("visual.ln_pre.bias", (W,))]
+    for i in range(spec.layers):
+        p = f"visual.transformer.resblocks.{i}."
+        keys += [(p + "ln_1.weight", (W,)), (p + "ln_1.bias", (W,)), (p + "attn.in_proj_weight", (3 * W, W)),
+                 (p + "attn.in_proj_bias", (3 * W,)), (p + "attn.out_proj.weight", (W, W)),
+                 (p + "attn.out_proj.bias", (W,)), (p + "ln_2.weight", (W,)), (p + "ln_2.bias", (W,)),
+                 (p + "mlp.c_fc.weight", (F, W)), (p + "mlp.c_fc.bias", (F,)), (p + "mlp.c_proj.weight", (W, F)),
+                 (p + "mlp.c_proj.bias", (W,))]
+    keys += [("visual.ln_post.weight", (W,)), ("visual.ln_post.bias", (W,)), ("visual.proj", (W, D))]
+    return keys
+
+
+def random_state_dict(spec: VitSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded fp32 weights (no checkpoints exist offline).  One CPU generator, tensors drawn in
+    `state_dict_keys` order; LayerNorm affine terms are perturbed so a dropped scale/shift shows;
+    q/k projections are scaled up so attention is far from uniform."""
+    g = torch.Generator().manual_seed(seed)
+    W, L = spec.width, max(spec.layers, 1)
+    sd = {}
+    for key, shape in state_dict_keys(spec):
+        n = torch.randn(shape, generator=g, dtype=torch.float32)
+        if key.endswith("conv1.weight"):
+            t = n * (spec.kdim ** -0.5)
+        elif key.endswith("ln_pre.weight") or key.endswith("ln_1.weight") or key.endswith("ln_2.weight") \
+                or key.endswith("ln_post.weight"):
+            t = 1.0 + 0.1 * n
+        elif ".ln_" in key and key.endswith(".bias"):
+            t = 0.1 * n
+        elif key.endswith("in_proj_weight"):
+            t = n * (W ** -0.5)
+            t[: 2 * W] *= 2.0
+        elif key.endswith("out_proj.weight"):
+            t = n * (W ** -0.5) * ((2 * L) ** -0.5)
+        elif key.endswith("c_fc.weight"):
+            t = n * (W ** -0.5)
+        elif key.endswith("c_proj.weight"):
+            t = n * (spec.mlp ** -0.5) * ((2 * L) ** -0.5)
+        elif key.endswith(".bias") or key.endswith("_bias"):
+            t = 0.02 * n
+        elif key.endswith("class_embedding") or key.endswith("positional_embedding"):
+            t = n * 0.5
+        elif key.endswith("visual.proj"):
+            t = n * (W ** -0.5)
+        else:
+            raise KeyError(key)
+        sd[key] = t.contiguous()
+    return sd
+
+
+def pack_weights(spec: VitSpec, sd: Dict[str, torch.Tensor]):
+    """state dict -> (bf16 blob, fp32 blob) in the layout include/wise_hip.h documents (CPU tensors)."""
+    W, F = spec.width, spec.mlp
+    f32 = lambda k: sd[k].detach().to(torch.float32).cpu()
+    conv = torch.zeros(W, spec.kpad, dtype=torch.float32)
+    conv[:, : spec.kdim] = f32("visual.conv1.weight").reshape(W, spec.kdim)
+    wb = [conv.reshape(-1)]
+    pf = [f32("visual.class_embedding").reshape(-1), f32("visual.positional_embedding").reshape(-1),
+          f32("visual.ln_pre.weight"), f32("visual.ln_pre.bias")]
+    for i in range(spec.layers):
+        p = f"visual.transformer.resblocks.{i}."
+        wb += [f32(p + "attn.in_proj_weight").reshape(-1), f32(p + "attn.out_proj.weight").reshape(-1),
+               f32(p + "mlp.c_fc.weight").reshape(-1), f32(p + "mlp.c_proj.weight").reshape(-1)]
+        pf += [f32(p + "ln_1.weight"), f32(p + "ln_1.bias"), f32(p + "attn.in_proj_bias"),
+               f32(p + "attn.out_proj.bias"), f32(p + "ln_2.weight"), f32(p + "ln_2.bias"), f32(p + "mlp.c_fc.bias"),
+               f32(p + "mlp.c_proj.bias")]
+    wb.append(f32("visual.proj").t().contiguous().reshape(-1))  # proj^T [D, W]
+    pf += [f32("visual.ln_post.weight"), f32("visual.ln_post.bias")]
+    wb_t = torch.cat(wb).to(torch.bfloat16).contiguous()
+    pf_t = torch.cat(pf).contiguous()
+    return wb_t, pf_t
+
+
+class VitEngine:
+    """Owns the device copies of the two weight blobs and a workspace; `forward` launches the HIP
+    pipeline on the current torch stream and returns a device tensor [B, D] fp32 (L2-normalised)."""
+
+    def __init__(self, spec: VitSpec, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 256):
+        self.spec = spec
+        self.lib = _lib.lib()
+        self.device = torch.device(device)
+        self.cfg = spec.c_config()
+        nb, nf = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.wise_vit_layout(C.byref(self.cfg), C.byref(nb), C.byref(nf)), "wise_vit_layout")
+        wb, pf = pack_weights(spec, sd)
+        if wb.numel() != nb.value or pf.numel() != nf.value:
+            raise RuntimeError(f"weight blob size mismatch: packed {wb.numel()}/{pf.numel()}, "
+                               f"library expects {nb.value}/{nf.value}")
+        self.wb = wb.to(self.device)
+        self.pf = pf.to(self.device)
+        self._ws = None
+        self._ws_batch = 0
+        self.reserve(max_batch)
+
+    def reserve(self, batch: int):
+        if batch <= self._ws_batch:
+            return
+        n = self.lib.wise_vit_workspace_bytes(C.byref(self.cfg), batch)
+        if n == 0:
+            raise RuntimeError("wise_vit_workspace_bytes: bad config")
+        self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._ws_batch = batch
+
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        S = self.spec.image_size
+        if images.dim() != 4 or tuple(images.shape[1:]) != (3, S, S):
+            raise ValueError(f"expected [B,3,{S},{S}], got {tuple(images.shape)}")
+        if images.dtype == torch.uint8:
+            kind = _lib.WISE_VIT_IN_U8
+        elif images.dtype == torch.float32:
+            kind = _lib.WISE_VIT_IN_F32
+        else:
+            raise ValueError(f"images must be float32 or uint8, got {images.dtype}")
+        x = images.to(self.device).contiguous()
+        B = x.shape[0]
+        self.reserve(B)
+        out = torch.empty(B, self.spec.embed_dim, dtype=torch.float32, device=self.device)
+        rc = self.lib.wise_vit_forward(C.byref(self.cfg), self.wb.data_ptr(), self.pf.data_ptr(), x.data_ptr(), kind, B,
+                                       out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "wise_vit_forward")
+        return out
+
+    def residual(self, batch: int) -> torch.Tensor:
+        """Residual stream [B*T, W] fp32 left by the last forward (parity tap)."""
+        out = torch.empty(batch * self.spec.tokens, self.spec.width, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.wise_vit_tap_residual(C.byref(self.cfg), batch, self._ws.data_ptr(), out.data_ptr(),
+                                                  _lib.stream_ptr()), "wise_vit_tap_residual")
+        return out

@@ -1,0 +1,116 @@
+"""faiss-shaped flat inner-product index whose rows live in HBM and whose search is the HIP scan.
+
+Stands where `faiss.IndexIDMap(faiss.IndexFlatIP(d))` stands in the reference
+(src/index/feature_search_index.py:47-52).  The attributes and methods are the ones WISE touches on
+`SearchIndex.index`: `d`, `ntotal`, `add_with_ids`, `search`,
+`reconstruct_batch`; it deliberately has no `nprobe`/`direct_map` (api/routes.py:899-909 guards
+both with hasattr/try).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class FlatIPIndex:
+    def __init__(self, d: int, device: str = "cuda"):
+        if d < 4 or d % 4 != 0 or d > 2048:
+            raise ValueError(f"FlatIPIndex: d={d} must be a multiple of 4 in [4, 2048]")
+        self.d = int(d)
+        self.device = torch.device(device)
+        self._chunks: List[torch.Tensor] = []
+        self._id_chunks: List[torch.Tensor] = []
+        self._X: Optional[torch.Tensor] = None  # [N,d] fp32 on device
+        self._ids: Optional[torch.Tensor] = None  # [N] int64 on device, None => id_base + row
+        self.id_base = 0
+        self._n = 0
+        self._ws: Optional[torch.Tensor] = None
+        self.is_trained = True
+
+    # -- construction ---------------------------------------------------------------------------
+    @property
+    def ntotal(self) -> int:
+        return self._n
+
+    def add_with_ids(self, x, ids) -> None:
+        """x [n,d] float32, ids [n] int64 (feature_search_index.py:81)."""
+        x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)) if not torch.is_tensor(x) else x
+        ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int64)) if not torch.is_tensor(ids) else ids
+        if x.dim() != 2 or x.shape[1] != self.d:
+            raise ValueError(f"add_with_ids: expected [n,{self.d}], got {tuple(x.shape)}")
+        if ids.shape != (x.shape[0],):
+            raise ValueError("add_with_ids: ids must have one entry per row")
+        self._chunks.append(x.to(self.device, torch.float32))
+        self._id_chunks.append(ids.to(self.device, torch.int64))
+        self._n += x.shape[0]
+
+    def adopt(self, X: torch.Tensor, ids: Optional[torch.Tensor] = None, id_base: int = 0) -> "FlatIPIndex":
+        """Take ownership of rows already resident in HBM (no copy). ids None => id = id_base + row."""
+        if X.dtype != torch.float32 or X.dim() != 2 or X.shape[1] != self.d or not X.is_contiguous():
+            raise ValueError("adopt: X must be contiguous float32 [N,d]")
+        if ids is not None and (ids.dtype != torch.int64 or ids.shape != (X.shape[0],)):
+            raise ValueError("adopt: ids must be int64 [N]")
+        self._chunks, self._id_chunks = [], []
+        self._X, self._ids, self.id_base, self._n = X, ids, int(id_base), X.shape[0]
+        return self
+
+    def _finalize(self):
+        if self._chunks:
+            parts = ([self._X] if self._X is not None else []) + self._chunks
+            idp = ([self._ids] if self._ids is not None else []) + self._id_chunks
+            if self._X is not None and self._ids is None:
+                idp = [torch.arange(self._X.shape[0], device=self.device, dtype=torch.int64) + self.id_base] + \
+                    self._id_chunks
+            self._X = torch.cat(parts, dim=0).contiguous()
+            self._ids = torch.cat(idp, dim=0).contiguous()
+            self._chunks, self._id_chunks = [], []
+        if self._X is None:
+            self._X = torch.empty(0, self.d, dtype=torch.float32, device=self.device)
+            self._ids = torch.empty(0, dtype=torch.int64, device=self.device)
+
+    # -- search ---------------------------------------------------------------------------------
+    def search_device(self, q: torch.Tensor, k: int):
+        """q [nq,d] fp32 on device -> (D [nq,k] fp32, I [nq,k] int64) on device, no host sync."""
+        lib = _lib.lib()
+        self._finalize()
+        if q.dim() != 2 or q.shape[1] != self.d:
+            raise ValueError(f"search: expected [nq,{self.d}], got {tuple(q.shape)}")
+        q = q.to(self.device, torch.float32).contiguous()
+        nq = q.shape[0]
+        D = torch.empty(nq, k, dtype=torch.float32, device=self.device)
+        I = torch.empty(nq, k, dtype=torch.int64, device=self.device)
+        if nq == 0:
+            return D, I
+        need = lib.wise_ip_topk_workspace_bytes(self._n, self.d, nq, k)
+        if need == 0:
+            raise ValueError(f"search: unsupported shape N={self._n} d={self.d} nq={nq} k={k}")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        rc = lib.wise_ip_topk_f32(self._X.data_ptr(), self._n, self.d, q.data_ptr(), nq, k, _lib.ptr(self._ids),
+                                  self.id_base, D.data_ptr(), I.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                  _lib.stream_ptr())
+        _lib.check(rc, "wise_ip_topk_f32")
+        return D, I
+
+    def search(self, x, k: int):
+        """faiss signature: x np.ndarray [nq,d] float32 -> (D, I) numpy (feature_search_index.py:113)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2:
+            raise ValueError("search: x must be 2-D")
+        D, I = self.search_device(torch.from_numpy(x).to(self.device), int(k))
+        return D.cpu().numpy(), I.cpu().numpy()
+
+    def reconstruct_batch(self, ids) -> np.ndarray:
+        """rows stored under the given external ids (api/routes.py:1078)."""
+        lib = _lib.lib()
+        self._finalize()
+        qi = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int64)).to(self.device)
+        out = torch.empty(qi.numel(), self.d, dtype=torch.float32, device=self.device)
+        rc = lib.wise_reconstruct_batch(self._X.data_ptr(), self._n, self.d, _lib.ptr(self._ids), self.id_base,
+                                        qi.data_ptr(), qi.numel(), out.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "wise_reconstruct_batch")
+        return out.cpu().numpy()
