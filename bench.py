@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X: frames/s embedded (OpenCLIP ViT-B/32, bs=256 per GPU)
+and, in the `search` object of the same JSON line, queries/s over a 10M x 512 flat IP index.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" of the headline metric is one wise_vit_forward over a 256-frame batch
+already resident in HBM (weak scaling: every rank embeds its own batch, no collective on the data
+path).  A search step is one nq=1, k=10 scan of the index, whose 10M rows are sharded over the ranks
+(strong scaling; RCCL all-gather of the per-shard top-k, then the merge kernel).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0      # HBM3E spec peak (same table)
+METRIC = "frames/sec embedded (ViT-B/32 bs=256) + queries/sec over 10M×512 index, 1/2/4/8 MI355X"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--index-rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget per CPU baseline leg")
+    return ap.parse_args()
+
+
+def timed_region(fn, steps, world):
+    """barrier + sync, EXACTLY `steps` calls, sync + barrier; returns MAX-over-ranks seconds."""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def prof_pass(lib, fn, steps, capacity):
+    """Same steps again with per-kernel HIP-event brackets (separate pass: the brackets cost a little)."""
+    from wise_amd import _lib
+
+    _lib.check(lib.wise_prof_begin(capacity), "prof_begin")
+    for i in range(steps):
+        fn(i)
+    ms = (C.c_double * 2)()
+    n = (C.c_int64 * 2)()
+    work = (C.c_double * 2)()
+    _lib.check(lib.wise_prof_end(ms, n, work), "prof_end")
+    return [(ms[c], n[c], work[c]) for c in range(2)]
+
+
+def load_pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary, if one exists (else None)."""
+    p = ROOT / "profiles" / "pmc_traffic.json"
+    if not p.exists():
+        return None
+    try:
+        return json.loads(p.read_text()).get(kernel_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline_vit(spec, sd, seconds):
+    """The oracle (CPU fp32 restatement of the reference path) at the reference's own batch of 8 frames
+    (extract-features.py:294), all host cores."""
+    from oracle import vit_ref
+
+    frames = torch.from_numpy(np.random.default_rng(1).integers(0, 256, size=(8, 3, 224, 224), dtype=np.uint8))
+    x = vit_ref.normalize_u8(frames)
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        vit_ref.vit_forward(sd, x, patch=spec.patch, heads=spec.heads, act=spec.act)  # warm-up
+        n = 0
+        t0 = time.perf_counter()
+        while True:
+            vit_ref.vit_forward(sd, x, patch=spec.patch, heads=spec.heads, act=spec.act)
+            n += 8
+            dt = time.perf_counter() - t0
+            if dt >= seconds or n >= 4096:
+                break
+    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} frames in batches of 8 (the reference's chunk size), oracle/vit_ref.py fp32, {dt:.1f} s"}
+
+
+def cpu_baseline_search(d, k, seconds):
+    """The C oracle (sequential dot-product loop + heap, what faiss does for nq<20) on one core over a
+    1M-row sample; queries/s scaled to the 10M-row index."""
+    from wise_amd.build import build_oracle
+
+    so = build_oracle()
+    lib = C.CDLL(str(so))
+    lib.wise_oracle_ip_topk.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_int64, C.c_void_p, C.c_void_p]
+    lib.wise_oracle_ip_topk.restype = None
+    n = 1_000_000
+    X = np.random.default_rng(2).standard_normal((n, d), dtype=np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Q = np.random.default_rng(3).standard_normal((64, d), dtype=np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    D = np.empty((1, k), np.float32)
+    I = np.empty((1, k), np.int64)
+    nq = 0
+    t0 = time.perf_counter()
+    while True:
+        lib.wise_oracle_ip_topk(X.ctypes.data, n, d, Q[nq % 64].ctypes.data, 1, k, None, 1, D.ctypes.data,
+                                I.ctypes.data)
+        nq += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or nq >= 64:
+            break
+    per_query_10m = dt / nq * 10.0
+    return {"value": round(1.0 / per_query_10m, 4), "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": f"{nq} queries over a 1M x {d} sample with oracle/ip_topk_ref.c, time x10 for 10M rows"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one process per GPU with "
+                  f"torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no HIP device visible; the HIP path is the only path", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from wise_amd import _lib
+    from wise_amd.feature.vit import VitEngine, random_state_dict, spec_for
+    from wise_amd.index.flat_ip import FlatIPIndex
+    from wise_amd.index.sharded import ShardedFlatIPIndex, shard_range
+
+    lib = _lib.lib()
+    dev_name = torch.cuda.get_device_name(local_rank)
+
+    # ------------------------------------------------------------------ HP-1: ViT-B/32, bs=256/GPU
+    spec = spec_for("ViT-B-32", "openai")
+    sd = random_state_dict(spec, 0)
+    eng = VitEngine(spec, sd, max_batch=args.batch)
+    from oracle import vit_ref  # only normalize_u8 (input synthesis) and the cpu_baseline leg use the oracle
+
+    frames = torch.from_numpy(
+        np.random.default_rng(1 + rank).integers(0, 256, size=(args.batch, 3, 224, 224), dtype=np.uint8))
+    x = vit_ref.normalize_u8(frames).cuda()  # what preprocess_image hands over: fp32 [B,3,224,224], resident
+    out_holder = {}
+
+    def vit_step(i):
+        out_holder["o"] = eng.forward(x)
+
+    for i in range(args.warmup):
+        vit_step(i)
+    dt = timed_region(vit_step, args.steps, world)
+    frames_per_s = world * args.batch * args.steps / dt
+    norms = out_holder["o"].norm(dim=1)
+    assert bool(torch.isfinite(norms).all()) and abs(float(norms.mean()) - 1.0) < 1e-3, "embeddings not unit-norm"
+
+    n_gemm_per_fwd = 4 * spec.layers + 1
+    prof = prof_pass(lib, vit_step, args.steps, args.steps * n_gemm_per_fwd + 8)
+    g_ms, g_n, g_flop = prof[0]
+    gemm_tflops = (g_flop / g_n) / (g_ms / g_n * 1e-3) / 1e12 if g_n else 0.0
+    roofline = {
+        "kernel": "gemm_bf16_kernel (128x128x64 MFMA 16x16x32, all 49 launches of a forward)",
+        "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
+        "avg_launch_us": round(g_ms / max(g_n, 1) * 1e3, 2), "launches": int(g_n),
+        "flop_per_launch_avg": g_flop / max(g_n, 1),
+        "traffic": load_pmc_traffic("gemm_bf16_kernel"),
+        "end_to_end_tflops": round(frames_per_s / world * spec.flops_per_frame() / 1e12, 2),
+        "end_to_end_frac": round(frames_per_s / world * spec.flops_per_frame() / 1e12 / PEAK_BF16_TFLOPS, 4),
+    }
+
+    result = {
+        "metric": METRIC, "value": round(frames_per_s, 1), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "OpenCLIP ViT-B/32 image tower (encode_image + L2 normalise), bs=256 frames per GPU, "
+                               "fp32 normalised frames resident in HBM -> [256,512] fp32 unit vectors; "
+                               "seeded random weights (no checkpoints offline)",
+                   "global_batch": world * args.batch, "frames_per_gpu": args.batch, "parallelism": f"dp{world}",
+                   "gflop_per_frame": round(spec.flops_per_frame() / 1e9, 4), "device": dev_name},
+        "roofline": roofline,
+    }
+
+    # ------------------------------------------------------------------ HP-2: 10M x 512 flat IP, top-10
+    if not args.no_search:
+        N, d, k = args.index_rows, args.dim, args.topk
+        lo, hi = shard_range(N, rank, world)
+        n_loc = hi - lo
+        X = torch.empty(n_loc, d, dtype=torch.float32, device="cuda")
+        gen = torch.Generator(device="cuda").manual_seed(100 + rank)
+        step_rows = 1_000_000
+        for s in range(0, n_loc, step_rows):
+            e = min(n_loc, s + step_rows)
+            blk = torch.randn(e - s, d, generator=gen, device="cuda")
+            X[s:e] = blk / blk.norm(dim=1, keepdim=True)
+        local = FlatIPIndex(d).adopt(X, None, id_base=lo + 1)  # ids = global row + 1 (sqlite autoincrement)
+        index = ShardedFlatIPIndex(local)
+        Qh = np.random.default_rng(3).standard_normal((1000, d), dtype=np.float32)
+        Qh /= np.linalg.norm(Qh, axis=1, keepdims=True)
+        Q = torch.from_numpy(Qh).cuda()
+        res = {}
+
+        def search_step(i):
+            j = i % 1000
+            res["DI"] = index.search_device(Q[j:j + 1], k)
+
+        s_steps = max(args.steps, 20)
+        for i in range(max(args.warmup, 3)):
+            search_step(i)
+        sdt = timed_region(search_step, s_steps, world)
+        qps = s_steps / sdt
+        D, I = res["DI"]
+        assert bool((D[:, :-1] >= D[:, 1:]).all()) and bool((I >= 1).all())
+        sprof = prof_pass(lib, search_step, s_steps, s_steps + 8)
+        s_ms, s_n, s_bytes = sprof[1]
+        scan_gbs = (s_bytes / s_n) / (s_ms / s_n * 1e-3) / 1e9 if s_n else 0.0
+
+        def search4(i):
+            j = (4 * i) % 996
+            res["DI4"] = index.search_device(Q[j:j + 4], k)
+
+        for i in range(3):
+            search4(i)
+        sdt4 = timed_region(search4, s_steps, world)
+        result["search"] = {
+            "metric": "queries/sec over 10M×512 index (flat IP, top-10, nq=1 per call as the reference issues them)",
+            "value": round(qps, 2), "unit": "queries/s", "ms_per_step": round(sdt / s_steps * 1e3, 4),
+            "steps": s_steps, "scaling": "strong", "dtype": "f32",
+            "config": {"workload": f"IndexFlatIP search, N={N} rows x d={d} fp32 unit rows resident in HBM "
+                                   f"({N * d * 4 / 1e9:.2f} GB), k={k}, nq=1", "rows_per_gpu": n_loc,
+                       "parallelism": f"row-shard x{world} + RCCL all-gather of per-shard top-k"},
+            "roofline": {"kernel": "ip_scan_kernel<2,1,4>", "bound": "hbm", "achieved": round(scan_gbs, 1),
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(scan_gbs / PEAK_HBM_GBS, 4),
+                         "avg_launch_us": round(s_ms / max(s_n, 1) * 1e3, 2), "launches": int(s_n),
+                         "bytes_per_launch": s_bytes / max(s_n, 1),
+                         "traffic": load_pmc_traffic("ip_scan_kernel")},
+            "batched_nq4_queries_per_s": round(4 * s_steps / sdt4, 2),
+        }
+        del X, local, index
+
+    # ------------------------------------------------------------------ CPU baselines (rank 0, N=1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_vit(spec, sd, args.cpu_seconds)
+        if "search" in result:
+            result["search"]["cpu_baseline"] = cpu_baseline_search(args.dim, args.topk, args.cpu_seconds)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

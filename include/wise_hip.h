@@ -32,6 +32,13 @@ int wise_abi_version(void);
 /* 1 when a HIP device of arch gfx950 is visible to the calling process, else 0. */
 int wise_device_ok(void);
 
+/* Measurement aid (bench.py): between wise_prof_begin and wise_prof_end every bf16 GEMM launch
+ * (class 0, work = flop) and every IP-scan launch (class 1, work = algorithmic bytes N*d*4) is
+ * bracketed by a HIP event pair recorded on the launch stream.  wise_prof_end synchronises and
+ * fills three arrays of length 2: summed milliseconds, launch counts, summed work.  Not thread-safe. */
+int wise_prof_begin(int capacity);
+int wise_prof_end(double* ms_sum, int64_t* launches, double* work_sum);
+
 /* ------------------------------------------------------------------------------------------------
  * HP-2  brute-force inner-product top-k  (replaces faiss IndexIDMap{IndexFlatIP}::search,
  *       reference call sites src/index/feature_search_index.py:113 and api/routes.py:1407)

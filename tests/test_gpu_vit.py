@@ -65,8 +65,9 @@ def test_gemm_identity_asymmetric():
     A = torch.eye(M, K)
     W = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) - 125  # exact in bf16 (|v| <= 125)
     out = torch.empty(M, N, dtype=torch.float32, device="cuda")
-    _lib.check(lib.wise_gemm_bf16(A.to(torch.bfloat16).cuda().data_ptr(), W.to(torch.bfloat16).cuda().data_ptr(), 0,
-                                  M, N, K, 4, out.data_ptr(), _lib.stream_ptr()), "gemm")
+    Ad, Wd = A.to(torch.bfloat16).cuda(), W.to(torch.bfloat16).cuda()  # keep alive across the launch
+    _lib.check(lib.wise_gemm_bf16(Ad.data_ptr(), Wd.data_ptr(), 0, M, N, K, 4, out.data_ptr(), _lib.stream_ptr()),
+               "gemm")
     assert torch.equal(out.cpu(), W.t().contiguous()[:M, :N])
 
 
@@ -78,10 +79,10 @@ def test_layernorm(rows, W):
     w = 1 + 0.1 * torch.randn(W, generator=g)
     b = 0.1 * torch.randn(W, generator=g)
     y = torch.empty(rows, W, dtype=torch.bfloat16, device="cuda")
-    _lib.check(lib.wise_layernorm_f32_bf16(x.cuda().data_ptr(), w.cuda().data_ptr(), b.cuda().data_ptr(), rows, W,
-                                           1e-5, y.data_ptr(), _lib.stream_ptr()), "ln")
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()  # keep alive across the launch
+    _lib.check(lib.wise_layernorm_f32_bf16(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), rows, W, 1e-5, y.data_ptr(),
+                                           _lib.stream_ptr()), "ln")
     ref = vit_ref.layer_norm(x, w, b)
-    assert torch.equal(y.cpu(), ref.to(torch.bfloat16)) or (y.float().cpu() - ref).abs().max() <= 2 ** -7 * ref.abs().max()
     # at most 1 bf16 ulp from the fp32 oracle rounded to bf16
     assert (y.float().cpu() - bf16_round(ref)).abs().max() <= 2 ** -7 * ref.abs().max()
 
@@ -95,8 +96,8 @@ def test_attention(B, T, H):
     qkv[:, : 2 * W] *= 2.0  # peaky softmax
     qkv = bf16_round(qkv)
     o = torch.full((B * T, W), float("nan"), dtype=torch.bfloat16, device="cuda")
-    _lib.check(lib.wise_attention_bf16(qkv.to(torch.bfloat16).cuda().data_ptr(), B, T, H, o.data_ptr(),
-                                       _lib.stream_ptr()), "attn")
+    qd = qkv.to(torch.bfloat16).cuda()  # keep alive across the launch
+    _lib.check(lib.wise_attention_bf16(qd.data_ptr(), B, T, H, o.data_ptr(), _lib.stream_ptr()), "attn")
     ref = vit_ref.attention_ref(qkv, B, T, H)
     got = o.float().cpu()
     assert torch.isfinite(got).all()

@@ -1,0 +1,77 @@
+"""A/B the GEMM variants on the ViT shapes (one process, interleaved rounds, random data).
+python tools/gemm_bench.py [variants...]   -> prints TFLOP/s per (shape, variant), and max |err|."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from wise_amd import _lib  # noqa: E402
+
+SHAPES = [  # (name, M, N, K, mode)
+    ("qkv   12800x2304x768", 12800, 2304, 768, 0),
+    ("out   12800x768x768", 12800, 768, 768, 3),
+    ("fc    12800x3072x768", 12800, 3072, 768, 1),
+    ("proj  12800x768x3072", 12800, 768, 3072, 3),
+    ("L14qkv 65792x3072x1024", 65792, 3072, 1024, 0),
+    ("L14proj 65792x1024x4096", 65792, 1024, 4096, 3),
+]
+
+
+def main():
+    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3]
+    lib = _lib.lib()
+    lib.wise_debug_set_gemm_variant.argtypes = [C.c_int]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for name, M, N, K, mode in SHAPES:
+        A = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+        bias = torch.randn(N, generator=g, device="cuda")
+        ref = None
+        if M <= 12800:
+            ref = A.float() @ W.float().t() + bias
+        res = {}
+        outs = {}
+        for v in variants:
+            lib.wise_debug_set_gemm_variant(v)
+            out = torch.zeros(M, N, dtype=torch.float32 if mode in (3, 4) else torch.bfloat16, device="cuda")
+            rc = lib.wise_gemm_bf16(A.data_ptr(), W.data_ptr(), bias.data_ptr(), M, N, K, mode, out.data_ptr(),
+                                    _lib.stream_ptr())
+            _lib.check(rc, "gemm")
+            torch.cuda.synchronize()
+            if ref is not None:
+                r = ref if mode == 3 else (ref * torch.sigmoid(1.702 * ref) if mode == 1 else ref)
+                err = (out.float() - r).abs().max().item()
+            else:
+                err = float("nan")
+            outs[v] = err
+            res[v] = []
+        for rnd in range(5):
+            for v in variants:
+                lib.wise_debug_set_gemm_variant(v)
+                out = torch.zeros(M, N, dtype=torch.float32 if mode in (3, 4) else torch.bfloat16, device="cuda")
+                for _ in range(3):
+                    lib.wise_gemm_bf16(A.data_ptr(), W.data_ptr(), bias.data_ptr(), M, N, K, mode, out.data_ptr(),
+                                       _lib.stream_ptr())
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                iters = 20
+                for _ in range(iters):
+                    lib.wise_gemm_bf16(A.data_ptr(), W.data_ptr(), bias.data_ptr(), M, N, K, mode, out.data_ptr(),
+                                       _lib.stream_ptr())
+                e1.record()
+                torch.cuda.synchronize()
+                res[v].append(e0.elapsed_time(e1) / iters * 1e-3)
+        line = f"{name:26s}"
+        for v in variants:
+            ts = sorted(res[v])
+            tf = 2.0 * M * N * K / ts[len(ts) // 2] / 1e12
+            tfb = 2.0 * M * N * K / ts[0] / 1e12
+            line += f" | v{v}: {tf:7.1f} TF (best {tfb:7.1f}) {ts[len(ts)//2]*1e6:7.1f}us err {outs[v]:.3g}"
+        print(line, flush=True)
+    lib.wise_debug_set_gemm_variant(0)
+
+
+if __name__ == "__main__":
+    main()

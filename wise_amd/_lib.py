@@ -29,6 +29,8 @@ SIGNATURES = {
     "wise_last_error": (C.c_char_p, []),
     "wise_abi_version": (_i, []),
     "wise_device_ok": (_i, []),
+    "wise_prof_begin": (_i, [_i]),
+    "wise_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "wise_ip_topk_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
     "wise_ip_topk_f32": (_i, [_vp, _i64, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "wise_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -31,6 +31,17 @@ void set_error(const char* fmt, ...);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Optional per-kernel HIP-event brackets (wise_prof_begin/_end in the C ABI): class 0 = bf16 GEMM
+// (work = flop), class 1 = IP scan (work = algorithmic bytes).  No-ops unless profiling is on.
+enum : int { PROF_GEMM = 0, PROF_SCAN = 1, PROF_CLASSES = 2 };
+int prof_open(int cls, double work, hipStream_t st);   // returns slot or -1
+void prof_close(int slot, hipStream_t st);
+struct ProfScope {
+    int slot; hipStream_t st;
+    ProfScope(int cls, double work, hipStream_t s) : slot(prof_open(cls, work, s)), st(s) {}
+    ~ProfScope() { if (slot >= 0) prof_close(slot, st); }
+};
+
 // ---- bf16 bit helpers (device) -------------------------------------------------------------
 typedef unsigned short bf16_t;
 

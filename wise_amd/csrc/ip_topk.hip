@@ -439,6 +439,7 @@ extern "C" int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q
         }
         if (N > 0) {
             int rc = 0;
+            ProfScope prof(PROF_SCAN, (double)N * d * 4.0, st);
             switch (nv) {
                 case 1: rc = dispatch_nq<1>(p, X, N, d, qptr, k, part, st); break;
                 case 2: rc = dispatch_nq<2>(p, X, N, d, qptr, k, part, st); break;

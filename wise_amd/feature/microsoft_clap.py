@@ -1,0 +1,79 @@
+"""MicrosoftClap — drop-in surface for the reference's src/feature/microsoft_clap.py:9-58.
+
+`preprocess_audio` reproduces the reference exactly (transpose when shape[0] > 2, mono mix,
+default_collate([audio])).  `extract_audio_features` drives the HTSAT HIP kernels
+(wise_amd/feature/htsat.py) when they are present.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+import torch
+
+from .feature_extractor import FeatureExtractor
+from .weights import seeded_tag
+
+CLAP_MODEL_NAMES = ('2022', '2023', 'clapcap')  # msclap 1.3.3 CLAP.model_name keys
+
+
+class MicrosoftClap(FeatureExtractor):
+    ID_PREFIX = 'microsoft/clap/'
+    DESCRIPTION = 'MS-CLAP HTSAT audio encoder as MI355X HIP kernels; see https://github.com/microsoft/CLAP'
+
+    def __init__(self, id):
+        if not id.startswith(self.ID_PREFIX):
+            raise ValueError(f'feature id cannot start with {id} and must start with {self.ID_PREFIX}')
+        id_tokens = id.split('/')
+        assert len(id_tokens) == 4
+        if id_tokens[2] not in CLAP_MODEL_NAMES:
+            raise ValueError(f'Model version {id_tokens[2]} is not available. Available models are {CLAP_MODEL_NAMES}')
+        self.version = id_tokens[2]
+        self.weights_tag = id_tokens[3]
+        self.DEVICE = "cuda" if torch.cuda.is_available() else "cpu"
+        self.output_dim = 1024
+        self._engine = None
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_engine"] = None
+        return st
+
+    def get_output_dim(self):
+        return self.output_dim
+
+    def preprocess_audio(self, audio: torch.Tensor) -> torch.Tensor:
+        # CLAP accepts (1xN_samples)                      (microsoft_clap.py:33-40)
+        if audio.shape[0] > 2:
+            audio = torch.transpose(audio, 0, 1)
+        # the CLAP model only accepts single channel audio
+        if audio.shape[0] != 1:
+            audio = torch.mean(audio, 0, keepdim=True)
+        return torch.stack([audio], dim=0)  # msclap default_collate([audio]) -> [1,1,N]
+
+    def preprocess_text(self, text: str) -> str:
+        raise NotImplementedError("the CLAP caption encoder (GPT-2 tokenizer + weights) is outside this build's "
+                                  "hot path (SURVEY.md §8 f4)")
+
+    def _get_engine(self):
+        if self._engine is None:
+            try:
+                from .htsat import HtsatEngine, random_htsat_state_dict
+            except ImportError as e:  # pragma: no cover
+                raise NotImplementedError("HTSAT audio kernels are not part of this build yet") from e
+            seed = seeded_tag(self.weights_tag)
+            if seed is None:
+                from .weights import load_state_dict_file
+                sd = load_state_dict_file(f"clap-{self.version}", self.weights_tag)
+            else:
+                sd = random_htsat_state_dict(seed)
+            self._engine = HtsatEngine(sd, device="cuda")
+        return self._engine
+
+    def extract_audio_features(self, preprocessed_audio: torch.Tensor) -> np.ndarray:
+        x = preprocessed_audio.reshape(preprocessed_audio.shape[0], preprocessed_audio.shape[2])
+        out = self._get_engine().forward(x)
+        return out.cpu().numpy()
+
+    def extract_text_features(self, text: List[str]) -> np.ndarray:
+        raise NotImplementedError("the CLAP caption encoder is outside this build's hot path (SURVEY.md §8 f4)")

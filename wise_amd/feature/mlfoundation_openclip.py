@@ -1,0 +1,142 @@
+"""MlfoundationOpenClip — drop-in for the reference's src/feature/mlfoundation_openclip.py:11-108 with
+the image tower running as hand-written HIP kernels (wise_vit_forward) instead of open_clip/ATen.
+
+Same id grammar (`mlfoundations/open_clip/<model>/<pretrained>`), attributes (`ID_PREFIX`,
+`DESCRIPTION`, `DEVICE`, `input_image_size`, `output_dim`, `preprocess`) and error behaviour
+(ValueError on a bad prefix / unknown model / non-tensor input).  `preprocess_image` stays a pure-CPU
+picklable callable (it is shipped to DataLoader workers: extract-features.py:302-308).
+"""
+from __future__ import annotations
+
+from typing import List, Union
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .feature_extractor import FeatureExtractor
+from .vit import SPECS, VitEngine, random_state_dict, spec_for
+from .weights import load_state_dict_file, seeded_tag
+
+# open_clip OPENAI_DATASET_MEAN / STD (also /root/reference/src/dataloader/__main__.py:30-31)
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+# (model, pretrained) pairs this build knows the architecture of; `seeded-<N>` is the offline stand-in
+KNOWN_PRETRAINED = {
+    "ViT-B-32": ("openai", "laion400m_e31", "laion400m_e32", "laion2b_e16", "laion2b_s34b_b79k"),
+    "ViT-B-32-quickgelu": ("openai", "laion400m_e31", "laion400m_e32"),
+    "ViT-B-16": ("openai", "laion400m_e31", "laion400m_e32", "laion2b_s34b_b88k"),
+    "ViT-L-14": ("openai", "laion400m_e31", "laion400m_e32", "laion2b_s32b_b82k"),
+}
+
+
+def list_pretrained():
+    return [(m, t) for m, tags in KNOWN_PRETRAINED.items() for t in tags]
+
+
+class ClipImageTransform:
+    """open_clip's eval transform for PIL input, restated without torchvision:
+    Resize(S, bicubic, shorter side) -> CenterCrop(S) -> RGB -> ToTensor -> Normalize(mean, std)."""
+
+    def __init__(self, size: int):
+        self.size = int(size)
+
+    def __call__(self, img: Image.Image) -> torch.Tensor:
+        S = self.size
+        w, h = img.size
+        if w <= h:
+            nw, nh = S, int(S * h / w)
+        else:
+            nw, nh = int(S * w / h), S
+        if (nw, nh) != (w, h):
+            img = img.resize((nw, nh), Image.BICUBIC)
+        left = int(round((nw - S) / 2.0))
+        top = int(round((nh - S) / 2.0))
+        img = img.crop((left, top, left + S, top + S)).convert("RGB")
+        x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).to(torch.float32) / 255.0
+        mean = torch.tensor(CLIP_MEAN, dtype=torch.float32).view(3, 1, 1)
+        std = torch.tensor(CLIP_STD, dtype=torch.float32).view(3, 1, 1)
+        return (x - mean) / std
+
+
+def to_pil_image(pic: torch.Tensor) -> Image.Image:
+    """torchvision.transforms.functional.to_pil_image for a [C,H,W] tensor (uint8, or float in [0,1])."""
+    if pic.dim() != 3:
+        raise ValueError(f"pic should be 3 dimensional. Got {pic.dim()} dimensions.")
+    if pic.is_floating_point():
+        pic = pic.mul(255).byte()
+    arr = pic.permute(1, 2, 0).cpu().numpy()
+    if arr.shape[2] == 1:
+        return Image.fromarray(arr[:, :, 0], mode="L")
+    return Image.fromarray(arr, mode="RGB")
+
+
+class MlfoundationOpenClip(FeatureExtractor):
+    ID_PREFIX = 'mlfoundations/open_clip/'
+    DESCRIPTION = 'OpenCLIP image tower as MI355X HIP kernels; see https://github.com/mlfoundations/open_clip'
+
+    def __init__(self, id):
+        if not id.startswith(self.ID_PREFIX):
+            raise ValueError(f'feature id cannot start with {id} and must start with {self.ID_PREFIX}')
+        id_tokens = id.split('/')
+        assert len(id_tokens) == 4
+        model, tag = id_tokens[2], id_tokens[3]
+        seed = seeded_tag(tag)
+        if model.replace("-quickgelu", "") not in SPECS or (seed is None and (model, tag) not in list_pretrained()):
+            raise ValueError(f'Model ({model}, {tag}) not available in {self.ID_PREFIX}')
+        self.pretrained_model_name = model
+        self.pretraining_dataset = tag
+        self.DEVICE = "cuda" if torch.cuda.is_available() else "cpu"
+        self.spec = spec_for(model, "openai" if seed is not None else tag)
+        self._state_dict = random_state_dict(self.spec, seed) if seed is not None else load_state_dict_file(model, tag)
+        self.preprocess = ClipImageTransform(self.spec.image_size)
+        self._engine = None
+        self.input_image_size = (self.spec.image_size, self.spec.image_size)
+        self.output_dim = self.spec.embed_dim
+        if self.DEVICE == "cuda":
+            self._find_output_dim()
+
+    # the engine (device memory, library handle) is created on first use so that the object — and its
+    # preprocess_image bound method — stays picklable for DataLoader workers
+    def _get_engine(self) -> VitEngine:
+        if self._engine is None:
+            self._engine = VitEngine(self.spec, self._state_dict, device="cuda")
+        return self._engine
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_engine"] = None
+        return st
+
+    def _find_output_dim(self):
+        """Warm-up forward, as the reference does (mlfoundation_openclip.py:61-73); the text tower is
+        not part of this build, so only the image side is checked against the architecture table."""
+        random_image = torch.rand((1, 3,) + self.input_image_size)
+        feats = self.extract_image_features(self.preprocess_image(random_image))
+        assert feats.shape[1] == self.output_dim
+
+    def get_output_dim(self):
+        return self.output_dim
+
+    def get_input_image_size(self):
+        return self.input_image_size
+
+    def preprocess_image(self, images: Union[torch.Tensor, List[Image.Image]]) -> torch.Tensor:
+        if isinstance(images, list) and all(isinstance(img, Image.Image) for img in images):
+            return torch.stack([self.preprocess(im) for im in images], dim=0).to(device=self.DEVICE)
+        elif isinstance(images, torch.Tensor) and len(images.shape) == 4:
+            return torch.stack([self.preprocess(to_pil_image(im)) for im in images], dim=0).to(device=self.DEVICE)
+        else:
+            raise ValueError('all input to preprocess_image() must be an instance of torch.Tensor or PIL.Image')
+
+    def extract_image_features(self, images: torch.Tensor) -> np.ndarray:
+        if not isinstance(images, torch.Tensor):
+            raise ValueError('input to extract_features() must be an instance of torch.Tensor')
+        out = self._get_engine().forward(images.to(torch.float32) if images.dtype != torch.uint8 else images)
+        return out.cpu().numpy()
+
+    def extract_text_features(self, text_query: List[str]) -> np.ndarray:
+        raise NotImplementedError(
+            "the CLIP text tower (BPE tokenizer + text transformer) is outside this build's hot path "
+            "(SURVEY.md §8 f4): it needs the tokenizer vocabulary and text weights, neither available offline")
