@@ -1,0 +1,257 @@
+"""CPU tests (-m "not gpu"): the plugin API mirrors the reference's surface and error behaviour, the
+feature stores round-trip (the reference's own store tests, src/feature/store/test_feature_store.py),
+the .faiss file IO round-trips, and the C-ABI library loads and exports every declared symbol."""
+import pickle
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+# ---------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    from wise_amd import _lib
+
+    lib = _lib.load()  # raises if the .so is missing or a symbol is absent
+    header = (ROOT / "include" / "wise_hip.h").read_text()
+    declared = set(re.findall(r"\b(wise_[a-z0-9_]+)\s*\(", header))
+    declared -= {"wise_vit_config"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in wise_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype"
+    assert lib.wise_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    from wise_amd import _lib
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        _lib.lib()
+    from wise_amd.index.flat_ip import FlatIPIndex
+
+    with pytest.raises(RuntimeError):  # rows live in HBM: without a device even building the index fails loudly
+        idx = FlatIPIndex(8)
+        idx.add_with_ids(np.zeros((2, 8), np.float32), np.array([1, 2]))
+        idx.search(np.zeros((1, 8), np.float32), 1)
+
+
+def test_product_path_does_not_import_oracle():
+    for py in (ROOT / "wise_amd").rglob("*.py"):
+        txt = py.read_text()
+        assert "import oracle" not in txt and "from oracle" not in txt, f"{py} imports the oracle"
+
+
+def test_argument_validation_without_gpu():
+    """host-side checks run before any launch: bad shapes come back as WISE_E_INVALID with a message."""
+    from wise_amd import _lib
+
+    lib = _lib.load()
+    assert lib.wise_ip_topk_workspace_bytes(1000, 510, 1, 10) > 0
+    assert lib.wise_ip_topk_workspace_bytes(1000, 512, 1, 5000) == 0
+    rc = lib.wise_ip_topk_f32(0, 10, 511, 0, 1, 10, 0, 0, 0, 0, 0, 0, 0)
+    assert rc == -1 and b"multiple of 4" in lib.wise_last_error()
+    cfg = _lib.VitConfig(224, 32, 768, 12, 12, 3072, 512, 0)
+    import ctypes as C
+
+    nb, nf = C.c_int64(), C.c_int64()
+    assert lib.wise_vit_layout(C.byref(cfg), C.byref(nb), C.byref(nf)) == 0
+    from wise_amd.feature.vit import pack_weights, random_state_dict, spec_for
+
+    spec = spec_for("ViT-B-32")
+    assert nb.value == 768 * 3072 + 12 * (3 * 768 * 768 + 768 * 768 + 2 * 3072 * 768) + 512 * 768
+    bad = _lib.VitConfig(224, 32, 700, 12, 12, 3072, 512, 0)
+    assert lib.wise_vit_layout(C.byref(bad), C.byref(nb), C.byref(nf)) == -1
+
+
+def test_weight_packing_layout():
+    from wise_amd.feature.vit import VitSpec, pack_weights, random_state_dict
+
+    spec = VitSpec("t", 28, 14, 128, 2, 2, 256, 32)
+    sd = random_state_dict(spec, 3)
+    wb, pf = pack_weights(spec, sd)
+    assert spec.kdim == 588 and spec.kpad == 640
+    conv = wb[: 128 * 640].float().reshape(128, 640)
+    assert torch.equal(conv[:, :588], sd["visual.conv1.weight"].reshape(128, 588).to(torch.bfloat16).float())
+    assert torch.count_nonzero(conv[:, 588:]) == 0
+    # proj is stored transposed at the very end
+    assert torch.equal(wb[-32 * 128:].float().reshape(32, 128), sd["visual.proj"].t().to(torch.bfloat16).float())
+    assert torch.equal(pf[:128], sd["visual.class_embedding"])
+    assert torch.equal(pf[-128:], sd["visual.ln_post.bias"])
+    # same seed, same weights (the GPU box regenerates them from the seed)
+    assert all(torch.equal(a, b) for a, b in zip(random_state_dict(spec, 3).values(), sd.values()))
+
+
+# ---------------------------------------------------------------- FeatureExtractor surface
+def test_feature_extractor_base_and_factory_errors():
+    from wise_amd.feature.feature_extractor import FeatureExtractor
+    from wise_amd.feature.feature_extractor_factory import FeatureExtractorFactory
+
+    with pytest.raises(NotImplementedError):
+        FeatureExtractor()
+    with pytest.raises(ValueError, match="must be formatted"):
+        FeatureExtractorFactory("mlfoundations/open_clip/ViT-B-32")
+    with pytest.raises(ValueError, match="Unknown feature extractor id"):
+        FeatureExtractorFactory("a/b/c/d")
+    with pytest.raises(ValueError, match="not available"):
+        FeatureExtractorFactory("mlfoundations/open_clip/ViT-Z-99/openai")
+    with pytest.raises(ValueError, match="not available"):
+        FeatureExtractorFactory("microsoft/clap/1999/Not-Applicable")
+
+
+def test_openclip_preprocess_matches_reference_transform():
+    """preprocess_image: list of PIL or 4-D tensor -> [n,3,224,224] fp32, OpenAI mean/std; else ValueError
+    (mlfoundation_openclip.py:81-90).  Shapes asserted by the reference's own test
+    (src/feature/test_feature_extractor.py:14-16,33)."""
+    from wise_amd.feature.feature_extractor_factory import FeatureExtractorFactory
+    from wise_amd.feature.mlfoundation_openclip import CLIP_MEAN, CLIP_STD
+
+    fx = FeatureExtractorFactory("mlfoundations/open_clip/ViT-L-14/seeded-0")
+    assert fx.get_input_image_size() == (224, 224) and fx.get_output_dim() == 768
+    imgs = [Image.new("RGB", (224, 224)) for _ in range(8)]
+    x = fx.preprocess_image(imgs)
+    assert x.shape == (8, 3, 224, 224) and x.dtype == torch.float32
+    black = torch.tensor([-m / s for m, s in zip(CLIP_MEAN, CLIP_STD)])
+    assert torch.allclose(x[0, :, 0, 0], black, atol=1e-6)
+    # tensor input (decoder output: uint8 [n,3,H,W]), shorter side resized to 224 then centre crop
+    frames = torch.randint(0, 256, (2, 3, 240, 320), dtype=torch.uint8)
+    y = fx.preprocess_image(frames)
+    assert y.shape == (2, 3, 224, 224)
+    ref = Image.fromarray(frames[0].permute(1, 2, 0).numpy()).resize((298, 224), Image.BICUBIC).crop((37, 0, 261, 224))
+    ref = (torch.from_numpy(np.asarray(ref)).permute(2, 0, 1).float() / 255 -
+           torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
+    assert torch.allclose(y[0], ref, atol=1e-6)
+    with pytest.raises(ValueError):
+        fx.preprocess_image("not an image")
+    with pytest.raises(ValueError):
+        fx.extract_image_features([1, 2, 3])
+    # picklable for DataLoader workers (extract-features.py:302-308)
+    fx2 = pickle.loads(pickle.dumps(fx))
+    assert torch.equal(fx2.preprocess_image(imgs[:1]), x[:1])
+
+
+def test_clap_preprocess_audio_quirks():
+    """microsoft_clap.py:33-40: transpose when shape[0] > 2, mono mix, collate -> [1,1,N]."""
+    from wise_amd.feature.feature_extractor_factory import FeatureExtractorFactory
+
+    fx = FeatureExtractorFactory("microsoft/clap/2023/seeded-0")
+    stereo = torch.randn(2, 192000)
+    out = fx.preprocess_audio(stereo)
+    assert out.shape == (1, 1, 192000) and torch.allclose(out[0, 0], stereo.mean(0))
+    assert fx.preprocess_audio(torch.randn(192000, 2)).shape == (1, 1, 192000)  # [N,C] is transposed
+    assert fx.preprocess_audio(torch.randn(1, 1000)).shape == (1, 1, 1000)
+    assert fx.get_output_dim() == 1024
+
+
+# ---------------------------------------------------------------- FeatureStore (reference: test_feature_store.py)
+def test_numpy_save_store_roundtrip(tmp_path):
+    from wise_amd.feature.store.feature_store_factory import FeatureStoreFactory, FeatureStoreType
+
+    st = FeatureStoreFactory.create_store(FeatureStoreType.NUMPY, "video", tmp_path)
+    st.enable_write(3, 10 ** 6)
+    feats = {i: np.random.default_rng(i).standard_normal((1, 4)).astype(np.float32) for i in range(7)}
+    for i, f in feats.items():
+        st.add(i, f)
+    st.close()
+    assert sorted(p.name for p in tmp_path.glob("*.npz")) == ["video-000000.npz", "video-000001.npz",
+                                                               "video-000002.npz"]
+    rd = FeatureStoreFactory.load_store("video", tmp_path)
+    rd.enable_read()
+    assert rd.feature_count == 7 and rd.feature_dim == 4
+    got = {int(i): f for i, f in rd}
+    assert all(np.array_equal(got[i], feats[i]) and got[i].shape == (1, 4) for i in feats)
+    ids, vecs = zip(*rd.iter_batch(4))
+    assert [len(b) for b in ids] == [3, 3, 1] and np.array_equal(np.concatenate(vecs)[0], feats[0][0])
+    with pytest.raises(ValueError):
+        st2 = FeatureStoreFactory.create_store(FeatureStoreType.NUMPY, "x", tmp_path)
+        st2.enable_write(3, 10)
+        st2.add(0, np.zeros((2, 4), np.float32))
+
+
+def test_webdataset_store_format_and_order(tmp_path):
+    """tar shards with '%010d.features.pyd' members holding pickled [1,D] arrays; read back in key order."""
+    import tarfile
+
+    from wise_amd.feature.store.feature_store_factory import FeatureStoreFactory, FeatureStoreType
+
+    st = FeatureStoreFactory.create_store(FeatureStoreType.WEBDATASET, "audio", str(tmp_path))
+    st.enable_write(2, 20 * 1024 * 1024)
+    data = {i: np.full((1, 5), i, np.float32) for i in (0, 3, 6, 7, 8)}
+    for i, f in data.items():
+        st.add(i, f)
+    st.close()
+    tars = sorted(tmp_path.glob("audio-*.tar"))
+    assert [t.name for t in tars] == ["audio-000000.tar", "audio-000001.tar", "audio-000002.tar"]
+    with tarfile.open(tars[0]) as t:
+        names = t.getnames()
+        assert names == ["0000000000.features.pyd", "0000000003.features.pyd"]
+        arr = pickle.loads(t.extractfile(names[1]).read())
+        assert arr.shape == (1, 5) and arr.dtype == np.float32 and arr[0, 0] == 3
+    rd = FeatureStoreFactory.load_store("audio", tmp_path)
+    rd.enable_read(shard_shuffle=False)
+    assert rd.feature_count == 5 and rd.feature_dim == 5
+    assert [i for i, _ in rd] == [0, 3, 6, 7, 8]
+    batches = list(rd.iter_batch(512))
+    assert batches[0][0] == [0, 3, 6, 7, 8] and batches[0][1].shape == (5, 5)
+    with pytest.raises(ValueError, match="failed to infer"):
+        FeatureStoreFactory.load_store("video", tmp_path)
+
+
+# ---------------------------------------------------------------- SearchIndex surface + .faiss IO
+def test_search_index_factory_and_file_io(tmp_path):
+    from wise_amd.feature.store.feature_store_factory import FeatureStoreFactory, FeatureStoreType
+    from wise_amd.index import faiss_io
+    from wise_amd.index.search_index import SearchIndex
+    from wise_amd.index.search_index_factory import SearchIndexFactory
+
+    with pytest.raises(NotImplementedError):
+        SearchIndex("video", "x", {})
+    with pytest.raises(ValueError, match="Unknown media_type"):
+        SearchIndexFactory("text", "id", {})
+    with pytest.raises(AssertionError, match="features_dir missing"):
+        SearchIndexFactory("video", "id", {"index_dir": tmp_path})
+    fdir, idir = tmp_path / "features", tmp_path / "index"
+    fdir.mkdir()
+    st = FeatureStoreFactory.create_store(FeatureStoreType.WEBDATASET, "video", str(fdir))
+    st.enable_write(2048, 20 * 1024 * 1024)
+    X = np.random.default_rng(0).standard_normal((1000, 16)).astype(np.float32)
+    for i in range(1000):
+        st.add(i + 1, X[i:i + 1])
+    st.close()
+    si = SearchIndexFactory("video", "mlfoundations/open_clip/ViT-B-32/seeded-0", {"features_dir": fdir,
+                                                                                  "index_dir": idir})
+    assert si.get_index_filename("IndexFlatIP") == idir / "video-IndexFlatIP.faiss"
+    assert not si.is_index_loaded()
+    si.create_index("IndexFlatIP")
+    fn = si.get_index_filename("IndexFlatIP")
+    assert fn.stat().st_size == 4 + 33 + 4 + 33 + 8 + 1000 * 16 * 4 + 8 + 1000 * 8
+    mtime = fn.stat().st_mtime_ns
+    si.create_index("IndexFlatIP")  # skip-if-exists
+    assert fn.stat().st_mtime_ns == mtime
+    Xr, ids = faiss_io.read_idmap_flat_ip(fn)
+    assert np.array_equal(np.asarray(Xr), X) and np.array_equal(ids, np.arange(1000) + 1)
+    with pytest.raises(NotImplementedError):
+        si.create_index("IndexIVFFlat", overwrite=True)
+    with pytest.raises(RuntimeError):
+        faiss_io.read_idmap_flat_ip(idir / "missing.faiss")
+    with pytest.raises(ValueError):
+        si.search("video", "cat", query_type="image")
+
+
+def test_shard_range_partition():
+    from wise_amd.index.sharded import shard_range
+
+    for n, w in [(10_000_000, 8), (7, 8), (0, 4), (1001, 3)]:
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 3, 3)

@@ -1,0 +1,100 @@
+"""FeatureSearchIndex — drop-in for the reference's src/index/feature_search_index.py:13-114 with the
+flat inner-product index resident in HBM and searched by the HIP scan+top-k kernels.
+
+Same constructor contract (asserts on 'features_dir'/'index_dir'), prompts, file naming
+(`{index_dir}/{media_type}-{index_type}.faiss`), skip-if-exists create, `load_index` that also
+builds the FeatureExtractor, and the prompt quirks of `search`.  Only
+`IndexFlatIP` is built; `IndexIVFFlat` (approximate) raises — the flat scan is the hot path here.
+"""
+from pathlib import Path
+
+import numpy as np
+
+from ..feature.feature_extractor_factory import FeatureExtractorFactory
+from ..feature.store.feature_store_factory import FeatureStoreFactory
+from . import faiss_io
+from .flat_ip import FlatIPIndex
+from .search_index import SearchIndex
+
+
+class FeatureSearchIndex(SearchIndex):
+    def __init__(self, media_type, asset_id, asset):
+        self.media_type = media_type
+        self.feature_extractor_id = asset_id
+
+        assert 'features_dir' in asset, "features_dir missing in assets"
+        self.features_dir = Path(asset['features_dir'])
+
+        assert 'index_dir' in asset, "index_dir missing in assets"
+        self.index_dir = Path(asset['index_dir'])
+
+        self.prompt = {
+            'image': 'This is a photo of a ',
+            'video': 'This is a photo of a ',
+            'audio': 'this is the sound of '
+        }
+
+    def get_index_filename(self, index_type):
+        return self.index_dir / (self.media_type + '-' + index_type + '.faiss')
+
+    def create_index(self, index_type, overwrite=False):
+        self.index_dir.mkdir(parents=True, exist_ok=True)
+        index_fn = self.get_index_filename(index_type)
+        if index_fn.exists() and overwrite is False:
+            print(f'{index_type} for {self.media_type} already exists')
+            return
+        if index_type != 'IndexFlatIP':
+            raise NotImplementedError(f'{index_type}: only IndexFlatIP is built by the MI355X path '
+                                      f'(exhaustive search is HBM-bound-fast; SURVEY.md §8 f4)')
+        self.index_type = index_type
+
+        feature_store = FeatureStoreFactory.load_store(self.media_type, self.features_dir)
+        feature_store.enable_read(shard_shuffle=False)
+        feature_count = feature_store.feature_count
+        feature_dim = feature_store.feature_dim
+
+        # the on-disk index is assembled on the host (I/O-bound: tar + unpickle per vector), 512 at a time
+        X = np.empty((feature_count, feature_dim), dtype=np.float32)
+        ids = np.empty((feature_count,), dtype=np.int64)
+        n = 0
+        print('Adding feature vectors to index')
+        for feature_ids_batch, feature_vectors_batch in feature_store.iter_batch():
+            m = len(feature_ids_batch)
+            X[n:n + m] = feature_vectors_batch
+            ids[n:n + m] = feature_ids_batch
+            n += m
+        faiss_io.write_idmap_flat_ip(index_fn, X[:n], ids[:n])
+        print(f'  saved index to {index_fn}')
+
+    def is_index_loaded(self):
+        return hasattr(self, 'index')
+
+    def load_index(self, index_type):
+        index_fn = self.get_index_filename(index_type)
+        if not index_fn.exists():
+            print(f'  index {index_fn} does not exist')
+            print(f'  use create-index.py script to create an index')
+        # like the reference (App. B.3) a missing file raises from the reader, it does not return False
+        X, ids = faiss_io.read_idmap_flat_ip(index_fn)
+        index = FlatIPIndex(X.shape[1])
+        for s in range(0, X.shape[0], 1 << 20):  # stream the memory-mapped rows into HBM
+            index.add_with_ids(np.ascontiguousarray(X[s:s + (1 << 20)]), ids[s:s + (1 << 20)])
+        self.index = index
+        self.feature_extractor = FeatureExtractorFactory(self.feature_extractor_id)
+        return True
+
+    def search(self, media_type, query, topk=5, query_type='text'):
+        if query_type != 'text':
+            raise ValueError('query_type={query_type} not implemented')
+
+        if media_type == 'audio':
+            if isinstance(query, str):
+                media_query_text = [query]
+            else:
+                media_query_text = [(self.prompt[media_type] + x) for x in query]
+        else:
+            media_query_text = [(self.prompt[media_type] + query)]
+
+        query_features = self.feature_extractor.extract_text_features(media_query_text)
+        dist, ids = self.index.search(query_features, topk)
+        return dist[0], ids[0]

@@ -66,11 +66,12 @@ class ShardedFlatIPIndex:
             return D, I
         W = self.world
         nq = D.shape[0]
-        Ds = torch.empty(W, nq, k, dtype=D.dtype, device=D.device)
-        Is = torch.empty(W, nq, k, dtype=I.dtype, device=I.device)
+        # concatenated along dim 0 (the layout every backend accepts), viewed as [W, nq, k]
+        Ds = torch.empty(W * nq, k, dtype=D.dtype, device=D.device)
+        Is = torch.empty(W * nq, k, dtype=I.dtype, device=I.device)
         dist.all_gather_into_tensor(Ds, D.contiguous(), group=self.group)
         dist.all_gather_into_tensor(Is, I.contiguous(), group=self.group)
-        return self._merge(Ds, Is, k)
+        return self._merge(Ds.view(W, nq, k), Is.view(W, nq, k), k)
 
     def search(self, x, k: int):
         import numpy as np
