@@ -100,7 +100,8 @@ def cpu_baseline_vit(spec, sd, seconds):
 
     frames = torch.from_numpy(np.random.default_rng(1).integers(0, 256, size=(8, 3, 224, 224), dtype=np.uint8))
     x = vit_ref.normalize_u8(frames)
-    threads = torch.get_num_threads()
+    threads = min(torch.get_num_threads(), 16)  # the GPU box's CPU share for one GPU
+    torch.set_num_threads(threads)
     with torch.no_grad():
         vit_ref.vit_forward(sd, x, patch=spec.patch, heads=spec.heads, act=spec.act)  # warm-up
         n = 0
