@@ -111,9 +111,28 @@ int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, const float
 int wise_vit_tap_residual(const wise_vit_config* cfg, int batch, const void* workspace, float* dst,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * HP-1 audio  MS-CLAP (version 2023) HTSAT audio encoder + projection (replaces
+ *       self.model.clap.audio_encoder(x)[0] + L2 normalise, reference call site
+ *       src/feature/microsoft_clap.py:49-50).  The architecture is fixed (msclap config_2023:
+ *       n_fft 1024, hop 320, 64 mel bands 50..8000 Hz at sr 44100, Swin depths 2-2-6-2, dims 96..768,
+ *       heads 4..32, window 8, projection 768->1024), so there is no config struct.
+ * wave [B, samples] fp32 (what preprocess_audio yields after the reshape at microsoft_clap.py:47-48);
+ * only the first 1024 STFT frames (6.8 s at hop 320) enter the model.  out [B,1024] fp32, unit rows.
+ * Weight blobs: layout in wise_amd/feature/htsat.py:pack_htsat_weights (msclap state-dict keys).
+ * ---------------------------------------------------------------------------------------------- */
+int wise_htsat_layout(int64_t* wb_elems, int64_t* pf_elems);
+size_t wise_htsat_workspace_bytes(int batch, int samples);
+int wise_htsat_forward(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
+                       float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* parity tap after a forward with the same (batch, samples): what 0 = BatchNorm'd log-mel
+ * [B*frames,64], 1 = residual stream; copies `count` floats. */
+int wise_htsat_tap(int what, const void* workspace, int batch, int samples, float* dst, int64_t count,
+                   void* stream);
+
 /* Building blocks, exported so the parity tests can pin each kernel separately. */
 /* C[M,N] = epilogue(A[M,K] bf16 @ Wt[N,K]^T bf16 + bias[N]) ; M%128==0 rows must be readable
- * (callers pad), N%128==0, K%64==0.
+ * (callers pad), N%4==0, K%32==0.
  * mode: 0 -> out_bf16 = acc+bias ; 1 -> out_bf16 = quickgelu(acc+bias) ; 2 -> out_bf16 = gelu(acc+bias)
  *       3 -> resid_f32 += acc+bias (in place, fp32 residual stream) ; 4 -> out_f32 = acc+bias */
 int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K,

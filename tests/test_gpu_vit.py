@@ -23,7 +23,9 @@ def cosine(a, b):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (12800, 768, 768), (1280, 2304, 768),
-                                    (640, 768, 3072), (12544, 768, 3072)])
+                                    (640, 768, 3072), (12544, 768, 3072),
+                                    # HTSAT shapes: N edge (N % 128 != 0) and K % 64 != 0
+                                    (256, 288, 96), (128, 96, 384), (384, 192, 96), (256, 576, 192), (128, 36, 32)])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_gemm_modes(M, N, K, mode):
     if M > 2000 and mode not in (0, 3):

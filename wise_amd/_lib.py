@@ -39,6 +39,10 @@ SIGNATURES = {
     "wise_vit_workspace_bytes": (_sz, [C.POINTER(VitConfig), _i]),
     "wise_vit_forward": (_i, [C.POINTER(VitConfig), _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "wise_vit_tap_residual": (_i, [C.POINTER(VitConfig), _i, _vp, _vp, _vp]),
+    "wise_htsat_layout": (_i, [C.POINTER(_i64), C.POINTER(_i64)]),
+    "wise_htsat_workspace_bytes": (_sz, [_i, _i]),
+    "wise_htsat_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "wise_htsat_tap": (_i, [_i, _vp, _i, _i, _vp, _i64, _vp]),
     "wise_gemm_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "wise_layernorm_f32_bf16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "wise_attention_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),

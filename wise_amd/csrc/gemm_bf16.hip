@@ -32,12 +32,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 
 // stage one 128x64 bf16 tile (rows row0.., k from k0) into a 16 KiB LDS tile
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int row0, int k0,
-                                           unsigned char* lds_tile, int wave, int lane) {
+                                           unsigned char* lds_tile, int wave, int lane, int row_last) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int r = (t * 4 + wave) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (r & 7);  // logical chunk held at physical chunk (lane&7)
-        const bf16_t* src = G + (size_t)(row0 + r) * ld + k0 + c * 8;
+        const int gr = min(row0 + r, row_last);  // N edge: rows past the matrix re-read the last row (never stored)
+        const bf16_t* src = G + (size_t)gr * ld + k0 + c * 8;
         glds16(src, lds_tile + (t * 4 + wave) * 1024);
     }
 }
@@ -57,6 +58,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const float* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        if (n >= N) continue;  // N edge (N % 4 == 0, so a lane's 4 columns are all in or all out)
         float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
     const int wm = wave >> 1, wn = wave & 1;
 
     // XCD-aware bijective remap: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles
-    const int tiles_n = N / BN;
+    const int tiles_n = (N + BN - 1) / BN;
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
     {
@@ -116,16 +118,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
-    stage_tile(A, K, m0, 0, smem, wave, lane);
-    stage_tile(Wt, K, n0, 0, smem + TILE_BYTES, wave, lane);
+    stage_tile(A, K, m0, 0, smem, wave, lane, M - 1);
+    stage_tile(Wt, K, n0, 0, smem + TILE_BYTES, wave, lane, N - 1);
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         __syncthreads();  // waits vmcnt(0): tile kt landed; everyone done reading buffer cur^1
         if (ABL != 1 && kt + 1 < nk) {
             unsigned char* nb = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile(A, K, m0, (kt + 1) * BK, nb, wave, lane);
-            stage_tile(Wt, K, n0, (kt + 1) * BK, nb + TILE_BYTES, wave, lane);
+            stage_tile(A, K, m0, (kt + 1) * BK, nb, wave, lane, M - 1);
+            stage_tile(Wt, K, n0, (kt + 1) * BK, nb + TILE_BYTES, wave, lane, N - 1);
         }
         const unsigned char* At = smem + cur * 2 * TILE_BYTES;
         const unsigned char* Bt = At + TILE_BYTES;
@@ -164,7 +166,7 @@ __device__ __forceinline__ int swz_chunk(int row, int c) {
 
 template <int BKT>
 __device__ __forceinline__ void stage_tile_ring(const bf16_t* __restrict__ G, int ld, int row0, int k0,
-                                                unsigned char* lds_tile, int wave, int lane) {
+                                                unsigned char* lds_tile, int wave, int lane, int row_last) {
     constexpr int RB = BKT * 2;              // row bytes
     constexpr int RPI = 1024 / RB;           // rows per wave-instruction
     constexpr int CPR = RB / 16;             // chunks per row
@@ -173,7 +175,7 @@ __device__ __forceinline__ void stage_tile_ring(const bf16_t* __restrict__ G, in
     for (int t = 0; t < ROUNDS; ++t) {
         const int r = (t * 4 + wave) * RPI + lane / CPR;
         const int c = swz_chunk<BKT>(r, lane % CPR);  // involution: logical chunk stored at phys (lane % CPR)
-        const bf16_t* src = G + (size_t)(row0 + r) * ld + k0 + c * 8;
+        const bf16_t* src = G + (size_t)min(row0 + r, row_last) * ld + k0 + c * 8;
         glds16(src, lds_tile + (t * 4 + wave) * 1024);
     }
 }
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_ring_kernel(const bf16_t* __re
     const int wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int tiles_n = N / BN;
+    const int tiles_n = (N + BN - 1) / BN;
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
     {
@@ -221,8 +223,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_ring_kernel(const bf16_t* __re
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) {
         if (s < nk) {
-            stage_tile_ring<BKT>(A, K, m0, s * BKT, smem + s * SB, wave, lane);
-            stage_tile_ring<BKT>(Wt, K, n0, s * BKT, smem + s * SB + TB, wave, lane);
+            stage_tile_ring<BKT>(A, K, m0, s * BKT, smem + s * SB, wave, lane, M - 1);
+            stage_tile_ring<BKT>(Wt, K, n0, s * BKT, smem + s * SB + TB, wave, lane, N - 1);
         }
     }
     int cur = 0;
@@ -239,8 +241,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_ring_kernel(const bf16_t* __re
             if (nt < nk) {
                 int ns = cur + STAGES - 1;
                 if (ns >= STAGES) ns -= STAGES;
-                stage_tile_ring<BKT>(A, K, m0, nt * BKT, smem + ns * SB, wave, lane);
-                stage_tile_ring<BKT>(Wt, K, n0, nt * BKT, smem + ns * SB + TB, wave, lane);
+                stage_tile_ring<BKT>(A, K, m0, nt * BKT, smem + ns * SB, wave, lane, M - 1);
+                stage_tile_ring<BKT>(Wt, K, n0, nt * BKT, smem + ns * SB + TB, wave, lane, N - 1);
             }
         }
         const unsigned char* At = smem + cur * SB;
@@ -275,7 +277,7 @@ static void launch_ring(const bf16_t* A, const bf16_t* Wt, const float* bias, in
                                   (int)lds);
         attr_set = true;
     }
-    const int grid = (M / BM) * (N / BN);
+    const int grid = (M / BM) * ((N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, Wt, bias, M, N, K, out);
 }
 
@@ -290,7 +292,7 @@ static void launch_gemm(const bf16_t* A, const bf16_t* Wt, const float* bias, in
                                   (int)lds);
         attr_set = true;
     }
-    const int grid = (M / BM) * (N / BN);
+    const int grid = (M / BM) * ((N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, Wt, bias, M, N, K, out);
 }
 
@@ -562,18 +564,21 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
 int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out,
               hipStream_t st) {
     WISE_CHECK_ARG(A && Wt && out, "gemm_bf16: null pointer");
-    WISE_CHECK_ARG(M > 0 && M % BM == 0 && N > 0 && N % BN == 0 && K > 0 && K % BK == 0,
-                   "gemm_bf16: M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, BM, BN, BK);
+    WISE_CHECK_ARG(M > 0 && M % BM == 0 && N > 0 && N % 4 == 0 && K > 0 && K % 32 == 0,
+                   "gemm_bf16: M=%d must be a multiple of %d, N=%d of 4, K=%d of 32", M, BM, N, K);
     ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
     int v = g_gemm_variant;
     if (v == 0) {
         // shape heuristic (measured, tools/gemm_bench.py): when a 256x192 tiling fits the chip in ONE
         // round (<= 256 tiles) it beats 128x128 (fewer staged bytes, no second-round tail); otherwise the
         // 128x128 tile at two blocks per CU wins because its epilogue overlaps the other block's main loop.
-        if (M % 256 == 0 && N % 192 == 0 && (long long)(M / 256) * (N / 192) <= 256) v = 5;
+        if (M % 256 == 0 && N % 192 == 0 && K % 64 == 0 && (long long)(M / 256) * (N / 192) <= 256) v = 5;
+        else if (K % 64 != 0) v = 1;  // K multiple of 32 only (HTSAT C=96): the BK=32 ring kernel
     } else if (v == 100) {
         v = 0;  // force the 128x128 kernel (A/B runs)
     }
+    if (K % 64 != 0) v = 1;
+    else if (N % BN != 0 && v != 1) v = 0;  // N edge is handled by the 128x128 kernels only
     switch (mode) {
         case EPI_BF16: launch_variant<EPI_BF16>(v, A, Wt, bias, M, N, K, out, st); break;
         case EPI_QUICKGELU: launch_variant<EPI_QUICKGELU>(v, A, Wt, bias, M, N, K, out, st); break;

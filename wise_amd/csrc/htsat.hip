@@ -1,0 +1,636 @@
+// HP-1 audio: MS-CLAP (2023) HTSAT audio encoder on gfx950.
+//
+// Replaces `self.model.clap.audio_encoder(x)[0]` + L2 normalise at
+// src/feature/microsoft_clap.py:49-50 (msclap 1.3.3 HTSAT_Swin_Transformer + Projection; arithmetic:
+// SURVEY.md App. A.2, restated in oracle/htsat_ref.py, whose Swin body is pinned to transformers'
+// ClapAudioModel).
+//
+// Pipeline (all hand-written HIP):
+//   frontend   one wave per STFT frame: reflect-padded, Hann-windowed 1024-point FFT in LDS, power,
+//              sparse Slaney mel filterbank (lane = band), 10*log10, BatchNorm folded to scale/shift
+//   embed      time-axis bicubic resample to 1024 frames + fold to the 256x256 image + 4x4/4 conv + LN,
+//              one wave per token, straight from the log-mel (the image is never materialised)
+//   Swin       LN -> qkv GEMM -> window attention (cyclic shift and window partition are pure
+//              addressing; rel-pos bias + shift mask fused into the softmax) -> proj GEMM(+resid)
+//              -> LN -> fc1 GEMM(+GELU) -> fc2 GEMM(+resid); PatchMerging = gather+LN kernel + GEMM
+//   head       final LN, token mean, Projection (linear1, GELU, linear2, LN(e1+e2)), L2 normalise
+#include "common.h"
+
+namespace wise {
+
+int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out,
+              hipStream_t st);
+int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows, int W, float eps, bf16_t* y,
+                       hipStream_t st);
+
+namespace htsat {
+constexpr int N_FFT = 1024, HOP = 320, N_MELS = 64, MELW = 32, MAXF = 1024;
+constexpr int EMBED = 96, LATENT = 768, OUT = 1024;
+constexpr int DEPTHS[4] = {2, 2, 6, 2};
+constexpr int HEADS[4] = {4, 8, 16, 32};
+
+// ------------------------------------------------------------------------------------------------
+// frontend: wave per frame
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frontend_kernel(const float* __restrict__ wave, int B, int N, int Fc,
+                                                       const float* __restrict__ hann,
+                                                       const float* __restrict__ mel_start,
+                                                       const float* __restrict__ mel_len,
+                                                       const float* __restrict__ mel_wt /*[MELW][64]*/,
+                                                       const float* __restrict__ bn_scale,
+                                                       const float* __restrict__ bn_shift,
+                                                       float* __restrict__ melbn /*[B,Fc,64]*/) {
+    __shared__ float2 tw[512];
+    __shared__ float2 bufs[4][N_FFT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int j = threadIdx.x; j < 512; j += 256) {
+        float s, c;
+        sincospif((float)j / 512.f, &s, &c);
+        tw[j] = make_float2(c, -s);  // exp(-2*pi*i*j/1024)
+    }
+    __syncthreads();
+    const long long fid = (long long)blockIdx.x * 4 + wv;
+    if (fid >= (long long)B * Fc) return;
+    const int b = (int)(fid / Fc), f = (int)(fid % Fc);
+    float2* buf = bufs[wv];
+    const float* w = wave + (size_t)b * N;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int n = u * 64 + lane;
+        int s = f * HOP - N_FFT / 2 + n;
+        if (s < 0) s = -s;
+        if (s >= N) s = 2 * (N - 1) - s;
+        buf[__brev((unsigned)n) >> 22] = make_float2(w[s] * hann[n], 0.f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int s = 1; s <= 10; ++s) {
+        const int half = 1 << (s - 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = u * 64 + lane;
+            const int j = k & (half - 1);
+            const int i0 = ((k >> (s - 1)) << s) + j;
+            const int i1 = i0 + half;
+            const float2 t = tw[j << (10 - s)];
+            const float2 a = buf[i0], q = buf[i1];
+            const float tr = t.x * q.x - t.y * q.y, ti = t.x * q.y + t.y * q.x;
+            buf[i0] = make_float2(a.x + tr, a.y + ti);
+            buf[i1] = make_float2(a.x - tr, a.y - ti);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // power of bins 0..512 into the (now dead) upper half of the buffer
+    float* pw = reinterpret_cast<float*>(buf + 513);
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+        const int k = u * 64 + lane;
+        if (k <= 512) {
+            const float2 v = buf[k];
+            pw[k] = v.x * v.x + v.y * v.y;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int st = (int)mel_start[lane], ln = (int)mel_len[lane];
+    float acc = 0.f;
+    for (int j = 0; j < MELW; ++j) {
+        const int k = min(st + j, 512);
+        const float wgt = (j < ln) ? mel_wt[j * 64 + lane] : 0.f;
+        acc = fmaf(wgt, pw[k], acc);
+    }
+    const float db = 10.f * log10f(fmaxf(acc, 1e-10f));
+    melbn[((size_t)b * Fc + f) * 64 + lane] = db * bn_scale[lane] + bn_shift[lane];
+}
+
+// ------------------------------------------------------------------------------------------------
+// embed: wave per token (b, i, j) of the 64x64 grid
+// image[R][c] with R = r*64 + f, c = t' holds mel[t = r*256 + t'][f] resampled to 1024 frames
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cubic1(float v) { const float A = -0.75f; return ((A + 2.f) * v - (A + 3.f)) * v * v + 1.f; }
+__device__ __forceinline__ float cubic2(float v) { const float A = -0.75f; return ((A * v - 5.f * A) * v + 8.f * A) * v - 4.f * A; }
+
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ melbn, int B, int Fc,
+                                                    const float* __restrict__ pw /*[96][16]*/,
+                                                    const float* __restrict__ pb, const float* __restrict__ lnw,
+                                                    const float* __restrict__ lnb, float* __restrict__ x) {
+    const int lane = threadIdx.x & 63;
+    const long long token = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (token >= (long long)B * 4096) return;
+    const int b = (int)(token >> 12), tok = (int)(token & 4095), i = tok >> 6, j = tok & 63;
+    float v = 0.f;
+    {
+        const int p = lane & 15, dy = p >> 2, dx = p & 3;
+        const int R = 4 * i + dy, r = R >> 6, fbin = R & 63;
+        const int t = r * 256 + 4 * j + dx;
+        const float* m = melbn + (size_t)b * Fc * 64 + fbin;
+        if (Fc == MAXF) {
+            v = m[(size_t)t * 64];
+        } else {
+            const float scale = (float)(Fc - 1) / (float)(MAXF - 1);
+            const float src = (float)t * scale;
+            const float fl = floorf(src);
+            const int i0 = (int)fl;
+            const float tt = src - fl;
+            const float w0 = cubic2(tt + 1.f), w1 = cubic1(tt), w2 = cubic1(1.f - tt), w3 = cubic2(2.f - tt);
+            const int a0 = min(max(i0 - 1, 0), Fc - 1), a1 = min(max(i0, 0), Fc - 1), a2 = min(max(i0 + 1, 0), Fc - 1),
+                      a3 = min(max(i0 + 2, 0), Fc - 1);
+            // same accumulation order as the oracle: taps 0..3 added in turn
+            v = m[(size_t)a0 * 64] * w0;
+            v += m[(size_t)a1 * 64] * w1;
+            v += m[(size_t)a2 * 64] * w2;
+            v += m[(size_t)a3 * 64] * w3;
+        }
+    }
+    float pv[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) pv[p] = __shfl(v, p, 64);
+    const int c0 = lane, c1 = lane + 64;
+    const bool has1 = c1 < EMBED;
+    float y0 = pb[c0], y1 = has1 ? pb[c1] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        y0 = fmaf(pw[c0 * 16 + p], pv[p], y0);
+        if (has1) y1 = fmaf(pw[c1 * 16 + p], pv[p], y1);
+    }
+    const float mean = wave_sum(y0 + (has1 ? y1 : 0.f)) / (float)EMBED;
+    const float d0 = y0 - mean, d1 = has1 ? y1 - mean : 0.f;
+    const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / (float)EMBED + 1e-5f);
+    float* xr = x + (size_t)token * EMBED;
+    xr[c0] = d0 * rstd * lnw[c0] + lnb[c0];
+    if (has1) xr[c1] = d1 * rstd * lnw[c1] + lnb[c1];
+}
+
+// ------------------------------------------------------------------------------------------------
+// window attention: wave per (image, window, head); 64 tokens, head dim 24 (padded to 32 for MFMA)
+// qkv [B*H*W, 3C] bf16 in ORIGINAL token order; the cyclic shift is done by addressing
+// ------------------------------------------------------------------------------------------------
+constexpr int VT_LD = 68;
+
+__global__ __launch_bounds__(256) void swin_attention_kernel(const bf16_t* __restrict__ qkv, int B, int H, int W, int C,
+                                                             int heads, int shift,
+                                                             const float* __restrict__ bias /*[heads][64][64]*/,
+                                                             bf16_t* __restrict__ o) {
+    __shared__ __attribute__((aligned(16))) bf16_t vt_all[4][32 * VT_LD];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nwx = W >> 3, nwin = (H >> 3) * nwx;
+    const long long item = (long long)blockIdx.x * 4 + wv;
+    if (item >= (long long)B * nwin * heads) return;
+    const int h = (int)(item % heads);
+    const int win = (int)((item / heads) % nwin);
+    const int b = (int)(item / ((long long)heads * nwin));
+    const int wy = win / nwx, wx = win % nwx;
+    const int C3 = 3 * C;
+    const bf16_t* base = qkv + (size_t)b * H * W * C3;
+    bf16_t* vt = vt_all[wv];
+    const int l15 = lane & 15, g = lane >> 4;
+
+    // token p (0..63) of this window -> row in the original layout, and its shift-region id
+    auto row_of = [&](int p) {
+        const int ys = wy * 8 + (p >> 3), xs = wx * 8 + (p & 7);
+        int y = ys + shift, x = xs + shift;
+        if (y >= H) y -= H;
+        if (x >= W) x -= W;
+        return y * W + x;
+    };
+    auto region_of = [&](int p) {
+        const int ys = wy * 8 + (p >> 3), xs = wx * 8 + (p & 7);
+        const int ry = (ys >= H - 8) + (ys >= H - 4), rx = (xs >= W - 8) + (xs >= W - 4);
+        return ry * 3 + rx;
+    };
+
+    // Q (B operand) and K (A operand) fragments: 8 bf16 of head dim 8g..8g+7, zero for g == 3
+    bf16x8 qf[4], kf[4];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = row_of(t * 16 + l15);
+        if (g < 3) {
+            qf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)r * C3 + h * 24 + g * 8);
+            kf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)r * C3 + C + h * 24 + g * 8);
+        } else {
+            qf[t] = zero8;
+            kf[t] = zero8;
+        }
+    }
+    // V^T image [32 dh][64 keys]: lane = key, 3 chunks of 8 dh; rows 24..31 zero
+    {
+        const int r = row_of(lane);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const short8 v = *reinterpret_cast<const short8*>(base + (size_t)r * C3 + 2 * C + h * 24 + c * 8);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) vt[(c * 8 + jj) * VT_LD + lane] = (bf16_t)v[jj];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) vt[(24 + jj) * VT_LD + lane] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // S^T[kt][qt] = K Q^T (one k-step of 32 >= 24)
+    f32x4 sacc[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+            sacc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], c, 0, 0, 0);
+        }
+    const float scale = 0.20412414523193154f;  // 24^-0.5
+    const float LOG2E = 1.4426950408889634f;
+    const float* bh = bias + (size_t)h * 4096;
+    int regk[4][4];
+    if (shift > 0) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) regk[kt][r] = region_of(kt * 16 + g * 4 + r);
+    }
+    f32x4 oacc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float linv[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int q = qt * 16 + l15;
+        const int regq = (shift > 0) ? region_of(q) : 0;
+        float mx = -INFINITY;
+        float s2[4][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const float4 bb = *reinterpret_cast<const float4*>(bh + q * 64 + kt * 16 + g * 4);
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = sacc[kt][qt][r] * scale + bv[r];
+                if (shift > 0 && regk[kt][r] != regq) s += -100.f;
+                s *= LOG2E;
+                s2[kt][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float ps = 0.f;
+        float p[4][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[kt][r] = exp2f(s2[kt][r] - mx);
+                ps += p[kt][r];
+            }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        linv[qt] = 1.f / ps;
+        // O^T += V^T P^T, two k-steps of 32 key slots (slot order permuted consistently on both sides)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (__bf16)p[2 * ks][r];
+                pf[4 + r] = (__bf16)p[2 * ks + 1][r];
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16_t* rowp = vt + (dt * 16 + l15) * VT_LD + ks * 32 + g * 4;
+                const uint2 lo = *reinterpret_cast<const uint2*>(rowp);
+                const uint2 hi = *reinterpret_cast<const uint2*>(rowp + 16);
+                union { uint4 u; bf16x8 f; } cv;
+                cv.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cv.f, pf, oacc[dt][qt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int r = row_of(qt * 16 + l15);
+        bf16_t* orow = o + ((size_t)b * H * W + r) * C + h * 24;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int dh = dt * 16 + g * 4;
+            if (dh < 24) {
+                uint2 pk;
+                pk.x = pack_bf16x2(oacc[dt][qt][0] * linv[qt], oacc[dt][qt][1] * linv[qt]);
+                pk.y = pack_bf16x2(oacc[dt][qt][2] * linv[qt], oacc[dt][qt][3] * linv[qt]);
+                *reinterpret_cast<uint2*>(orow + dh) = pk;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PatchMerging gather + LN: x fp32 [B,H,W,C] -> y bf16 [B,(H/2)(W/2),4C], segments x0|x1|x2|x3 =
+// (2i,2j) (2i+1,2j) (2i,2j+1) (2i+1,2j+1); wave per output token; NV = ceil(C/64) float4 per lane
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void merge_ln_kernel(const float* __restrict__ x, int B, int H, int W, int C,
+                                                       const float* __restrict__ w, const float* __restrict__ bb,
+                                                       bf16_t* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int H2 = H >> 1, W2 = W >> 1;
+    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= (long long)B * H2 * W2) return;
+    const int b = (int)(tok / (H2 * W2)), ij = (int)(tok % (H2 * W2)), i = ij / W2, j = ij % W2;
+    const int c4 = C >> 2;  // float4 per segment; C float4 in total
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int idx = u * 64 + lane;
+        if (idx < C) {
+            const int seg = idx / c4, off = idx % c4;
+            const int yy = 2 * i + (seg & 1), xx = 2 * j + (seg >> 1);
+            v[u] = reinterpret_cast<const float4*>(x + (((size_t)b * H + yy) * W + xx) * C)[off];
+        } else
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+    }
+    const float n = (float)(4 * C);
+    const float mean = wave_sum(s) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        if (u * 64 + lane < C) {
+            const float a0 = v[u].x - mean, a1 = v[u].y - mean, a2 = v[u].z - mean, a3 = v[u].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / n + 1e-5f);
+    uint2* yr = reinterpret_cast<uint2*>(y + (size_t)tok * 4 * C);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int idx = u * 64 + lane;
+        if (idx < C) {
+            const float4 ww = reinterpret_cast<const float4*>(w)[idx];
+            const float4 b4 = reinterpret_cast<const float4*>(bb)[idx];
+            uint2 pk;
+            pk.x = pack_bf16x2((v[u].x - mean) * rstd * ww.x + b4.x, (v[u].y - mean) * rstd * ww.y + b4.y);
+            pk.y = pack_bf16x2((v[u].z - mean) * rstd * ww.z + b4.z, (v[u].w - mean) * rstd * ww.w + b4.w);
+            yr[idx] = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: block per clip. x [B*64, 768] fp32 -> LN -> token mean -> Projection -> L2 normalise
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ nw,
+                                                   const float* __restrict__ nb, const bf16_t* __restrict__ w1,
+                                                   const bf16_t* __restrict__ w2, const float* __restrict__ lw,
+                                                   const float* __restrict__ lb, float* __restrict__ out) {
+    __shared__ float lat[LATENT];
+    __shared__ float part[4][LATENT];  // per-wave partial token sums, added in a fixed order (deterministic)
+    __shared__ float e1[OUT], ge[OUT], e[OUT];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* xb = x + (size_t)blockIdx.x * 64 * LATENT;
+    // each wave normalises 16 tokens; 768 = 12 per lane
+    float accl[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) accl[u] = 0.f;
+    for (int t = wv; t < 64; t += 4) {
+        const float* r = xb + (size_t)t * LATENT;
+        float v[12], s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) { v[u] = r[u * 64 + lane]; s += v[u]; }
+        const float mean = wave_sum(s) / (float)LATENT;
+        float q = 0.f;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) { const float d = v[u] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / (float)LATENT + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < 12; ++u) accl[u] += (v[u] - mean) * rstd * nw[u * 64 + lane] + nb[u * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < 12; ++u) part[wv][u * 64 + lane] = accl[u];
+    __syncthreads();
+    for (int c = tid; c < LATENT; c += 256) lat[c] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) * (1.f / 64.f);
+    __syncthreads();
+    // e1 = W1 @ latent (1024 x 768), wave per output row
+    for (int r = wv; r < OUT; r += 4) {
+        const bf16_t* wr = w1 + (size_t)r * LATENT;
+        float acc = 0.f;
+        for (int c = lane * 8; c < LATENT; c += 512) {
+            const short8 pv = *reinterpret_cast<const short8*>(wr + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(lat[c + j], bf16_to_f32((bf16_t)pv[j]), acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) { e1[r] = acc; ge[r] = gelu_erf(acc); }
+    }
+    __syncthreads();
+    for (int r = wv; r < OUT; r += 4) {
+        const bf16_t* wr = w2 + (size_t)r * OUT;
+        float acc = 0.f;
+        for (int c = lane * 8; c < OUT; c += 512) {
+            const short8 pv = *reinterpret_cast<const short8*>(wr + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(ge[c + j], bf16_to_f32((bf16_t)pv[j]), acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) e[r] = e1[r] + acc;
+    }
+    __syncthreads();
+    float s = 0.f;
+    for (int c = tid; c < OUT; c += 256) s += e[c];
+    s = wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)OUT;
+    __syncthreads();
+    float q = 0.f;
+    for (int c = tid; c < OUT; c += 256) { const float d = e[c] - mean; q += d * d; }
+    q = wave_sum(q);
+    if (lane == 0) red[wv] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)OUT + 1e-5f);
+    __syncthreads();
+    float sq = 0.f;
+    for (int c = tid; c < OUT; c += 256) {
+        const float y = (e[c] - mean) * rstd * lw[c] + lb[c];
+        e[c] = y;
+        sq += y * y;
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) red[4 + wv] = sq;
+    __syncthreads();
+    const float nrm = sqrtf(red[4] + red[5] + red[6] + red[7]);
+    for (int c = tid; c < OUT; c += 256) out[(size_t)blockIdx.x * OUT + c] = e[c] / nrm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// blob layout + workspace
+// ------------------------------------------------------------------------------------------------
+struct Offsets {
+    // fp32 blob
+    size_t bn_scale, bn_shift, mel_start, mel_len, mel_wt, hann, pe_w, pe_b, pe_nw, pe_nb;
+    size_t blk_f[4][6];    // start of each block's fp32 params
+    size_t merge_f[3];     // merge norm w,b
+    size_t fin_nw, fin_nb, pj_lw, pj_lb, total_f;
+    // bf16 blob
+    size_t blk_b[4][6];
+    size_t merge_b[3];
+    size_t pj_w1, pj_w2, total_b;
+};
+static Offsets offsets() {
+    Offsets o;
+    size_t f = 0, w = 0;
+    o.bn_scale = f; f += 64; o.bn_shift = f; f += 64; o.mel_start = f; f += 64; o.mel_len = f; f += 64;
+    o.mel_wt = f; f += 64 * MELW; o.hann = f; f += N_FFT; o.pe_w = f; f += EMBED * 16; o.pe_b = f; f += EMBED;
+    o.pe_nw = f; f += EMBED; o.pe_nb = f; f += EMBED;
+    for (int i = 0; i < 4; ++i) {
+        const size_t C = (size_t)EMBED << i;
+        for (int j = 0; j < DEPTHS[i]; ++j) {
+            o.blk_f[i][j] = f; f += 13 * C + 4096 * (size_t)HEADS[i];
+            o.blk_b[i][j] = w; w += 12 * C * C;
+        }
+        if (i < 3) {
+            o.merge_f[i] = f; f += 8 * C;
+            o.merge_b[i] = w; w += 8 * C * C;
+        }
+    }
+    o.fin_nw = f; f += LATENT; o.fin_nb = f; f += LATENT; o.pj_lw = f; f += OUT; o.pj_lb = f; f += OUT;
+    o.total_f = f;
+    o.pj_w1 = w; w += (size_t)OUT * LATENT; o.pj_w2 = w; w += (size_t)OUT * OUT;
+    o.total_b = w;
+    return o;
+}
+
+struct Ws {
+    size_t mel, x, h, qkv, a, total;
+    int Fc;
+};
+static Ws workspace(int B, int N) {
+    Ws w;
+    const int frames = 1 + N / HOP;
+    w.Fc = frames < MAXF ? frames : MAXF;
+    const size_t rows1 = align_up((size_t)B * 4096, 128) + 128;  // stage-1 rows (padded); rows*C is largest at stage 1
+    size_t off = 0;
+    w.mel = off; off += align_up((size_t)B * w.Fc * 64 * 4, 256);
+    w.x = off; off += align_up(rows1 * EMBED * 4, 256);
+    w.h = off; off += align_up(rows1 * EMBED * 2, 256);
+    w.qkv = off; off += align_up(rows1 * EMBED * 3 * 2, 256);
+    w.a = off; off += align_up(rows1 * EMBED * 4 * 2, 256);
+    w.total = off;
+    return w;
+}
+
+}  // namespace htsat
+}  // namespace wise
+
+using namespace wise;
+using namespace wise::htsat;
+
+extern "C" int wise_htsat_layout(int64_t* wb_elems, int64_t* pf_elems) {
+    const Offsets o = offsets();
+    if (wb_elems) *wb_elems = (int64_t)o.total_b;
+    if (pf_elems) *pf_elems = (int64_t)o.total_f;
+    return WISE_OK;
+}
+
+extern "C" size_t wise_htsat_workspace_bytes(int batch, int samples) {
+    if (batch < 1 || samples < N_FFT / 2 + 1) return 0;
+    return workspace(batch, samples).total;
+}
+
+extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
+                                  float* out, void* workspace_ptr, size_t workspace_bytes, void* stream) {
+    WISE_CHECK_ARG(wb && pf && wave && out, "htsat_forward: null pointer");
+    WISE_CHECK_ARG(batch >= 1 && samples >= N_FFT / 2 + 1, "htsat_forward: batch=%d samples=%d", batch, samples);
+    const Ws ws = workspace(batch, samples);
+    if (!workspace_ptr || workspace_bytes < ws.total) {
+        set_error("htsat_forward: workspace %zu < %zu bytes", workspace_bytes, ws.total);
+        return WISE_E_WORKSPACE;
+    }
+    WISE_CHECK_ARG(((uintptr_t)workspace_ptr & 255) == 0 && ((uintptr_t)wb & 15) == 0 && ((uintptr_t)pf & 15) == 0,
+                   "htsat_forward: workspace must be 256-byte and weight blobs 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const Offsets o = offsets();
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace_ptr);
+    float* mel = reinterpret_cast<float*>(wsb + ws.mel);
+    float* x = reinterpret_cast<float*>(wsb + ws.x);
+    bf16_t* h = reinterpret_cast<bf16_t*>(wsb + ws.h);
+    bf16_t* qkv = reinterpret_cast<bf16_t*>(wsb + ws.qkv);
+    bf16_t* a = reinterpret_cast<bf16_t*>(wsb + ws.a);
+    const int B = batch, Fc = ws.Fc;
+    int rc;
+
+    hipLaunchKernelGGL(frontend_kernel, dim3((unsigned)(((long long)B * Fc + 3) / 4)), dim3(256), 0, st, wave, B,
+                       samples, Fc, pf + o.hann, pf + o.mel_start, pf + o.mel_len, pf + o.mel_wt, pf + o.bn_scale,
+                       pf + o.bn_shift, mel);
+    WISE_LAUNCH_CHECK("htsat frontend_kernel");
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)(((long long)B * 4096 + 3) / 4)), dim3(256), 0, st, mel, B, Fc,
+                       pf + o.pe_w, pf + o.pe_b, pf + o.pe_nw, pf + o.pe_nb, x);
+    WISE_LAUNCH_CHECK("htsat embed_kernel");
+
+    int H = 64;
+    for (int i = 0; i < 4; ++i) {
+        const int C = EMBED << i, heads = HEADS[i];
+        const int M = B * H * H;
+        const int Mp = (M + 127) / 128 * 128;
+        for (int j = 0; j < DEPTHS[i]; ++j) {
+            const float* p = pf + o.blk_f[i][j];
+            const bf16_t* wq = wb + o.blk_b[i][j];
+            const float* n1w = p; const float* n1b = p + C; const float* rb = p + 2 * C;
+            const float* qb = rb + 4096 * (size_t)heads; const float* pb = qb + 3 * C;
+            const float* n2w = pb + C; const float* n2b = n2w + C; const float* f1b = n2b + C; const float* f2b = f1b + 4 * C;
+            const bf16_t* wproj = wq + (size_t)3 * C * C; const bf16_t* wf1 = wproj + (size_t)C * C;
+            const bf16_t* wf2 = wf1 + (size_t)4 * C * C;
+            const int shift = (j % 2 == 1 && H > 8) ? 4 : 0;
+            if ((rc = layernorm_f32_bf16(x, n1w, n1b, M, C, 1e-5f, h, st))) return rc;
+            if ((rc = gemm_bf16(h, wq, qb, Mp, 3 * C, C, 0, qkv, st))) return rc;
+            {
+                const long long items = (long long)B * (H / 8) * (H / 8) * heads;
+                hipLaunchKernelGGL(swin_attention_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, B, H,
+                                   H, C, heads, shift, rb, h);
+                WISE_LAUNCH_CHECK("htsat swin_attention_kernel");
+            }
+            if ((rc = gemm_bf16(h, wproj, pb, Mp, C, C, 3, x, st))) return rc;
+            if ((rc = layernorm_f32_bf16(x, n2w, n2b, M, C, 1e-5f, h, st))) return rc;
+            if ((rc = gemm_bf16(h, wf1, f1b, Mp, 4 * C, C, 2, a, st))) return rc;
+            if ((rc = gemm_bf16(a, wf2, f2b, Mp, C, 4 * C, 3, x, st))) return rc;
+        }
+        if (i < 3) {
+            const float* mp = pf + o.merge_f[i];
+            const long long toks = (long long)B * (H / 2) * (H / 2);
+            const dim3 grid((unsigned)((toks + 3) / 4)), block(256);
+            switch ((C + 63) / 64) {
+                case 2: hipLaunchKernelGGL(merge_ln_kernel<2>, grid, block, 0, st, x, B, H, H, C, mp, mp + 4 * C, h); break;
+                case 3: hipLaunchKernelGGL(merge_ln_kernel<3>, grid, block, 0, st, x, B, H, H, C, mp, mp + 4 * C, h); break;
+                case 6: hipLaunchKernelGGL(merge_ln_kernel<6>, grid, block, 0, st, x, B, H, H, C, mp, mp + 4 * C, h); break;
+                default: set_error("htsat: unexpected C=%d", C); return WISE_E_UNSUPPORTED;
+            }
+            WISE_LAUNCH_CHECK("htsat merge_ln_kernel");
+            const int M2 = (int)toks, M2p = (M2 + 127) / 128 * 128;
+            if ((rc = gemm_bf16(h, wb + o.merge_b[i], nullptr, M2p, 2 * C, 4 * C, 4, x, st))) return rc;
+            H >>= 1;
+        }
+    }
+    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, st, x, pf + o.fin_nw, pf + o.fin_nb, wb + o.pj_w1,
+                       wb + o.pj_w2, pf + o.pj_lw, pf + o.pj_lb, out);
+    WISE_LAUNCH_CHECK("htsat head_kernel");
+    return WISE_OK;
+}
+
+extern "C" int wise_htsat_tap(int what, const void* workspace_ptr, int batch, int samples, float* dst, int64_t count,
+                              void* stream) {
+    WISE_CHECK_ARG(workspace_ptr && dst && count > 0 && batch >= 1, "htsat_tap: bad argument");
+    const Ws ws = workspace(batch, samples);
+    const unsigned char* wsb = reinterpret_cast<const unsigned char*>(workspace_ptr);
+    const size_t off = (what == 0) ? ws.mel : ws.x;
+    hipError_t e = hipMemcpyAsync(dst, wsb + off, (size_t)count * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("htsat_tap: %s", hipGetErrorString(e)); return (int)e; }
+    return WISE_OK;
+}

@@ -1,0 +1,178 @@
+"""Host side of the MS-CLAP (version 2023) HTSAT audio encoder: state-dict layout, seeded initialiser,
+weight packing, and the engine that drives `wise_htsat_forward` (include/wise_hip.h).
+
+Weights are addressed by msclap 1.3.3 state-dict keys under `clap.audio_encoder.` (what
+`msclap.CLAP(version='2023')` loads, reference call site src/feature/microsoft_clap.py:31), so a real
+checkpoint is a pure data problem.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Tuple
+
+import torch
+
+from .. import _lib
+
+N_FFT, HOP, N_MELS = 1024, 320, 64
+SPEC_SIZE, FREQ_RATIO, WINDOW = 256, 4, 8
+DEPTHS = (2, 2, 6, 2)
+HEADS = (4, 8, 16, 32)
+EMBED = 96
+LATENT = 768
+OUT_DIM = 1024
+MAX_FRAMES = SPEC_SIZE * FREQ_RATIO  # 1024
+
+
+def state_dict_keys() -> List[Tuple[str, Tuple[int, ...]]]:
+    """(key, shape) in the order the seeded initialiser draws them (front-end buffers are not weights:
+    the STFT kernels / mel filterbank are fixed functions of the config and are rebuilt, not loaded)."""
+    pre = "base.htsat."
+    keys = [(pre + "bn0.weight", (N_MELS,)), (pre + "bn0.bias", (N_MELS,)), (pre + "bn0.running_mean", (N_MELS,)),
+            (pre + "bn0.running_var", (N_MELS,)), (pre + "patch_embed.proj.weight", (EMBED, 1, 4, 4)),
+            (pre + "patch_embed.proj.bias", (EMBED,)), (pre + "patch_embed.norm.weight", (EMBED,)),
+            (pre + "patch_embed.norm.bias", (EMBED,))]
+    for i, depth in enumerate(DEPTHS):
+        Cd = EMBED << i
+        for j in range(depth):
+            p = f"{pre}layers.{i}.blocks.{j}."
+            keys += [(p + "norm1.weight", (Cd,)), (p + "norm1.bias", (Cd,)),
+                     (p + "attn.relative_position_bias_table", ((2 * WINDOW - 1) ** 2, HEADS[i])),
+                     (p + "attn.qkv.weight", (3 * Cd, Cd)), (p + "attn.qkv.bias", (3 * Cd,)),
+                     (p + "attn.proj.weight", (Cd, Cd)), (p + "attn.proj.bias", (Cd,)),
+                     (p + "norm2.weight", (Cd,)), (p + "norm2.bias", (Cd,)),
+                     (p + "mlp.fc1.weight", (4 * Cd, Cd)), (p + "mlp.fc1.bias", (4 * Cd,)),
+                     (p + "mlp.fc2.weight", (Cd, 4 * Cd)), (p + "mlp.fc2.bias", (Cd,))]
+        if i < 3:
+            p = f"{pre}layers.{i}.downsample."
+            keys += [(p + "norm.weight", (4 * Cd,)), (p + "norm.bias", (4 * Cd,)), (p + "reduction.weight", (2 * Cd, 4 * Cd))]
+    keys += [(pre + "norm.weight", (LATENT,)), (pre + "norm.bias", (LATENT,)),
+             ("projection.linear1.weight", (OUT_DIM, LATENT)), ("projection.linear2.weight", (OUT_DIM, OUT_DIM)),
+             ("projection.layer_norm.weight", (OUT_DIM,)), ("projection.layer_norm.bias", (OUT_DIM,))]
+    return keys
+
+
+def random_htsat_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded fp32 weights (no checkpoint exists offline); one CPU generator, `state_dict_keys` order."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for key, shape in state_dict_keys():
+        n = torch.randn(shape, generator=g, dtype=torch.float32)
+        fan_in = shape[-1] if len(shape) == 2 else 16
+        if key.endswith("bn0.running_mean"):
+            t = -30.0 + 5.0 * n            # log-mel dB of 0.1-amplitude noise sits around -30 dB
+        elif key.endswith("bn0.running_var"):
+            t = 100.0 * (1.0 + 0.2 * n).abs() + 1.0
+        elif key.endswith("norm.weight") or key.endswith("norm1.weight") or key.endswith("norm2.weight") \
+                or key.endswith("bn0.weight") or key.endswith("layer_norm.weight"):
+            t = 1.0 + 0.1 * n
+        elif key.endswith("relative_position_bias_table"):
+            t = 0.5 * n
+        elif key.endswith("patch_embed.proj.weight"):
+            t = n * 0.25
+        elif key.endswith("qkv.weight"):
+            t = n * (fan_in ** -0.5)
+            t[: 2 * shape[1]] *= 1.5      # sharper attention than a default init gives
+        elif key.endswith(".weight") and len(shape) == 2:
+            t = n * (fan_in ** -0.5) * (0.5 if ("fc2" in key or "attn.proj" in key) else 1.0)
+        elif key.endswith(".bias"):
+            t = (0.1 if "norm" in key or "bn0" in key else 0.02) * n
+        else:
+            raise KeyError(key)
+        sd[key] = t.contiguous()
+    return sd
+
+
+class HtsatEngine:
+    """Device copies of the packed weights + workspace; forward(wave [B,N] fp32) -> [B,1024] fp32 device
+    tensor, L2-normalised (microsoft_clap.py:49-50)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 128,
+                 max_samples: int = 480000):
+        self.lib = _lib.lib()
+        self.device = torch.device(device)
+        nb, nf = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.wise_htsat_layout(C.byref(nb), C.byref(nf)), "wise_htsat_layout")
+        wb, pf = pack_htsat_weights(sd)
+        if wb.numel() != nb.value or pf.numel() != nf.value:
+            raise RuntimeError(f"HTSAT blob size mismatch: packed {wb.numel()}/{pf.numel()}, "
+                               f"library expects {nb.value}/{nf.value}")
+        self.wb, self.pf = wb.to(self.device), pf.to(self.device)
+        self._ws = None
+        self._ws_key = (0, 0)
+        self._last = (0, 0)
+        self.reserve(max_batch, max_samples)
+
+    def reserve(self, batch: int, samples: int):
+        if batch <= self._ws_key[0] and samples <= self._ws_key[1]:
+            return
+        batch, samples = max(batch, self._ws_key[0]), max(samples, self._ws_key[1])
+        n = self.lib.wise_htsat_workspace_bytes(batch, samples)
+        if n == 0:
+            raise RuntimeError("wise_htsat_workspace_bytes: bad shape")
+        self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._ws_key = (batch, samples)
+
+    def forward(self, wave: torch.Tensor) -> torch.Tensor:
+        if wave.dim() != 2:
+            raise ValueError(f"expected [B, samples], got {tuple(wave.shape)}")
+        x = wave.to(self.device, torch.float32).contiguous()
+        B, N = x.shape
+        if N < N_FFT // 2 + 1:
+            raise ValueError(f"audio too short for a reflect-padded STFT: {N} samples")
+        self.reserve(B, N)
+        out = torch.empty(B, OUT_DIM, dtype=torch.float32, device=self.device)
+        rc = self.lib.wise_htsat_forward(self.wb.data_ptr(), self.pf.data_ptr(), x.data_ptr(), B, N, out.data_ptr(),
+                                         self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "wise_htsat_forward")
+        self._last = (B, N)
+        return out
+
+    def tap(self, what: int, rows: int, cols: int) -> torch.Tensor:
+        """parity taps: 0 = log-mel+bn [B*frames,64] fp32, 1 = residual stream x fp32 [rows, cols]."""
+        out = torch.empty(rows, cols, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.wise_htsat_tap(what, self._ws.data_ptr(), self._last[0], self._last[1], out.data_ptr(),
+                                           rows * cols, _lib.stream_ptr()), "wise_htsat_tap")
+        return out
+
+
+def pack_htsat_weights(sd: Dict[str, torch.Tensor]):
+    """state dict -> (bf16 blob, fp32 blob) in the order wise_htsat_layout() documents (CPU tensors).
+
+    bf16: per block qkv [3C,C], proj [C,C], fc1 [4C,C], fc2 [C,4C]; per stage<3 reduction [2C,4C];
+          then projection.linear1 [1024,768], linear2 [1024,1024]
+    fp32: bn0 scale[64], shift[64] (running stats folded), mel filterbank (sparse: start[64], len[64], weights^T [MELW,64]),
+          hann[1024], patch conv w [96,16], b[96], norm w,b; per block norm1 w,b, rel-pos bias expanded [heads,64,64],
+          qkv bias, proj bias, norm2 w,b, fc1 bias, fc2 bias; per stage<3 merge norm w,b [4C]; final norm w,b;
+          projection LN w,b
+    """
+    from . import htsat_frontend as fe
+
+    f32 = lambda k: sd[k].detach().to(torch.float32).cpu()
+    pre = "base.htsat."
+    wb, pf = [], []
+    scale = f32(pre + "bn0.weight") / torch.sqrt(f32(pre + "bn0.running_var") + 1e-5)
+    shift = f32(pre + "bn0.bias") - f32(pre + "bn0.running_mean") * scale
+    start, length, weights = fe.sparse_mel()
+    pf += [scale, shift, start.to(torch.float32), length.to(torch.float32), weights.t().contiguous().reshape(-1),
+           fe.hann_periodic(),
+           f32(pre + "patch_embed.proj.weight").reshape(-1), f32(pre + "patch_embed.proj.bias"),
+           f32(pre + "patch_embed.norm.weight"), f32(pre + "patch_embed.norm.bias")]
+    rel_idx = fe.rel_pos_index().reshape(-1)
+    for i, depth in enumerate(DEPTHS):
+        for j in range(depth):
+            p = f"{pre}layers.{i}.blocks.{j}."
+            wb += [f32(p + "attn.qkv.weight").reshape(-1), f32(p + "attn.proj.weight").reshape(-1),
+                   f32(p + "mlp.fc1.weight").reshape(-1), f32(p + "mlp.fc2.weight").reshape(-1)]
+            bias = f32(p + "attn.relative_position_bias_table")[rel_idx].reshape(64, 64, HEADS[i]).permute(2, 0, 1)
+            pf += [f32(p + "norm1.weight"), f32(p + "norm1.bias"), bias.contiguous().reshape(-1),
+                   f32(p + "attn.qkv.bias"), f32(p + "attn.proj.bias"), f32(p + "norm2.weight"),
+                   f32(p + "norm2.bias"), f32(p + "mlp.fc1.bias"), f32(p + "mlp.fc2.bias")]
+        if i < 3:
+            p = f"{pre}layers.{i}.downsample."
+            wb.append(f32(p + "reduction.weight").reshape(-1))
+            pf += [f32(p + "norm.weight"), f32(p + "norm.bias")]
+    wb += [f32("projection.linear1.weight").reshape(-1), f32("projection.linear2.weight").reshape(-1)]
+    pf += [f32(pre + "norm.weight"), f32(pre + "norm.bias"), f32("projection.layer_norm.weight"),
+           f32("projection.layer_norm.bias")]
+    return torch.cat(wb).to(torch.bfloat16).contiguous(), torch.cat(pf).contiguous()
