@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the CLAP-HTSAT and ViT-L/14 legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget per CPU baseline leg")
     return ap.parse_args()
 
@@ -277,6 +278,56 @@ def main():
             "batched_nq4_queries_per_s": round(4 * s_steps / sdt4, 2),
         }
         del X, local, index
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ other BASELINE configs (short legs)
+    if not args.no_extra:
+        extra = {}
+        # cfg-5: MS-CLAP HTSAT, 10-s clips @48 kHz, bs=128 per GPU (weak scaling, no collective)
+        from wise_amd.feature.htsat import HtsatEngine, random_htsat_state_dict
+
+        ab = 128
+        heng = HtsatEngine(random_htsat_state_dict(0), max_batch=ab, max_samples=480000)
+        wav = 0.1 * torch.randn(ab, 480000, generator=torch.Generator(device="cuda").manual_seed(4 + rank),
+                                device="cuda")
+        hold = {}
+
+        def clap_step(i):
+            hold["o"] = heng.forward(wav)
+
+        for i in range(2):
+            clap_step(i)
+        a_steps = max(3, min(args.steps, 10))
+        adt = timed_region(clap_step, a_steps, world)
+        assert abs(float(hold["o"].norm(dim=1).mean()) - 1.0) < 1e-3
+        extra["clap_htsat"] = {"value": round(world * ab * a_steps / adt, 1), "unit": "clips/s",
+                               "ms_per_step": round(adt / a_steps * 1e3, 3), "steps": a_steps,
+                               "config": {"workload": "MS-CLAP 2023 HTSAT audio encoder + projection, 10-s clips "
+                                                      "(480000 samples @48 kHz), bs=128 per GPU", "dtype": "bf16",
+                                          "gflop_per_clip": 11.82},
+                               "tflops": round(world * ab * a_steps / adt * 11.82e9 / 1e12 / world, 2)}
+        del heng, wav
+        torch.cuda.empty_cache()
+        # cfg-4 (image half): ViT-L/14 at bs=256 per GPU
+        lspec = spec_for("ViT-L-14", "openai")
+        leng = VitEngine(lspec, random_state_dict(lspec, 0), max_batch=args.batch)
+
+        def l14_step(i):
+            hold["l"] = leng.forward(x)
+
+        for i in range(2):
+            l14_step(i)
+        l_steps = max(3, min(args.steps, 5))
+        ldt = timed_region(l14_step, l_steps, world)
+        lfps = world * args.batch * l_steps / ldt
+        extra["vit_l14"] = {"value": round(lfps, 1), "unit": "frames/s", "ms_per_step": round(ldt / l_steps * 1e3, 3),
+                            "steps": l_steps, "config": {"workload": "OpenCLIP ViT-L/14 image tower, bs=256 per GPU",
+                                                         "gflop_per_frame": round(lspec.flops_per_frame() / 1e9, 2)},
+                            "tflops": round(lfps / world * lspec.flops_per_frame() / 1e12, 2),
+                            "frac_of_bf16_peak": round(lfps / world * lspec.flops_per_frame() / 1e12 / PEAK_BF16_TFLOPS, 4)}
+        del leng
+        torch.cuda.empty_cache()
+        result["extra"] = extra
 
     # ------------------------------------------------------------------ CPU baselines (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

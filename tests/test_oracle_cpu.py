@@ -110,3 +110,39 @@ def test_merge_oracle_properties():
     Dm, Im = ip_topk_ref.merge_topk(np.stack(parts_D), np.stack(parts_I), 10)
     assert np.array_equal(Im, I) and np.array_equal(Dm, D)  # sharded search == unsharded search
     assert ip_topk_ref.recall_at_k(Im, I) == 1.0
+
+
+def test_htsat_oracle_reproduces_golden_and_layout(golden_dir):
+    """oracle/htsat_ref.py against tests/golden/htsat.npz (made next to the HF ClapAudioModel pin), and the
+    packed blobs against the library's layout."""
+    import ctypes as C
+
+    from oracle import htsat_ref
+    from wise_amd import _lib
+    from wise_amd.feature.htsat import pack_htsat_weights, random_htsat_state_dict
+    from wise_amd.feature import htsat_frontend as fe
+
+    g = np.load(golden_dir / "htsat.npz")
+    assert float(g["pin_latent"]) < 1e-4 and float(g["pin_stft"]) < 1e-4
+    sd = random_htsat_state_dict(int(g["weight_seed"]))
+    rng = np.random.default_rng(int(g["wave_seed"]))
+    wave = torch.from_numpy((0.1 * rng.standard_normal((2, 192000))).astype(np.float32))
+    with torch.no_grad():
+        mel = htsat_ref.logmel(wave[:1])
+        assert mel.shape == (1, 601, 64) and np.allclose(mel[:, :8].numpy(), g["mel_head"][:1], atol=1e-4)
+        out = htsat_ref.htsat_forward(sd, wave[:1])
+    assert np.allclose(out.numpy(), g["out"][:1], atol=2e-5)
+    # product-side tables equal the oracle's restatement
+    assert np.array_equal(fe.mel_filterbank(), htsat_ref.mel_filterbank())
+    start, length, w = fe.sparse_mel()
+    dense = np.zeros((64, 513), np.float32)
+    for b in range(64):
+        dense[b, start[b]: start[b] + length[b]] = w[b, : length[b]]
+    assert np.array_equal(dense, fe.mel_filterbank())
+    assert torch.equal(fe.rel_pos_index(), htsat_ref.rel_pos_index())
+    lib = _lib.load()
+    nb, nf = C.c_int64(), C.c_int64()
+    assert lib.wise_htsat_layout(C.byref(nb), C.byref(nf)) == 0
+    wb, pf = pack_htsat_weights(sd)
+    assert (wb.numel(), pf.numel()) == (nb.value, nf.value)
+    assert lib.wise_htsat_workspace_bytes(128, 480000) > 0 and lib.wise_htsat_workspace_bytes(1, 100) == 0

@@ -1,0 +1,42 @@
+"""A/B the ViT forward (frames/s) under library knobs: python tools/vit_bench.py [model] [batch]"""
+import ctypes as C
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from wise_amd import _lib  # noqa: E402
+from wise_amd.feature.vit import VitEngine, random_state_dict, spec_for  # noqa: E402
+
+
+def main():
+    model = sys.argv[1] if len(sys.argv) > 1 else "ViT-B-32"
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    lib = _lib.lib()
+    spec = spec_for(model, "openai")
+    eng = VitEngine(spec, random_state_dict(spec, 0), max_batch=B)
+    x = torch.randn(B, 3, 224, 224, device="cuda")
+    ref = None
+    for streams in (1, 2, 1, 2):
+        lib.wise_debug_set_vit_streams(streams)
+        for _ in range(5):
+            o = eng.forward(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 20 if model == "ViT-B-32" else 5
+        for _ in range(n):
+            o = eng.forward(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        if ref is None:
+            ref = o.clone()
+        same = torch.equal(o, ref)
+        print(f"{model} B={B} streams={streams}: {dt*1e3:8.3f} ms/step  {B/dt:10.1f} frames/s  "
+              f"{B/dt*spec.flops_per_frame()/1e12:7.1f} TFLOP/s  bit-identical-to-first={same}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

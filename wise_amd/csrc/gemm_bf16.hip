@@ -20,6 +20,8 @@ namespace wise {
 
 enum : int { EPI_BF16 = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4 };
 
+__device__ int g_group_m = 0;        // 0 = default; tuning knob (bits 16..23 of wise_debug_set_gemm_variant)
+__device__ int g_dephase = 0;        // tuning knob (bits 24..27): initial s_sleep units for the second block per CU
 __device__ int g_skip_epilogue = 0;  // timing-only ablation (tools/gemm_bench.py), set via wise_debug_set_gemm_variant
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -89,6 +91,27 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const float* __rest
     }
 }
 
+
+// Tile order.  Blocks b, b+8, ... share an XCD (round-robin dispatch), so the remap first gives each
+// XCD a contiguous run of virtual ids, then walks them in GROUP_M x tiles_n bands, m fastest inside a
+// band ("grouped ordering"): the ~64 tiles an XCD has resident at once form a ~8x8 patch of the output
+// that shares 8 A panels and 8 W panels, which fits the XCD's 4 MiB L2.  With plain n-fastest order the
+// resident set spans every W panel (3.5 MB at N=2304) and thrashes: PMC showed 139 MB fetched from
+// the memory side for a GEMM whose operands total 23 MB.  Placement only affects speed.
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int group_m, int* tm, int* tn) {
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per_group = group_m * tiles_n;
+    const int gid = bid / per_group;
+    const int first_m = gid * group_m;
+    const int gsize = min(tiles_m - first_m, group_m);
+    const int in_group = bid - gid * per_group;
+    *tm = first_m + in_group % gsize;
+    *tn = in_group / gsize;
+}
+
 template <int MODE, int ABL = 0>  // ABL (timing-only builds): 1 = no staging in the loop, 2 = no LDS reads / MFMA
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
                                                            const bf16_t* __restrict__ Wt,
@@ -102,13 +125,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
 
     // XCD-aware bijective remap: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles
     const int tiles_n = (N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm, tn;
+    tile_coords(M / BM, tiles_n, g_group_m ? g_group_m : 8, &tm, &tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     f32x4 acc[4][4];
@@ -116,6 +134,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // De-phase the two blocks that share a CU: all tiles cost the same, so co-resident blocks otherwise
+    // reach their (HBM-write-bound) epilogues together and the chip alternates between an MFMA phase and a
+    // store phase.  The second block per CU of the first dispatch round starts late by ~half a tile.
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+        const int d = g_dephase;
+        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     const int nk = K / BK;
     stage_tile(A, K, m0, 0, smem, wave, lane, M - 1);
@@ -190,7 +216,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MODE, int BKT, int STAGES, int MINB>
+template <int MODE, int BKT, int STAGES, int MINB, int ABL = 0>
 __global__ __launch_bounds__(256, MINB) void gemm_ring_kernel(const bf16_t* __restrict__ A,
                                                               const bf16_t* __restrict__ Wt,
                                                               const float* __restrict__ bias, int M, int N, int K,
@@ -204,13 +230,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_ring_kernel(const bf16_t* __re
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tiles_n = (N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm, tn;
+    tile_coords(M / BM, tiles_n, g_group_m ? g_group_m : 8, &tm, &tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     f32x4 acc[4][4];
@@ -247,6 +268,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_ring_kernel(const bf16_t* __re
         }
         const unsigned char* At = smem + cur * SB;
         const unsigned char* Bt = At + TB;
+        if (ABL == 2) { cur = (cur + 1 == STAGES) ? 0 : cur + 1; continue; }
 #pragma unroll
         for (int s = 0; s < BKT / 32; ++s) {
             const int chunk = s * 4 + (lane >> 4);
@@ -266,10 +288,10 @@ __global__ __launch_bounds__(256, MINB) void gemm_ring_kernel(const bf16_t* __re
     epilogue<MODE>(acc, bias, out, N, m0, n0, wm, wn, lane);
 }
 
-template <int MODE, int BKT, int STAGES, int MINB>
+template <int MODE, int BKT, int STAGES, int MINB, int ABL = 0>
 static void launch_ring(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
                         hipStream_t st) {
-    auto kern = gemm_ring_kernel<MODE, BKT, STAGES, MINB>;
+    auto kern = gemm_ring_kernel<MODE, BKT, STAGES, MINB, ABL>;
     const size_t lds = (size_t)STAGES * 2 * 128 * BKT * 2;
     static bool attr_set = false;
     if (!attr_set) {
@@ -364,13 +386,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const bf16_t* __restri
     const int wm = wave >> 2, wn = wave & 3;
 
     const int tiles_n = N / BNB;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm, tn;
+    tile_coords(M / BMB, tiles_n, g_group_m ? g_group_m : 4, &tm, &tn);
     const int m0 = tm * BMB, n0 = tn * BNB;
 
     f32x4 acc[8][NT];
@@ -441,7 +458,7 @@ __device__ __forceinline__ void stage_rows8_ring(const bf16_t* __restrict__ G, i
     }
 }
 
-template <int MODE, int NT, int BKT, int STAGES>
+template <int MODE, int NT, int BKT, int STAGES, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bigring_kernel(const bf16_t* __restrict__ A,
                                                               const bf16_t* __restrict__ Wt,
                                                               const float* __restrict__ bias, int M, int N, int K,
@@ -455,13 +472,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bigring_kernel(const bf16_t* __re
     const int wm = wave >> 2, wn = wave & 3;
 
     const int tiles_n = N / BNB;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm, tn;
+    tile_coords(M / BMB, tiles_n, g_group_m ? g_group_m : 4, &tm, &tn);
     const int m0 = tm * BMB, n0 = tn * BNB;
 
     f32x4 acc[8][NT];
@@ -497,6 +509,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bigring_kernel(const bf16_t* __re
         }
         const unsigned char* At = smem + cur * SB;
         const unsigned char* Bt = At + TA;
+        if (ABL == 2) { cur = (cur + 1 == STAGES) ? 0 : cur + 1; continue; }
 #pragma unroll
         for (int s = 0; s < BKT / 32; ++s) {
             const int chunk = s * 4 + (lane >> 4);
@@ -516,10 +529,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bigring_kernel(const bf16_t* __re
     epilogue_big<MODE, NT>(acc, bias, out, N, m0, n0, wm, wn, lane);
 }
 
-template <int MODE, int NT, int BKT, int STAGES>
+template <int MODE, int NT, int BKT, int STAGES, int ABL = 0>
 static void launch_bigring(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
                            hipStream_t st) {
-    auto kern = gemm_bigring_kernel<MODE, NT, BKT, STAGES>;
+    auto kern = gemm_bigring_kernel<MODE, NT, BKT, STAGES, ABL>;
     const size_t lds = (size_t)STAGES * (256 + 64 * NT) * BKT * 2;
     static bool attr_set = false;
     if (!attr_set) {
@@ -554,6 +567,18 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
         case 12: if (M % 256 == 0 && N % 192 == 0) { launch_bigring<MODE, 3, 32, 4>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 13: if (M % 256 == 0 && N % 256 == 0) { launch_bigring<MODE, 4, 32, 3>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 14: if (M % 256 == 0) { launch_bigring<MODE, 2, 32, 2>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 15: if (M % 256 == 0) { launch_bigring<MODE, 2, 32, 4>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 16: launch_ring<MODE, 32, 2, 4>(A, Wt, bias, M, N, K, out, st); break;   // 32 KB LDS: 4 blocks/CU
+        case 17: launch_ring<MODE, 32, 3, 3>(A, Wt, bias, M, N, K, out, st); break;   // 48 KB LDS: 3 blocks/CU
+        case 20: launch_ring<MODE, 64, 4, 1, 2>(A, Wt, bias, M, N, K, out, st); break;   // load-only ablations
+        case 21: launch_ring<MODE, 32, 4, 2, 2>(A, Wt, bias, M, N, K, out, st); break;
+        case 22: if (M % 256 == 0 && N % 256 == 0) { launch_bigring<MODE, 4, 32, 4, 2>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 23: if (M % 256 == 0) { launch_bigring<MODE, 2, 64, 3, 2>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 8: launch_gemm<MODE, 1>(A, Wt, bias, M, N, K, out, st); break;
         case 9: launch_gemm<MODE, 2>(A, Wt, bias, M, N, K, out, st); break;
@@ -603,5 +628,9 @@ extern "C" int wise_debug_set_gemm_variant(int v) {
     wise::g_gemm_variant = v & 0xFF;
     int skip = (v >> 8) & 1;  // bit 8: skip epilogue stores (timing-only ablation)
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_skip_epilogue), &skip, sizeof(int));
+    int dp = (v >> 24) & 0x3F;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_dephase), &dp, sizeof(int));
+    int gm = (v >> 16) & 0xFF;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_group_m), &gm, sizeof(int));
     return 0;
 }

@@ -329,6 +329,62 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const float* __restric
     }
 }
 
+// ln_post on the class-token rows only: x[b*T, :] -> y[b, :] bf16 ; wave per image
+template <int NV>
+__global__ __launch_bounds__(256) void cls_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, int B, int T, int W, float eps,
+                                                     bf16_t* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int img = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (img >= B) return;
+    const int w4 = W >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)img * T * W);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = (c < w4) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (i * 64 + lane < w4) {
+            float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
+    uint2* yr = reinterpret_cast<uint2*>(y + (size_t)img * W);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < w4) {
+            const float4 ww = reinterpret_cast<const float4*>(w)[c];
+            const float4 bb = reinterpret_cast<const float4*>(b)[c];
+            uint2 pk;
+            pk.x = pack_bf16x2((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y);
+            pk.y = pack_bf16x2((v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+            yr[c] = pk;
+        }
+    }
+}
+
+// out[r,:] = e[r,:] / ||e[r,:]||_2 (no epsilon: mlfoundation_openclip.py:100) ; wave per row
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ e, int rows, int D,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* er = e + (size_t)r * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += er[c] * er[c];
+    const float nrm = sqrtf(wave_sum(s));
+    for (int c = lane; c < D; c += 64) out[(size_t)r * D + c] = er[c] / nrm;
+}
+
 // out[b,:] = normalize( ln_post(x[b*T, :]) @ proj ), projT bf16 [D, W]; one block (256 thr) per image
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ bb, const bf16_t* __restrict__ projT,
@@ -445,45 +501,11 @@ static void launch_embed(const float* po, const float* cls, const float* pos, co
                        1e-5f, x);
 }
 
-}  // namespace wise
-
-using namespace wise;
-
-extern "C" int wise_vit_layout(const wise_vit_config* cfg, int64_t* wb_elems, int64_t* pf_elems) {
-    VitDims d;
-    int rc = vit_dims(cfg, &d);
-    if (rc) return rc;
-    VitOffsets o = vit_offsets(d);
-    if (wb_elems) *wb_elems = (int64_t)o.total_b;
-    if (pf_elems) *pf_elems = (int64_t)o.total_f;
-    return WISE_OK;
-}
-
-extern "C" size_t wise_vit_workspace_bytes(const wise_vit_config* cfg, int batch) {
-    VitDims d;
-    if (vit_dims(cfg, &d) || batch < 1) return 0;
-    return vit_ws(d, batch).total;
-}
-
-extern "C" int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, const float* pf, const void* images,
-                                int in_kind, int batch, float* out, void* workspace, size_t workspace_bytes,
-                                void* stream) {
-    VitDims d;
-    int rc = vit_dims(cfg, &d);
-    if (rc) return rc;
-    WISE_CHECK_ARG(wb && pf && images && out, "vit_forward: null pointer");
-    WISE_CHECK_ARG(batch >= 1, "vit_forward: batch=%d", batch);
-    WISE_CHECK_ARG(in_kind == WISE_VIT_IN_F32 || in_kind == WISE_VIT_IN_U8, "vit_forward: in_kind=%d", in_kind);
+// one contiguous part of the batch on one stream; `wsb` is that part's own workspace region
+static int vit_forward_part(const wise_vit_config* cfg, const VitDims& d, const VitOffsets& o, const bf16_t* wb,
+                            const float* pf, const void* images, int in_kind, int batch, float* out,
+                            unsigned char* wsb, hipStream_t st) {
     const VitWs ws = vit_ws(d, batch);
-    if (!workspace || workspace_bytes < ws.total) {
-        set_error("vit_forward: workspace %zu < %zu bytes", workspace_bytes, ws.total);
-        return WISE_E_WORKSPACE;
-    }
-    WISE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wb & 15) == 0 && ((uintptr_t)pf & 15) == 0,
-                   "vit_forward: workspace must be 256-byte and weight blobs 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    const VitOffsets o = vit_offsets(d);
-    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
     float* x = reinterpret_cast<float*>(wsb + ws.x);
     bf16_t* h = reinterpret_cast<bf16_t*>(wsb + ws.h);
     bf16_t* qkv = reinterpret_cast<bf16_t*>(wsb + ws.qkv);
@@ -491,6 +513,7 @@ extern "C" int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, 
     float* patch_out = reinterpret_cast<float*>(wsb + ws.qkv);
     bf16_t* patches = a;
     const int W = d.W;
+    int rc;
 
     // 1. patch gather + conv1-as-GEMM (no bias)
     if (in_kind == WISE_VIT_IN_U8)
@@ -532,11 +555,124 @@ extern "C" int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, 
         if ((rc = gemm_bf16(h, lwb + o.c_fc, lpf + o.fc_b, ws.Mp, d.F, W, cfg->act == 0 ? 1 : 2, a, st))) return rc;
         if ((rc = gemm_bf16(a, lwb + o.c_proj, lpf + o.proj_b, ws.Mp, W, d.F, 3, x, st))) return rc;
     }
-    // 4. ln_post(cls) @ proj, L2 normalise
-    hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(256), (size_t)(W + d.D) * 4, st, x, pf + o.ln_post_w,
-                       pf + o.ln_post_b, wb + o.projT, d.T, W, d.D, 1e-5f, out);
-    WISE_LAUNCH_CHECK("head_kernel");
+    // 4. ln_post(cls) -> bf16 [Bp,W] (aliases h) ; @ proj -> fp32 [Bp,D] (aliases qkv) ; L2 normalise rows
+    {
+        const int Bp = (batch + 127) / 128 * 128;
+        // cls rows are x[b*T, :]: a strided LayerNorm, row stride T*W
+        const int nv = (W / 4 + 63) / 64;
+        const dim3 grid((batch + 3) / 4), block(256);
+        float* e = reinterpret_cast<float*>(qkv);
+#define CLS_CASE(n) case n: hipLaunchKernelGGL(cls_ln_kernel<n>, grid, block, 0, st, x, pf + o.ln_post_w, pf + o.ln_post_b, \
+                                               batch, d.T, W, 1e-5f, h); break;
+        switch (nv) {
+            CLS_CASE(1) CLS_CASE(2) CLS_CASE(3) CLS_CASE(4) CLS_CASE(5) CLS_CASE(6) CLS_CASE(7) CLS_CASE(8)
+            default: set_error("vit_forward: width %d too large", W); return WISE_E_UNSUPPORTED;
+        }
+#undef CLS_CASE
+        WISE_LAUNCH_CHECK("cls_ln_kernel");
+        if ((rc = gemm_bf16(h, wb + o.projT, nullptr, Bp, d.D, W, 4, e, st))) return rc;
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, e, batch, d.D, out);
+        WISE_LAUNCH_CHECK("l2norm_rows_kernel");
+    }
     return WISE_OK;
+}
+
+// Two halves of a batch are independent; running them on two internal streams lets one half's GEMM
+// tails and barrier bubbles be filled by the other half's kernels (and its LayerNorm / attention
+// traffic overlap the GEMM main loops).  Fork/join with events, so the call stays stream-ordered for
+// the caller and graph-capturable once the internal streams exist (first call creates them).
+static hipStream_t g_side[2] = {nullptr, nullptr};
+static hipEvent_t g_ev_fork = nullptr, g_ev_join[2] = {nullptr, nullptr};
+static int g_vit_streams = 2;
+
+static int ensure_side_streams() {
+    if (g_side[0]) return WISE_OK;
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = hipStreamCreateWithFlags(&g_side[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g_ev_join[i], hipEventDisableTiming);
+        if (e != hipSuccess) { set_error("vit_forward: side stream: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    hipError_t e = hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming);
+    if (e != hipSuccess) { set_error("vit_forward: event: %s", hipGetErrorString(e)); return (int)e; }
+    return WISE_OK;
+}
+
+static int vit_parts(int batch) { return (g_vit_streams >= 2 && batch >= 64) ? 2 : 1; }
+static size_t vit_total_ws(const VitDims& d, int batch) {
+    if (vit_parts(batch) == 1) return vit_ws(d, batch).total;
+    const int b0 = (batch + 1) / 2;
+    return vit_ws(d, b0).total + vit_ws(d, batch - b0).total;
+}
+
+}  // namespace wise
+
+using namespace wise;
+
+extern "C" int wise_debug_set_vit_streams(int n) {
+    g_vit_streams = n;
+    return 0;
+}
+
+extern "C" int wise_vit_layout(const wise_vit_config* cfg, int64_t* wb_elems, int64_t* pf_elems) {
+    VitDims d;
+    int rc = vit_dims(cfg, &d);
+    if (rc) return rc;
+    VitOffsets o = vit_offsets(d);
+    if (wb_elems) *wb_elems = (int64_t)o.total_b;
+    if (pf_elems) *pf_elems = (int64_t)o.total_f;
+    return WISE_OK;
+}
+
+extern "C" size_t wise_vit_workspace_bytes(const wise_vit_config* cfg, int batch) {
+    VitDims d;
+    if (vit_dims(cfg, &d) || batch < 1) return 0;
+    // valid for either stream setting
+    const size_t one = vit_ws(d, batch).total;
+    const int b0 = (batch + 1) / 2;
+    const size_t two = batch >= 2 ? vit_ws(d, b0).total + vit_ws(d, batch - b0).total : one;
+    return one > two ? one : two;
+}
+
+extern "C" int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, const float* pf, const void* images,
+                                int in_kind, int batch, float* out, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    VitDims d;
+    int rc = vit_dims(cfg, &d);
+    if (rc) return rc;
+    WISE_CHECK_ARG(wb && pf && images && out, "vit_forward: null pointer");
+    WISE_CHECK_ARG(batch >= 1, "vit_forward: batch=%d", batch);
+    WISE_CHECK_ARG(in_kind == WISE_VIT_IN_F32 || in_kind == WISE_VIT_IN_U8, "vit_forward: in_kind=%d", in_kind);
+    const size_t need = vit_total_ws(d, batch);
+    if (!workspace || workspace_bytes < need) {
+        set_error("vit_forward: workspace %zu < %zu bytes", workspace_bytes, need);
+        return WISE_E_WORKSPACE;
+    }
+    WISE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wb & 15) == 0 && ((uintptr_t)pf & 15) == 0,
+                   "vit_forward: workspace must be 256-byte and weight blobs 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const VitOffsets o = vit_offsets(d);
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+    if (vit_parts(batch) == 1) return vit_forward_part(cfg, d, o, wb, pf, images, in_kind, batch, out, wsb, st);
+
+    if ((rc = ensure_side_streams())) return rc;
+    const int b0 = (batch + 1) / 2, b1 = batch - b0;
+    const size_t img_elem = (in_kind == WISE_VIT_IN_U8) ? 1 : 4;
+    const size_t img_stride = (size_t)3 * d.S * d.S * img_elem;
+    const unsigned char* img = reinterpret_cast<const unsigned char*>(images);
+    hipError_t e = hipEventRecord(g_ev_fork, st);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamWaitEvent(g_side[i], g_ev_fork, 0);
+    if (e != hipSuccess) { set_error("vit_forward: fork: %s", hipGetErrorString(e)); return (int)e; }
+    rc = vit_forward_part(cfg, d, o, wb, pf, img, in_kind, b0, out, wsb, g_side[0]);
+    if (!rc)
+        rc = vit_forward_part(cfg, d, o, wb, pf, img + (size_t)b0 * img_stride, in_kind, b1, out + (size_t)b0 * d.D,
+                              wsb + vit_ws(d, b0).total, g_side[1]);
+    // always join, even after an error, so the caller's stream never runs ahead of the side streams
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e2 = hipEventRecord(g_ev_join[i], g_side[i]);
+        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(st, g_ev_join[i], 0);
+        if (e2 != hipSuccess && !rc) { set_error("vit_forward: join: %s", hipGetErrorString(e2)); rc = (int)e2; }
+    }
+    return rc;
 }
 
 extern "C" int wise_vit_tap_residual(const wise_vit_config* cfg, int batch, const void* workspace, float* dst,
@@ -545,10 +681,20 @@ extern "C" int wise_vit_tap_residual(const wise_vit_config* cfg, int batch, cons
     int rc = vit_dims(cfg, &d);
     if (rc) return rc;
     WISE_CHECK_ARG(workspace && dst && batch >= 1, "vit_tap_residual: bad argument");
-    const VitWs ws = vit_ws(d, batch);
-    hipError_t e = hipMemcpyAsync(dst, reinterpret_cast<const unsigned char*>(workspace) + ws.x,
-                                  (size_t)ws.M * d.W * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
-    if (e != hipSuccess) { set_error("vit_tap_residual: %s", hipGetErrorString(e)); return (int)e; }
+    const unsigned char* wsb = reinterpret_cast<const unsigned char*>(workspace);
+    const int parts = vit_parts(batch);
+    const int b0 = parts == 2 ? (batch + 1) / 2 : batch;
+    size_t base = 0;
+    float* dp = dst;
+    for (int i = 0; i < parts; ++i) {
+        const int bi = i == 0 ? b0 : batch - b0;
+        const VitWs ws = vit_ws(d, bi);
+        hipError_t e = hipMemcpyAsync(dp, wsb + base + ws.x, (size_t)ws.M * d.W * 4, hipMemcpyDeviceToDevice,
+                                      (hipStream_t)stream);
+        if (e != hipSuccess) { set_error("vit_tap_residual: %s", hipGetErrorString(e)); return (int)e; }
+        dp += (size_t)ws.M * d.W;
+        base += ws.total;
+    }
     return WISE_OK;
 }
 
