@@ -40,13 +40,18 @@ __global__ __launch_bounds__(256) void frontend_kernel(const float* __restrict__
                                                        const float* __restrict__ bn_scale,
                                                        const float* __restrict__ bn_shift,
                                                        float* __restrict__ melbn /*[B,Fc,64]*/) {
-    __shared__ float2 tw[512];
+    // per-stage compact twiddle tables: tw[half + j] = exp(-i*pi*j/half), j < half, so that the 64 lanes
+    // of a butterfly step read consecutive entries (one shared 512-entry table read with stride
+    // 1024/(2*half) puts all lanes of the middle stages on one bank)
+    __shared__ float2 tw[1024];
     __shared__ float2 bufs[4][N_FFT];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int j = threadIdx.x; j < 512; j += 256) {
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+        const int half = idx ? (1 << (31 - __clz(idx))) : 1;
+        const int j = idx - half;
         float s, c;
-        sincospif((float)j / 512.f, &s, &c);
-        tw[j] = make_float2(c, -s);  // exp(-2*pi*i*j/1024)
+        sincospif(idx ? (float)j / (float)half : 0.f, &s, &c);
+        tw[idx] = make_float2(c, -s);
     }
     __syncthreads();
     const long long fid = (long long)blockIdx.x * 4 + wv;
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(const float* __restrict__
             const int j = k & (half - 1);
             const int i0 = ((k >> (s - 1)) << s) + j;
             const int i1 = i0 + half;
-            const float2 t = tw[j << (10 - s)];
+            const float2 t = tw[half + j];
             const float2 a = buf[i0], q = buf[i1];
             const float tr = t.x * q.x - t.y * q.y, ti = t.x * q.y + t.y * q.x;
             buf[i0] = make_float2(a.x + tr, a.y + ti);
@@ -118,18 +123,19 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ me
                                                     const float* __restrict__ pw /*[96][16]*/,
                                                     const float* __restrict__ pb, const float* __restrict__ lnw,
                                                     const float* __restrict__ lnb, float* __restrict__ x) {
-    const int lane = threadIdx.x & 63;
-    const long long token = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (token >= (long long)B * 4096) return;
-    const int b = (int)(token >> 12), tok = (int)(token & 4095), i = tok >> 6, j = tok & 63;
-    float v = 0.f;
+    // block = one row i of the 64x64 token grid of one clip: image rows 4i..4i+3 = mel bins f0..f0+3 of
+    // time block r, all 256 image columns.  Thread t' resamples its 4 pixels (one float4 of 4 adjacent mel
+    // bins per tap), then each wave embeds 16 tokens with the conv weights held in registers.
+    __shared__ float pix[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x >> 6, i = blockIdx.x & 63;
     {
-        const int p = lane & 15, dy = p >> 2, dx = p & 3;
-        const int R = 4 * i + dy, r = R >> 6, fbin = R & 63;
-        const int t = r * 256 + 4 * j + dx;
-        const float* m = melbn + (size_t)b * Fc * 64 + fbin;
+        const int r = i >> 4, f0 = (4 * i) & 63;
+        const int t = r * 256 + threadIdx.x;
+        const float* m = melbn + (size_t)b * Fc * 64 + f0;
+        float4 v;
         if (Fc == MAXF) {
-            v = m[(size_t)t * 64];
+            v = *reinterpret_cast<const float4*>(m + (size_t)t * 64);
         } else {
             const float scale = (float)(Fc - 1) / (float)(MAXF - 1);
             const float src = (float)t * scale;
@@ -139,30 +145,45 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ me
             const float w0 = cubic2(tt + 1.f), w1 = cubic1(tt), w2 = cubic1(1.f - tt), w3 = cubic2(2.f - tt);
             const int a0 = min(max(i0 - 1, 0), Fc - 1), a1 = min(max(i0, 0), Fc - 1), a2 = min(max(i0 + 1, 0), Fc - 1),
                       a3 = min(max(i0 + 2, 0), Fc - 1);
+            const float4 q0 = *reinterpret_cast<const float4*>(m + (size_t)a0 * 64);
+            const float4 q1 = *reinterpret_cast<const float4*>(m + (size_t)a1 * 64);
+            const float4 q2 = *reinterpret_cast<const float4*>(m + (size_t)a2 * 64);
+            const float4 q3 = *reinterpret_cast<const float4*>(m + (size_t)a3 * 64);
             // same accumulation order as the oracle: taps 0..3 added in turn
-            v = m[(size_t)a0 * 64] * w0;
-            v += m[(size_t)a1 * 64] * w1;
-            v += m[(size_t)a2 * 64] * w2;
-            v += m[(size_t)a3 * 64] * w3;
+            v.x = q0.x * w0; v.x += q1.x * w1; v.x += q2.x * w2; v.x += q3.x * w3;
+            v.y = q0.y * w0; v.y += q1.y * w1; v.y += q2.y * w2; v.y += q3.y * w3;
+            v.z = q0.z * w0; v.z += q1.z * w1; v.z += q2.z * w2; v.z += q3.z * w3;
+            v.w = q0.w * w0; v.w += q1.w * w1; v.w += q2.w * w2; v.w += q3.w * w3;
         }
+        pix[0][threadIdx.x] = v.x; pix[1][threadIdx.x] = v.y; pix[2][threadIdx.x] = v.z; pix[3][threadIdx.x] = v.w;
     }
-    float pv[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) pv[p] = __shfl(v, p, 64);
     const int c0 = lane, c1 = lane + 64;
     const bool has1 = c1 < EMBED;
-    float y0 = pb[c0], y1 = has1 ? pb[c1] : 0.f;
+    float w0r[16], w1r[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-        y0 = fmaf(pw[c0 * 16 + p], pv[p], y0);
-        if (has1) y1 = fmaf(pw[c1 * 16 + p], pv[p], y1);
+        w0r[p] = pw[c0 * 16 + p];
+        w1r[p] = has1 ? pw[c1 * 16 + p] : 0.f;
     }
-    const float mean = wave_sum(y0 + (has1 ? y1 : 0.f)) / (float)EMBED;
-    const float d0 = y0 - mean, d1 = has1 ? y1 - mean : 0.f;
-    const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / (float)EMBED + 1e-5f);
-    float* xr = x + (size_t)token * EMBED;
-    xr[c0] = d0 * rstd * lnw[c0] + lnb[c0];
-    if (has1) xr[c1] = d1 * rstd * lnw[c1] + lnb[c1];
+    const float b0 = pb[c0], b1 = has1 ? pb[c1] : 0.f;
+    const float g0 = lnw[c0], g1 = has1 ? lnw[c1] : 0.f, h0 = lnb[c0], h1 = has1 ? lnb[c1] : 0.f;
+    __syncthreads();
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = wv * 16 + jj;
+        float y0 = b0, y1 = b1;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const float pv = pix[p >> 2][4 * j + (p & 3)];
+            y0 = fmaf(w0r[p], pv, y0);
+            y1 = fmaf(w1r[p], pv, y1);
+        }
+        const float mean = wave_sum(y0 + (has1 ? y1 : 0.f)) / (float)EMBED;
+        const float d0 = y0 - mean, d1 = has1 ? y1 - mean : 0.f;
+        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / (float)EMBED + 1e-5f);
+        float* xr = x + ((size_t)blockIdx.x * 64 + j) * EMBED;
+        xr[c0] = d0 * rstd * g0 + h0;
+        if (has1) xr[c1] = d1 * rstd * g1 + h1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,17 +407,12 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ nw,
-                                                   const float* __restrict__ nb, const bf16_t* __restrict__ w1,
-                                                   const bf16_t* __restrict__ w2, const float* __restrict__ lw,
-                                                   const float* __restrict__ lb, float* __restrict__ out) {
-    __shared__ float lat[LATENT];
+// latent: block per clip. x [B*64, 768] fp32 -> final LN -> token mean -> bf16 [B, 768]
+__global__ __launch_bounds__(256) void latent_kernel(const float* __restrict__ x, const float* __restrict__ nw,
+                                                     const float* __restrict__ nb, bf16_t* __restrict__ lat) {
     __shared__ float part[4][LATENT];  // per-wave partial token sums, added in a fixed order (deterministic)
-    __shared__ float e1[OUT], ge[OUT], e[OUT];
-    __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* xb = x + (size_t)blockIdx.x * 64 * LATENT;
-    // each wave normalises 16 tokens; 768 = 12 per lane
     float accl[12];
 #pragma unroll
     for (int u = 0; u < 12; ++u) accl[u] = 0.f;
@@ -416,58 +432,36 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
 #pragma unroll
     for (int u = 0; u < 12; ++u) part[wv][u * 64 + lane] = accl[u];
     __syncthreads();
-    for (int c = tid; c < LATENT; c += 256) lat[c] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) * (1.f / 64.f);
-    __syncthreads();
-    // e1 = W1 @ latent (1024 x 768), wave per output row
-    for (int r = wv; r < OUT; r += 4) {
-        const bf16_t* wr = w1 + (size_t)r * LATENT;
-        float acc = 0.f;
-        for (int c = lane * 8; c < LATENT; c += 512) {
-            const short8 pv = *reinterpret_cast<const short8*>(wr + c);
+    for (int c = tid; c < LATENT; c += 256)
+        lat[(size_t)blockIdx.x * LATENT + c] =
+            f32_to_bf16(((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) * (1.f / 64.f));
+}
+
+// out[b,:] = normalize( LayerNorm(e[b,:]) ) with e = e1 + e2 already summed by the GEMM epilogue; wave per clip
+__global__ __launch_bounds__(256) void proj_ln_norm_kernel(const float* __restrict__ e, int B,
+                                                           const float* __restrict__ lw, const float* __restrict__ lb,
+                                                           float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* er = e + (size_t)b * OUT;
+    float v[16], s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc = fmaf(lat[c + j], bf16_to_f32((bf16_t)pv[j]), acc);
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) { e1[r] = acc; ge[r] = gelu_erf(acc); }
-    }
-    __syncthreads();
-    for (int r = wv; r < OUT; r += 4) {
-        const bf16_t* wr = w2 + (size_t)r * OUT;
-        float acc = 0.f;
-        for (int c = lane * 8; c < OUT; c += 512) {
-            const short8 pv = *reinterpret_cast<const short8*>(wr + c);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc = fmaf(ge[c + j], bf16_to_f32((bf16_t)pv[j]), acc);
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) e[r] = e1[r] + acc;
-    }
-    __syncthreads();
-    float s = 0.f;
-    for (int c = tid; c < OUT; c += 256) s += e[c];
-    s = wave_sum(s);
-    if (lane == 0) red[wv] = s;
-    __syncthreads();
-    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)OUT;
-    __syncthreads();
+    for (int u = 0; u < 16; ++u) { v[u] = er[u * 64 + lane]; s += v[u]; }
+    const float mean = wave_sum(s) / (float)OUT;
     float q = 0.f;
-    for (int c = tid; c < OUT; c += 256) { const float d = e[c] - mean; q += d * d; }
-    q = wave_sum(q);
-    if (lane == 0) red[wv] = q;
-    __syncthreads();
-    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)OUT + 1e-5f);
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const float d = v[u] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)OUT + 1e-5f);
     float sq = 0.f;
-    for (int c = tid; c < OUT; c += 256) {
-        const float y = (e[c] - mean) * rstd * lw[c] + lb[c];
-        e[c] = y;
-        sq += y * y;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        v[u] = (v[u] - mean) * rstd * lw[u * 64 + lane] + lb[u * 64 + lane];
+        sq += v[u] * v[u];
     }
-    sq = wave_sum(sq);
-    if (lane == 0) red[4 + wv] = sq;
-    __syncthreads();
-    const float nrm = sqrtf(red[4] + red[5] + red[6] + red[7]);
-    for (int c = tid; c < OUT; c += 256) out[(size_t)blockIdx.x * OUT + c] = e[c] / nrm;
+    const float nrm = sqrtf(wave_sum(sq));
+#pragma unroll
+    for (int u = 0; u < 16; ++u) out[(size_t)b * OUT + u * 64 + lane] = v[u] / nrm;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -571,7 +565,7 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
                        samples, Fc, pf + o.hann, pf + o.mel_start, pf + o.mel_len, pf + o.mel_wt, pf + o.bn_scale,
                        pf + o.bn_shift, mel);
     WISE_LAUNCH_CHECK("htsat frontend_kernel");
-    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)(((long long)B * 4096 + 3) / 4)), dim3(256), 0, st, mel, B, Fc,
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)(B * 64)), dim3(256), 0, st, mel, B, Fc,
                        pf + o.pe_w, pf + o.pe_b, pf + o.pe_nw, pf + o.pe_nb, x);
     WISE_LAUNCH_CHECK("htsat embed_kernel");
 
@@ -618,9 +612,20 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
             H >>= 1;
         }
     }
-    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, st, x, pf + o.fin_nw, pf + o.fin_nb, wb + o.pj_w1,
-                       wb + o.pj_w2, pf + o.pj_lw, pf + o.pj_lb, out);
-    WISE_LAUNCH_CHECK("htsat head_kernel");
+    // head: final LN + token mean -> latent bf16 [Bp,768] (aliases h); Projection as three small GEMMs:
+    // e = lat@W1^T (fp32, aliases qkv), g = gelu(lat@W1^T) (bf16, aliases a), e += g@W2^T; then LN + L2 norm
+    {
+        const int Bp = (B + 127) / 128 * 128;
+        float* e = reinterpret_cast<float*>(qkv);
+        hipLaunchKernelGGL(latent_kernel, dim3(B), dim3(256), 0, st, x, pf + o.fin_nw, pf + o.fin_nb, h);
+        WISE_LAUNCH_CHECK("htsat latent_kernel");
+        if ((rc = gemm_bf16(h, wb + o.pj_w1, nullptr, Bp, OUT, LATENT, 4, e, st))) return rc;
+        if ((rc = gemm_bf16(h, wb + o.pj_w1, nullptr, Bp, OUT, LATENT, 2, a, st))) return rc;
+        if ((rc = gemm_bf16(a, wb + o.pj_w2, nullptr, Bp, OUT, OUT, 3, e, st))) return rc;
+        hipLaunchKernelGGL(proj_ln_norm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, e, B, pf + o.pj_lw, pf + o.pj_lb,
+                           out);
+        WISE_LAUNCH_CHECK("htsat proj_ln_norm_kernel");
+    }
     return WISE_OK;
 }
 
