@@ -14,6 +14,10 @@ SHAPES = [  # (name, M, N, K, mode)
     ("out   12800x768x768", 12800, 768, 768, 3),
     ("fc    12800x3072x768", 12800, 3072, 768, 1),
     ("proj  12800x768x3072", 12800, 768, 3072, 3),
+    ("h-qkv  6400x2304x768", 6400, 2304, 768, 0),
+    ("h-out  6400x768x768", 6400, 768, 768, 3),
+    ("h-fc   6400x3072x768", 6400, 3072, 768, 1),
+    ("h-proj 6400x768x3072", 6400, 768, 3072, 3),
     ("L14qkv 65792x3072x1024", 65792, 3072, 1024, 0),
     ("L14proj 65792x1024x4096", 65792, 1024, 4096, 3),
 ]

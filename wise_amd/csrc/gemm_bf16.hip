@@ -21,6 +21,7 @@ namespace wise {
 enum : int { EPI_BF16 = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4 };
 
 __device__ int g_group_m = 0;        // 0 = default; tuning knob (bits 16..23 of wise_debug_set_gemm_variant)
+__device__ int g_epi_lds = 1;        // bf16 epilogue through LDS (bit 30 of the debug knob turns it off)
 __device__ int g_dephase = 0;        // tuning knob (bits 24..27): initial s_sleep units for the second block per CU
 __device__ int g_skip_epilogue = 0;  // timing-only ablation (tools/gemm_bench.py), set via wise_debug_set_gemm_variant
 
@@ -112,6 +113,57 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int group_
     *tn = in_group / gsize;
 }
 
+// bf16-output epilogue through LDS: the MFMA layout gives a lane 4 consecutive columns of one row
+// (8-byte pieces, 32-byte row segments: four store instructions per 128-byte line).  Each wave writes its
+// 64x64 sub-tile to a private LDS image (144-byte row stride) and reads it back row-major, so that every
+// global store instruction writes 8 complete 128-byte row segments with 16 bytes per lane.
+// Precondition: all waves of the block have finished reading the staging buffers (block barrier).
+template <int MODE>
+__device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[4][4], const float* __restrict__ bias,
+                                             bf16_t* __restrict__ out, int N, int m0, int n0, int wm, int wn, int lane,
+                                             int wave, unsigned char* smem) {
+    constexpr int RS = 144;
+    unsigned char* my = smem + wave * (64 * RS);
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + g * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && n < N) bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z,
+                  v3 = acc[i][j][3] + bv.w;
+            if (MODE == EPI_QUICKGELU) {
+                v0 = act_quickgelu(v0); v1 = act_quickgelu(v1); v2 = act_quickgelu(v2); v3 = act_quickgelu(v3);
+            } else if (MODE == EPI_GELU) {
+                v0 = act_gelu(v0); v1 = act_gelu(v1); v2 = act_gelu(v2); v3 = act_gelu(v3);
+            }
+            uint2 pk;
+            pk.x = pack_bf16x2(v0, v1);
+            pk.y = pack_bf16x2(v2, v3);
+            *reinterpret_cast<uint2*>(my + (i * 16 + l15) * RS + (j * 16 + g * 4) * 2) = pk;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool skip = g_skip_epilogue != 0;
+    const int chunk = lane & 7;
+    const int n = n0 + wn * 64 + chunk * 8;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int row = t * 8 + (lane >> 3);
+        const uint4 v = *reinterpret_cast<const uint4*>(my + row * RS + chunk * 16);
+        if (skip && v.x != 0x12345678u) continue;
+        bf16_t* dst = out + (size_t)(m0 + wm * 64 + row) * N + n;
+        if (n + 8 <= N)
+            *reinterpret_cast<uint4*>(dst) = v;
+        else if (n + 4 <= N)
+            *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
+    }
+}
+
 template <int MODE, int ABL = 0>  // ABL (timing-only builds): 1 = no staging in the loop, 2 = no LDS reads / MFMA
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
                                                            const bf16_t* __restrict__ Wt,
@@ -174,7 +226,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
         }
     }
 
-    epilogue<MODE>(acc, bias, out, N, m0, n0, wm, wn, lane);
+    if ((MODE == EPI_BF16 || MODE == EPI_QUICKGELU || MODE == EPI_GELU) && (N & 7) == 0 && g_epi_lds) {
+        __syncthreads();  // staging buffers are dead from here on
+        epilogue_lds<MODE>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
+    } else {
+        epilogue<MODE>(acc, bias, out, N, m0, n0, wm, wn, lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -303,6 +360,101 @@ static void launch_ring(const bf16_t* A, const bf16_t* Wt, const float* bias, in
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, Wt, bias, M, N, K, out);
 }
 
+// Persistent variant of the 128x128 kernel: a fixed grid (2 blocks per CU) walks the tiles; the next
+// tile's first K-step is staged BEFORE the epilogue of the current one, so the epilogue's stores and
+// the prologue's load latency overlap instead of adding up.
+__device__ __forceinline__ void tile_coords_id(int id, int tiles_m, int tiles_n, int group_m, int* tm, int* tn) {
+    const int per_group = group_m * tiles_n;
+    const int gid = id / per_group;
+    const int first_m = gid * group_m;
+    const int gsize = min(tiles_m - first_m, group_m);
+    const int in_group = id - gid * per_group;
+    *tm = first_m + in_group % gsize;
+    *tn = in_group / gsize;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const bf16_t* __restrict__ A,
+                                                              const bf16_t* __restrict__ Wt,
+                                                              const float* __restrict__ bias, int M, int N, int K,
+                                                              void* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = M / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+    const int gm = g_group_m ? g_group_m : 8;
+    // blocks b, b+8, ... share an XCD: give each XCD a contiguous run of slots
+    const int per_xcd = gridDim.x >> 3;
+    int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int nk = K / BK;
+    int tm, tn;
+    if (tile < ntiles) {
+        tile_coords_id(tile, tiles_m, tiles_n, gm, &tm, &tn);
+        stage_tile(A, K, tm * BM, 0, smem, wave, lane, M - 1);
+        stage_tile(Wt, K, tn * BN, 0, smem + TILE_BYTES, wave, lane, N - 1);
+    }
+    while (tile < ntiles) {
+        const int m0 = tm * BM, n0 = tn * BN;
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            __syncthreads();
+            if (kt + 1 < nk) {
+                unsigned char* nb = smem + (cur ^ 1) * 2 * TILE_BYTES;
+                stage_tile(A, K, m0, (kt + 1) * BK, nb, wave, lane, M - 1);
+                stage_tile(Wt, K, n0, (kt + 1) * BK, nb + TILE_BYTES, wave, lane, N - 1);
+            }
+            const unsigned char* At = smem + cur * 2 * TILE_BYTES;
+            const unsigned char* Bt = At + TILE_BYTES;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int chunk = s * 4 + (lane >> 4);
+                bf16x8 af[4], wf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = lds_frag(At, wm * 64 + i * 16 + (lane & 15), chunk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[j] = lds_frag(Bt, wn * 64 + j * 16 + (lane & 15), chunk);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // every wave is done reading LDS: buffer 0 may take the next tile
+        const int next = tile + gridDim.x;
+        if (next < ntiles) {
+            tile_coords_id(next, tiles_m, tiles_n, gm, &tm, &tn);
+            stage_tile(A, K, tm * BM, 0, smem, wave, lane, M - 1);
+            stage_tile(Wt, K, tn * BN, 0, smem + TILE_BYTES, wave, lane, N - 1);
+        }
+        epilogue<MODE>(acc, bias, out, N, m0, n0, wm, wn, lane);
+        tile = next;
+    }
+}
+
+template <int MODE>
+static void launch_persist(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
+                           hipStream_t st) {
+    auto kern = gemm_persist_kernel<MODE>;
+    const size_t lds = 4 * TILE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    const int ntiles = (M / BM) * ((N + BN - 1) / BN);
+    int grid = 512;
+    if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, Wt, bias, M, N, K, out);
+}
+
 template <int MODE, int ABL = 0>
 static void launch_gemm(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
                         hipStream_t st) {
@@ -374,7 +526,7 @@ __device__ __forceinline__ void stage_rows8(const bf16_t* __restrict__ G, int ld
     }
 }
 
-template <int MODE, int NT>
+template <int MODE, int NT, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                           const float* __restrict__ bias, int M, int N, int K,
                                                           void* __restrict__ out) {
@@ -402,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const bf16_t* __restri
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         __syncthreads();
-        if (kt + 1 < nk) {
+        if (ABL != 1 && kt + 1 < nk) {
             unsigned char* nb = smem + (cur ^ 1) * SB;
             stage_rows8<BMB>(A, K, m0, (kt + 1) * 64, nb, wave, lane);
             stage_rows8<BNB>(Wt, K, n0, (kt + 1) * 64, nb + TA, wave, lane);
@@ -427,10 +579,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const bf16_t* __restri
     epilogue_big<MODE, NT>(acc, bias, out, N, m0, n0, wm, wn, lane);
 }
 
-template <int MODE, int NT>
+template <int MODE, int NT, int ABL = 0>
 static void launch_big(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
                        hipStream_t st) {
-    auto kern = gemm_big_kernel<MODE, NT>;
+    auto kern = gemm_big_kernel<MODE, NT, ABL>;
     const size_t lds = (size_t)2 * (256 + 64 * NT) * 128;
     static bool attr_set = false;
     if (!attr_set) {
@@ -572,6 +724,9 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 15: if (M % 256 == 0) { launch_bigring<MODE, 2, 32, 4>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 31: if (M % 256 == 0 && N % 256 == 0) { launch_big<MODE, 4, 1>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 30: launch_persist<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 16: launch_ring<MODE, 32, 2, 4>(A, Wt, bias, M, N, K, out, st); break;   // 32 KB LDS: 4 blocks/CU
         case 17: launch_ring<MODE, 32, 3, 3>(A, Wt, bias, M, N, K, out, st); break;   // 48 KB LDS: 3 blocks/CU
         case 20: launch_ring<MODE, 64, 4, 1, 2>(A, Wt, bias, M, N, K, out, st); break;   // load-only ablations
@@ -628,6 +783,8 @@ extern "C" int wise_debug_set_gemm_variant(int v) {
     wise::g_gemm_variant = v & 0xFF;
     int skip = (v >> 8) & 1;  // bit 8: skip epilogue stores (timing-only ablation)
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_skip_epilogue), &skip, sizeof(int));
+    int el = ((v >> 30) & 1) ? 0 : 1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_epi_lds), &el, sizeof(int));
     int dp = (v >> 24) & 0x3F;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_dephase), &dp, sizeof(int));
     int gm = (v >> 16) & 0xFF;

@@ -577,17 +577,18 @@ static int vit_forward_part(const wise_vit_config* cfg, const VitDims& d, const 
     return WISE_OK;
 }
 
-// Two halves of a batch are independent; running them on two internal streams lets one half's GEMM
-// tails and barrier bubbles be filled by the other half's kernels (and its LayerNorm / attention
+// Parts of a batch are independent; running them on separate internal streams lets one part's GEMM
+// tails and barrier bubbles be filled by the other parts' kernels (and their LayerNorm / attention
 // traffic overlap the GEMM main loops).  Fork/join with events, so the call stays stream-ordered for
 // the caller and graph-capturable once the internal streams exist (first call creates them).
-static hipStream_t g_side[2] = {nullptr, nullptr};
-static hipEvent_t g_ev_fork = nullptr, g_ev_join[2] = {nullptr, nullptr};
+constexpr int MAX_PARTS = 4;
+static hipStream_t g_side[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
+static hipEvent_t g_ev_fork = nullptr, g_ev_join[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
 static int g_vit_streams = 2;
 
 static int ensure_side_streams() {
     if (g_side[0]) return WISE_OK;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MAX_PARTS; ++i) {
         hipError_t e = hipStreamCreateWithFlags(&g_side[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g_ev_join[i], hipEventDisableTiming);
         if (e != hipSuccess) { set_error("vit_forward: side stream: %s", hipGetErrorString(e)); return (int)e; }
@@ -597,11 +598,25 @@ static int ensure_side_streams() {
     return WISE_OK;
 }
 
-static int vit_parts(int batch) { return (g_vit_streams >= 2 && batch >= 64) ? 2 : 1; }
-static size_t vit_total_ws(const VitDims& d, int batch) {
-    if (vit_parts(batch) == 1) return vit_ws(d, batch).total;
-    const int b0 = (batch + 1) / 2;
-    return vit_ws(d, b0).total + vit_ws(d, batch - b0).total;
+// number of parts for a batch under `streams`, and part i's [begin, end) images
+static int parts_for(int batch, int streams) {
+    int p = streams < 1 ? 1 : (streams > MAX_PARTS ? MAX_PARTS : streams);
+    while (p > 1 && batch / p < 32) --p;  // keep every part at least 32 images
+    return p;
+}
+static int vit_parts(int batch) { return parts_for(batch, g_vit_streams); }
+static void part_range(int batch, int parts, int i, int* lo, int* hi) {
+    *lo = (int)((long long)batch * i / parts);
+    *hi = (int)((long long)batch * (i + 1) / parts);
+}
+static size_t total_ws_for(const VitDims& d, int batch, int parts) {
+    size_t t = 0;
+    for (int i = 0; i < parts; ++i) {
+        int lo, hi;
+        part_range(batch, parts, i, &lo, &hi);
+        t += vit_ws(d, hi - lo).total;
+    }
+    return t;
 }
 
 }  // namespace wise
@@ -626,11 +641,12 @@ extern "C" int wise_vit_layout(const wise_vit_config* cfg, int64_t* wb_elems, in
 extern "C" size_t wise_vit_workspace_bytes(const wise_vit_config* cfg, int batch) {
     VitDims d;
     if (vit_dims(cfg, &d) || batch < 1) return 0;
-    // valid for either stream setting
-    const size_t one = vit_ws(d, batch).total;
-    const int b0 = (batch + 1) / 2;
-    const size_t two = batch >= 2 ? vit_ws(d, b0).total + vit_ws(d, batch - b0).total : one;
-    return one > two ? one : two;
+    size_t best = 0;  // valid for every stream setting
+    for (int s = 1; s <= MAX_PARTS; ++s) {
+        const size_t t = total_ws_for(d, batch, parts_for(batch, s));
+        if (t > best) best = t;
+    }
+    return best;
 }
 
 extern "C" int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, const float* pf, const void* images,
@@ -642,7 +658,8 @@ extern "C" int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, 
     WISE_CHECK_ARG(wb && pf && images && out, "vit_forward: null pointer");
     WISE_CHECK_ARG(batch >= 1, "vit_forward: batch=%d", batch);
     WISE_CHECK_ARG(in_kind == WISE_VIT_IN_F32 || in_kind == WISE_VIT_IN_U8, "vit_forward: in_kind=%d", in_kind);
-    const size_t need = vit_total_ws(d, batch);
+    const int parts = vit_parts(batch);
+    const size_t need = total_ws_for(d, batch, parts);
     if (!workspace || workspace_bytes < need) {
         set_error("vit_forward: workspace %zu < %zu bytes", workspace_bytes, need);
         return WISE_E_WORKSPACE;
@@ -652,22 +669,25 @@ extern "C" int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, 
     hipStream_t st = (hipStream_t)stream;
     const VitOffsets o = vit_offsets(d);
     unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
-    if (vit_parts(batch) == 1) return vit_forward_part(cfg, d, o, wb, pf, images, in_kind, batch, out, wsb, st);
+    if (parts == 1) return vit_forward_part(cfg, d, o, wb, pf, images, in_kind, batch, out, wsb, st);
 
     if ((rc = ensure_side_streams())) return rc;
-    const int b0 = (batch + 1) / 2, b1 = batch - b0;
     const size_t img_elem = (in_kind == WISE_VIT_IN_U8) ? 1 : 4;
     const size_t img_stride = (size_t)3 * d.S * d.S * img_elem;
     const unsigned char* img = reinterpret_cast<const unsigned char*>(images);
     hipError_t e = hipEventRecord(g_ev_fork, st);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamWaitEvent(g_side[i], g_ev_fork, 0);
+    for (int i = 0; i < parts && e == hipSuccess; ++i) e = hipStreamWaitEvent(g_side[i], g_ev_fork, 0);
     if (e != hipSuccess) { set_error("vit_forward: fork: %s", hipGetErrorString(e)); return (int)e; }
-    rc = vit_forward_part(cfg, d, o, wb, pf, img, in_kind, b0, out, wsb, g_side[0]);
-    if (!rc)
-        rc = vit_forward_part(cfg, d, o, wb, pf, img + (size_t)b0 * img_stride, in_kind, b1, out + (size_t)b0 * d.D,
-                              wsb + vit_ws(d, b0).total, g_side[1]);
+    size_t base = 0;
+    for (int i = 0; i < parts && !rc; ++i) {
+        int lo, hi;
+        part_range(batch, parts, i, &lo, &hi);
+        rc = vit_forward_part(cfg, d, o, wb, pf, img + (size_t)lo * img_stride, in_kind, hi - lo,
+                              out + (size_t)lo * d.D, wsb + base, g_side[i]);
+        base += vit_ws(d, hi - lo).total;
+    }
     // always join, even after an error, so the caller's stream never runs ahead of the side streams
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < parts; ++i) {
         hipError_t e2 = hipEventRecord(g_ev_join[i], g_side[i]);
         if (e2 == hipSuccess) e2 = hipStreamWaitEvent(st, g_ev_join[i], 0);
         if (e2 != hipSuccess && !rc) { set_error("vit_forward: join: %s", hipGetErrorString(e2)); rc = (int)e2; }
@@ -683,12 +703,12 @@ extern "C" int wise_vit_tap_residual(const wise_vit_config* cfg, int batch, cons
     WISE_CHECK_ARG(workspace && dst && batch >= 1, "vit_tap_residual: bad argument");
     const unsigned char* wsb = reinterpret_cast<const unsigned char*>(workspace);
     const int parts = vit_parts(batch);
-    const int b0 = parts == 2 ? (batch + 1) / 2 : batch;
     size_t base = 0;
     float* dp = dst;
     for (int i = 0; i < parts; ++i) {
-        const int bi = i == 0 ? b0 : batch - b0;
-        const VitWs ws = vit_ws(d, bi);
+        int lo, hi;
+        part_range(batch, parts, i, &lo, &hi);
+        const VitWs ws = vit_ws(d, hi - lo);
         hipError_t e = hipMemcpyAsync(dp, wsb + base + ws.x, (size_t)ws.M * d.W * 4, hipMemcpyDeviceToDevice,
                                       (hipStream_t)stream);
         if (e != hipSuccess) { set_error("vit_tap_residual: %s", hipGetErrorString(e)); return (int)e; }
