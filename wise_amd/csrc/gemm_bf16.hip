@@ -752,7 +752,8 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
         // shape heuristic (measured, tools/gemm_bench.py): when a 256x192 tiling fits the chip in ONE
         // round (<= 256 tiles) it beats 128x128 (fewer staged bytes, no second-round tail); otherwise the
         // 128x128 tile at two blocks per CU wins because its epilogue overlaps the other block's main loop.
-        if (M % 256 == 0 && N % 192 == 0 && K % 64 == 0 && (long long)(M / 256) * (N / 192) <= 256) v = 5;
+        const long long t5 = (long long)(M / 256) * (N / 192);
+        if (M % 256 == 0 && N % 192 == 0 && K % 64 == 0 && t5 <= 256 && t5 >= 160) v = 5;
         else if (K % 64 != 0) v = 1;  // K multiple of 32 only (HTSAT C=96): the BK=32 ring kernel
     } else if (v == 100) {
         v = 0;  // force the 128x128 kernel (A/B runs)
