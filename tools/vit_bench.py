@@ -20,7 +20,7 @@ def main():
     eng = VitEngine(spec, random_state_dict(spec, 0), max_batch=B)
     x = torch.randn(B, 3, 224, 224, device="cuda")
     ref = None
-    for streams in (1, 2, 3, 4, 2, 4):
+    for streams in (1, 2, 1, 2):
         lib.wise_debug_set_vit_streams(streams)
         for _ in range(5):
             o = eng.forward(x)

@@ -89,14 +89,16 @@ int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows,
 // stand, the B operand of O^T = V^T P^T (MFMA k-slot order permuted consistently on the V^T side).
 // V^T comes from a wave-private LDS image [64 dh][64 keys (+4 pad)].
 // ------------------------------------------------------------------------------------------------
-constexpr int VT_LD = 68;  // bf16 elements per V^T row (64 keys + pad) = 136 B
+constexpr int V_RS = 144;  // bytes per V row in LDS (64 dh bf16 = 128 B + 16 B pad)
+using short4v = __attribute__((ext_vector_type(4))) short;
 
+template <int QT>
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, int B, int T, int H,
                                                         bf16_t* __restrict__ o) {
-    __shared__ __attribute__((aligned(16))) bf16_t vt_all[4][64 * VT_LD];
+    __shared__ __attribute__((aligned(16))) unsigned char v_all[4][64 * V_RS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int nqc = (T + 63) >> 6;
+    const int nqc = (T + 16 * QT - 1) / (16 * QT);
     const long long item = (long long)blockIdx.x * 4 + wave;  // (b, h, qc)
     if (item >= (long long)B * H * nqc) return;
     const int qc = (int)(item % nqc);
@@ -104,33 +106,35 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     const int b = (int)(item / ((long long)nqc * H));
     const int W = H * 64, W3 = 3 * W;
     const bf16_t* base = qkv + (size_t)b * T * W3;
-    bf16_t* vt = vt_all[wave];
+    unsigned char* vimg = v_all[wave];
     const int l15 = lane & 15, g = lane >> 4;
 
     // Q fragments: B operand, lane holds Q[query = qt*16 + l15][dh = s*32 + 8g .. +7]
-    bf16x8 qf[4][2];
+    bf16x8 qf[QT][2];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-        int t = qc * 64 + qt * 16 + l15;
+    for (int qt = 0; qt < QT; ++qt) {
+        int t = qc * (16 * QT) + qt * 16 + l15;
         if (t >= T) t = T - 1;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
             qf[qt][s] = *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + h * 64 + s * 32 + g * 8);
     }
 
-    f32x4 oacc[4][4];  // [dt][qt]: O^T[dh = dt*16 + g*4 + r][query = qt*16 + l15]
+    f32x4 oacc[4][QT];  // [dt][qt]: O^T[dh = dt*16 + g*4 + r][query = qt*16 + l15]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mrun[4], lrun[4];
+        for (int j = 0; j < QT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun[QT], lrun[QT];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) { mrun[qt] = -INFINITY; lrun[qt] = 0.f; }
+    for (int qt = 0; qt < QT; ++qt) { mrun[qt] = -INFINITY; lrun[qt] = 0.f; }
     const float sc = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
 
     const int nkb = (T + 63) >> 6;
     for (int kb = 0; kb < nkb; ++kb) {
-        // ---- V^T image: 8 passes, lane reads 16 B of V row (key = p*8 + lane/8, dh = (lane&7)*8 ..)
+        // ---- V image, row-major [64 keys][64 dh]: 8 passes, lane copies 16 B of V row key = p*8 + lane/8;
+        //      the transpose the PV product needs is done by ds_read_b64_tr_b16 on the way out
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -138,16 +142,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
             int t = kb * 64 + key;
             const bool valid = t < T;
             if (!valid) t = T - 1;
-            short8 v = *reinterpret_cast<const short8*>(base + (size_t)t * W3 + 2 * W + h * 64 + (lane & 7) * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) vt[((lane & 7) * 8 + j) * VT_LD + key] = valid ? (bf16_t)v[j] : (bf16_t)0;
+            uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)t * W3 + 2 * W + h * 64 + (lane & 7) * 8);
+            if (!valid) v = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(vimg + key * V_RS + (lane & 7) * 16) = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // ---- S^T[kt][qt] = K Q^T
-        f32x4 sacc[4][4];
+        f32x4 sacc[4][QT];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             int t = kb * 64 + kt * 16 + l15;
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
             bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + W + h * 64 + g * 8);
             bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + W + h * 64 + 32 + g * 8);
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[qt][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[qt][1], c, 0, 0, 0);
@@ -163,9 +167,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
             }
         }
         // ---- online softmax per query column (qt, l15); this lane holds keys kt*16 + g*4 + r
-        bf16x8 pf[2][4];  // [ks][qt] B operand of the PV product
+        bf16x8 pf[2][QT];  // [ks][qt] B operand of the PV product
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
@@ -213,25 +217,29 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const bf16_t* rowp = vt + (dt * 16 + l15) * VT_LD + ks * 32 + g * 4;
-                const uint2 lo = *reinterpret_cast<const uint2*>(rowp);
-                const uint2 hi = *reinterpret_cast<const uint2*>(rowp + 16);
-                union { uint4 u; bf16x8 f; } cv;
-                cv.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                // transposed LDS read: the 16 lanes of group g fetch a 4-key x 16-dh block; lane 4q+p supplies
+                // the address of key row q, dh 4p..4p+3 and receives dh column (dt*16 + l15) of the 4 keys
+                const unsigned char* blk = vimg + (ks * 32 + g * 4 + (l15 >> 2)) * V_RS + (dt * 16 + (l15 & 3) * 4) * 2;
+                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4v*)(blk));
+                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4v*)(blk + 16 * V_RS));
+                union { short8 s; bf16x8 f; } cv;
+                cv.s = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
                     oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cv.f, pf[ks][qt], oacc[dt][qt], 0, 0, 0);
             }
         }
     }
     // ---- normalise and store O[query][h*64 + dt*16 + g*4 + r]
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         float l = lrun[qt];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.f / l;
-        const int t = qc * 64 + qt * 16 + l15;
+        const int t = qc * (16 * QT) + qt * 16 + l15;
         if (t < T) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -244,11 +252,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     }
 }
 
+static int g_attn_qt = 0;  // query tiles (of 16) per wave; 0 = by sequence length (debug knob overrides)
+
 int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st) {
     WISE_CHECK_ARG(qkv && o && B > 0 && T > 0 && H > 0, "attention: bad argument");
-    const int nqc = (T + 63) / 64;
+    // 32 queries per wave (126 VGPRs, 4 waves/SIMD) hides latency best when one key block covers T; longer
+    // sequences prefer 64 queries per wave (K/V re-read half as often)
+    const int qt = g_attn_qt ? (g_attn_qt == 4 ? 4 : 2) : (T <= 64 ? 2 : 4);
+    const int nqc = (T + 16 * qt - 1) / (16 * qt);
     const long long items = (long long)B * H * nqc;
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, B, T, H, o);
+    const dim3 grid((unsigned)((items + 3) / 4)), block(256);
+    if (qt == 4)
+        hipLaunchKernelGGL(attention_kernel<4>, grid, block, 0, st, qkv, B, T, H, o);
+    else
+        hipLaunchKernelGGL(attention_kernel<2>, grid, block, 0, st, qkv, B, T, H, o);
     WISE_LAUNCH_CHECK("attention_kernel");
     return WISE_OK;
 }
@@ -624,7 +641,8 @@ static size_t total_ws_for(const VitDims& d, int batch, int parts) {
 using namespace wise;
 
 extern "C" int wise_debug_set_vit_streams(int n) {
-    g_vit_streams = n;
+    g_vit_streams = n & 0xFF;
+    if (n >> 8) g_attn_qt = n >> 8;  // bits 8..: attention query tiles per wave (2 or 4)
     return 0;
 }
 
