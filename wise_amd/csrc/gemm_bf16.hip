@@ -696,6 +696,184 @@ static void launch_bigring(const bf16_t* A, const bf16_t* Wt, const float* bias,
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
 }
 
+// bf16 epilogue through LDS for the 8-wave 256x256 tile (wave = 128 rows x 64 columns): same idea as
+// epilogue_lds, done in two 64-row halves so the eight wave-private images (64 x 144 B) fit 128 KiB.
+// Precondition: block barrier after the last fragment read.
+template <int MODE>
+__device__ __forceinline__ void epilogue_big_lds(f32x4 (&acc)[8][4], const float* __restrict__ bias,
+                                                 bf16_t* __restrict__ out, int N, int m0, int n0, int wm, int wn,
+                                                 int lane, int wave, unsigned char* smem) {
+    constexpr int RS = 144;
+    unsigned char* my = smem + wave * (64 * RS);
+    const int l15 = lane & 15, g = lane >> 4;
+    const bool skip = g_skip_epilogue != 0;
+    const int chunk = lane & 7;
+    const int ncol = n0 + wn * 64 + chunk * 8;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + g * 4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = half * 4 + ii;
+                float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z,
+                      v3 = acc[i][j][3] + bv.w;
+                if (MODE == EPI_QUICKGELU) {
+                    v0 = act_quickgelu(v0); v1 = act_quickgelu(v1); v2 = act_quickgelu(v2); v3 = act_quickgelu(v3);
+                } else if (MODE == EPI_GELU) {
+                    v0 = act_gelu(v0); v1 = act_gelu(v1); v2 = act_gelu(v2); v3 = act_gelu(v3);
+                }
+                uint2 pk;
+                pk.x = pack_bf16x2(v0, v1);
+                pk.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(my + (ii * 16 + l15) * RS + (j * 16 + g * 4) * 2) = pk;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = t * 8 + (lane >> 3);
+            const uint4 v = *reinterpret_cast<const uint4*>(my + row * RS + chunk * 16);
+            if (skip && v.x != 0x12345678u) continue;
+            *reinterpret_cast<uint4*>(out + (size_t)(m0 + wm * 128 + half * 64 + row) * N + ncol) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong kernel: 256x256 tile, 8 waves, 4-stage ring of 32-deep K-tiles (128 KiB LDS, one block per
+// CU).  Each K-tile is two barrier-separated parts per wave: L = {counted vmcnt, barrier, issue the
+// LDS-DMA of tile kt+3, read this tile's 12 fragments} and M = {32 MFMAs on registers only}.  Waves 4-7
+// execute ONE extra barrier before the loop (waves 0-3 one after it), so the two waves that share a SIMD
+// are always half a step apart: while one issues its MFMA cluster the other is in its L part.
+//   RAW: before EVERY barrier a wave waits until its own loads of the tile the OTHER group will read
+//        next have landed (at most the two youngest tiles stay in flight);
+//   WAR: tile kt+3 overwrites the slot of tile kt-1, whose fragment reads both groups retired
+//        (lgkmcnt(0)) before the barrier that precedes the overwrite.
+// ------------------------------------------------------------------------------------------------
+// WROWS = rows per wave: 128 -> 256x256 tile (waves 2x4, 4 stages of 32 KiB); 64 -> 256x128 tile
+// (waves 4x2, 5 stages of 24 KiB) for shapes whose 256x256 tiling leaves a long tail.
+template <int MODE, int WROWS>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+                                                         const float* __restrict__ bias, int M, int N, int K,
+                                                         void* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BKT = 32, NT = 4, MI = WROWS / 16;
+    constexpr int WM_WAVES = 256 / WROWS, WN_WAVES = 8 / WM_WAVES, BNB = WN_WAVES * 64;
+    constexpr int STAGES = (WROWS == 128) ? 4 : 5;
+    constexpr int TA = 256 * BKT * 2, TBt = BNB * BKT * 2, SB = TA + TBt;
+    constexpr int GPS = SB / 8192;                  // LDS-DMA instructions per thread per K-tile
+    constexpr int INFL = (STAGES - 2) * GPS;        // loads of the STAGES-2 youngest tiles may stay in flight
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
+    const bool late = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;  // waves 4-7 run half a step behind
+
+    const int tiles_n = N / BNB;
+    int tm, tn;
+    tile_coords(M / 256, tiles_n, g_group_m ? g_group_m : 4, &tm, &tn);
+    const int m0 = tm * 256, n0 = tn * BNB;
+
+    f32x4 acc[MI][NT];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BKT;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) {
+        if (s < nk) {
+            stage_rows8_ring<256, BKT>(A, K, m0, s * BKT, smem + s * SB, wave, lane);
+            stage_rows8_ring<BNB, BKT>(Wt, K, n0, s * BKT, smem + s * SB + TA, wave, lane);
+        }
+    }
+    if (late) {
+        // the early group reads tile 0 right after this barrier: my share of it must have landed
+        if (nk >= STAGES - 1) wait_vmcnt<INFL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    }
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // ---- L part
+        if (kt + STAGES - 2 < nk) wait_vmcnt<INFL>(); else wait_vmcnt<0>();   // my share of tile kt has landed
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + STAGES - 1 < nk) {
+            int ns = cur + STAGES - 1;
+            if (ns >= STAGES) ns -= STAGES;
+            stage_rows8_ring<256, BKT>(A, K, m0, (kt + STAGES - 1) * BKT, smem + ns * SB, wave, lane);
+            stage_rows8_ring<BNB, BKT>(Wt, K, n0, (kt + STAGES - 1) * BKT, smem + ns * SB + TA, wave, lane);
+        }
+        const unsigned char* At = smem + cur * SB;
+        const unsigned char* Bt = At + TA;
+        const int chunk = lane >> 4;
+        bf16x8 wf[NT], af[MI];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = lds_frag_ring<BKT>(Bt, wn * 64 + j * 16 + (lane & 15), chunk);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = lds_frag_ring<BKT>(At, wm * WROWS + i * 16 + (lane & 15), chunk);
+        // my share of tile kt+1 has landed before the barrier after which the other group may read it
+        if (kt + STAGES - 1 < nk) wait_vmcnt<INFL>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- M part: registers only
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+    constexpr bool BF16OUT = (MODE == EPI_BF16 || MODE == EPI_QUICKGELU || MODE == EPI_GELU);
+    if constexpr (WROWS == 128) {
+        if (BF16OUT && g_epi_lds) {
+            __syncthreads();  // both groups are past their last fragment read: the ring is dead
+            epilogue_big_lds<MODE>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
+        } else {
+            epilogue_big<MODE, NT>(acc, bias, out, N, m0, n0, wm, wn, lane);
+        }
+    } else {
+        if (BF16OUT && g_epi_lds) {
+            __syncthreads();
+            epilogue_lds<MODE>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
+        } else {
+            epilogue<MODE>(acc, bias, out, N, m0, n0, wm, wn, lane);
+        }
+    }
+}
+
+template <int MODE, int WROWS>
+static void launch_pp(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
+                      hipStream_t st) {
+    auto kern = gemm_pp_kernel<MODE, WROWS>;
+    constexpr int BNB = (WROWS == 128) ? 256 : 128;
+    constexpr int STAGES = (WROWS == 128) ? 4 : 5;
+    const size_t lds = (size_t)STAGES * (256 + BNB) * 32 * 2;  // 128 KiB / 120 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    const int grid = (M / 256) * (N / BNB);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
+}
+
 static int g_gemm_variant = 0;
   // 0: 2-stage BK=64 ; 1: ring BK=32 x4 (2 blocks/CU) ; 2: ring BK=64 x4 (1 block/CU) ; 3: ring BK=64 x3
 
@@ -726,6 +904,10 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 31: if (M % 256 == 0 && N % 256 == 0) { launch_big<MODE, 4, 1>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 40: if (M % 256 == 0 && N % 256 == 0) { launch_pp<MODE, 128>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 41: if (M % 256 == 0 && N % 128 == 0) { launch_pp<MODE, 64>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 30: launch_persist<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 16: launch_ring<MODE, 32, 2, 4>(A, Wt, bias, M, N, K, out, st); break;   // 32 KB LDS: 4 blocks/CU
         case 17: launch_ring<MODE, 32, 3, 3>(A, Wt, bias, M, N, K, out, st); break;   // 48 KB LDS: 3 blocks/CU
@@ -753,12 +935,17 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
         // round (<= 256 tiles) it beats 128x128 (fewer staged bytes, no second-round tail); otherwise the
         // 128x128 tile at two blocks per CU wins because its epilogue overlaps the other block's main loop.
         const long long t5 = (long long)(M / 256) * (N / 192);
-        if (M % 256 == 0 && N % 192 == 0 && K % 64 == 0 && t5 <= 256 && t5 >= 160) v = 5;
+        // the 256x256 ping-pong kernel (one block per CU) has the fastest main loop but no co-resident block to
+        // hide its epilogue or its tail: take it only when its tiles fill whole rounds of the 256 CUs well
+        const long long t256 = (long long)(M / 256) * (N / 256);
+        const double eff256 = t256 ? (double)t256 / (double)(((t256 + 255) / 256) * 256) : 0.0;
+        if (M % 256 == 0 && N % 256 == 0 && t256 >= 200 && (eff256 >= 0.85 || (K >= 2048 && eff256 >= 0.80))) v = 40;
+        else if (M % 256 == 0 && N % 192 == 0 && K % 64 == 0 && t5 <= 256 && t5 >= 160) v = 5;
         else if (K % 64 != 0) v = 1;  // K multiple of 32 only (HTSAT C=96): the BK=32 ring kernel
     } else if (v == 100) {
         v = 0;  // force the 128x128 kernel (A/B runs)
     }
-    if (K % 64 != 0) v = 1;
+    if (K % 64 != 0 && v != 40) v = 1;
     else if (N % BN != 0 && v != 1) v = 0;  // N edge is handled by the 128x128 kernels only
     switch (mode) {
         case EPI_BF16: launch_variant<EPI_BF16>(v, A, Wt, bias, M, N, K, out, st); break;

@@ -498,8 +498,9 @@ struct VitWs {
 };
 static VitWs vit_ws(const VitDims& d, int B) {
     VitWs w;
-    w.M = B * d.T; w.Mp = (w.M + 127) / 128 * 128;
-    w.Mpatch = B * d.g * d.g; w.Mpp = (w.Mpatch + 127) / 128 * 128;
+    // rows padded to 256 so every GEMM tiling (128- and 256-row tiles) sees whole tiles
+    w.M = B * d.T; w.Mp = (w.M + 255) / 256 * 256;
+    w.Mpatch = B * d.g * d.g; w.Mpp = (w.Mpatch + 255) / 256 * 256;
     size_t off = 0;
     w.x = off; off += align_up((size_t)w.Mp * d.W * 4, 256);
     w.h = off; off += align_up((size_t)w.Mp * d.W * 2, 256);
@@ -574,7 +575,7 @@ static int vit_forward_part(const wise_vit_config* cfg, const VitDims& d, const 
     }
     // 4. ln_post(cls) -> bf16 [Bp,W] (aliases h) ; @ proj -> fp32 [Bp,D] (aliases qkv) ; L2 normalise rows
     {
-        const int Bp = (batch + 127) / 128 * 128;
+        const int Bp = (batch + 255) / 256 * 256;
         // cls rows are x[b*T, :]: a strided LayerNorm, row stride T*W
         const int nv = (W / 4 + 63) / 64;
         const dim3 grid((batch + 3) / 4), block(256);
