@@ -875,6 +875,7 @@ static void launch_pp(const bf16_t* A, const bf16_t* Wt, const float* bias, int 
 }
 
 static int g_gemm_variant = 0;
+static int g_split_m = 1;  // split M between the ping-pong kernel and the 128x128 kernel (bit 29 of the knob: off)
   // 0: 2-stage BK=64 ; 1: ring BK=32 x4 (2 blocks/CU) ; 2: ring BK=64 x4 (1 block/CU) ; 3: ring BK=64 x3
 
 template <int MODE>
@@ -923,28 +924,8 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
     }
 }
 
-int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out,
-              hipStream_t st) {
-    WISE_CHECK_ARG(A && Wt && out, "gemm_bf16: null pointer");
-    WISE_CHECK_ARG(M > 0 && M % BM == 0 && N > 0 && N % 4 == 0 && K > 0 && K % 32 == 0,
-                   "gemm_bf16: M=%d must be a multiple of %d, N=%d of 4, K=%d of 32", M, BM, N, K);
-    ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
-    int v = g_gemm_variant;
-    if (v == 0) {
-        // shape heuristic (measured, tools/gemm_bench.py): when a 256x192 tiling fits the chip in ONE
-        // round (<= 256 tiles) it beats 128x128 (fewer staged bytes, no second-round tail); otherwise the
-        // 128x128 tile at two blocks per CU wins because its epilogue overlaps the other block's main loop.
-        const long long t5 = (long long)(M / 256) * (N / 192);
-        // the 256x256 ping-pong kernel (one block per CU) has the fastest main loop but no co-resident block to
-        // hide its epilogue or its tail: take it only when its tiles fill whole rounds of the 256 CUs well
-        const long long t256 = (long long)(M / 256) * (N / 256);
-        const double eff256 = t256 ? (double)t256 / (double)(((t256 + 255) / 256) * 256) : 0.0;
-        if (M % 256 == 0 && N % 256 == 0 && t256 >= 200 && (eff256 >= 0.85 || (K >= 2048 && eff256 >= 0.80))) v = 40;
-        else if (M % 256 == 0 && N % 192 == 0 && K % 64 == 0 && t5 <= 256 && t5 >= 160) v = 5;
-        else if (K % 64 != 0) v = 1;  // K multiple of 32 only (HTSAT C=96): the BK=32 ring kernel
-    } else if (v == 100) {
-        v = 0;  // force the 128x128 kernel (A/B runs)
-    }
+static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode,
+                       void* out, hipStream_t st) {
     if (K % 64 != 0 && v != 40) v = 1;
     else if (N % BN != 0 && v != 1) v = 0;  // N edge is handled by the 128x128 kernels only
     switch (mode) {
@@ -959,6 +940,54 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
     return WISE_OK;
 }
 
+// shape heuristic (measured with tools/gemm_bench.py on MI355X)
+static int auto_variant(int M, int N, int K) {
+    if (K % 64 != 0) return 1;  // K multiple of 32 only (HTSAT C=96): the BK=32 ring kernel
+    // when a 256x192 tiling fits the chip in ONE well-filled round it beats 128x128 (fewer staged bytes, no
+    // second-round tail); otherwise the 128x128 tile at two blocks per CU wins because its epilogue overlaps
+    // the other block's main loop
+    const long long t5 = (long long)(M / 256) * (N / 192);
+    if (M % 256 == 0 && N % 192 == 0 && t5 <= 256 && t5 >= 160) return 5;
+    return 0;
+}
+
+int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out,
+              hipStream_t st) {
+    WISE_CHECK_ARG(A && Wt && out, "gemm_bf16: null pointer");
+    WISE_CHECK_ARG(M > 0 && M % BM == 0 && N > 0 && N % 4 == 0 && K > 0 && K % 32 == 0,
+                   "gemm_bf16: M=%d must be a multiple of %d, N=%d of 4, K=%d of 32", M, BM, N, K);
+    ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
+    int v = g_gemm_variant;
+    if (v == 100) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);  // force 128x128 (A/B runs)
+    if (v != 0) return launch_mode(v, A, Wt, bias, M, N, K, mode, out, st);
+
+    // The 256x256 ping-pong kernel (one block per CU) has the fastest main loop but no co-resident block to
+    // hide its epilogue or its tail.  Give it the rows whose tiles fill whole rounds of the 256 CUs and hand the
+    // remaining rows to the two-blocks-per-CU kernels (same stream, so the two launches are ordered).
+    if (M % 256 == 0 && N % 256 == 0) {
+        const int tiles_m = M / 256, tiles_n = N / 256;
+        const long long t256 = (long long)tiles_m * tiles_n;
+        const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+        if (t256 >= 200 && (eff256 >= 0.85 || (K >= 2048 && eff256 >= 0.80)))
+            return launch_mode(40, A, Wt, bias, M, N, K, mode, out, st);
+        // (measured: worth it only when the ping-pong part spans several rounds; at 1-2 rounds the second
+        // launch's own tail and the lost overlap cost more than the 128x128 kernel's slower main loop)
+        if (t256 >= 3 * 256 && g_split_m) {
+            const int rounds = (int)(t256 / 256);
+            const int m_pp = (rounds * 256) / tiles_n;  // m-tiles whose tiles fill `rounds` rounds (within one row)
+            if (m_pp >= 1 && m_pp < tiles_m && (long long)m_pp * tiles_n >= 200) {
+                const int M1 = m_pp * 256, M2 = M - M1;
+                int rc = launch_mode(40, A, Wt, bias, M1, N, K, mode, out, st);
+                if (rc) return rc;
+                const size_t esz = (mode == EPI_RESID || mode == EPI_F32) ? 4 : 2;
+                return launch_mode(auto_variant(M2, N, K), A + (size_t)M1 * K, Wt, bias, M2, N, K, mode,
+                                   reinterpret_cast<unsigned char*>(out) + (size_t)M1 * N * esz, st);
+            }
+        }
+    }
+    return launch_mode(auto_variant(M, N, K), A, Wt, bias, M, N, K, mode, out, st);
+}
+
 }  // namespace wise
 
 extern "C" int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, int mode,
@@ -969,6 +998,7 @@ extern "C" int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float
 // tuning knob for A/B runs (tools/gemm_bench.py); not part of the stable ABI
 extern "C" int wise_debug_set_gemm_variant(int v) {
     wise::g_gemm_variant = v & 0xFF;
+    wise::g_split_m = ((v >> 29) & 1) ? 0 : 1;
     int skip = (v >> 8) & 1;  // bit 8: skip epilogue stores (timing-only ablation)
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_skip_epilogue), &skip, sizeof(int));
     int el = ((v >> 30) & 1) ? 0 : 1;
