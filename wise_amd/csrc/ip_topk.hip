@@ -230,15 +230,18 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(const u64* __restrict_
 
     WaveList wl;
     wl.init(lds + (size_t)wave * cap, cap, k, lane);
-    // wave w takes lists w, w+nwaves, ...
-    for (int p = wave; p < P; p += nwaves) {
-        const u64* src = part + ((size_t)p * qstride + q) * k;
-        for (int i0 = 0; i0 < k; i0 += 64) {
-            int i = i0 + lane;
-            u64 key = (i < k) ? src[i] : 0;
-            bool pass = (key != 0) && (key > wl.tau);
-            wl.offer(pass, key, lane, 64);
+    // the P lists of this query hold P*k keys in all: every offer carries 64 of them (one per lane), whatever k
+    // is; waves take 64-key chunks round-robin
+    const long long total = (long long)P * k;
+    for (long long c0 = (long long)wave * 64; c0 < total; c0 += (long long)nwaves * 64) {
+        const long long i = c0 + lane;
+        u64 key = 0;
+        if (i < total) {
+            const int p = (int)(i / k), j = (int)(i - (long long)p * k);
+            key = part[((size_t)p * qstride + q) * k + j];
         }
+        const bool pass = (key != 0) && (key > wl.tau);
+        wl.offer(pass, key, lane, 64);
     }
     wl.compact(lane);
     __syncthreads();
@@ -340,6 +343,8 @@ struct ScanPlan {
     size_t lds;
 };
 
+static int g_scan_rows = 4, g_scan_blocks_per_cu = 0;  // tuning knobs (wise_debug_set_scan)
+
 static ScanPlan plan_scan(long long N, int d, int nq, int k) {
     ScanPlan p;
     p.cap = list_cap(k);
@@ -350,8 +355,9 @@ static ScanPlan plan_scan(long long N, int d, int nq, int k) {
     while (nqp * 2 <= nq && nqp * 2 <= 4 && nv * nqp * 2 <= 8 && (size_t)4 * nqp * 2 * p.cap * 8 <= 64 * 1024) nqp <<= 1;
     p.nq_per_pass = nqp;
     p.lds = (size_t)4 * nqp * p.cap * 8;
-    p.rows = 4;
+    p.rows = (g_scan_rows == 8 && nqp == 1 && nv <= 2) ? 8 : 4;
     int blocks_per_cu = (p.lds > 40 * 1024) ? 2 : 4;
+    if (g_scan_blocks_per_cu > 0) blocks_per_cu = g_scan_blocks_per_cu;
     p.grid = 256 * blocks_per_cu;
     long long ngroups = (N + p.rows - 1) / p.rows;
     long long need = (ngroups + 3) / 4;
@@ -363,6 +369,13 @@ static ScanPlan plan_scan(long long N, int d, int nq, int k) {
 template <int NV, int NQ>
 static void launch_scan(const ScanPlan& p, const float* X, long long N, int d, const float* Q, int k, u64* part,
                         hipStream_t st) {
+    if constexpr (NQ == 1 && NV <= 2) {
+        if (p.rows == 8) {
+            hipLaunchKernelGGL((ip_scan_kernel<NV, NQ, 8>), dim3(p.grid), dim3(256), p.lds, st,
+                               reinterpret_cast<const f32x4*>(X), N, d / 4, Q, k, p.cap, part);
+            return;
+        }
+    }
     auto kern = ip_scan_kernel<NV, NQ, 4>;
     if (p.lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -389,6 +402,12 @@ static int dispatch_nq(const ScanPlan& p, const float* X, long long N, int d, co
 }  // namespace wise
 
 using namespace wise;
+
+extern "C" int wise_debug_set_scan(int rows, int blocks_per_cu) {
+    g_scan_rows = rows;
+    g_scan_blocks_per_cu = blocks_per_cu;
+    return 0;
+}
 
 extern "C" size_t wise_ip_topk_workspace_bytes(int64_t N, int d, int nq, int k) {
     if (N < 0 || d < 4 || nq < 1 || k < 1 || k > 2048) return 0;
