@@ -1,0 +1,52 @@
+"""Result-merge rules of the reference CLI (search.py:192-445), checked on hand-worked cases that follow the rules
+the reference states in its docstrings (:285-310, :372-396)."""
+from wise_amd.search.merge import merge_modalities, merge_ranked_hits, segments_overlap
+
+
+def test_segments_overlap_rules():
+    assert segments_overlap(2.0, [1.0, 3.0]) and segments_overlap([1.0, 3.0], 3.0)        # point inside segment
+    assert not segments_overlap(3.5, [1.0, 3.0])
+    assert segments_overlap([0.0, 4.0], [2.0, 6.0])                                        # iou = 2/6
+    assert not segments_overlap([0.0, 4.0], [3.97, 8.0])                                   # 0.03/8 < 0.01
+    assert not segments_overlap([0.0, 4.0], [5.0, 8.0])                                    # disjoint -> negative
+    assert segments_overlap([2.0], [2.0, 2.0]) is True                                     # single-element list = point
+
+
+def test_merge_ranked_hits_video_frames():
+    # 2 fps frames of one file: ranks 0,1,2 are 0.5 s apart, rank 3 is another file, rank 4 same file but far in time
+    files = ['a.mp4', 'a.mp4', 'a.mp4', 'b.mp4', 'a.mp4', 'a.mp4']
+    pts = [10.0, 10.5, 11.0, 3.0, 50.0, 11.5]
+    scores = [0.9, 0.8, 0.7, 0.6, 0.5, 0.4]
+    f, p, s, r = merge_ranked_hits(files, pts, scores, pts_tolerance=1.0, rank_tolerance=20)
+    # chain 10.0-10.5-11.0-11.5 merges through pairwise-close members even though 10.0 and 11.5 are 1.5 s apart
+    assert f == ['a.mp4', 'b.mp4', 'a.mp4']
+    assert p == [[10.0, 11.5], [3.0], [50.0]]
+    assert s == [0.9, 0.6, 0.5]                      # merged entry keeps the best-ranked member's score
+    assert r == [[0, 1, 2, 5], [3], [4]]
+    # rank tolerance: the same hits with tolerance 1 cannot pull in rank 5 (|2-5| > 1)
+    f, p, s, r = merge_ranked_hits(files, pts, scores, pts_tolerance=1.0, rank_tolerance=1)
+    assert p[0] == [10.0, 11.0] and r[0] == [0, 1, 2] and f == ['a.mp4', 'b.mp4', 'a.mp4', 'a.mp4']
+    # image search: tolerances 0 merge nothing but exact duplicates
+    f, p, s, r = merge_ranked_hits(['x', 'x'], [1.0, 1.0], [0.5, 0.4], 0, 0)
+    assert f == ['x', 'x']                            # same time but rank distance 1 > 0
+
+
+def test_merge_ranked_hits_audio_ranges_use_midpoints():
+    files = ['a.mp4', 'a.mp4', 'a.mp4']
+    pts = [[0.0, 4.0], [4.0, 8.0], [20.0, 24.0]]     # audio hits are [pts, pts + 4] ranges
+    f, p, s, r = merge_ranked_hits(files, pts, [0.9, 0.8, 0.7], pts_tolerance=4.0, rank_tolerance=20)
+    assert p == [[0.0, 8.0], [20.0, 24.0]] and r == [[0, 1], [2]] and s == [0.9, 0.7]
+
+
+def test_merge_modalities_sums_scores_of_overlapping_hits():
+    video = {'match_filename_list': ['a.mp4', 'b.mp4'], 'match_pts_list': [[10.0, 11.5], [3.0]],
+             'match_score_list': [0.30, 0.28], 'search_time_sec': 0.1, 'query': ['cooking'], 'in': ['video']}
+    audio = {'match_filename_list': ['b.mp4', 'a.mp4', 'a.mp4'], 'match_pts_list': [[0.0, 4.0], [8.0, 12.0], [40.0, 44.0]],
+             'match_score_list': [0.50, 0.20, 0.90], 'search_time_sec': 0.2, 'query': ['music'], 'in': ['audio'],
+             'not_in': ['image']}
+    m = merge_modalities(video, audio)
+    assert m['match_filename_list'] == ['b.mp4', 'a.mp4']            # 0.78 > 0.50, the 40-44 s audio hit has no video
+    assert m['match_score_list'] == [0.28 + 0.50, 0.30 + 0.20]
+    assert m['match_pts_list'] == [[0.0, 4.0], [8.0, 12.0]]          # hull of point 3.0 with [0,4]; [10,11.5] with [8,12]
+    assert m['merged_rank_list'] == [[1, 0], [0, 1]]
+    assert m['in'] == ['video', 'audio'] and m['not_in'] == ['image'] and abs(m['search_time_sec'] - 0.3) < 1e-12
