@@ -129,3 +129,35 @@ def test_full_size_properties():
     # linearity: scores for 2q are 2x, same ids
     D2, I2 = idx.search_device(2.0 * X[rows], 10)
     assert torch.equal(I2, I) and torch.allclose(D2, 2 * D, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,d,nq,k", [
+    (4097, 512, 8, 10), (5000, 512, 32, 10), (33333, 512, 70, 10), (31, 512, 9, 5), (1000, 64, 33, 16),
+    (20000, 256, 64, 1), (50000, 512, 40, 16),
+])
+def test_batched_mfma_path_against_oracle(N, d, nq, k):
+    """nq >= 8, k <= 16, d % 32 == 0, d <= 512 runs on the fp32 matrix cores (ip_topk_mfma.hip): same contract."""
+    X = unit_rows(N, d, 300 + N % 89)
+    Q = unit_rows(nq, d, 17)
+    ids = (np.arange(N, dtype=np.int64) * 2 + 7)
+    idx = FlatIPIndex(d)
+    idx.add_with_ids(X, ids)
+    D, I = idx.search(Q, k)
+    check_against_oracle(X, Q, k, ids, D, I)
+
+
+def test_batched_path_matches_single_query_path_and_ties():
+    """A query's result must not depend on whether it travelled alone (VALU kernel) or in a batch (MFMA kernel);
+    identical rows come back lowest row first in both."""
+    N, d = 30000, 512
+    X = unit_rows(N, d, 5)
+    X[[100, 7, 29999, 15000]] = X[3]
+    idx = FlatIPIndex(d)
+    idx.add_with_ids(X, np.arange(N, dtype=np.int64) + 1)
+    Q = np.concatenate([X[3:4], unit_rows(19, d, 6)], axis=0)
+    Db, Ib = idx.search(Q, 10)
+    assert list(Ib[0, :5]) == [4, 8, 101, 15001, 30000]
+    for q in range(0, 20, 7):
+        Ds, Is = idx.search(Q[q:q + 1], 10)
+        assert np.array_equal(Is[0], Ib[q]), q
+        assert np.allclose(Ds[0], Db[q], atol=2e-6)

@@ -15,20 +15,20 @@ lib = _lib.lib()
 X = torch.randn(N, d, device="cuda")
 X /= X.norm(dim=1, keepdim=True)
 idx = FlatIPIndex(d).adopt(X, None, id_base=1)
-Q = torch.randn(64, d, device="cuda")
+Q = torch.randn(96, d, device="cuda")
 Q /= Q.norm(dim=1, keepdim=True)
 ref = None
-for rows, bpc in ((4, 0), (8, 0), (4, 2), (8, 2), (4, 8), (8, 8), (4, 0)):
+for rows, bpc in ((4, 0), (4 + 256, 0)):
     lib.wise_debug_set_scan(rows, bpc)
     idx._ws = None  # workspace size depends on the grid
-    for nq in (1, 4):
+    for nq in (1, 4, 8, 32, 64):
         for _ in range(3):
             D, I = idx.search_device(Q[:nq], 10)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n = 20
         for i in range(n):
-            D, I = idx.search_device(Q[i:i + nq], 10)
+            D, I = idx.search_device(Q[(i % 2):(i % 2) + nq] if nq > 32 else Q[i:i + nq], 10)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         if nq == 1:

@@ -14,24 +14,9 @@
 //   list fills.  Nothing but the k best keys per block ever goes back to HBM.
 // Kernel 2 (merge_keys_kernel): one block per query folds the per-block lists into the final
 //   top-k with the same threshold lists, then translates row -> external id (IndexIDMap).
-#include "common.h"
+#include "topk_common.h"
 
 namespace wise {
-
-typedef unsigned long long u64;
-
-__device__ __forceinline__ unsigned f32_order(float f) {
-    unsigned u = __float_as_uint(f);
-    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-__device__ __forceinline__ float f32_unorder(unsigned o) {
-    unsigned u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
-    return __uint_as_float(u);
-}
-// larger key = better: higher score first, then lower row
-__device__ __forceinline__ u64 make_key(float score, unsigned row) {
-    return ((u64)f32_order(score) << 32) | (u64)(0xFFFFFFFFu - row);
-}
 
 __device__ __forceinline__ void wave_lds_fence() {
     // one wave executes its DS instructions in order; this only stops the compiler reordering them
@@ -344,6 +329,7 @@ struct ScanPlan {
 };
 
 static int g_scan_rows = 4, g_scan_blocks_per_cu = 0;  // tuning knobs (wise_debug_set_scan)
+static int g_use_mfma = 1;                              // batched queries on the fp32 matrix cores
 
 static ScanPlan plan_scan(long long N, int d, int nq, int k) {
     ScanPlan p;
@@ -404,8 +390,9 @@ static int dispatch_nq(const ScanPlan& p, const float* X, long long N, int d, co
 using namespace wise;
 
 extern "C" int wise_debug_set_scan(int rows, int blocks_per_cu) {
-    g_scan_rows = rows;
+    g_scan_rows = rows & 0xFF;
     g_scan_blocks_per_cu = blocks_per_cu;
+    g_use_mfma = (rows >> 8) & 1 ? 0 : 1;  // bit 8: force the VALU kernel for batched queries
     return 0;
 }
 
@@ -413,8 +400,13 @@ extern "C" size_t wise_ip_topk_workspace_bytes(int64_t N, int d, int nq, int k) 
     if (N < 0 || d < 4 || nq < 1 || k < 1 || k > 2048) return 0;
     ScanPlan p = plan_scan(N, d, nq, k);
     // part keys [grid][nq_per_pass][k] + padded query block
-    return align_up((size_t)p.grid * p.nq_per_pass * k * sizeof(u64), 256) +
-           align_up((size_t)p.nq_per_pass * d * sizeof(float), 256) + 256;
+    size_t valu = align_up((size_t)p.grid * p.nq_per_pass * k * sizeof(u64), 256) +
+                  align_up((size_t)p.nq_per_pass * d * sizeof(float), 256) + 256;
+    if (g_use_mfma && mfma_scan_supported(d, nq, k)) {
+        size_t mf = align_up(mfma_scan_part_bytes(N, k), 256) + align_up((size_t)MFMA_QB * d * sizeof(float), 256) + 256;
+        if (mf > valu) valu = mf;
+    }
+    return valu;
 }
 
 extern "C" int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, int k, const int64_t* ids,
@@ -432,6 +424,34 @@ extern "C" int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q
         return WISE_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (g_use_mfma && N > 0 && mfma_scan_supported(d, nq, k)) {
+        // batched path: 32 queries share one pass over X on the fp32 matrix cores
+        u64* mpart = reinterpret_cast<u64*>(workspace);
+        float* mq = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) +
+                                             align_up(mfma_scan_part_bytes(N, k), 256));
+        const int cap = list_cap(k);
+        int mwv = 8192 / cap;
+        if (mwv < 1) mwv = 1;
+        if (mwv > 16) mwv = 16;
+        for (int q0 = 0; q0 < nq; q0 += MFMA_QB) {
+            const int nqa = (nq - q0 < MFMA_QB) ? nq - q0 : MFMA_QB;
+            hipError_t e = hipSuccess;
+            if (nqa < MFMA_QB) e = hipMemsetAsync(mq, 0, (size_t)MFMA_QB * d * sizeof(float), st);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(mq, Q + (size_t)q0 * d, (size_t)nqa * d * sizeof(float), hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) { set_error("ip_topk: query staging: %s", hipGetErrorString(e)); return (int)e; }
+            {
+                ProfScope prof(PROF_SCAN, (double)N * d * 4.0, st);
+                int rc = mfma_scan_launch(X, N, d, mq, nqa, k, mpart, st);
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart,
+                               mfma_scan_lists(N), MFMA_QB, k, cap, reinterpret_cast<const long long*>(ids),
+                               (long long)id_base, outD, reinterpret_cast<long long*>(outI), q0);
+            WISE_LAUNCH_CHECK("merge_keys_kernel");
+        }
+        return WISE_OK;
+    }
     ScanPlan p = plan_scan(N, d, nq, k);
     u64* part = reinterpret_cast<u64*>(workspace);
     float* qpad = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) +

@@ -1,0 +1,173 @@
+// HP-2, batched queries: brute-force inner-product scan for up to 32 queries per pass on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-for-bit a k-ordered fmaf chain),
+// so that a batch of queries shares ONE pass over the database.  Serves the batched form of the search
+// the reference issues one query at a time (src/index/feature_search_index.py:113; the 3842 sequential
+// queries of docs/Retrieval-Evaluation.md:36-45) — SURVEY.md §8 f3.
+//
+// Roofline: still HBM-bound.  Per 32 rows x 512 dims (64 KB of X) a SIMD issues 256 MFMAs of 64 cycles =
+// 16.4k cycles, against ~27k cycles of HBM time for those bytes at 5.9 TB/s chip-wide.
+//
+// Structure (block = 4 independent waves, one block per CU):
+//   Q [32][d] lives in LDS for the block's lifetime (16-byte chunks XOR-swizzled by query so that the 32
+//   lanes of an MFMA B-operand read hit distinct banks);
+//   each wave streams 32-row x 32-column chunks of X through a private 3-deep LDS ring by 16-byte LDS-DMA
+//   (lane-linear destination, swizzle on the SOURCE address), waits with a counted vmcnt, reads its A
+//   fragments, re-issues the ring slot, and feeds 16 MFMAs per chunk; no block barrier in the loop;
+//   k-permutation: lane (i, h) holds columns h*16..h*16+15 of row i — the same permutation on the Q side;
+//   selection: after a 32-row group a lane holds, for ITS query, the scores of 16 rows; candidates that beat
+//   the lane's threshold are insertion-sorted into a lane-private k-entry list in LDS (rare after warm-up).
+//   (Measured alternatives that were slower: the lists in registers with a branch-free bubble, and fragment
+//   reads software-pipelined one chunk ahead.)  Known limit: a chunk row is 128 contiguous bytes, so a 2-KB
+//   database row is visited 16 times; the scan runs at ~3.1 TB/s, about half of the single-query kernel.
+// The per-lane lists (8 per block and query) are folded by merge_keys_kernel.
+#include "topk_common.h"
+
+namespace wise {
+
+constexpr int CW = 32;          // columns per chunk
+constexpr int RING = 3;         // chunks in flight per wave
+constexpr int CHUNK_BYTES = 32 * CW * 4;  // 4 KiB
+
+__device__ __forceinline__ void glds16_x(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __restrict__ X, long long N, int d,
+                                                              const float* __restrict__ qpad, int nq, int k,
+                                                              u64* __restrict__ part /*[P][32][k]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;  // MFMA row/query index and k-half
+    const int d4 = d >> 2;                   // 16-byte chunks per row
+    float* Qs = reinterpret_cast<float*>(smem);                                  // 32*d floats
+    unsigned char* ring = smem + (size_t)32 * d * 4 + (size_t)wave * RING * CHUNK_BYTES;
+    u64* lists = reinterpret_cast<u64*>(smem + (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES) +
+                 (size_t)wave * MFMA_KL * 64;                                    // entry e of lane l: lists[e*64 + l]
+
+    // ---- Q -> LDS, chunk c of query j stored at chunk (c & ~15) | ((c & 15) ^ (j & 15))
+    for (int idx = threadIdx.x; idx < 32 * d4; idx += 256) {
+        const int j = idx / d4, c = idx - j * d4;
+        const float4 v = reinterpret_cast<const float4*>(qpad)[idx];
+        const int pc = (c & ~15) | ((c & 15) ^ (j & 15));
+        reinterpret_cast<float4*>(Qs)[j * d4 + pc] = v;
+    }
+    for (int e = 0; e < MFMA_KL; ++e) lists[e * 64 + lane] = 0;
+    __syncthreads();
+
+    const int nch = d / CW;
+    const long long ngroups = (N + 31) / 32;
+    const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+    const long long my_groups = gw < ngroups ? (ngroups - gw + nw - 1) / nw : 0;
+    const long long steps = my_groups * nch;
+
+    // LDS-DMA of chunk s: 4 instructions of 8 rows x 128 B; swizzle on the source address
+    auto issue = [&](long long s) {
+        const long long g = gw + (s / nch) * nw;
+        const int c0 = (int)(s % nch) * CW;
+        unsigned char* dst = ring + (int)(s % RING) * CHUNK_BYTES;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = u * 8 + (lane >> 3);
+            const int lc = (lane & 7) ^ ((row >> 1) & 7);  // logical chunk kept at physical chunk (lane & 7)
+            long long grow = g * 32 + row;
+            if (grow >= N) grow = N - 1;  // stay in bounds; masked at selection
+            glds16_x(X + grow * d + c0 + lc * 4, dst + u * 1024);
+        }
+    };
+
+    for (long long s = 0; s < RING && s < steps; ++s) issue(s);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    u64 tau = 0;
+    int cnt = 0;
+    const bool active = i < nq;  // lanes of padded queries never select
+
+    for (long long s = 0; s < steps; ++s) {
+        // chunk s has landed when at most the RING-1 younger chunks (4 DMA each) are outstanding
+        if (s + RING - 1 < steps) wait_vm<(RING - 1) * 4>(); else wait_vm<0>();
+        const unsigned char* buf = ring + (int)(s % RING) * CHUNK_BYTES;
+        const int c0 = (int)(s % nch) * CW;
+        float4 xf[4], qf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int lc = h * 4 + t;  // logical 16-byte chunk of the 128-byte chunk row
+            xf[t] = *reinterpret_cast<const float4*>(buf + i * 128 + ((lc ^ ((i >> 1) & 7)) << 4));
+            const int qc = (c0 >> 2) + lc;  // chunk index within the query row
+            qf[t] = reinterpret_cast<const float4*>(Qs)[i * d4 + ((qc & ~15) | ((qc & 15) ^ (i & 15)))];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + RING < steps) issue(s + RING);  // the slot's fragments are in registers: refill it
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[t].x, qf[t].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[t].y, qf[t].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[t].z, qf[t].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[t].w, qf[t].w, acc, 0, 0, 0);
+        }
+        if ((int)(s % nch) == nch - 1) {
+            // ---- a 32-row group is complete: this lane holds query i, rows (r&3) + 8*(r>>2) + 4*h
+            const long long row0 = (gw + (s / nch) * nw) * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const u64 key = make_key(acc[r], (unsigned)row);
+                const bool pass = active && row < N && key > tau;
+                if (__ballot(pass) != 0) {
+                    if (pass) {
+                        // insertion into the lane's descending list (entries past cnt are 0)
+                        int pos = cnt;
+                        for (int e = 0; e < cnt; ++e)
+                            if (lists[e * 64 + lane] < key) { pos = e; break; }
+                        const int last = cnt < k ? cnt : k - 1;
+                        for (int e = last; e > pos; --e) lists[e * 64 + lane] = lists[(e - 1) * 64 + lane];
+                        if (pos < k) lists[pos * 64 + lane] = key;
+                        if (cnt < k) ++cnt;
+                        tau = (cnt == k) ? lists[(k - 1) * 64 + lane] : 0;
+                    }
+                }
+                acc[r] = 0.f;
+            }
+        }
+    }
+    // ---- publish: list (block, wave, h) of query i -> part[P_idx][i][0..k)
+    const size_t pidx = ((size_t)blockIdx.x * 4 + wave) * 2 + h;
+    u64* dst = part + (pidx * MFMA_QB + i) * k;
+    for (int e = 0; e < k; ++e) dst[e] = (active && e < cnt) ? lists[e * 64 + lane] : 0;
+}
+
+static int mfma_grid(long long N) {
+    long long need = ((N + 31) / 32 + 3) / 4;
+    if (need < 1) need = 1;
+    return need < 256 ? (int)need : 256;
+}
+
+bool mfma_scan_supported(int d, int nq, int k) {
+    // Q must fit LDS beside the rings and lists (32*d*4 <= 64 KiB), chunks are 32 columns, lists hold 16
+    return nq >= 8 && k <= MFMA_KL && d % CW == 0 && d >= CW && d <= 512;
+}
+int mfma_scan_lists(long long N) { return mfma_grid(N) * 8; }
+size_t mfma_scan_part_bytes(long long N, int k) { return (size_t)mfma_scan_lists(N) * MFMA_QB * k * sizeof(u64); }
+
+int mfma_scan_launch(const float* X, long long N, int d, const float* qpad, int nq, int k, u64* part, hipStream_t st) {
+    const size_t lds = (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES + (size_t)4 * MFMA_KL * 64 * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_mfma_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ip_scan_mfma_kernel, dim3(mfma_grid(N)), dim3(256), lds, st, X, N, d, qpad, nq, k, part);
+    WISE_LAUNCH_CHECK("ip_scan_mfma_kernel");
+    return WISE_OK;
+}
+
+}  // namespace wise
