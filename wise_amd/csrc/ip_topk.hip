@@ -330,6 +330,7 @@ struct ScanPlan {
 
 static int g_scan_rows = 4, g_scan_blocks_per_cu = 0;  // tuning knobs (wise_debug_set_scan)
 static int g_use_mfma = 1;                              // batched queries on the fp32 matrix cores
+extern int g_mfma_abl;
 
 static ScanPlan plan_scan(long long N, int d, int nq, int k) {
     ScanPlan p;
@@ -393,6 +394,7 @@ extern "C" int wise_debug_set_scan(int rows, int blocks_per_cu) {
     g_scan_rows = rows & 0xFF;
     g_scan_blocks_per_cu = blocks_per_cu;
     g_use_mfma = (rows >> 8) & 1 ? 0 : 1;  // bit 8: force the VALU kernel for batched queries
+    g_mfma_abl = (rows >> 9) & 3;
     return 0;
 }
 

@@ -40,7 +40,7 @@ __device__ __forceinline__ void wait_vm() {
 
 __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __restrict__ X, long long N, int d,
                                                               const float* __restrict__ qpad, int nq, int k,
-                                                              u64* __restrict__ part /*[P][32][k]*/) {
+                                                              u64* __restrict__ part /*[P][32][k]*/, int abl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;  // MFMA row/query index and k-half
@@ -49,6 +49,9 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
     unsigned char* ring = smem + (size_t)32 * d * 4 + (size_t)wave * RING * CHUNK_BYTES;
     u64* lists = reinterpret_cast<u64*>(smem + (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES) +
                  (size_t)wave * MFMA_KL * 64;                                    // entry e of lane l: lists[e*64 + l]
+    // block-shared threshold per query: the best k-th key any of the block's 8 lists of that query has reached
+    u64* tauq = reinterpret_cast<u64*>(smem + (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES) +
+                (size_t)4 * MFMA_KL * 64;
 
     // ---- Q -> LDS, chunk c of query j stored at chunk (c & ~15) | ((c & 15) ^ (j & 15))
     for (int idx = threadIdx.x; idx < 32 * d4; idx += 256) {
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
         reinterpret_cast<float4*>(Qs)[j * d4 + pc] = v;
     }
     for (int e = 0; e < MFMA_KL; ++e) lists[e * 64 + lane] = 0;
+    if (threadIdx.x < 32) tauq[threadIdx.x] = 0;
     __syncthreads();
 
     const int nch = d / CW;
@@ -67,10 +71,15 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
     const long long steps = my_groups * nch;
 
     // LDS-DMA of chunk s: 4 instructions of 8 rows x 128 B; swizzle on the source address
-    auto issue = [&](long long s) {
-        const long long g = gw + (s / nch) * nw;
-        const int c0 = (int)(s % nch) * CW;
-        unsigned char* dst = ring + (int)(s % RING) * CHUNK_BYTES;
+    long long ig = gw;   // group / chunk / ring slot of the next DMA to issue
+    int ic = 0, islot = 0;
+    auto issue = [&]() {
+        const long long g = ig;
+        const int c0 = ic * CW;
+        unsigned char* dst = ring + islot * CHUNK_BYTES;
+        if (++ic == nch) { ic = 0; ig += nw; }
+        if (++islot == RING) islot = 0;
+        if (abl == 1) return;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = u * 8 + (lane >> 3);
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
         }
     };
 
-    for (long long s = 0; s < RING && s < steps; ++s) issue(s);
+    for (long long s = 0; s < RING && s < steps; ++s) issue();
 
     f32x16 acc;
 #pragma unroll
@@ -90,11 +99,14 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
     int cnt = 0;
     const bool active = i < nq;  // lanes of padded queries never select
 
+    long long cg = gw;   // group / chunk / ring slot being consumed
+    int cc = 0, cslot = 0;
     for (long long s = 0; s < steps; ++s) {
         // chunk s has landed when at most the RING-1 younger chunks (4 DMA each) are outstanding
         if (s + RING - 1 < steps) wait_vm<(RING - 1) * 4>(); else wait_vm<0>();
-        const unsigned char* buf = ring + (int)(s % RING) * CHUNK_BYTES;
-        const int c0 = (int)(s % nch) * CW;
+        const unsigned char* buf = ring + cslot * CHUNK_BYTES;
+        const int c0 = cc * CW;
+        if (++cslot == RING) cslot = 0;
         float4 xf[4], qf[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -105,7 +117,8 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (s + RING < steps) issue(s + RING);  // the slot's fragments are in registers: refill it
+        if (s + RING < steps) issue();  // the slot's fragments are in registers: refill it
+        if (abl != 2)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[t].x, qf[t].x, acc, 0, 0, 0);
@@ -113,9 +126,15 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[t].z, qf[t].z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[t].w, qf[t].w, acc, 0, 0, 0);
         }
-        if ((int)(s % nch) == nch - 1) {
+        if (++cc == nch) {
+            cc = 0;
             // ---- a 32-row group is complete: this lane holds query i, rows (r&3) + 8*(r>>2) + 4*h
-            const long long row0 = (gw + (s / nch) * nw) * 32;
+            const long long row0 = cg * 32;
+            cg += nw;
+            {   // adopt the block's threshold for this query (another list may have reached a better k-th key)
+                const u64 shared_tau = tauq[i];
+                tau = shared_tau > tau ? shared_tau : tau;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -131,7 +150,11 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
                         for (int e = last; e > pos; --e) lists[e * 64 + lane] = lists[(e - 1) * 64 + lane];
                         if (pos < k) lists[pos * 64 + lane] = key;
                         if (cnt < k) ++cnt;
-                        tau = (cnt == k) ? lists[(k - 1) * 64 + lane] : 0;
+                        if (cnt == k) {
+                            const u64 kth = lists[(k - 1) * 64 + lane];
+                            const u64 seen = atomicMax(&tauq[i], kth);   // ds_max_rtn_u64
+                            tau = kth > seen ? kth : seen;
+                        }
                     }
                 }
                 acc[r] = 0.f;
@@ -143,6 +166,8 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
     u64* dst = part + (pidx * MFMA_QB + i) * k;
     for (int e = 0; e < k; ++e) dst[e] = (active && e < cnt) ? lists[e * 64 + lane] : 0;
 }
+
+int g_mfma_abl = 0;  // ablation knob (wise_debug_set_scan): 1 = no DMA, 2 = no MFMA
 
 static int mfma_grid(long long N) {
     long long need = ((N + 31) / 32 + 3) / 4;
@@ -158,14 +183,15 @@ int mfma_scan_lists(long long N) { return mfma_grid(N) * 8; }
 size_t mfma_scan_part_bytes(long long N, int k) { return (size_t)mfma_scan_lists(N) * MFMA_QB * k * sizeof(u64); }
 
 int mfma_scan_launch(const float* X, long long N, int d, const float* qpad, int nq, int k, u64* part, hipStream_t st) {
-    const size_t lds = (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES + (size_t)4 * MFMA_KL * 64 * 8;
+    const size_t lds = (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES + (size_t)4 * MFMA_KL * 64 * 8 + 32 * 8;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_mfma_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(ip_scan_mfma_kernel, dim3(mfma_grid(N)), dim3(256), lds, st, X, N, d, qpad, nq, k, part);
+    hipLaunchKernelGGL(ip_scan_mfma_kernel, dim3(mfma_grid(N)), dim3(256), lds, st, X, N, d, qpad, nq, k, part,
+                       g_mfma_abl);
     WISE_LAUNCH_CHECK("ip_scan_mfma_kernel");
     return WISE_OK;
 }
