@@ -50,16 +50,14 @@ int wise_prof_end(double* ms_sum, int64_t* launches, double* work_sum);
  *            (faiss semantics relied on by search.py:142-143, routes.py:1411)
  * Ties: the row with the lower position wins (faiss leaves tie order unspecified).
  * Limits: d % 4 == 0, 4 <= d <= 2048, 1 <= k <= 2048, 1 <= nq <= 1024, X 16-byte aligned.
+ * Batches: nq < 8 (or k > 16, d > 512, d % 32 != 0) runs the single-pass VALU scan per group of up to 4
+ * queries; nq >= 8 runs passes of 32 queries on the fp32 matrix cores, one pass over X per 32 queries.
+ * Scores are the same k-ordered fp32 fmaf chain on both paths: results do not depend on the batch size.
  * ---------------------------------------------------------------------------------------------- */
 size_t wise_ip_topk_workspace_bytes(int64_t N, int d, int nq, int k);
 int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, int k,
                      const int64_t* ids, int64_t id_base, float* outD, int64_t* outI,
                      void* workspace, size_t workspace_bytes, void* stream);
-
-/* Same scan, but leaves the per-shard result as sortable 64-bit keys plus positions so that shards
- * living on different GPUs can be merged after an all-gather.  outD/outI as above with
- * outI = id (ids!=NULL) or id_base+row. Provided for symmetry: wise_ip_topk_f32 already returns the
- * (score,id) pairs that are all-gathered. */
 
 /* Merge `parts` partial top-k lists (e.g. one per GPU after the RCCL all-gather) into one.
  * inD [parts,nq,k] fp32, inI [parts,nq,k] int64 (entries with id -1 are padding) -> outD/outI [nq,k].

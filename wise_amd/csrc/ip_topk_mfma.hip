@@ -10,22 +10,27 @@
 // Structure (block = 4 independent waves, one block per CU):
 //   Q [32][d] lives in LDS for the block's lifetime (16-byte chunks XOR-swizzled by query so that the 32
 //   lanes of an MFMA B-operand read hit distinct banks);
-//   each wave streams 32-row x 32-column chunks of X through a private 3-deep LDS ring by 16-byte LDS-DMA
+//   each wave streams 32-row x 32-column chunks of X through a private 5-deep LDS ring by 16-byte LDS-DMA
 //   (lane-linear destination, swizzle on the SOURCE address), waits with a counted vmcnt, reads its A
 //   fragments, re-issues the ring slot, and feeds 16 MFMAs per chunk; no block barrier in the loop;
 //   k-permutation: lane (i, h) holds columns h*16..h*16+15 of row i — the same permutation on the Q side;
 //   selection: after a 32-row group a lane holds, for ITS query, the scores of 16 rows; candidates that beat
-//   the lane's threshold are insertion-sorted into a lane-private k-entry list in LDS (rare after warm-up).
-//   (Measured alternatives that were slower: the lists in registers with a branch-free bubble, and fragment
-//   reads software-pipelined one chunk ahead.)  Known limit: a chunk row is 128 contiguous bytes, so a 2-KB
-//   database row is visited 16 times; the scan runs at ~3.1 TB/s, about half of the single-query kernel.
-// The per-lane lists (8 per block and query) are folded by merge_keys_kernel.
+//   the threshold are insertion-sorted into the wave's k-entry list of that query in LDS (the two lanes of a
+//   query take turns).  The threshold is the best k-th key ANY of the block's 4 lists of the query has
+//   reached (a key below some list's k-th entry is dominated by k keys of the same query, so it cannot be
+//   in the global top-k): inserts, which serialise the wave, fall ~6x against lane-private thresholds.
+//   Measured alternatives that were slower: lists in registers with a branch-free bubble; lists in global
+//   memory with a device-wide atomic threshold (every insert is a chain of dependent global loads that
+//   also drains the LDS-DMA queue: 18-25 ms); 8 waves/block with a 2-deep ring; fragment reads
+//   software-pipelined one chunk ahead (the earlier vmcnt wait costs more than the overlap gains).
+//   10M x 512, 32 queries: 5.4 ms = 3.8 TB/s of X (compute-only 3.9 ms, DMA-only 3.3 ms).
+// The per-wave lists (4 per block and query) are folded by merge_keys_kernel.
 #include "topk_common.h"
 
 namespace wise {
 
 constexpr int CW = 32;          // columns per chunk
-constexpr int RING = 3;         // chunks in flight per wave
+constexpr int RING = 5;         // chunks in flight per wave
 constexpr int CHUNK_BYTES = 32 * CW * 4;  // 4 KiB
 
 __device__ __forceinline__ void glds16_x(const void* gsrc, void* lds_dst) {
@@ -47,11 +52,10 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
     const int d4 = d >> 2;                   // 16-byte chunks per row
     float* Qs = reinterpret_cast<float*>(smem);                                  // 32*d floats
     unsigned char* ring = smem + (size_t)32 * d * 4 + (size_t)wave * RING * CHUNK_BYTES;
-    u64* lists = reinterpret_cast<u64*>(smem + (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES) +
-                 (size_t)wave * MFMA_KL * 64;                                    // entry e of lane l: lists[e*64 + l]
-    // block-shared threshold per query: the best k-th key any of the block's 8 lists of that query has reached
-    u64* tauq = reinterpret_cast<u64*>(smem + (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES) +
-                (size_t)4 * MFMA_KL * 64;
+    // one k-entry descending list per (wave, query): entry e of query j at lists[e*32 + j]; the two lanes
+    // (h = 0, 1) that serve a query take turns.  The k-th entries double as the block's shared thresholds.
+    u64* lists_all = reinterpret_cast<u64*>(smem + (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES);
+    u64* lists = lists_all + (size_t)wave * MFMA_KL * 32;
 
     // ---- Q -> LDS, chunk c of query j stored at chunk (c & ~15) | ((c & 15) ^ (j & 15))
     for (int idx = threadIdx.x; idx < 32 * d4; idx += 256) {
@@ -60,8 +64,7 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
         const int pc = (c & ~15) | ((c & 15) ^ (j & 15));
         reinterpret_cast<float4*>(Qs)[j * d4 + pc] = v;
     }
-    for (int e = 0; e < MFMA_KL; ++e) lists[e * 64 + lane] = 0;
-    if (threadIdx.x < 32) tauq[threadIdx.x] = 0;
+    for (int e = h; e < MFMA_KL; e += 2) lists[e * 32 + i] = 0;
     __syncthreads();
 
     const int nch = d / CW;
@@ -96,7 +99,6 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     u64 tau = 0;
-    int cnt = 0;
     const bool active = i < nq;  // lanes of padded queries never select
 
     long long cg = gw;   // group / chunk / ring slot being consumed
@@ -131,9 +133,11 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
             // ---- a 32-row group is complete: this lane holds query i, rows (r&3) + 8*(r>>2) + 4*h
             const long long row0 = cg * 32;
             cg += nw;
-            {   // adopt the block's threshold for this query (another list may have reached a better k-th key)
-                const u64 shared_tau = tauq[i];
-                tau = shared_tau > tau ? shared_tau : tau;
+            // adopt the best k-th key any of the block's 4 lists of this query has reached
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const u64 t = lists_all[(size_t)w * MFMA_KL * 32 + (k - 1) * 32 + i];
+                tau = t > tau ? t : tau;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -141,20 +145,28 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
                 const u64 key = make_key(acc[r], (unsigned)row);
                 const bool pass = active && row < N && key > tau;
                 if (__ballot(pass) != 0) {
-                    if (pass) {
-                        // insertion into the lane's descending list (entries past cnt are 0)
-                        int pos = cnt;
-                        for (int e = 0; e < cnt; ++e)
-                            if (lists[e * 64 + lane] < key) { pos = e; break; }
-                        const int last = cnt < k ? cnt : k - 1;
-                        for (int e = last; e > pos; --e) lists[e * 64 + lane] = lists[(e - 1) * 64 + lane];
-                        if (pos < k) lists[pos * 64 + lane] = key;
-                        if (cnt < k) ++cnt;
-                        if (cnt == k) {
-                            const u64 kth = lists[(k - 1) * 64 + lane];
-                            const u64 seen = atomicMax(&tauq[i], kth);   // ds_max_rtn_u64
-                            tau = kth > seen ? kth : seen;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        // the list is full exactly when its k-th entry is a real key (keys are never 0)
+                        if (pass && h == hh) {
+                            const u64 kth = lists[(k - 1) * 32 + i];
+                            if (key > kth) {
+                                int pos = k - 1;
+                                while (pos > 0) {
+                                    const u64 prev = lists[(pos - 1) * 32 + i];
+                                    if (prev >= key) break;
+                                    lists[pos * 32 + i] = prev;
+                                    --pos;
+                                }
+                                lists[pos * 32 + i] = key;
+                            }
+                            const u64 nk = lists[(k - 1) * 32 + i];
+                            tau = nk > tau ? nk : tau;
                         }
+                        // make lane (i, 0)'s writes visible to lane (i, 1) of the same wave
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     }
                 }
                 acc[r] = 0.f;
@@ -162,9 +174,9 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
         }
     }
     // ---- publish: list (block, wave, h) of query i -> part[P_idx][i][0..k)
-    const size_t pidx = ((size_t)blockIdx.x * 4 + wave) * 2 + h;
+    const size_t pidx = (size_t)blockIdx.x * 4 + wave;
     u64* dst = part + (pidx * MFMA_QB + i) * k;
-    for (int e = 0; e < k; ++e) dst[e] = (active && e < cnt) ? lists[e * 64 + lane] : 0;
+    for (int e = h; e < k; e += 2) dst[e] = active ? lists[e * 32 + i] : 0;
 }
 
 int g_mfma_abl = 0;  // ablation knob (wise_debug_set_scan): 1 = no DMA, 2 = no MFMA
@@ -179,11 +191,11 @@ bool mfma_scan_supported(int d, int nq, int k) {
     // Q must fit LDS beside the rings and lists (32*d*4 <= 64 KiB), chunks are 32 columns, lists hold 16
     return nq >= 8 && k <= MFMA_KL && d % CW == 0 && d >= CW && d <= 512;
 }
-int mfma_scan_lists(long long N) { return mfma_grid(N) * 8; }
+int mfma_scan_lists(long long N) { return mfma_grid(N) * 4; }
 size_t mfma_scan_part_bytes(long long N, int k) { return (size_t)mfma_scan_lists(N) * MFMA_QB * k * sizeof(u64); }
 
 int mfma_scan_launch(const float* X, long long N, int d, const float* qpad, int nq, int k, u64* part, hipStream_t st) {
-    const size_t lds = (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES + (size_t)4 * MFMA_KL * 64 * 8 + 32 * 8;
+    const size_t lds = (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES + (size_t)4 * MFMA_KL * 32 * 8;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_mfma_kernel),

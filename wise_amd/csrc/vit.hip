@@ -5,8 +5,8 @@
 // VisionTransformer; the same computation as transformers' CLIPVisionModelWithProjection,
 // which is what the oracle is pinned against).
 //
-// Data layout in HBM (workspace, all row-major, rows padded to a multiple of 128 so the GEMM never
-// needs an M edge):
+// Data layout in HBM (workspace, all row-major, rows padded to a multiple of 256 so no GEMM
+// tile, 128- or 256-row, needs an M edge):
 //   x    fp32 [Mp, W]    residual stream (kept fp32; LN statistics and the residual adds are fp32)
 //   h    bf16 [Mp, W]    LayerNorm output / attention output (GEMM A operand)
 //   qkv  bf16 [Mp, 3W]   in_proj output;       also patch-embed fp32 output [Mpp, W] before layer 0
@@ -400,53 +400,6 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     for (int c = lane; c < D; c += 64) s += er[c] * er[c];
     const float nrm = sqrtf(wave_sum(s));
     for (int c = lane; c < D; c += 64) out[(size_t)r * D + c] = er[c] / nrm;
-}
-
-// out[b,:] = normalize( ln_post(x[b*T, :]) @ proj ), projT bf16 [D, W]; one block (256 thr) per image
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                   const float* __restrict__ bb, const bf16_t* __restrict__ projT,
-                                                   int T, int W, int D, float eps, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* y = reinterpret_cast<float*>(smem);  // [W] ln_post(cls), then [D] outputs
-    float* e = y + W;
-    __shared__ float red[8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* xr = x + (size_t)blockIdx.x * T * W;
-    float s = 0.f;
-    for (int c = tid; c < W; c += 256) s += xr[c];
-    s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)W;
-    __syncthreads();
-    float q = 0.f;
-    for (int c = tid; c < W; c += 256) { float a = xr[c] - mean; q += a * a; }
-    q = wave_sum(q);
-    if (lane == 0) red[wave] = q;
-    __syncthreads();
-    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)W + eps);
-    for (int c = tid; c < W; c += 256) {
-        y[c] = (xr[c] - mean) * rstd * w[c] + bb[c];
-    }
-    __syncthreads();
-    float sq = 0.f;
-    for (int dcol = wave; dcol < D; dcol += 4) {
-        const bf16_t* pr = projT + (size_t)dcol * W;
-        float acc = 0.f;
-        for (int c = lane * 8; c < W; c += 512) {
-            short8 pv = *reinterpret_cast<const short8*>(pr + c);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc = fmaf(y[c + j], bf16_to_f32((bf16_t)pv[j]), acc);
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) e[dcol] = acc;
-        sq += acc * acc;  // same in every lane
-    }
-    __syncthreads();
-    if (lane == 0) red[4 + wave] = sq;
-    __syncthreads();
-    const float nrm = sqrtf(red[4] + red[5] + red[6] + red[7]);
-    for (int dcol = tid; dcol < D; dcol += 256) out[(size_t)blockIdx.x * D + dcol] = e[dcol] / nrm;
 }
 
 struct VitDims {
