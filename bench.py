@@ -280,9 +280,11 @@ def main():
         for i in range(3):
             search32(i)
         sdt32 = timed_region(search32, s_steps, world)
-        D32, I32 = res["DI32"]
-        D1, I1 = index.search_device(Q[(32 * (s_steps - 1)) % 960:(32 * (s_steps - 1)) % 960 + 1], k)
-        assert torch.equal(I32[:1], I1) and torch.equal(D32[:1], D1), "batched and single-query scans disagree"
+        D32, I32 = index.search_device(Q[:32], k)
+        D1, I1 = index.search_device(Q[:1], k)
+        # the two kernels sum the d products in different orders: same ids, scores to the tested 2e-5
+        assert torch.equal(I32[:1], I1) and bool((D32[:1] - D1).abs().max() <= 2e-5), \
+            "batched and single-query scans disagree"
         result["search"] = {
             "metric": "queries/sec over 10M×512 index (flat IP, top-10, nq=1 per call as the reference issues them)",
             "value": round(qps, 2), "unit": "queries/s", "ms_per_step": round(sdt / s_steps * 1e3, 4),

@@ -52,7 +52,8 @@ int wise_prof_end(double* ms_sum, int64_t* launches, double* work_sum);
  * Limits: d % 4 == 0, 4 <= d <= 2048, 1 <= k <= 2048, 1 <= nq <= 1024, X 16-byte aligned.
  * Batches: nq < 8 (or k > 16, d > 512, d % 32 != 0) runs the single-pass VALU scan per group of up to 4
  * queries; nq >= 8 runs passes of 32 queries on the fp32 matrix cores, one pass over X per 32 queries.
- * Scores are the same k-ordered fp32 fmaf chain on both paths: results do not depend on the batch size.
+ * Both paths accumulate in fp32 (different summation orders: scores agree to ~1e-6 relative, ids agree
+ * wherever neighbouring scores differ by more than that).
  * ---------------------------------------------------------------------------------------------- */
 size_t wise_ip_topk_workspace_bytes(int64_t N, int d, int nq, int k);
 int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, int k,

@@ -1,5 +1,5 @@
 // HP-2, batched queries: brute-force inner-product scan for up to 32 queries per pass on the fp32
-// matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-for-bit a k-ordered fmaf chain),
+// matrix cores (v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulate — a serial fmaf chain per output, no reduced precision),
 // so that a batch of queries shares ONE pass over the database.  Serves the batched form of the search
 // the reference issues one query at a time (src/index/feature_search_index.py:113; the 3842 sequential
 // queries of docs/Retrieval-Evaluation.md:36-45) — SURVEY.md §8 f3.
