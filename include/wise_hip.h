@@ -129,6 +129,40 @@ int wise_htsat_forward(const uint16_t* wb, const float* pf, const float* wave, i
 int wise_htsat_tap(int what, const void* workspace, int batch, int samples, float* dst, int64_t count,
                    void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * HP-1  image transform on the GPU: replaces the per-frame CPU loop of
+ *       MlfoundationOpenClip.preprocess_image, src/feature/mlfoundation_openclip.py:81-90, for uint8 frames
+ *       [n,3,H,W] (the decoder's output, src/dataloader/dataset.py:298):
+ *       to_pil_image -> Resize(S, BICUBIC, shorter side) -> CenterCrop(S)   => uint8 [n,3,S,S],
+ *       bit-identical to Pillow's 8-bit antialiased resampler; ToTensor + Normalize happen inside
+ *       wise_vit_forward(in_kind = WISE_VIT_IN_U8).
+ *
+ * A plan belongs to one (H, W, S).  plan_init and tables are host-only (no GPU needed); the caller copies the
+ * `table_bytes` blob to the device once and passes it to every wise_preproc_u8 call for that geometry.
+ * Limits: H, W <= 16384; S % 4 == 0; the staged input of one output tile must fit 64 KiB of LDS
+ * (downscale factors up to ~20x).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct wise_preproc_plan {
+    int32_t H, W, S;            /* input frame size, output edge */
+    int32_t new_w, new_h;       /* size after Resize(S) (torchvision: long side = int(S*long/short)) */
+    int32_t left, top;          /* CenterCrop origin inside the resized image */
+    int32_t tile;               /* output tile edge of one workgroup */
+    int32_t ndh, ndv;           /* dwords of padded taps per output column / row */
+    int32_t max_cols4, max_rows4; /* staged input rectangle of the worst tile: column dwords, rows / 4 */
+    int32_t lds_bytes;
+    int32_t reserved;
+    uint64_t table_bytes;       /* size of the tap-table blob */
+} wise_preproc_plan;
+int wise_preproc_plan_init(int H, int W, int S, wise_preproc_plan* plan);
+int wise_preproc_tables(const wise_preproc_plan* plan, void* host_tables);
+/* frames uint8 [n,3,H,W] (device) -> out uint8 [n,3,S,S] (device, 4-byte aligned). */
+int wise_preproc_u8(const wise_preproc_plan* plan, const void* dev_tables, const uint8_t* frames, int n,
+                    uint8_t* out, void* stream);
+/* Pillow's tap table of one axis (first input index, count, 22-bit fixed-point coefficients [out][ksize]);
+ * host-only, exported so that the tables can be pinned against the oracle without a GPU. */
+int wise_preproc_taps(int in_size, int out_size, int* ksize, int* first, int* count, int* coef,
+                      int coef_capacity);
+
 /* Building blocks, exported so the parity tests can pin each kernel separately. */
 /* C[M,N] = epilogue(A[M,K] bf16 @ Wt[N,K]^T bf16 + bias[N]) ; M%128==0 rows must be readable
  * (callers pad), N%4==0, K%32==0.

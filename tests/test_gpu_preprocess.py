@@ -1,0 +1,78 @@
+"""SURVEY.md §8 f2 on the GPU: wise_preproc_u8 (through the C ABI) against Pillow-rendered golden vectors and the
+oracle, bit for bit; then the whole uint8 -> embedding path against the reference's CPU PIL loop."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import preprocess_ref as ref
+from oracle.make_golden_preprocess import CASES, case_input
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(Path(__file__).parent / "golden" / "preprocess.npz")
+
+
+@pytest.fixture(scope="module")
+def pre224():
+    from wise_amd.feature.preprocess import ClipPreprocessor
+    return ClipPreprocessor(224)
+
+
+@pytest.mark.parametrize("H,W,S,seed", CASES)
+def test_kernel_reproduces_pillow_golden(H, W, S, seed):
+    from wise_amd.feature.preprocess import ClipPreprocessor
+    frame = torch.from_numpy(case_input(H, W, seed))[None].cuda()
+    out = ClipPreprocessor(S)(frame)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()[0]
+    want = GOLD[f"out_{H}x{W}_{S}_{seed}"]
+    assert got.shape == want.shape and np.array_equal(got, want), \
+        f"{int((got != want).sum())} bytes differ, max {int(np.abs(got.astype(int) - want).max())}"
+
+
+@pytest.mark.parametrize("H,W,n", [(240, 320, 19), (270, 481, 5), (720, 1280, 9), (64, 48, 3), (226, 224, 8)])
+def test_batches_match_oracle(pre224, H, W, n):
+    frames = np.random.default_rng(H * 7 + W).integers(0, 256, (n, 3, H, W), dtype=np.uint8)
+    dev = torch.from_numpy(frames).cuda()
+    got = pre224(dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), ref.clip_preprocess_u8(frames, 224))
+
+
+def test_constant_and_extreme_frames(pre224):
+    """Saturation: clip8 must clamp overshoot of the negative bicubic lobes exactly as Pillow does."""
+    H, W = 300, 400
+    f = np.zeros((4, 3, H, W), dtype=np.uint8)
+    f[1] = 255
+    f[2, :, ::2, :] = 255                      # horizontal stripes
+    f[3, :, :, (np.arange(W) // 3) % 2 == 0] = 255   # vertical bars
+    got = pre224(torch.from_numpy(f).cuda()).cpu().numpy()
+    want = ref.clip_preprocess_u8(f, 224)
+    assert np.array_equal(got, want)
+    assert got[0].max() == 0 and got[1].min() == 255
+
+
+def test_bad_input_raises(pre224):
+    with pytest.raises(ValueError):
+        pre224(torch.zeros(2, 3, 32, 32, dtype=torch.float32))
+    with pytest.raises(ValueError):
+        pre224(torch.zeros(3, 32, 32, dtype=torch.uint8))
+
+
+def test_uint8_frames_to_embeddings_match_the_cpu_pil_path():
+    """extract(preprocess_image_device(u8)) == extract(preprocess_image(u8)): the reference's CPU loop
+    (mlfoundation_openclip.py:81-101) and the all-GPU path give the same embeddings."""
+    from wise_amd.feature.feature_extractor_factory import FeatureExtractorFactory
+    fx = FeatureExtractorFactory("mlfoundations/open_clip/ViT-B-32/seeded-0")
+    frames = torch.from_numpy(np.random.default_rng(2).integers(0, 256, (8, 3, 240, 320), dtype=np.uint8))
+    cpu_path = fx.extract_image_features(fx.preprocess_image(frames))
+    dev_u8 = fx.preprocess_image_device(frames.cuda())
+    # the uint8 crop is what PIL produced before ToTensor
+    pil_u8 = ref.clip_preprocess_u8(frames.numpy(), 224)
+    assert np.array_equal(dev_u8.cpu().numpy(), pil_u8)
+    gpu_path = fx.extract_image_features(dev_u8)
+    cos = (cpu_path * gpu_path).sum(axis=1)
+    assert cos.min() > 1 - 1e-4, cos
+    with pytest.raises(ValueError):
+        fx.preprocess_image_device(frames.float())

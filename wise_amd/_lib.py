@@ -43,6 +43,10 @@ SIGNATURES = {
     "wise_htsat_workspace_bytes": (_sz, [_i, _i]),
     "wise_htsat_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "wise_htsat_tap": (_i, [_i, _vp, _i, _i, _vp, _i64, _vp]),
+    "wise_preproc_plan_init": (_i, [_i, _i, _i, _vp]),
+    "wise_preproc_tables": (_i, [_vp, _vp]),
+    "wise_preproc_u8": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "wise_preproc_taps": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i]),
     "wise_gemm_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "wise_layernorm_f32_bf16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "wise_attention_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),

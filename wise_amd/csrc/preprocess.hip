@@ -1,0 +1,363 @@
+// the image transform in front of the tower, on the GPU.
+//
+// Replaces, for uint8 frames [n,3,H,W] as the decoder hands them over (src/dataloader/dataset.py:298), the
+// per-frame CPU loop of src/feature/mlfoundation_openclip.py:81-90:
+//     F.to_pil_image -> Resize(S, BICUBIC, shorter side) -> CenterCrop(S) -> [ToTensor -> Normalize]
+// The bracketed part is already fused into the patch gather of the tower (vit.hip, WISE_VIT_IN_U8); this file
+// produces the uint8 [n,3,S,S] crop.  The arithmetic is Pillow's 8-bit resampler (libImaging/Resample.c), which
+// is exact integer work and is reproduced bit for bit:
+//   * taps per output position from `precompute_coeffs` (double; support = 2 * max(scale, 1): antialiased),
+//     rounded to 22-bit fixed point by `normalize_coeffs_8bpc`                         [host, plan_init]
+//   * horizontal pass over the input rows, each result rounded to uint8 (`clip8`), then the vertical pass over
+//     that uint8 image, rounded again                                                   [device, fused]
+// Only the S x S crop is produced, so only the columns/rows it depends on are ever read.
+//
+// Kernel: one workgroup per (plane, TS x TS output tile).  It stages the input rectangle the tile depends on in
+// LDS (dword loads when W % 4 == 0), runs the horizontal pass LDS -> LDS and the vertical pass LDS -> HBM.
+// Bound: HBM (input bytes read once + halo, S*S bytes written per plane); VALU work is ~2 * taps MACs / output.
+//   * every LDS data access is a dword holding 4 taps' bytes: the tap rows are stored on the host already
+//     shifted by (first input index & 3) and zero-padded to whole dwords, so the kernel has no alignment
+//     cases — a zero coefficient annihilates whatever byte sits under it;
+//   * a lane owns 4 rows (horizontal) / 4 columns (vertical) and shares one 16-byte coefficient read between
+//     them; rows/columns are stored 4-way interleaved with an odd dword stride so lanes hit distinct banks;
+//   * tiles of one plane are consecutive on one XCD (block id -> XCD is round-robin), so the halo a tile
+//     shares with its neighbours is served by that XCD's L2.
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+// host: Pillow's tap tables.  Floating point must not be contracted into FMAs: the products and sums below
+// are the ones Resample.c performs, in its order.
+#pragma clang fp contract(off)
+
+namespace wise {
+
+constexpr int PREC = 32 - 8 - 2;  // Resample.c PRECISION_BITS for 8-bit channels
+
+static double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+struct Taps {
+    int ksize = 0;
+    std::vector<int> first, count, coef;  // coef[out][ksize]
+};
+
+static void pillow_taps(int in_size, int out_size, Taps& t) {
+    t.first.assign(out_size, 0);
+    t.count.assign(out_size, 0);
+    if (in_size == out_size) {  // Pillow skips a pass whose size does not change: identity taps
+        t.ksize = 1;
+        t.coef.assign(out_size, 1 << PREC);
+        for (int i = 0; i < out_size; ++i) { t.first[i] = i; t.count[i] = 1; }
+        return;
+    }
+    const double scale = (double)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * filterscale;
+    t.ksize = (int)ceil(support) * 2 + 1;
+    t.coef.assign((size_t)out_size * t.ksize, 0);
+    std::vector<double> k(t.ksize);
+    const double ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = 0.0 + (xx + 0.5) * scale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) {
+            const double w = bicubic_filter((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; ++x) {
+            if (ww != 0.0) k[x] /= ww;
+            t.coef[(size_t)xx * t.ksize + x] =
+                k[x] < 0 ? (int)(-0.5 + k[x] * (1 << PREC)) : (int)(0.5 + k[x] * (1 << PREC));
+        }
+        t.first[xx] = xmin;
+        t.count[xx] = xmax;
+    }
+}
+
+// torchvision CenterCrop: int(round(v / 2.0)) with Python's round-half-to-even
+static int half_round_even(int v) {
+    const int f = v / 2;
+    if ((v & 1) == 0) return f;
+    return (f & 1) ? f + 1 : f;
+}
+
+struct AxisTables {
+    int nd = 0;                      // dwords of padded taps per output
+    std::vector<int> start;          // [S] first input dword
+    std::vector<int> coef;           // [S][nd*4]
+    std::vector<int> t0, tn;         // per tile: first staged dword, number of staged dwords
+    int max_n = 0;
+};
+
+static void axis_tables(const Taps& t, int off, int S, int tile, int in_size, AxisTables& a) {
+    a.nd = 1;
+    for (int i = 0; i < S; ++i) a.nd = std::max(a.nd, ((t.first[i + off] & 3) + t.count[i + off] + 3) / 4);
+    a.start.resize(S);
+    a.coef.assign((size_t)S * a.nd * 4, 0);
+    for (int i = 0; i < S; ++i) {
+        const int f = t.first[i + off];
+        a.start[i] = f >> 2;
+        for (int k = 0; k < t.count[i + off]; ++k)
+            a.coef[(size_t)i * a.nd * 4 + (f & 3) + k] = t.coef[(size_t)(i + off) * t.ksize + k];
+    }
+    const int nt = (S + tile - 1) / tile;
+    a.t0.resize(nt);
+    a.tn.resize(nt);
+    a.max_n = 0;
+    (void)in_size;
+    for (int ti = 0; ti < nt; ++ti) {
+        const int lo = ti * tile, hi = std::min(S, lo + tile);
+        int d0 = a.start[lo], d1 = 0;
+        for (int i = lo; i < hi; ++i) { d0 = std::min(d0, a.start[i]); d1 = std::max(d1, a.start[i] + a.nd); }
+        a.t0[ti] = d0;
+        a.tn[ti] = d1 - d0;
+        a.max_n = std::max(a.max_n, d1 - d0);
+    }
+}
+
+struct HostPlan {
+    wise_preproc_plan p;
+    AxisTables h, v;
+};
+
+static int build_plan(int H, int W, int S, HostPlan& hp) {
+    WISE_CHECK_ARG(H >= 1 && W >= 1 && H <= 16384 && W <= 16384, "preproc: frame %dx%d out of range", H, W);
+    WISE_CHECK_ARG(S >= 4 && S <= 1024 && S % 4 == 0, "preproc: output edge %d must be a multiple of 4 in [4,1024]", S);
+    wise_preproc_plan& p = hp.p;
+    p = wise_preproc_plan{};
+    p.H = H; p.W = W; p.S = S;
+    // torchvision Resize(S): shorter side -> S, longer side -> int(S * long / short)
+    if (W <= H) { p.new_w = S; p.new_h = (int)((double)((long long)S * H) / (double)W); }
+    else        { p.new_w = (int)((double)((long long)S * W) / (double)H); p.new_h = S; }
+    WISE_CHECK_ARG(p.new_w <= 65536 && p.new_h <= 65536, "preproc: aspect ratio of %dx%d too extreme", H, W);
+    p.left = half_round_even(p.new_w - S);
+    p.top = half_round_even(p.new_h - S);
+    Taps th, tv;
+    pillow_taps(W, p.new_w, th);
+    pillow_taps(H, p.new_h, tv);
+    for (int tile : {32, 16, 8}) {
+        if (tile > S && tile != 8) continue;
+        axis_tables(th, p.left, S, tile, W, hp.h);
+        axis_tables(tv, p.top, S, tile, H, hp.v);
+        p.tile = tile;
+        p.ndh = hp.h.nd; p.ndv = hp.v.nd;
+        p.max_cols4 = hp.h.max_n; p.max_rows4 = hp.v.max_n;
+        const long long cs = p.max_cols4 | 1, rs = p.max_rows4 | 1;
+        const long long words = (long long)p.max_rows4 * 4 * cs + (long long)tile * rs +
+                                (long long)tile * (p.ndh + p.ndv) * 4 + 2 * tile;
+        p.lds_bytes = (int)std::min<long long>(words * 4, 1 << 30);
+        if (words * 4 <= 64 * 1024) break;
+    }
+    WISE_CHECK_ARG(p.lds_bytes <= 64 * 1024, "preproc: %dx%d -> %d needs %d B of LDS per tile (downscale too large)", H,
+                   W, S, p.lds_bytes);
+    const int nt = (S + p.tile - 1) / p.tile;
+    p.table_bytes = (uint64_t)4 * ((size_t)2 * S + (size_t)S * (p.ndh + p.ndv) * 4 + (size_t)4 * nt);
+    return WISE_OK;
+}
+
+}  // namespace wise
+
+using namespace wise;
+
+extern "C" int wise_preproc_plan_init(int H, int W, int S, wise_preproc_plan* plan) {
+    WISE_CHECK_ARG(plan, "preproc: null plan");
+    HostPlan hp;
+    const int rc = build_plan(H, W, S, hp);
+    if (rc) return rc;
+    *plan = hp.p;
+    return WISE_OK;
+}
+
+// blob (int32): hstart[S] | vstart[S] | hcoef[S][ndh*4] | vcoef[S][ndv*4] | hc0[nt] | hcn[nt] | vr0[nt] | vrn[nt]
+extern "C" int wise_preproc_tables(const wise_preproc_plan* plan, void* host_tables) {
+    WISE_CHECK_ARG(plan && host_tables, "preproc: null argument");
+    HostPlan hp;
+    const int rc = build_plan(plan->H, plan->W, plan->S, hp);
+    if (rc) return rc;
+    WISE_CHECK_ARG(hp.p.table_bytes == plan->table_bytes && hp.p.tile == plan->tile, "preproc: plan does not match");
+    int* o = static_cast<int*>(host_tables);
+    auto put = [&](const std::vector<int>& v) { std::copy(v.begin(), v.end(), o); o += v.size(); };
+    put(hp.h.start); put(hp.v.start); put(hp.h.coef); put(hp.v.coef);
+    put(hp.h.t0); put(hp.h.tn); put(hp.v.t0); put(hp.v.tn);
+    return WISE_OK;
+}
+
+// Pillow's raw tap table for one axis (tests pin it against the oracle without a GPU).
+extern "C" int wise_preproc_taps(int in_size, int out_size, int* ksize, int* first, int* count, int* coef,
+                                 int coef_capacity) {
+    WISE_CHECK_ARG(in_size >= 1 && out_size >= 1 && ksize && first && count && coef, "preproc_taps: bad argument");
+    Taps t;
+    pillow_taps(in_size, out_size, t);
+    WISE_CHECK_ARG((long long)out_size * t.ksize <= coef_capacity, "preproc_taps: need %lld coefficients",
+                   (long long)out_size * t.ksize);
+    *ksize = t.ksize;
+    std::copy(t.first.begin(), t.first.end(), first);
+    std::copy(t.count.begin(), t.count.end(), count);
+    std::copy(t.coef.begin(), t.coef.end(), coef);
+    return WISE_OK;
+}
+
+namespace wise {
+
+__device__ __forceinline__ int clip8(int acc) {
+    int v = acc >> PREC;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// 4 taps: bytes of w times c.x..c.w
+__device__ __forceinline__ int mac4(unsigned w, const int4& c, int acc) {
+    acc += (int)(w & 255u) * c.x;
+    acc += (int)((w >> 8) & 255u) * c.y;
+    acc += (int)((w >> 16) & 255u) * c.z;
+    acc += (int)(w >> 24) * c.w;
+    return acc;
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void clip_resize_kernel(const unsigned char* __restrict__ frames, int planes, int H,
+                                                          int W, int S, int TS, int ndh, int ndv, int CS, int RS,
+                                                          int max_rows4, const int* __restrict__ tab,
+                                                          unsigned char* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nt = (S + TS - 1) / TS, tiles = nt * nt;
+    // blocks b, b+8, b+16 ... share an XCD: give each plane's tiles to one XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int plane = (slot / tiles) * 8 + xcd;
+    if (plane >= planes) return;
+    const int t = slot % tiles, ty = t / nt, tx = t % nt;
+
+    const int* hstart = tab;
+    const int* vstart = tab + S;
+    const int* hcoef = tab + 2 * S;
+    const int* vcoef = hcoef + (size_t)S * ndh * 4;
+    const int* tl = vcoef + (size_t)S * ndv * 4;
+    const int c0 = tl[tx], cn = tl[nt + tx], r0 = tl[2 * nt + ty], rn4 = tl[3 * nt + ty];
+
+    unsigned* in32 = reinterpret_cast<unsigned*>(smem);                   // [max_rows4*4][CS], rows 4-way interleaved
+    unsigned* tmp32 = in32 + (size_t)max_rows4 * 4 * CS;                  // [TS][RS], columns 4-way interleaved
+    int* hco = reinterpret_cast<int*>(tmp32 + (size_t)TS * RS);           // [TS][ndh*4]
+    int* vco = hco + TS * ndh * 4;                                        // [TS][ndv*4]
+    int* hst = vco + TS * ndv * 4;                                        // [TS]
+    int* vst = hst + TS;                                                  // [TS]
+
+    const int tid = threadIdx.x;
+    const unsigned char* src = frames + (size_t)plane * H * W;
+    const int x0 = tx * TS, y0 = ty * TS;
+
+    // ---- stage the input rectangle (rows r0*4 .. +rn4*4, dwords c0 .. +cn) and the tile's taps
+    const int rows = rn4 * 4;
+    const int wd = ALIGNED ? (W >> 2) : ((W + 3) >> 2);
+    const int cload = min(cn, wd - c0);  // dwords that exist in the frame
+    for (int idx = tid; idx < rows * cload; idx += 256) {
+        const int r = idx / cload, j = idx - r * cload;
+        const int gr = min(r0 * 4 + r, H - 1);  // rows past the frame only ever meet zero taps
+        unsigned v;
+        if (ALIGNED) {
+            v = *reinterpret_cast<const unsigned*>(src + (size_t)gr * W + (size_t)(c0 + j) * 4);
+        } else {
+            const unsigned char* p = src + (size_t)gr * W;
+            const int c = (c0 + j) * 4;
+            v = (unsigned)p[c];
+            if (c + 1 < W) v |= (unsigned)p[c + 1] << 8;
+            if (c + 2 < W) v |= (unsigned)p[c + 2] << 16;
+            if (c + 3 < W) v |= (unsigned)p[c + 3] << 24;
+        }
+        in32[((r & 3) * rn4 + (r >> 2)) * CS + j] = v;
+    }
+    for (int idx = tid; idx < TS * ndh * 4; idx += 256) {
+        const int i = idx / (ndh * 4);
+        hco[idx] = (x0 + i < S) ? hcoef[(size_t)(x0 + i) * ndh * 4 + (idx - i * ndh * 4)] : 0;
+    }
+    for (int idx = tid; idx < TS * ndv * 4; idx += 256) {
+        const int i = idx / (ndv * 4);
+        vco[idx] = (y0 + i < S) ? vcoef[(size_t)(y0 + i) * ndv * 4 + (idx - i * ndv * 4)] : 0;
+    }
+    if (tid < TS) {
+        hst[tid] = (x0 + tid < S) ? hstart[x0 + tid] - c0 : 0;
+        vst[tid] = (y0 + tid < S) ? vstart[y0 + tid] - r0 : 0;
+    }
+    __syncthreads();
+
+    // ---- horizontal pass: item (x, rg) = output column x of input rows 4*rg .. 4*rg+3
+    const int XG = TS >> 2;
+    for (int idx = tid; idx < TS * rn4; idx += 256) {
+        const int x = idx / rn4, rg = idx - x * rn4;
+        const int base = hst[x];
+        const int4* co = reinterpret_cast<const int4*>(hco + x * ndh * 4);
+        int a0 = 1 << (PREC - 1), a1 = a0, a2 = a0, a3 = a0;
+        for (int j = 0; j < ndh; ++j) {
+            const int4 c = co[j];
+            a0 = mac4(in32[(0 * rn4 + rg) * CS + base + j], c, a0);
+            a1 = mac4(in32[(1 * rn4 + rg) * CS + base + j], c, a1);
+            a2 = mac4(in32[(2 * rn4 + rg) * CS + base + j], c, a2);
+            a3 = mac4(in32[(3 * rn4 + rg) * CS + base + j], c, a3);
+        }
+        tmp32[((x & 3) * XG + (x >> 2)) * RS + rg] =
+            (unsigned)clip8(a0) | ((unsigned)clip8(a1) << 8) | ((unsigned)clip8(a2) << 16) | ((unsigned)clip8(a3) << 24);
+    }
+    __syncthreads();
+
+    // ---- vertical pass: item (y, xg) = output row y of columns 4*xg .. 4*xg+3, one dword store
+    for (int idx = tid; idx < TS * XG; idx += 256) {
+        const int y = idx / XG, xg = idx - y * XG;
+        if (y0 + y >= S || x0 + xg * 4 >= S) continue;
+        const int base = vst[y];
+        const int4* co = reinterpret_cast<const int4*>(vco + y * ndv * 4);
+        int a0 = 1 << (PREC - 1), a1 = a0, a2 = a0, a3 = a0;
+        for (int j = 0; j < ndv; ++j) {
+            const int4 c = co[j];
+            a0 = mac4(tmp32[(0 * XG + xg) * RS + base + j], c, a0);
+            a1 = mac4(tmp32[(1 * XG + xg) * RS + base + j], c, a1);
+            a2 = mac4(tmp32[(2 * XG + xg) * RS + base + j], c, a2);
+            a3 = mac4(tmp32[(3 * XG + xg) * RS + base + j], c, a3);
+        }
+        const unsigned v =
+            (unsigned)clip8(a0) | ((unsigned)clip8(a1) << 8) | ((unsigned)clip8(a2) << 16) | ((unsigned)clip8(a3) << 24);
+        *reinterpret_cast<unsigned*>(out + ((size_t)plane * S + (y0 + y)) * S + x0 + xg * 4) = v;
+    }
+}
+
+}  // namespace wise
+
+extern "C" int wise_preproc_u8(const wise_preproc_plan* plan, const void* dev_tables, const uint8_t* frames, int n,
+                               uint8_t* out, void* stream) {
+    WISE_CHECK_ARG(plan && dev_tables && frames && out, "preproc: null argument");
+    WISE_CHECK_ARG(n >= 1 && n <= (1 << 20), "preproc: n=%d", n);
+    HostPlan hp;
+    int rc = build_plan(plan->H, plan->W, plan->S, hp);
+    if (rc) return rc;
+    const wise_preproc_plan& p = hp.p;
+    WISE_CHECK_ARG(p.table_bytes == plan->table_bytes && p.tile == plan->tile && p.lds_bytes == plan->lds_bytes,
+                   "preproc: plan was not made by wise_preproc_plan_init for %dx%d -> %d", p.H, p.W, p.S);
+    WISE_CHECK_ARG(((uintptr_t)dev_tables & 15) == 0 && ((uintptr_t)out & 3) == 0, "preproc: tables/out misaligned");
+    const int planes = n * 3;
+    const int nt = (p.S + p.tile - 1) / p.tile;
+    const long long blocks = (long long)((planes + 7) / 8) * 8 * nt * nt;
+    WISE_CHECK_ARG(blocks < (1ll << 31), "preproc: too many tiles (%lld)", blocks);
+    const int CS = p.max_cols4 | 1, RS = p.max_rows4 | 1;
+    const bool aligned = (p.W % 4 == 0) && (((uintptr_t)frames & 3) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (aligned)
+        hipLaunchKernelGGL(clip_resize_kernel<true>, dim3((unsigned)blocks), dim3(256), p.lds_bytes, st, frames, planes,
+                           p.H, p.W, p.S, p.tile, p.ndh, p.ndv, CS, RS, p.max_rows4, (const int*)dev_tables, out);
+    else
+        hipLaunchKernelGGL(clip_resize_kernel<false>, dim3((unsigned)blocks), dim3(256), p.lds_bytes, st, frames, planes,
+                           p.H, p.W, p.S, p.tile, p.ndh, p.ndv, CS, RS, p.max_rows4, (const int*)dev_tables, out);
+    WISE_LAUNCH_CHECK("clip_resize_kernel");
+    return WISE_OK;
+}

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ i
             const int c = k / (P * P), py = (k / P) % P, px = k % P;
             const size_t src = (((size_t)b * 3 + c) * S + gy * P + py) * S + gx * P + px;
             if (sizeof(TIN) == 1)
-                v = ((float)img[src] * (1.f / 255.f) - mean[c]) / stdv[c];
+                v = ((float)img[src] / 255.f - mean[c]) / stdv[c];  // ToTensor's true division, then Normalize
             else
                 v = (float)img[src];
         }

@@ -92,6 +92,7 @@ class MlfoundationOpenClip(FeatureExtractor):
         self._state_dict = random_state_dict(self.spec, seed) if seed is not None else load_state_dict_file(model, tag)
         self.preprocess = ClipImageTransform(self.spec.image_size)
         self._engine = None
+        self._gpu_preprocess = None
         self.input_image_size = (self.spec.image_size, self.spec.image_size)
         self.output_dim = self.spec.embed_dim
         if self.DEVICE == "cuda":
@@ -107,6 +108,7 @@ class MlfoundationOpenClip(FeatureExtractor):
     def __getstate__(self):
         st = dict(self.__dict__)
         st["_engine"] = None
+        st["_gpu_preprocess"] = None
         return st
 
     def _find_output_dim(self):
@@ -129,6 +131,17 @@ class MlfoundationOpenClip(FeatureExtractor):
             return torch.stack([self.preprocess(to_pil_image(im)) for im in images], dim=0).to(device=self.DEVICE)
         else:
             raise ValueError('all input to preprocess_image() must be an instance of torch.Tensor or PIL.Image')
+
+    def preprocess_image_device(self, images: torch.Tensor) -> torch.Tensor:
+        """GPU form of preprocess_image for decoded uint8 frames [n,3,H,W]: the same
+        Resize -> CenterCrop as the PIL loop above, bit for bit, as one kernel; returns uint8 [n,3,S,S] on the
+        device.  ToTensor + Normalize are applied by the tower when extract_image_features receives uint8."""
+        if not isinstance(images, torch.Tensor) or len(images.shape) != 4 or images.dtype != torch.uint8:
+            raise ValueError('input to preprocess_image_device() must be a uint8 torch.Tensor [n,3,H,W]')
+        if self._gpu_preprocess is None:
+            from .preprocess import ClipPreprocessor
+            self._gpu_preprocess = ClipPreprocessor(self.spec.image_size, device="cuda")
+        return self._gpu_preprocess(images)
 
     def extract_image_features(self, images: torch.Tensor) -> np.ndarray:
         if not isinstance(images, torch.Tensor):

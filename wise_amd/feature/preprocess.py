@@ -1,0 +1,97 @@
+"""GPU image transform: uint8 frames [n,3,H,W] on the device -> uint8 [n,3,S,S].
+
+Device-side replacement for the per-frame CPU loop of the reference's
+`MlfoundationOpenClip.preprocess_image` (src/feature/mlfoundation_openclip.py:81-90):
+`to_pil_image -> Resize(S, BICUBIC) -> CenterCrop(S)`; `ToTensor -> Normalize` are applied by the tower's
+patch gather when it is fed uint8 (`WISE_VIT_IN_U8`).  Results are bit-identical to Pillow's.
+Binds `wise_preproc_*` of include/wise_hip.h; there is no CPU path here (the CPU path is the reference's own
+PIL loop, kept in mlfoundation_openclip.py for DataLoader workers).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class PreprocPlan(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("H", "W", "S", "new_w", "new_h", "left", "top", "tile", "ndh", "ndv",
+                                          "max_cols4", "max_rows4", "lds_bytes", "reserved")] + \
+               [("table_bytes", C.c_uint64)]
+
+
+def make_plan(H: int, W: int, S: int) -> PreprocPlan:
+    """Geometry + table sizes for one (H, W, S); host-only (works without a GPU)."""
+    lib = _lib.load()
+    plan = PreprocPlan()
+    rc = lib.wise_preproc_plan_init(int(H), int(W), int(S), C.byref(plan))
+    if rc != 0:
+        raise ValueError(lib.wise_last_error().decode())
+    return plan
+
+
+def plan_tables(plan: PreprocPlan) -> np.ndarray:
+    """The int32 tap-table blob of a plan (host)."""
+    lib = _lib.load()
+    buf = np.empty(plan.table_bytes // 4, dtype=np.int32)
+    rc = lib.wise_preproc_tables(C.byref(plan), buf.ctypes.data)
+    if rc != 0:
+        raise ValueError(lib.wise_last_error().decode())
+    return buf
+
+
+def pillow_taps(in_size: int, out_size: int):
+    """(ksize, first[out], count[out], coef[out,ksize]) exactly as the library computes them (host-only)."""
+    lib = _lib.load()
+    scale = max(in_size / out_size, 1.0)
+    cap = out_size * (int(np.ceil(2.0 * scale)) * 2 + 1)
+    ks = C.c_int(0)
+    first = np.empty(out_size, dtype=np.int32)
+    count = np.empty(out_size, dtype=np.int32)
+    coef = np.zeros(cap, dtype=np.int32)
+    rc = lib.wise_preproc_taps(int(in_size), int(out_size), C.byref(ks), first.ctypes.data, count.ctypes.data,
+                               coef.ctypes.data, cap)
+    if rc != 0:
+        raise ValueError(lib.wise_last_error().decode())
+    return ks.value, first, count, coef[:out_size * ks.value].reshape(out_size, ks.value)
+
+
+class ClipPreprocessor:
+    """Callable: device uint8 [n,3,H,W] -> device uint8 [n,3,S,S].  Plans and device tables are cached per
+    frame geometry (a video collection has a handful of distinct sizes)."""
+
+    def __init__(self, size: int, device: str = "cuda"):
+        self.size = int(size)
+        self.device = device
+        self._plans: Dict[Tuple[int, int], Tuple[PreprocPlan, torch.Tensor]] = {}
+
+    def _plan(self, H: int, W: int):
+        key = (H, W)
+        hit = self._plans.get(key)
+        if hit is None:
+            plan = make_plan(H, W, self.size)
+            tables = torch.from_numpy(plan_tables(plan)).to(self.device)
+            hit = (plan, tables)
+            self._plans[key] = hit
+        return hit
+
+    def __call__(self, frames: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        if not isinstance(frames, torch.Tensor) or frames.dtype != torch.uint8 or frames.dim() != 4 \
+                or frames.shape[1] != 3:
+            raise ValueError('GPU preprocess takes a uint8 tensor [n,3,H,W]')
+        lib = _lib.lib()  # raises without a gfx950 device
+        frames = frames.to(self.device).contiguous()
+        n, _, H, W = frames.shape
+        plan, tables = self._plan(H, W)
+        S = self.size
+        if out is None:
+            out = torch.empty((n, 3, S, S), dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = lib.wise_preproc_u8(C.byref(plan), tables.data_ptr(), frames.data_ptr(), n, out.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError(lib.wise_last_error().decode())
+        return out
