@@ -54,13 +54,24 @@ def test_plan_geometry_matches_torchvision_rules():
 
 
 def test_plan_tables_hold_the_cropped_taps():
-    """The blob is the oracle's taps for the cropped columns/rows, shifted by (first & 3) into whole dwords."""
+    """The blob is the oracle's taps for the cropped columns/rows, shifted by (first & 3) into whole dwords and
+    stored as three byte planes of (tap + 2^22) per group of four taps (the v_dot4_u32_u8 operand form)."""
+
+    def unpack(planes):  # [S, nd*4] int32 = [S][nd]{p2,p1,p0,0} -> taps [S, nd*4]
+        q = planes.reshape(planes.shape[0], -1, 4).view(np.uint32)
+        assert not q[:, :, 3].any()
+        taps = np.zeros(q.shape[:2] + (4,), dtype=np.int64)
+        for b in range(4):
+            byte = lambda v: ((v >> (8 * b)) & 255).astype(np.int64)
+            taps[:, :, b] = (byte(q[:, :, 0]) << 16) + (byte(q[:, :, 1]) << 8) + byte(q[:, :, 2]) - (1 << 22)
+        return taps.reshape(planes.shape[0], -1).astype(np.int32)
+
     H, W, S = 480, 854, 224
     plan = pp.make_plan(H, W, S)
     tab = pp.plan_tables(plan)
     hstart, vstart = tab[:S], tab[S:2 * S]
-    hco = tab[2 * S:2 * S + S * plan.ndh * 4].reshape(S, plan.ndh * 4)
-    vco = tab[2 * S + S * plan.ndh * 4:2 * S + S * (plan.ndh + plan.ndv) * 4].reshape(S, plan.ndv * 4)
+    hco = unpack(tab[2 * S:2 * S + S * plan.ndh * 4].reshape(S, plan.ndh * 4))
+    vco = unpack(tab[2 * S + S * plan.ndh * 4:2 * S + S * (plan.ndh + plan.ndv) * 4].reshape(S, plan.ndv * 4))
     _, hb, hk = ref.precompute_coeffs(W, plan.new_w)
     for x in range(S):
         f, n = hb[x + plan.left]

@@ -99,7 +99,8 @@ static int half_round_even(int v) {
 struct AxisTables {
     int nd = 0;                      // dwords of padded taps per output
     std::vector<int> start;          // [S] first input dword
-    std::vector<int> coef;           // [S][nd*4]
+    std::vector<int> coef;           // [S][nd*4] taps shifted by (first & 3), zero padded
+    std::vector<int> packed;         // [S][nd][4] the same taps as byte planes (device form)
     std::vector<int> t0, tn;         // per tile: first staged dword, number of staged dwords
     int max_n = 0;
 };
@@ -115,6 +116,20 @@ static void axis_tables(const Taps& t, int off, int S, int tile, int in_size, Ax
         for (int k = 0; k < t.count[i + off]; ++k)
             a.coef[(size_t)i * a.nd * 4 + (f & 3) + k] = t.coef[(size_t)(i + off) * t.ksize + k];
     }
+    // device form: tap c is kept as c + 2^22 (>= 0, < 2^24) split into three byte planes, so that four taps are
+    // one v_dot4_u32_u8 per plane; per output and dword j: {plane2, plane1, plane0, 0}
+    a.packed.assign((size_t)S * a.nd * 4, 0);
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < a.nd; ++j) {
+            unsigned pl[3] = {0, 0, 0};
+            for (int b = 0; b < 4; ++b) {
+                const unsigned c = (unsigned)(a.coef[((size_t)i * a.nd + j) * 4 + b] + (1 << PREC));
+                pl[0] |= ((c >> 16) & 255u) << (8 * b);
+                pl[1] |= ((c >> 8) & 255u) << (8 * b);
+                pl[2] |= (c & 255u) << (8 * b);
+            }
+            for (int q = 0; q < 3; ++q) a.packed[((size_t)i * a.nd + j) * 4 + q] = (int)pl[q];
+        }
     const int nt = (S + tile - 1) / tile;
     a.t0.resize(nt);
     a.tn.resize(nt);
@@ -183,7 +198,7 @@ extern "C" int wise_preproc_plan_init(int H, int W, int S, wise_preproc_plan* pl
     return WISE_OK;
 }
 
-// blob (int32): hstart[S] | vstart[S] | hcoef[S][ndh*4] | vcoef[S][ndv*4] | hc0[nt] | hcn[nt] | vr0[nt] | vrn[nt]
+// blob (int32): hstart[S] | vstart[S] | hplanes[S][ndh][4] | vplanes[S][ndv][4] | hc0[nt] | hcn[nt] | vr0[nt] | vrn[nt]
 extern "C" int wise_preproc_tables(const wise_preproc_plan* plan, void* host_tables) {
     WISE_CHECK_ARG(plan && host_tables, "preproc: null argument");
     HostPlan hp;
@@ -192,7 +207,7 @@ extern "C" int wise_preproc_tables(const wise_preproc_plan* plan, void* host_tab
     WISE_CHECK_ARG(hp.p.table_bytes == plan->table_bytes && hp.p.tile == plan->tile, "preproc: plan does not match");
     int* o = static_cast<int*>(host_tables);
     auto put = [&](const std::vector<int>& v) { std::copy(v.begin(), v.end(), o); o += v.size(); };
-    put(hp.h.start); put(hp.v.start); put(hp.h.coef); put(hp.v.coef);
+    put(hp.h.start); put(hp.v.start); put(hp.h.packed); put(hp.v.packed);
     put(hp.h.t0); put(hp.h.tn); put(hp.v.t0); put(hp.v.tn);
     return WISE_OK;
 }
@@ -214,19 +229,36 @@ extern "C" int wise_preproc_taps(int in_size, int out_size, int* ksize, int* fir
 
 namespace wise {
 
+// Resample.c clip8: arithmetic shift by PRECISION_BITS, clamp to 0..255.  The shift is kept opaque: left to
+// itself the compiler fuses "clamp two shifted ints and pack them" into v_ashr_pk_u8_i32, which on gfx950
+// writes only the low half of its destination while the code that follows ORs the whole register (measured:
+// bytes 2 and 3 of every packed dword came out OR-ed with stale accumulator bits).
 __device__ __forceinline__ int clip8(int acc) {
-    int v = acc >> PREC;
+    int v;
+    asm("v_ashrrev_i32 %0, 22, %1" : "=v"(v) : "v"(acc));
+    static_assert(PREC == 22, "shift literal above");
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-// 4 taps: bytes of w times c.x..c.w
-__device__ __forceinline__ int mac4(unsigned w, const int4& c, int acc) {
-    acc += (int)(w & 255u) * c.x;
-    acc += (int)((w >> 8) & 255u) * c.y;
-    acc += (int)((w >> 16) & 255u) * c.z;
-    acc += (int)(w >> 24) * c.w;
-    return acc;
-}
+// Four taps at once: the data dword's bytes against the three byte planes of (tap + 2^22), plus the byte sum
+// that takes the 2^22 offset out again.  All arithmetic is mod 2^32; the true sum fits an int (Resample.c
+// accumulates in one), so the wrapped result is the true result.
+struct TapAcc {
+    unsigned p2 = 0, p1 = 0, p0 = 0, ps = 0;
+    __device__ __forceinline__ void add(unsigned w, const int4& c) {
+        p2 = __builtin_amdgcn_udot4(w, (unsigned)c.x, p2, false);
+        p1 = __builtin_amdgcn_udot4(w, (unsigned)c.y, p1, false);
+        p0 = __builtin_amdgcn_udot4(w, (unsigned)c.z, p0, false);
+        ps = __builtin_amdgcn_udot4(w, 0x01010101u, ps, false);
+    }
+    __device__ __forceinline__ unsigned byte() const {
+        const int acc = (int)((p2 << 16) + (p1 << 8) + p0 - (ps << PREC) + (1u << (PREC - 1)));
+        return (unsigned)clip8(acc);
+    }
+};
+
+// idx / d for idx < 2^16, d < 2^12 (m = floor((2^32-1)/d) + 1)
+__device__ __forceinline__ int fast_div(int idx, int d, unsigned m) { return d == 1 ? idx : (int)__umulhi((unsigned)idx, m); }
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void clip_resize_kernel(const unsigned char* __restrict__ frames, int planes, int H,
@@ -250,8 +282,8 @@ __global__ __launch_bounds__(256) void clip_resize_kernel(const unsigned char* _
 
     unsigned* in32 = reinterpret_cast<unsigned*>(smem);                   // [max_rows4*4][CS], rows 4-way interleaved
     unsigned* tmp32 = in32 + (size_t)max_rows4 * 4 * CS;                  // [TS][RS], columns 4-way interleaved
-    int* hco = reinterpret_cast<int*>(tmp32 + (size_t)TS * RS);           // [TS][ndh*4]
-    int* vco = hco + TS * ndh * 4;                                        // [TS][ndv*4]
+    int* hco = reinterpret_cast<int*>(tmp32 + (size_t)TS * RS);           // [TS][ndh][4]
+    int* vco = hco + TS * ndh * 4;                                        // [TS][ndv][4]
     int* hst = vco + TS * ndv * 4;                                        // [TS]
     int* vst = hst + TS;                                                  // [TS]
 
@@ -263,8 +295,9 @@ __global__ __launch_bounds__(256) void clip_resize_kernel(const unsigned char* _
     const int rows = rn4 * 4;
     const int wd = ALIGNED ? (W >> 2) : ((W + 3) >> 2);
     const int cload = min(cn, wd - c0);  // dwords that exist in the frame
+    const unsigned m_cload = 0xFFFFFFFFu / (unsigned)cload + 1u;
     for (int idx = tid; idx < rows * cload; idx += 256) {
-        const int r = idx / cload, j = idx - r * cload;
+        const int r = fast_div(idx, cload, m_cload), j = idx - r * cload;
         const int gr = min(r0 * 4 + r, H - 1);  // rows past the frame only ever meet zero taps
         unsigned v;
         if (ALIGNED) {
@@ -279,13 +312,10 @@ __global__ __launch_bounds__(256) void clip_resize_kernel(const unsigned char* _
         }
         in32[((r & 3) * rn4 + (r >> 2)) * CS + j] = v;
     }
-    for (int idx = tid; idx < TS * ndh * 4; idx += 256) {
-        const int i = idx / (ndh * 4);
-        hco[idx] = (x0 + i < S) ? hcoef[(size_t)(x0 + i) * ndh * 4 + (idx - i * ndh * 4)] : 0;
-    }
-    for (int idx = tid; idx < TS * ndv * 4; idx += 256) {
-        const int i = idx / (ndv * 4);
-        vco[idx] = (y0 + i < S) ? vcoef[(size_t)(y0 + i) * ndv * 4 + (idx - i * ndv * 4)] : 0;
+    {
+        const int nh = min(TS, S - x0) * ndh * 4, nv = min(TS, S - y0) * ndv * 4;
+        for (int idx = tid; idx < TS * ndh * 4; idx += 256) hco[idx] = idx < nh ? hcoef[(size_t)x0 * ndh * 4 + idx] : 0;
+        for (int idx = tid; idx < TS * ndv * 4; idx += 256) vco[idx] = idx < nv ? vcoef[(size_t)y0 * ndv * 4 + idx] : 0;
     }
     if (tid < TS) {
         hst[tid] = (x0 + tid < S) ? hstart[x0 + tid] - c0 : 0;
@@ -294,41 +324,42 @@ __global__ __launch_bounds__(256) void clip_resize_kernel(const unsigned char* _
     __syncthreads();
 
     // ---- horizontal pass: item (x, rg) = output column x of input rows 4*rg .. 4*rg+3
-    const int XG = TS >> 2;
+    const int XG = TS >> 2, xg_shift = 31 - __clz(XG);
+    const unsigned m_rn4 = 0xFFFFFFFFu / (unsigned)rn4 + 1u;
     for (int idx = tid; idx < TS * rn4; idx += 256) {
-        const int x = idx / rn4, rg = idx - x * rn4;
-        const int base = hst[x];
+        const int x = fast_div(idx, rn4, m_rn4), rg = idx - x * rn4;
         const int4* co = reinterpret_cast<const int4*>(hco + x * ndh * 4);
-        int a0 = 1 << (PREC - 1), a1 = a0, a2 = a0, a3 = a0;
+        const unsigned* d0 = in32 + rg * CS + hst[x];
+        const int rstride = rn4 * CS;
+        TapAcc a0, a1, a2, a3;
         for (int j = 0; j < ndh; ++j) {
             const int4 c = co[j];
-            a0 = mac4(in32[(0 * rn4 + rg) * CS + base + j], c, a0);
-            a1 = mac4(in32[(1 * rn4 + rg) * CS + base + j], c, a1);
-            a2 = mac4(in32[(2 * rn4 + rg) * CS + base + j], c, a2);
-            a3 = mac4(in32[(3 * rn4 + rg) * CS + base + j], c, a3);
+            a0.add(d0[j], c);
+            a1.add(d0[rstride + j], c);
+            a2.add(d0[2 * rstride + j], c);
+            a3.add(d0[3 * rstride + j], c);
         }
-        tmp32[((x & 3) * XG + (x >> 2)) * RS + rg] =
-            (unsigned)clip8(a0) | ((unsigned)clip8(a1) << 8) | ((unsigned)clip8(a2) << 16) | ((unsigned)clip8(a3) << 24);
+        tmp32[((x & 3) * XG + (x >> 2)) * RS + rg] = a0.byte() | (a1.byte() << 8) | (a2.byte() << 16) | (a3.byte() << 24);
     }
     __syncthreads();
 
     // ---- vertical pass: item (y, xg) = output row y of columns 4*xg .. 4*xg+3, one dword store
     for (int idx = tid; idx < TS * XG; idx += 256) {
-        const int y = idx / XG, xg = idx - y * XG;
+        const int y = idx >> xg_shift, xg = idx & (XG - 1);
         if (y0 + y >= S || x0 + xg * 4 >= S) continue;
-        const int base = vst[y];
         const int4* co = reinterpret_cast<const int4*>(vco + y * ndv * 4);
-        int a0 = 1 << (PREC - 1), a1 = a0, a2 = a0, a3 = a0;
+        const unsigned* d0 = tmp32 + xg * RS + vst[y];
+        const int cstride = XG * RS;
+        TapAcc a0, a1, a2, a3;
         for (int j = 0; j < ndv; ++j) {
             const int4 c = co[j];
-            a0 = mac4(tmp32[(0 * XG + xg) * RS + base + j], c, a0);
-            a1 = mac4(tmp32[(1 * XG + xg) * RS + base + j], c, a1);
-            a2 = mac4(tmp32[(2 * XG + xg) * RS + base + j], c, a2);
-            a3 = mac4(tmp32[(3 * XG + xg) * RS + base + j], c, a3);
+            a0.add(d0[j], c);
+            a1.add(d0[cstride + j], c);
+            a2.add(d0[2 * cstride + j], c);
+            a3.add(d0[3 * cstride + j], c);
         }
-        const unsigned v =
-            (unsigned)clip8(a0) | ((unsigned)clip8(a1) << 8) | ((unsigned)clip8(a2) << 16) | ((unsigned)clip8(a3) << 24);
-        *reinterpret_cast<unsigned*>(out + ((size_t)plane * S + (y0 + y)) * S + x0 + xg * 4) = v;
+        *reinterpret_cast<unsigned*>(out + ((size_t)plane * S + (y0 + y)) * S + x0 + xg * 4) =
+            a0.byte() | (a1.byte() << 8) | (a2.byte() << 16) | (a3.byte() << 24);
     }
 }
 
