@@ -148,6 +148,21 @@ def cpu_baseline_search(d, k, seconds):
             "sample": f"{nq} queries over a 1M x {d} sample with oracle/ip_topk_ref.c, time x10 for 10M rows"}
 
 
+def cpu_baseline_preprocess(S, seconds=3.0):
+    """The reference's own CPU path for this step (mlfoundation_openclip.py:81-90): per-frame PIL resize + crop +
+    ToTensor/Normalize, one core, as a DataLoader worker runs it."""
+    from wise_amd.feature.mlfoundation_openclip import ClipImageTransform, to_pil_image
+    tr = ClipImageTransform(S)
+    frames = torch.from_numpy(np.random.default_rng(7).integers(0, 256, (64, 3, 240, 320), dtype=np.uint8))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        tr(to_pil_image(frames[n % 64]))
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
+            "sample": f"{n} frames 240x320 through the PIL transform the reference calls (Pillow), {dt:.1f} s"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -351,6 +366,47 @@ def main():
                             "frac_of_bf16_peak": round(lfps / world * lspec.flops_per_frame() / 1e12 / PEAK_BF16_TFLOPS, 4)}
         del leng
         torch.cuda.empty_cache()
+        # f2: decoded uint8 frames [256,3,240,320] resident in HBM -> GPU transform -> ViT-B/32 (uint8 in)
+        from wise_amd.feature.preprocess import ClipPreprocessor, make_plan
+
+        fh, fw = 240, 320
+        raw = torch.randint(0, 256, (args.batch, 3, fh, fw), dtype=torch.uint8, device="cuda",
+                            generator=torch.Generator(device="cuda").manual_seed(7 + rank))
+        pre = ClipPreprocessor(spec.image_size)
+        crop = torch.empty((args.batch, 3, spec.image_size, spec.image_size), dtype=torch.uint8, device="cuda")
+
+        def u8_step(i):
+            pre(raw, crop)
+            hold["u"] = eng.forward(crop)
+
+        for i in range(3):
+            u8_step(i)
+        u_steps = max(5, min(args.steps, 20))
+        udt = timed_region(u8_step, u_steps, world)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(20):
+            pre(raw, crop)
+        e1.record()
+        torch.cuda.synchronize()
+        pre_us = e0.elapsed_time(e1) / 20 * 1e3
+        plan = make_plan(fh, fw, spec.image_size)
+        sx, sy = fw / plan.new_w, fh / plan.new_h
+        need_w = min(fw, int(spec.image_size * sx + 4 * max(sx, 1.0)) + 1)   # columns / rows the crop depends on
+        need_h = min(fh, int(spec.image_size * sy + 4 * max(sy, 1.0)) + 1)
+        pre_bytes = args.batch * 3 * (need_w * need_h + spec.image_size ** 2)
+        extra["u8_frames_to_embeddings"] = {
+            "value": round(world * args.batch * u_steps / udt, 1), "unit": "frames/s",
+            "ms_per_step": round(udt / u_steps * 1e3, 3), "steps": u_steps,
+            "config": {"workload": f"uint8 decoded frames [{args.batch},3,{fh},{fw}] resident in HBM -> Pillow-exact "
+                                   f"bicubic resize + centre crop kernel -> ViT-B/32 with ToTensor/Normalize fused "
+                                   f"into the patch gather"},
+            "preprocess_kernel": {"kernel": "clip_resize_kernel", "avg_launch_us": round(pre_us, 1), "bound": "hbm",
+                                  "bytes_per_launch": pre_bytes,
+                                  "achieved": round(pre_bytes / pre_us / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": round(pre_bytes / pre_us / 1e3 / PEAK_HBM_GBS, 4),
+                                  "frames_per_s": round(args.batch / pre_us * 1e6, 0)}}
+        del raw, crop
         result["extra"] = extra
 
     # ------------------------------------------------------------------ CPU baselines (rank 0, N=1 only)
@@ -358,6 +414,8 @@ def main():
         result["cpu_baseline"] = cpu_baseline_vit(spec, sd, args.cpu_seconds)
         if "search" in result:
             result["search"]["cpu_baseline"] = cpu_baseline_search(args.dim, args.topk, args.cpu_seconds)
+        if "extra" in result and "u8_frames_to_embeddings" in result["extra"]:
+            result["extra"]["u8_frames_to_embeddings"]["cpu_baseline"] = cpu_baseline_preprocess(spec.image_size)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
