@@ -130,6 +130,37 @@ int wise_htsat_tap(int what, const void* workspace, int batch, int samples, floa
                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * HP-2 query side: OpenCLIP text tower — replaces `self.model.encode_text(tokens)` + L2
+ *       normalise, reference call site src/feature/mlfoundation_openclip.py:103-108 (reached from
+ *       FeatureSearchIndex.search, src/index/feature_search_index.py:112).  Token ids in, unit vectors out;
+ *       tokenising stays on the host (wise_amd/feature/clip_tokenizer.py).
+ *
+ *   wb  bf16 : per layer in_proj [3W,W], out_proj [W,W], c_fc [F,W], c_proj [W,F]; then text_projection^T [D,W]
+ *   pf  fp32 : token_embedding [V,W], positional_embedding [T,W]; per layer ln_1 w,b, in_proj_bias [3W],
+ *              out_proj bias [W], ln_2 w,b, c_fc bias [F], c_proj bias [W]; then ln_final w,b
+ * (open_clip 2.24.0 state-dict keys without the `visual.` prefix; see wise_amd/feature/text.py)
+ * tokens int32 [batch, context] (device): <start_of_text> ... <end_of_text> 0 0 ...; the pooled row is
+ * argmax(tokens[b]) as in open_clip (the end-of-text id is the largest id of the vocabulary).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct wise_text_config {
+    int32_t context;    /* T: 77 */
+    int32_t vocab;      /* V: 49408 */
+    int32_t width;      /* W: 512 (ViT-B/32), 768 (ViT-L/14); multiple of 128, head dim 64 */
+    int32_t layers;     /* L: 12 */
+    int32_t heads;      /* H = W/64 */
+    int32_t mlp;        /* F = 4W */
+    int32_t embed_dim;  /* D: 512 / 768 */
+    int32_t act;        /* 0 = QuickGELU, 1 = erf GELU */
+} wise_text_config;
+int wise_text_layout(const wise_text_config* cfg, int64_t* wb_elems, int64_t* pf_elems);
+size_t wise_text_workspace_bytes(const wise_text_config* cfg, int batch);
+int wise_text_forward(const wise_text_config* cfg, const uint16_t* wb, const float* pf, const int32_t* tokens,
+                      int batch, float* out /* [batch, D] fp32, L2-normalised */, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* parity tap: residual stream fp32 [batch*context, W] of the last forward with the same batch */
+int wise_text_tap_residual(const wise_text_config* cfg, int batch, const void* workspace, float* dst, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HP-1  image transform on the GPU: replaces the per-frame CPU loop of
  *       MlfoundationOpenClip.preprocess_image, src/feature/mlfoundation_openclip.py:81-90, for uint8 frames
  *       [n,3,H,W] (the decoder's output, src/dataloader/dataset.py:298):
@@ -175,6 +206,8 @@ int wise_layernorm_f32_bf16(const float* x, const float* w, const float* b, int 
                             float eps, uint16_t* y, void* stream);
 /* qkv [B*T, 3*H*64] bf16 (q|k|v packed like in_proj) -> o [B*T, H*64] bf16 ; softmax(QK^T/8)V */
 int wise_attention_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream);
+/* the same with the causal mask of the text tower: query t attends keys <= t */
+int wise_attention_causal_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,10 @@ class VitConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("image_size", "patch", "width", "layers", "heads", "mlp", "embed_dim", "act")]
 
 
+class TextConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("context", "vocab", "width", "layers", "heads", "mlp", "embed_dim", "act")]
+
+
 # every symbol include/wise_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 SIGNATURES = {
@@ -43,6 +47,10 @@ SIGNATURES = {
     "wise_htsat_workspace_bytes": (_sz, [_i, _i]),
     "wise_htsat_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "wise_htsat_tap": (_i, [_i, _vp, _i, _i, _vp, _i64, _vp]),
+    "wise_text_layout": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "wise_text_workspace_bytes": (_sz, [_vp, _i]),
+    "wise_text_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "wise_text_tap_residual": (_i, [_vp, _i, _vp, _vp, _vp]),
     "wise_preproc_plan_init": (_i, [_i, _i, _i, _vp]),
     "wise_preproc_tables": (_i, [_vp, _vp]),
     "wise_preproc_u8": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
@@ -50,6 +58,7 @@ SIGNATURES = {
     "wise_gemm_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "wise_layernorm_f32_bf16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "wise_attention_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "wise_attention_causal_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
 }
 
 

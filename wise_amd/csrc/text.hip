@@ -1,0 +1,175 @@
+// OpenCLIP text tower (`encode_text`) on gfx950 — the query side of HP-2.
+//
+// Replaces `self.model.encode_text(tokens)` + L2 normalise at src/feature/mlfoundation_openclip.py:103-108
+// (arithmetic: open_clip 2.24.0 `CLIP.encode_text` / `TextTransformer`; the same computation as transformers'
+// CLIPTextModelWithProjection, which is what the oracle is pinned against):
+//   x = token_embedding[tokens] + positional_embedding            [B, 77, W] fp32
+//   L pre-LN residual blocks with a causal attention mask          (shared with the image tower: vit.hip)
+//   ln_final on the end-of-text row only: row argmax(tokens[b])   (LayerNorm is per row, so normalising just
+//   @ text_projection [W, D] ; L2 normalise                         the pooled row is the same arithmetic)
+// Tokenising is host work (wise_amd/feature/clip_tokenizer.py); this file takes int32 token ids.
+#include <algorithm>
+
+#include "transformer.h"
+
+namespace wise {
+
+// x[b*T + t, :] = tok_emb[tokens[b,t], :] + pos_emb[t, :] ; also eot[b] = first argmax_t tokens[b,t].
+// One wave per token row; wave 0 of each sequence's first row finds the end-of-text position.
+__global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__ tokens, const float* __restrict__ tok_emb,
+                                                         const float* __restrict__ pos_emb, int B, int T, int W,
+                                                         int vocab, float* __restrict__ x, int* __restrict__ eot) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * T) return;
+    const int b = row / T, t = row - b * T;
+    int id = tokens[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // ids are validated on the host; stay in bounds regardless
+    const float4* e = reinterpret_cast<const float4*>(tok_emb + (size_t)id * W);
+    const float4* p = reinterpret_cast<const float4*>(pos_emb + (size_t)t * W);
+    float4* xr = reinterpret_cast<float4*>(x + (size_t)row * W);
+    for (int c = lane; c < (W >> 2); c += 64) {
+        const float4 a = e[c], q = p[c];
+        xr[c] = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
+    }
+    if (t == 0) {
+        // torch.argmax returns the first maximal index; T <= 128: two candidates per lane
+        int best = -1, best_t = 0;
+        for (int tt = lane; tt < T; tt += 64) {
+            const int v = tokens[b * T + tt];
+            if (v > best) { best = v; best_t = tt; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const int ov = __shfl_xor(best, off, 64), ot = __shfl_xor(best_t, off, 64);
+            if (ov > best || (ov == best && ot < best_t)) { best = ov; best_t = ot; }
+        }
+        if (lane == 0) eot[b] = best_t;
+    }
+}
+
+struct TextDims {
+    int T, V, W, L, H, F, D;
+};
+static int text_dims(const wise_text_config* c, TextDims* d) {
+    WISE_CHECK_ARG(c, "text: null config");
+    d->T = c->context; d->V = c->vocab; d->W = c->width; d->L = c->layers; d->H = c->heads; d->F = c->mlp;
+    d->D = c->embed_dim;
+    WISE_CHECK_ARG(d->T >= 1 && d->T <= 128, "text: context %d must be in [1,128]", d->T);
+    WISE_CHECK_ARG(d->V >= 2, "text: vocab %d", d->V);
+    WISE_CHECK_ARG(d->W > 0 && d->W % 128 == 0 && d->H * 64 == d->W && d->W <= 4096,
+                   "text: width %d must be heads*64 and a multiple of 128", d->W);
+    WISE_CHECK_ARG(d->F > 0 && d->F % 128 == 0, "text: mlp %d must be a multiple of 128", d->F);
+    WISE_CHECK_ARG(d->D > 0 && d->D % 4 == 0 && d->L >= 0, "text: bad dims");
+    WISE_CHECK_ARG(c->act == 0 || c->act == 1, "text: act must be 0 (quick_gelu) or 1 (gelu)");
+    return WISE_OK;
+}
+
+struct TextOffsets {
+    size_t layer0_b, per_layer_b, in_proj, out_proj, c_fc, c_proj, projT, total_b;                     // bf16 blob
+    size_t tok, pos, layer0_f, per_layer_f, ln1_w, ln1_b, in_b, out_b, ln2_w, ln2_b, fc_b, proj_b, lnf_w, lnf_b,
+        total_f;                                                                                       // fp32 blob
+};
+static TextOffsets text_offsets(const TextDims& d) {
+    TextOffsets o;
+    const size_t W = d.W, F = d.F;
+    o.layer0_b = 0;
+    o.in_proj = 0; o.out_proj = 3 * W * W; o.c_fc = o.out_proj + W * W; o.c_proj = o.c_fc + F * W;
+    o.per_layer_b = o.c_proj + W * F;
+    o.projT = o.per_layer_b * d.L;
+    o.total_b = o.projT + (size_t)d.D * W;
+    o.tok = 0; o.pos = (size_t)d.V * W; o.layer0_f = o.pos + (size_t)d.T * W;
+    o.ln1_w = 0; o.ln1_b = W; o.in_b = 2 * W; o.out_b = 5 * W; o.ln2_w = 6 * W; o.ln2_b = 7 * W; o.fc_b = 8 * W;
+    o.proj_b = o.fc_b + F;
+    o.per_layer_f = o.proj_b + W;
+    o.lnf_w = o.layer0_f + o.per_layer_f * d.L; o.lnf_b = o.lnf_w + W;
+    o.total_f = o.lnf_b + W;
+    return o;
+}
+
+struct TextWs {
+    size_t x, h, qkv, a, eot, total;
+    int M, Mp;
+};
+static TextWs text_ws(const TextDims& d, int B) {
+    TextWs w;
+    w.M = B * d.T; w.Mp = (w.M + 255) / 256 * 256;
+    const size_t Bp = (size_t)(B + 255) / 256 * 256;
+    size_t off = 0;
+    w.x = off; off += align_up((size_t)w.Mp * d.W * 4, 256);
+    // h also holds the pooled rows [Bp, W]; qkv also holds the projected rows fp32 [Bp, D]
+    w.h = off; off += align_up(std::max((size_t)w.Mp, Bp) * d.W * 2, 256);
+    w.qkv = off; off += align_up(std::max((size_t)w.Mp * 3 * d.W * 2, Bp * d.D * 4), 256);
+    w.a = off; off += align_up((size_t)w.Mp * d.F * 2, 256);
+    w.eot = off; off += align_up((size_t)B * 4, 256);
+    w.total = off;
+    return w;
+}
+
+}  // namespace wise
+
+using namespace wise;
+
+extern "C" int wise_text_layout(const wise_text_config* cfg, int64_t* wb_elems, int64_t* pf_elems) {
+    TextDims d;
+    int rc = text_dims(cfg, &d);
+    if (rc) return rc;
+    const TextOffsets o = text_offsets(d);
+    if (wb_elems) *wb_elems = (int64_t)o.total_b;
+    if (pf_elems) *pf_elems = (int64_t)o.total_f;
+    return WISE_OK;
+}
+
+extern "C" size_t wise_text_workspace_bytes(const wise_text_config* cfg, int batch) {
+    TextDims d;
+    if (text_dims(cfg, &d) || batch < 1) return 0;
+    return text_ws(d, batch).total;
+}
+
+extern "C" int wise_text_forward(const wise_text_config* cfg, const uint16_t* wb, const float* pf, const int32_t* tokens,
+                                 int batch, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    TextDims d;
+    int rc = text_dims(cfg, &d);
+    if (rc) return rc;
+    WISE_CHECK_ARG(wb && pf && tokens && out, "text_forward: null pointer");
+    WISE_CHECK_ARG(batch >= 1 && batch <= (1 << 20), "text_forward: batch=%d", batch);
+    const TextWs ws = text_ws(d, batch);
+    if (!workspace || workspace_bytes < ws.total) {
+        set_error("text_forward: workspace %zu < %zu bytes", workspace_bytes, ws.total);
+        return WISE_E_WORKSPACE;
+    }
+    WISE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wb & 15) == 0 && ((uintptr_t)pf & 15) == 0,
+                   "text_forward: workspace must be 256-byte and weight blobs 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const TextOffsets o = text_offsets(d);
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+    float* x = reinterpret_cast<float*>(wsb + ws.x);
+    bf16_t* h = reinterpret_cast<bf16_t*>(wsb + ws.h);
+    bf16_t* qkv = reinterpret_cast<bf16_t*>(wsb + ws.qkv);
+    bf16_t* a = reinterpret_cast<bf16_t*>(wsb + ws.a);
+    int* eot = reinterpret_cast<int*>(wsb + ws.eot);
+
+    hipLaunchKernelGGL(text_embed_kernel, dim3((ws.M + 3) / 4), dim3(256), 0, st, tokens, pf + o.tok, pf + o.pos, batch,
+                       d.T, d.W, d.V, x, eot);
+    WISE_LAUNCH_CHECK("text_embed_kernel");
+    const BlockWeights bw = {wb + o.layer0_b, o.per_layer_b, o.in_proj, o.out_proj, o.c_fc, o.c_proj,
+                             pf + o.layer0_f, o.per_layer_f, o.ln1_w, o.ln1_b, o.in_b, o.out_b, o.ln2_w, o.ln2_b,
+                             o.fc_b, o.proj_b};
+    if ((rc = transformer_blocks(bw, d.L, d.W, d.H, d.F, cfg->act, batch, d.T, true, x, h, qkv, a, st))) return rc;
+    return pooled_head(x, pf + o.lnf_w, pf + o.lnf_b, wb + o.projT, batch, d.T, d.W, d.D, eot, h,
+                       reinterpret_cast<float*>(qkv), out, st);
+}
+
+// parity tap: the residual stream x [batch*context, W] after a forward with the same batch
+extern "C" int wise_text_tap_residual(const wise_text_config* cfg, int batch, const void* workspace, float* dst,
+                                      void* stream) {
+    TextDims d;
+    int rc = text_dims(cfg, &d);
+    if (rc) return rc;
+    WISE_CHECK_ARG(workspace && dst && batch >= 1, "text_tap_residual: bad argument");
+    const TextWs ws = text_ws(d, batch);
+    hipError_t e = hipMemcpyAsync(dst, reinterpret_cast<const unsigned char*>(workspace) + ws.x,
+                                  (size_t)ws.M * d.W * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("text_tap_residual: %s", hipGetErrorString(e)); return (int)e; }
+    return WISE_OK;
+}

@@ -1,0 +1,25 @@
+// Pieces of the pre-LN transformer shared by the image tower (vit.hip) and the text tower (text.hip).
+#pragma once
+#include "common.h"
+
+namespace wise {
+
+int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out,
+              hipStream_t st);
+int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows, int W, float eps, bf16_t* y,
+                       hipStream_t st);
+// head dim 64; causal = query t attends keys <= t (CLIP text tower), otherwise no mask
+int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st, bool causal);
+
+// where one residual block's weights sit: bf16 blob (in_proj [3W,W], out_proj [W,W], c_fc [F,W], c_proj [W,F])
+// and fp32 blob (ln_1 w,b, in_proj bias, out_proj bias, ln_2 w,b, c_fc bias, c_proj bias); element offsets
+struct BlockWeights {
+    const bf16_t* wb; size_t per_layer_b, in_proj, out_proj, c_fc, c_proj;
+    const float* pf; size_t per_layer_f, ln1_w, ln1_b, in_b, out_b, ln2_w, ln2_b, fc_b, proj_b;
+};
+int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int act, int batch, int T, bool causal,
+                       float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st);
+int pooled_head(const float* x, const float* ln_w, const float* ln_b, const bf16_t* projT, int batch, int T, int W,
+                int D, const int* pos, bf16_t* hb, float* e, float* out, hipStream_t st);
+
+}  // namespace wise

@@ -11,12 +11,9 @@
 //   h    bf16 [Mp, W]    LayerNorm output / attention output (GEMM A operand)
 //   qkv  bf16 [Mp, 3W]   in_proj output;       also patch-embed fp32 output [Mpp, W] before layer 0
 //   a    bf16 [Mp, F]    MLP hidden;           also the im2col patches bf16 [Mpp, Kp] before layer 0
-#include "common.h"
+#include "transformer.h"
 
 namespace wise {
-
-int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out,
-              hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row in registers, exact two-pass statistics in fp32
@@ -92,7 +89,7 @@ int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows,
 constexpr int V_RS = 144;  // bytes per V row in LDS (64 dh bf16 = 128 B + 16 B pad)
 using short4v = __attribute__((ext_vector_type(4))) short;
 
-template <int QT>
+template <int QT, bool CAUSAL>
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, int B, int T, int H,
                                                         bf16_t* __restrict__ o) {
     __shared__ __attribute__((aligned(16))) unsigned char v_all[4][64 * V_RS];
@@ -130,7 +127,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     for (int qt = 0; qt < QT; ++qt) { mrun[qt] = -INFINITY; lrun[qt] = 0.f; }
     const float sc = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
 
-    const int nkb = (T + 63) >> 6;
+    // causal (text tower): query t sees keys <= t, so key blocks past the chunk's last query are skipped
+    const int q_last = min(T, (qc + 1) * (16 * QT)) - 1;
+    const int nkb = CAUSAL ? (q_last >> 6) + 1 : (T + 63) >> 6;
     for (int kb = 0; kb < nkb; ++kb) {
         // ---- V image, row-major [64 keys][64 dh]: 8 passes, lane copies 16 B of V row key = p*8 + lane/8;
         //      the transpose the PV product needs is done by ds_read_b64_tr_b16 on the way out
@@ -171,12 +170,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             float mx = -INFINITY;
+            const int key_lim = CAUSAL ? min(T, qc * (16 * QT) + qt * 16 + l15 + 1) : T;  // keys this query sees
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb * 64 + kt * 16 + g * 4 + r;
-                    float s2 = (key < T) ? sacc[kt][qt][r] * sc : -INFINITY;
+                    float s2 = (key < key_lim) ? sacc[kt][qt][r] * sc : -INFINITY;
                     sacc[kt][qt][r] = s2;
                     mx = fmaxf(mx, s2);
                 }
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 
 static int g_attn_qt = 0;  // query tiles (of 16) per wave; 0 = by sequence length (debug knob overrides)
 
-int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st) {
+int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st, bool causal) {
     WISE_CHECK_ARG(qkv && o && B > 0 && T > 0 && H > 0, "attention: bad argument");
     // 32 queries per wave (126 VGPRs, 4 waves/SIMD) hides latency best when one key block covers T; longer
     // sequences prefer 64 queries per wave (K/V re-read half as often)
@@ -262,10 +262,15 @@ int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_
     const int nqc = (T + 16 * qt - 1) / (16 * qt);
     const long long items = (long long)B * H * nqc;
     const dim3 grid((unsigned)((items + 3) / 4)), block(256);
-    if (qt == 4)
-        hipLaunchKernelGGL(attention_kernel<4>, grid, block, 0, st, qkv, B, T, H, o);
+    if (causal) {
+        if (qt == 4)
+            hipLaunchKernelGGL((attention_kernel<4, true>), grid, block, 0, st, qkv, B, T, H, o);
+        else
+            hipLaunchKernelGGL((attention_kernel<2, true>), grid, block, 0, st, qkv, B, T, H, o);
+    } else if (qt == 4)
+        hipLaunchKernelGGL((attention_kernel<4, false>), grid, block, 0, st, qkv, B, T, H, o);
     else
-        hipLaunchKernelGGL(attention_kernel<2>, grid, block, 0, st, qkv, B, T, H, o);
+        hipLaunchKernelGGL((attention_kernel<2, false>), grid, block, 0, st, qkv, B, T, H, o);
     WISE_LAUNCH_CHECK("attention_kernel");
     return WISE_OK;
 }
@@ -346,16 +351,17 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const float* __restric
     }
 }
 
-// ln_post on the class-token rows only: x[b*T, :] -> y[b, :] bf16 ; wave per image
+// LayerNorm of ONE row per sequence: x[b*T + pos[b], :] -> y[b, :] bf16 (pos == nullptr: row 0, the class
+// token; the text tower passes its end-of-text positions) ; wave per sequence
 template <int NV>
 __global__ __launch_bounds__(256) void cls_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, int B, int T, int W, float eps,
-                                                     bf16_t* __restrict__ y) {
+                                                     bf16_t* __restrict__ y, const int* __restrict__ pos) {
     const int lane = threadIdx.x & 63;
     const int img = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (img >= B) return;
     const int w4 = W >> 2;
-    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)img * T * W);
+    const float4* xr = reinterpret_cast<const float4*>(x + ((size_t)img * T + (pos ? pos[img] : 0)) * W);
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
@@ -400,6 +406,46 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     for (int c = lane; c < D; c += 64) s += er[c] * er[c];
     const float nrm = sqrtf(wave_sum(s));
     for (int c = lane; c < D; c += 64) out[(size_t)r * D + c] = er[c] / nrm;
+}
+
+// L pre-LN residual blocks over x fp32 [B*T (padded to 256), W]; h / qkv / a are the bf16 scratch operands
+int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int act, int batch, int T, bool causal,
+                       float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st) {
+    const int M = batch * T, Mp = (M + 255) / 256 * 256;
+    int rc;
+    for (int l = 0; l < L; ++l) {
+        const bf16_t* lwb = bw.wb + bw.per_layer_b * l;
+        const float* lpf = bw.pf + bw.per_layer_f * l;
+        if ((rc = layernorm_f32_bf16(x, lpf + bw.ln1_w, lpf + bw.ln1_b, M, W, 1e-5f, h, st))) return rc;
+        if ((rc = gemm_bf16(h, lwb + bw.in_proj, lpf + bw.in_b, Mp, 3 * W, W, 0, qkv, st))) return rc;
+        if ((rc = attention_bf16(qkv, batch, T, H, h, st, causal))) return rc;
+        if ((rc = gemm_bf16(h, lwb + bw.out_proj, lpf + bw.out_b, Mp, W, W, 3, x, st))) return rc;
+        if ((rc = layernorm_f32_bf16(x, lpf + bw.ln2_w, lpf + bw.ln2_b, M, W, 1e-5f, h, st))) return rc;
+        if ((rc = gemm_bf16(h, lwb + bw.c_fc, lpf + bw.fc_b, Mp, F, W, act == 0 ? 1 : 2, a, st))) return rc;
+        if ((rc = gemm_bf16(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, W, F, 3, x, st))) return rc;
+    }
+    return WISE_OK;
+}
+
+// out[b,:] = normalize( LN(x[b*T + pos[b], :]) @ proj ), projT bf16 [D,W]; hb bf16 [Bp,W] and e fp32 [Bp,D] scratch
+int pooled_head(const float* x, const float* ln_w, const float* ln_b, const bf16_t* projT, int batch, int T, int W,
+                int D, const int* pos, bf16_t* hb, float* e, float* out, hipStream_t st) {
+    const int Bp = (batch + 255) / 256 * 256;
+    const int nv = (W / 4 + 63) / 64;
+    const dim3 grid((batch + 3) / 4), block(256);
+#define CLS_CASE(n) case n: hipLaunchKernelGGL(cls_ln_kernel<n>, grid, block, 0, st, x, ln_w, ln_b, batch, T, W, 1e-5f, \
+                                               hb, pos); break;
+    switch (nv) {
+        CLS_CASE(1) CLS_CASE(2) CLS_CASE(3) CLS_CASE(4) CLS_CASE(5) CLS_CASE(6) CLS_CASE(7) CLS_CASE(8)
+        default: set_error("pooled_head: width %d too large", W); return WISE_E_UNSUPPORTED;
+    }
+#undef CLS_CASE
+    WISE_LAUNCH_CHECK("cls_ln_kernel");
+    int rc;
+    if ((rc = gemm_bf16(hb, projT, nullptr, Bp, D, W, 4, e, st))) return rc;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, e, batch, D, out);
+    WISE_LAUNCH_CHECK("l2norm_rows_kernel");
+    return WISE_OK;
 }
 
 struct VitDims {
@@ -515,36 +561,14 @@ static int vit_forward_part(const wise_vit_config* cfg, const VitDims& d, const 
         WISE_LAUNCH_CHECK("embed_lnpre_kernel");
     }
     // 3. transformer blocks
-    for (int l = 0; l < d.L; ++l) {
-        const bf16_t* lwb = wb + o.layer0_b + o.per_layer_b * l;
-        const float* lpf = pf + o.layer0_f + o.per_layer_f * l;
-        if ((rc = layernorm_f32_bf16(x, lpf + o.ln1_w, lpf + o.ln1_b, ws.M, W, 1e-5f, h, st))) return rc;
-        if ((rc = gemm_bf16(h, lwb + o.in_proj, lpf + o.in_b, ws.Mp, 3 * W, W, 0, qkv, st))) return rc;
-        if ((rc = attention_bf16(qkv, batch, d.T, d.H, h, st))) return rc;
-        if ((rc = gemm_bf16(h, lwb + o.out_proj, lpf + o.out_b, ws.Mp, W, W, 3, x, st))) return rc;
-        if ((rc = layernorm_f32_bf16(x, lpf + o.ln2_w, lpf + o.ln2_b, ws.M, W, 1e-5f, h, st))) return rc;
-        if ((rc = gemm_bf16(h, lwb + o.c_fc, lpf + o.fc_b, ws.Mp, d.F, W, cfg->act == 0 ? 1 : 2, a, st))) return rc;
-        if ((rc = gemm_bf16(a, lwb + o.c_proj, lpf + o.proj_b, ws.Mp, W, d.F, 3, x, st))) return rc;
-    }
+    const BlockWeights bw = {wb + o.layer0_b, o.per_layer_b, o.in_proj, o.out_proj, o.c_fc, o.c_proj,
+                             pf + o.layer0_f, o.per_layer_f, o.ln1_w, o.ln1_b, o.in_b, o.out_b, o.ln2_w, o.ln2_b,
+                             o.fc_b, o.proj_b};
+    if ((rc = transformer_blocks(bw, d.L, W, d.H, d.F, cfg->act, batch, d.T, false, x, h, qkv, a, st))) return rc;
     // 4. ln_post(cls) -> bf16 [Bp,W] (aliases h) ; @ proj -> fp32 [Bp,D] (aliases qkv) ; L2 normalise rows
-    {
-        const int Bp = (batch + 255) / 256 * 256;
-        // cls rows are x[b*T, :]: a strided LayerNorm, row stride T*W
-        const int nv = (W / 4 + 63) / 64;
-        const dim3 grid((batch + 3) / 4), block(256);
-        float* e = reinterpret_cast<float*>(qkv);
-#define CLS_CASE(n) case n: hipLaunchKernelGGL(cls_ln_kernel<n>, grid, block, 0, st, x, pf + o.ln_post_w, pf + o.ln_post_b, \
-                                               batch, d.T, W, 1e-5f, h); break;
-        switch (nv) {
-            CLS_CASE(1) CLS_CASE(2) CLS_CASE(3) CLS_CASE(4) CLS_CASE(5) CLS_CASE(6) CLS_CASE(7) CLS_CASE(8)
-            default: set_error("vit_forward: width %d too large", W); return WISE_E_UNSUPPORTED;
-        }
-#undef CLS_CASE
-        WISE_LAUNCH_CHECK("cls_ln_kernel");
-        if ((rc = gemm_bf16(h, wb + o.projT, nullptr, Bp, d.D, W, 4, e, st))) return rc;
-        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, e, batch, d.D, out);
-        WISE_LAUNCH_CHECK("l2norm_rows_kernel");
-    }
+    if ((rc = pooled_head(x, pf + o.ln_post_w, pf + o.ln_post_b, wb + o.projT, batch, d.T, W, d.D, nullptr, h,
+                          reinterpret_cast<float*>(qkv), out, st)))
+        return rc;
     return WISE_OK;
 }
 
@@ -696,5 +720,9 @@ extern "C" int wise_layernorm_f32_bf16(const float* x, const float* w, const flo
 }
 
 extern "C" int wise_attention_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream) {
-    return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream);
+    return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, false);
+}
+
+extern "C" int wise_attention_causal_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream) {
+    return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, true);
 }
