@@ -93,3 +93,44 @@ def test_bad_tokens_raise():
         eng.forward(torch.full((1, 77), TINY.vocab, dtype=torch.int32))
     with pytest.raises(ValueError):
         eng.forward(torch.zeros(1, 77, dtype=torch.float32))
+
+
+def test_extractor_text_features_and_end_to_end_search(tmp_path):
+    """The reference's query path end to end (feature_search_index.py:100-114): prompt + text -> tokenizer ->
+    text tower -> IndexFlatIP search, through the drop-in classes; the oracle replays it on the CPU."""
+    from oracle import ip_topk_ref
+    from wise_amd.feature.feature_extractor_factory import FeatureExtractorFactory
+    from wise_amd.feature.store.feature_store_factory import FeatureStoreFactory, FeatureStoreType
+    from wise_amd.index.search_index_factory import SearchIndexFactory
+
+    fid = "mlfoundations/open_clip/ViT-B-32/seeded-0"
+    fx = FeatureExtractorFactory(fid)
+    texts = ["This is a photo of a dog", "cat", "people cheering at a football match"]
+    feats = fx.extract_text_features(texts)
+    assert feats.shape == (3, 512) and feats.dtype == np.float32 and feats.flags["C_CONTIGUOUS"]
+    assert np.allclose(np.linalg.norm(feats, axis=1), 1.0, atol=1e-5)
+    tokens = fx.preprocess_text(texts)
+    assert tokens.shape == (3, 77)
+    sd = random_text_state_dict(fx.text_spec, 0)
+    with torch.no_grad():
+        want = text_ref.text_forward(sd, tokens, heads=fx.text_spec.heads, act=fx.text_spec.act).numpy()
+    assert ((feats * want).sum(axis=1)).min() > 1 - COS_TOL
+
+    # index of image embeddings, then a text query through FeatureSearchIndex.search
+    fdir, idir = tmp_path / "features", tmp_path / "index"
+    fdir.mkdir()
+    frames = torch.from_numpy(np.random.default_rng(5).integers(0, 256, (96, 3, 224, 224), dtype=np.uint8))
+    X = fx.extract_image_features(frames.cuda())
+    st = FeatureStoreFactory.create_store(FeatureStoreType.WEBDATASET, "video", str(fdir))
+    st.enable_write(2048, 20 * 1024 * 1024)
+    for i in range(X.shape[0]):
+        st.add(i + 1, X[i:i + 1])
+    st.close()
+    si = SearchIndexFactory("video", fid, {"features_dir": fdir, "index_dir": idir})
+    si.create_index("IndexFlatIP")
+    assert si.load_index("IndexFlatIP") is True
+    dist, ids = si.search("video", "dog", topk=5)
+    assert dist.shape == (5,) and ids.shape == (5,) and ids.dtype == np.int64
+    q = fx.extract_text_features(["This is a photo of a dog"])      # the prompt the reference prepends (:24-28,:110)
+    D, I = ip_topk_ref.ip_topk(X, q, 5, ids=np.arange(96, dtype=np.int64) + 1)
+    assert np.array_equal(ids, I[0]) and np.allclose(dist, D[0], atol=2e-5)

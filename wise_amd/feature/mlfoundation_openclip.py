@@ -15,6 +15,8 @@ import torch
 from PIL import Image
 
 from .feature_extractor import FeatureExtractor
+from .clip_tokenizer import ClipTokenizer
+from .text import TextEngine, random_text_state_dict, text_spec_for
 from .vit import SPECS, VitEngine, random_state_dict, spec_for
 from .weights import load_state_dict_file, seeded_tag
 
@@ -93,6 +95,12 @@ class MlfoundationOpenClip(FeatureExtractor):
         self.preprocess = ClipImageTransform(self.spec.image_size)
         self._engine = None
         self._gpu_preprocess = None
+        # text tower (query side): built on first use; seeded models may run on the merge-less
+        # byte tokenizer because open_clip's merge file does not exist offline
+        self.text_spec = text_spec_for(model, "openai" if seed is not None else tag)
+        self._seed = seed
+        self._text_engine = None
+        self._tokenizer = None
         self.input_image_size = (self.spec.image_size, self.spec.image_size)
         self.output_dim = self.spec.embed_dim
         if self.DEVICE == "cuda":
@@ -109,6 +117,7 @@ class MlfoundationOpenClip(FeatureExtractor):
         st = dict(self.__dict__)
         st["_engine"] = None
         st["_gpu_preprocess"] = None
+        st["_text_engine"] = None
         return st
 
     def _find_output_dim(self):
@@ -117,6 +126,7 @@ class MlfoundationOpenClip(FeatureExtractor):
         random_image = torch.rand((1, 3,) + self.input_image_size)
         feats = self.extract_image_features(self.preprocess_image(random_image))
         assert feats.shape[1] == self.output_dim
+        assert self.text_spec.embed_dim == self.output_dim  # both towers embed into the same space (:67-73)
 
     def get_output_dim(self):
         return self.output_dim
@@ -149,7 +159,25 @@ class MlfoundationOpenClip(FeatureExtractor):
         out = self._get_engine().forward(images.to(torch.float32) if images.dtype != torch.uint8 else images)
         return out.cpu().numpy()
 
+    @property
+    def tokenizer(self) -> ClipTokenizer:
+        if self._tokenizer is None:
+            self._tokenizer = ClipTokenizer.default(self.text_spec.context, allow_merge_less=self._seed is not None)
+            if self._tokenizer.vocab_size > self.text_spec.vocab:
+                raise RuntimeError("tokenizer vocabulary larger than the model's token embedding")
+        return self._tokenizer
+
+    def _get_text_engine(self) -> TextEngine:
+        if self._text_engine is None:
+            sd = random_text_state_dict(self.text_spec, self._seed) if self._seed is not None else self._state_dict
+            self._text_engine = TextEngine(self.text_spec, sd, device="cuda")
+        return self._text_engine
+
+    def preprocess_text(self, text: Union[str, List[str]]) -> torch.Tensor:
+        """Token ids [n, 77] (what `self.tokenizer(text_query)` is at mlfoundation_openclip.py:106)."""
+        return self.tokenizer(text)
+
     def extract_text_features(self, text_query: List[str]) -> np.ndarray:
-        raise NotImplementedError(
-            "the CLIP text tower (BPE tokenizer + text transformer) is outside this build's hot path "
-            "(SURVEY.md §8 f4): it needs the tokenizer vocabulary and text weights, neither available offline")
+        """encode_text + L2 normalise (mlfoundation_openclip.py:103-108) on the HIP text tower."""
+        tokens = self.tokenizer(text_query)
+        return self._get_text_engine().forward(tokens).cpu().numpy()
