@@ -407,6 +407,38 @@ def main():
                                   "frac": round(pre_bytes / pre_us / 1e3 / PEAK_HBM_GBS, 4),
                                   "frames_per_s": round(args.batch / pre_us * 1e6, 0)}}
         del raw, crop
+        # f4: the query side — CLIP text tower (ViT-B/32 text), one query at a time and in batches of 256
+        from wise_amd.feature.text import EOT_TOKEN, SOT_TOKEN, TextEngine, random_text_state_dict, text_spec_for
+
+        tspec = text_spec_for("ViT-B-32", "openai")
+        teng = TextEngine(tspec, random_text_state_dict(tspec, 0), max_batch=256)
+        trng = np.random.default_rng(11 + rank)
+        toks = np.zeros((256, tspec.context), dtype=np.int32)
+        for i in range(256):
+            k = int(trng.integers(3, 20))
+            toks[i, 0] = SOT_TOKEN
+            toks[i, 1:1 + k] = trng.integers(1, SOT_TOKEN, k)
+            toks[i, 1 + k] = EOT_TOKEN
+        toks = torch.from_numpy(toks).cuda()
+
+        def text1(i):
+            hold["t"] = teng.forward(toks[i % 256:i % 256 + 1])
+
+        def text256(i):
+            hold["t"] = teng.forward(toks)
+
+        for i in range(3):
+            text1(i); text256(i)
+        t_steps = max(10, min(args.steps, 50))
+        tdt1 = timed_region(text1, t_steps, world)
+        tdt256 = timed_region(text256, t_steps, world)
+        extra["clip_text_tower"] = {
+            "value": round(world * 256 * t_steps / tdt256, 1), "unit": "queries/s (batches of 256)",
+            "single_query_ms": round(tdt1 / t_steps * 1e3, 4), "ms_per_batch256": round(tdt256 / t_steps * 1e3, 3),
+            "config": {"workload": "OpenCLIP ViT-B/32 text tower: token ids [n,77] resident in HBM -> unit vectors "
+                                   "[n,512]; seeded weights", "gflop_per_query": round(tspec.flops_per_query() / 1e9, 3)},
+            "tflops_batch256": round(256 * t_steps / tdt256 * tspec.flops_per_query() / 1e12, 2)}
+        del teng, toks
         result["extra"] = extra
 
     # ------------------------------------------------------------------ CPU baselines (rank 0, N=1 only)

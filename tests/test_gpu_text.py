@@ -134,3 +134,20 @@ def test_extractor_text_features_and_end_to_end_search(tmp_path):
     q = fx.extract_text_features(["This is a photo of a dog"])      # the prompt the reference prepends (:24-28,:110)
     D, I = ip_topk_ref.ip_topk(X, q, 5, ids=np.arange(96, dtype=np.int64) + 1)
     assert np.array_equal(ids, I[0]) and np.allclose(dist, D[0], atol=2e-5)
+
+
+def test_graph_replay_equals_direct_launch():
+    """Small batches run from a captured hipGraph; the result must be the direct launch's, bit for bit, and the
+    graph must pick up new token ids on every replay."""
+    spec = text_spec_for("ViT-B-32", "openai")
+    eng = TextEngine(spec, random_text_state_dict(spec, 0), max_batch=8)
+    toks = torch.from_numpy(seeded_tokens(6, spec.context, 41, spec.vocab))
+    eng.graph_max_batch = 0
+    direct = [eng.forward(toks[i:i + 1]).cpu() for i in range(6)]
+    direct2 = eng.forward(toks[:2]).cpu()
+    eng.graph_max_batch = 4
+    for rep in range(2):
+        for i in range(6):
+            assert torch.equal(eng.forward(toks[i:i + 1]).cpu(), direct[i])
+    assert torch.equal(eng.forward(toks[:2]).cpu(), direct2)
+    assert len(eng._graphs) == 2
