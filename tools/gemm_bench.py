@@ -23,8 +23,18 @@ SHAPES = [  # (name, M, N, K, mode)
 ]
 
 
+SQUARE = [  # calibration against the guide's 256x256 8-phase figures (1320-1340 TF @4096^3, ~1470 @8192^3)
+    ("sq4096", 4096, 4096, 4096, 0),
+    ("sq8192", 8192, 8192, 8192, 0),
+]
+
+
 def main():
-    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3]
+    args = sys.argv[1:]
+    if "--square" in args:
+        args.remove("--square")
+        SHAPES[:] = SQUARE
+    variants = [int(v) for v in args] or [0, 1, 2, 3]
     lib = _lib.lib()
     lib.wise_debug_set_gemm_variant.argtypes = [C.c_int]
     g = torch.Generator(device="cuda").manual_seed(0)

@@ -164,6 +164,54 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[4][4], const float* __
     }
 }
 
+// fp32-output epilogue (modes 3 and 4) through LDS, for one 64x64 sub-tile of a wave.  The MFMA layout gives a
+// lane 16 bytes of one row and a wave instruction 16 different rows: 64-byte row fragments, half cache lines,
+// and for mode 3 a read-modify-write of each of them.  Here the wave parks the sub-tile in a private 16 KiB LDS
+// image (256-byte rows, 16-byte chunks XOR-swizzled by row so both directions are conflict-free) and walks it
+// row-major: every global access is 4 rows x 256 contiguous bytes.  The residual rows are loaded BEFORE the
+// transposition so that their latency hides under it.
+// Precondition: the block has finished with the staging buffers (block barrier); `my` is the wave's 16 KiB.
+template <int MODE>
+__device__ __forceinline__ void epilogue_f32_lds_64x64(const f32x4 (*acc)[4] /*[4][4]*/, const float* __restrict__ bias,
+                                                       float* __restrict__ out, int N, int row0, int col0, int lane,
+                                                       unsigned char* my) {
+    const int l15 = lane & 15, g = lane >> 4;
+    const int n = col0 + l15 * 4;           // this lane's 4 columns on the row-major walk
+    const bool in = n + 4 <= N;
+    float4 res[16];
+    if (MODE == EPI_RESID) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            res[t] = in ? *reinterpret_cast<const float4*>(out + (size_t)(row0 + t * 4 + g) * N + n)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nb = col0 + j * 16 + g * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && nb < N) bv = *reinterpret_cast<const float4*>(bias + nb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 16 + l15;
+            const float4 v = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z,
+                                         acc[i][j][3] + bv.w);
+            *reinterpret_cast<float4*>(my + r * 256 + (((j * 4 + g) ^ (r & 15)) << 4)) = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool skip = g_skip_epilogue != 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int r = t * 4 + g;
+        float4 v = *reinterpret_cast<const float4*>(my + r * 256 + ((l15 ^ (r & 15)) << 4));
+        if (skip && v.x != 123456.75f) continue;
+        if (MODE == EPI_RESID) { v.x += res[t].x; v.y += res[t].y; v.z += res[t].z; v.w += res[t].w; }
+        if (in) *reinterpret_cast<float4*>(out + (size_t)(row0 + t * 4 + g) * N + n) = v;
+    }
+}
+
 template <int MODE, int ABL = 0>  // ABL (timing-only builds): 1 = no staging in the loop, 2 = no LDS reads / MFMA
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
                                                            const bf16_t* __restrict__ Wt,
@@ -229,6 +277,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
     if ((MODE == EPI_BF16 || MODE == EPI_QUICKGELU || MODE == EPI_GELU) && (N & 7) == 0 && g_epi_lds) {
         __syncthreads();  // staging buffers are dead from here on
         epilogue_lds<MODE>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
+    } else if ((MODE == EPI_RESID || MODE == EPI_F32) && g_epi_lds) {
+        __syncthreads();
+        epilogue_f32_lds_64x64<MODE>(acc, bias, reinterpret_cast<float*>(out), N, m0 + wm * 64, n0 + wn * 64, lane,
+                                     smem + wave * 16384);
     } else {
         epilogue<MODE>(acc, bias, out, N, m0, n0, wm, wn, lane);
     }
