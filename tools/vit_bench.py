@@ -20,8 +20,10 @@ def main():
     eng = VitEngine(spec, random_state_dict(spec, 0), max_batch=B)
     x = torch.randn(B, 3, 224, 224, device="cuda")
     ref = None
-    for streams in (1, 2, 1, 2):
+    configs = [(1, 0), (2, 0), (1, 1), (2, 1)] * 3   # (streams, gemm flags: bit 0 = no 320-row tiling)
+    for streams, flags in configs:
         lib.wise_debug_set_vit_streams(streams)
+        lib.wise_debug_set_gemm_flags(flags)
         for _ in range(5):
             o = eng.forward(x)
         torch.cuda.synchronize()
@@ -34,7 +36,7 @@ def main():
         if ref is None:
             ref = o.clone()
         same = torch.equal(o, ref)
-        print(f"{model} B={B} streams={streams}: {dt*1e3:8.3f} ms/step  {B/dt:10.1f} frames/s  "
+        print(f"{model} B={B} streams={streams} flags={flags}: {dt*1e3:8.3f} ms/step  {B/dt:10.1f} frames/s  "
               f"{B/dt*spec.flops_per_frame()/1e12:7.1f} TFLOP/s  bit-identical-to-first={same}", flush=True)
 
 

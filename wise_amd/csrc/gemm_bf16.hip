@@ -50,7 +50,11 @@ __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* lds_tile, int ro
     return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 
-__device__ __forceinline__ float act_quickgelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
+// x * sigmoid(1.702 x) on the two native transcendentals (v_exp_f32 is 2^x, v_rcp_f32 ~1 ulp): an IEEE divide
+// costs ~10 more instructions per element and the epilogue applies this to 128-160 elements per thread
+__device__ __forceinline__ float act_quickgelu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+}
 __device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)][n0 + wn*64 + j*16 + (lane>>4)*4 + r]
@@ -527,8 +531,8 @@ static void launch_gemm(const bf16_t* A, const bf16_t* Wt, const float* bias, in
 // half the staged bytes per flop of the 128x128 tile (staging, not MFMA, bounds that one: measured
 // 13.5 TB/s L2->LDS chip-wide).  Same LDS image, swizzle and transposed-product epilogue.
 // ------------------------------------------------------------------------------------------------
-template <int MODE, int NT>
-__device__ __forceinline__ void epilogue_big(f32x4 (&acc)[8][NT], const float* __restrict__ bias,
+template <int MODE, int NT, int MI = 8>
+__device__ __forceinline__ void epilogue_big(f32x4 (&acc)[MI][NT], const float* __restrict__ bias,
                                              void* __restrict__ out, int N, int m0, int n0, int wm, int wn, int lane) {
     const bool skip = g_skip_epilogue != 0;
     // epilogue: acc[i][j][r] = C[m0 + wm*128 + i*16 + (lane&15)][n0 + wn*16*NT + j*16 + (lane>>4)*4 + r]
@@ -537,8 +541,8 @@ __device__ __forceinline__ void epilogue_big(f32x4 (&acc)[8][NT], const float* _
         const int n = n0 + wn * (16 * NT) + j * 16 + (lane >> 4) * 4;
         float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (MI * 16) + i * 16 + (lane & 15);
             float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z,
                   v3 = acc[i][j][3] + bv.w;
             const size_t off = (size_t)m * N + n;
@@ -652,10 +656,12 @@ template <int ROWS, int BKT>
 __device__ __forceinline__ void stage_rows8_ring(const bf16_t* __restrict__ G, int ld, int row0, int k0,
                                                  unsigned char* lds_tile, int wave, int lane) {
     constexpr int RB = BKT * 2, RPI = 1024 / RB, CPR = RB / 16;
-    constexpr int ROUNDS = ROWS * RB / 1024 / 8;
+    constexpr int UNITS = ROWS * RB / 1024;        // 1-KiB wave instructions in the tile
+    constexpr int ROUNDS = (UNITS + 7) / 8;        // the last round may be partial (320-row tile: waves 0-3 only)
 #pragma unroll
     for (int t = 0; t < ROUNDS; ++t) {
         const int u = t * 8 + wave;
+        if (UNITS % 8 != 0 && u >= UNITS) break;
         const int r = u * RPI + lane / CPR;
         const int c = swz_chunk<BKT>(r, lane % CPR);
         glds16(G + (size_t)(row0 + r) * ld + k0 + c * 8, lds_tile + u * 1024);
@@ -751,12 +757,12 @@ static void launch_bigring(const bf16_t* A, const bf16_t* Wt, const float* bias,
 // bf16 epilogue through LDS for the 8-wave 256x256 tile (wave = 128 rows x 64 columns): same idea as
 // epilogue_lds, done in two 64-row halves so the eight wave-private images (64 x 144 B) fit 128 KiB.
 // Precondition: block barrier after the last fragment read.
-template <int MODE>
-__device__ __forceinline__ void epilogue_big_lds(f32x4 (&acc)[8][4], const float* __restrict__ bias,
+template <int MODE, int MI = 8>
+__device__ __forceinline__ void epilogue_big_lds(f32x4 (&acc)[MI][4], const float* __restrict__ bias,
                                                  bf16_t* __restrict__ out, int N, int m0, int n0, int wm, int wn,
                                                  int lane, int wave, unsigned char* smem) {
-    constexpr int RS = 144;
-    unsigned char* my = smem + wave * (64 * RS);
+    constexpr int RS = 144, HI = MI / 2, HROWS = HI * 16;  // i-tiles / rows per half (MI = 8: 64, MI = 10: 80)
+    unsigned char* my = smem + wave * (HROWS * RS);
     const int l15 = lane & 15, g = lane >> 4;
     const bool skip = g_skip_epilogue != 0;
     const int chunk = lane & 7;
@@ -769,8 +775,8 @@ __device__ __forceinline__ void epilogue_big_lds(f32x4 (&acc)[8][4], const float
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int i = half * 4 + ii;
+            for (int ii = 0; ii < HI; ++ii) {
+                const int i = half * HI + ii;
                 float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z,
                       v3 = acc[i][j][3] + bv.w;
                 if (MODE == EPI_QUICKGELU) {
@@ -788,11 +794,11 @@ __device__ __forceinline__ void epilogue_big_lds(f32x4 (&acc)[8][4], const float
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+        for (int t = 0; t < HROWS / 8; ++t) {
             const int row = t * 8 + (lane >> 3);
             const uint4 v = *reinterpret_cast<const uint4*>(my + row * RS + chunk * 16);
             if (skip && v.x != 0x12345678u) continue;
-            *reinterpret_cast<uint4*>(out + (size_t)(m0 + wm * 128 + half * 64 + row) * N + ncol) = v;
+            *reinterpret_cast<uint4*>(out + (size_t)(m0 + wm * (MI * 16) + half * HROWS + row) * N + ncol) = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -812,27 +818,33 @@ __device__ __forceinline__ void epilogue_big_lds(f32x4 (&acc)[8][4], const float
 //        (lgkmcnt(0)) before the barrier that precedes the overwrite.
 // ------------------------------------------------------------------------------------------------
 // WROWS = rows per wave: 128 -> 256x256 tile (waves 2x4, 4 stages of 32 KiB); 64 -> 256x128 tile
-// (waves 4x2, 5 stages of 24 KiB) for shapes whose 256x256 tiling leaves a long tail.
+// (waves 4x2, 5 stages of 24 KiB) for shapes whose 256x256 tiling leaves a long tail; 160 -> 320x256 tile
+// (waves 2x4, 4 stages of 36 KiB) for shapes that fill the chip in whole rounds only with 320-row tiles
+// (M = 6400, N = 3072: 240 tiles).  A 320-row A tile is 20 KiB per stage = 2.5 rounds of the 8 waves, so waves
+// 0-3 (the early group) issue one LDS-DMA more per K-tile than waves 4-7: the counted vmcnt differs per group.
 template <int MODE, int WROWS>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                          const float* __restrict__ bias, int M, int N, int K,
                                                          void* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BKT = 32, NT = 4, MI = WROWS / 16;
-    constexpr int WM_WAVES = 256 / WROWS, WN_WAVES = 8 / WM_WAVES, BNB = WN_WAVES * 64;
-    constexpr int STAGES = (WROWS == 128) ? 4 : 5;
-    constexpr int TA = 256 * BKT * 2, TBt = BNB * BKT * 2, SB = TA + TBt;
-    constexpr int GPS = SB / 8192;                  // LDS-DMA instructions per thread per K-tile
-    constexpr int INFL = (STAGES - 2) * GPS;        // loads of the STAGES-2 youngest tiles may stay in flight
+    constexpr int BMB = (WROWS == 64) ? 256 : 2 * WROWS;
+    constexpr int WM_WAVES = BMB / WROWS, WN_WAVES = 8 / WM_WAVES, BNB = WN_WAVES * 64;
+    constexpr int STAGES = (WROWS == 64) ? 5 : 4;
+    constexpr int TA = BMB * BKT * 2, TBt = BNB * BKT * 2, SB = TA + TBt;
+    // LDS-DMA instructions per thread per K-tile: waves 0-3 take the partial last round of a 320-row A tile
+    constexpr int GPS_E = (TA / 1024 + 7) / 8 + TBt / 8192, GPS_L = TA / 8192 + TBt / 8192;
+    constexpr int INFL_E = (STAGES - 2) * GPS_E, INFL_L = (STAGES - 2) * GPS_L;  // STAGES-2 youngest tiles in flight
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
     const bool late = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;  // waves 4-7 run half a step behind
+    auto wait_inflight = [&]() { if (INFL_E == INFL_L || late) wait_vmcnt<INFL_L>(); else wait_vmcnt<INFL_E>(); };
 
     const int tiles_n = N / BNB;
     int tm, tn;
-    tile_coords(M / 256, tiles_n, g_group_m ? g_group_m : 4, &tm, &tn);
-    const int m0 = tm * 256, n0 = tn * BNB;
+    tile_coords(M / BMB, tiles_n, g_group_m ? g_group_m : 4, &tm, &tn);
+    const int m0 = tm * BMB, n0 = tn * BNB;
 
     f32x4 acc[MI][NT];
 #pragma unroll
@@ -844,25 +856,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) {
         if (s < nk) {
-            stage_rows8_ring<256, BKT>(A, K, m0, s * BKT, smem + s * SB, wave, lane);
+            stage_rows8_ring<BMB, BKT>(A, K, m0, s * BKT, smem + s * SB, wave, lane);
             stage_rows8_ring<BNB, BKT>(Wt, K, n0, s * BKT, smem + s * SB + TA, wave, lane);
         }
     }
     if (late) {
         // the early group reads tile 0 right after this barrier: my share of it must have landed
-        if (nk >= STAGES - 1) wait_vmcnt<INFL>(); else wait_vmcnt<0>();
+        if (nk >= STAGES - 1) wait_inflight(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
     }
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // ---- L part
-        if (kt + STAGES - 2 < nk) wait_vmcnt<INFL>(); else wait_vmcnt<0>();   // my share of tile kt has landed
+        if (kt + STAGES - 2 < nk) wait_inflight(); else wait_vmcnt<0>();   // my share of tile kt has landed
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (kt + STAGES - 1 < nk) {
             int ns = cur + STAGES - 1;
             if (ns >= STAGES) ns -= STAGES;
-            stage_rows8_ring<256, BKT>(A, K, m0, (kt + STAGES - 1) * BKT, smem + ns * SB, wave, lane);
+            stage_rows8_ring<BMB, BKT>(A, K, m0, (kt + STAGES - 1) * BKT, smem + ns * SB, wave, lane);
             stage_rows8_ring<BNB, BKT>(Wt, K, n0, (kt + STAGES - 1) * BKT, smem + ns * SB + TA, wave, lane);
         }
         const unsigned char* At = smem + cur * SB;
@@ -874,7 +886,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[i] = lds_frag_ring<BKT>(At, wm * WROWS + i * 16 + (lane & 15), chunk);
         // my share of tile kt+1 has landed before the barrier after which the other group may read it
-        if (kt + STAGES - 1 < nk) wait_vmcnt<INFL>(); else wait_vmcnt<0>();
+        if (kt + STAGES - 1 < nk) wait_inflight(); else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -892,12 +904,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
     }
     if (!late) __builtin_amdgcn_s_barrier();
     constexpr bool BF16OUT = (MODE == EPI_BF16 || MODE == EPI_QUICKGELU || MODE == EPI_GELU);
-    if constexpr (WROWS == 128) {
+    if constexpr (WROWS != 64) {
         if (BF16OUT && g_epi_lds) {
             __syncthreads();  // both groups are past their last fragment read: the ring is dead
-            epilogue_big_lds<MODE>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
+            epilogue_big_lds<MODE, MI>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
         } else {
-            epilogue_big<MODE, NT>(acc, bias, out, N, m0, n0, wm, wn, lane);
+            epilogue_big<MODE, NT, MI>(acc, bias, out, N, m0, n0, wm, wn, lane);
         }
     } else {
         if (BF16OUT && g_epi_lds) {
@@ -913,20 +925,23 @@ template <int MODE, int WROWS>
 static void launch_pp(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
                       hipStream_t st) {
     auto kern = gemm_pp_kernel<MODE, WROWS>;
-    constexpr int BNB = (WROWS == 128) ? 256 : 128;
-    constexpr int STAGES = (WROWS == 128) ? 4 : 5;
-    const size_t lds = (size_t)STAGES * (256 + BNB) * 32 * 2;  // 128 KiB / 120 KiB
+    constexpr int BNB = (WROWS == 64) ? 128 : 256;
+    constexpr int BMB = (WROWS == 64) ? 256 : 2 * WROWS;
+    constexpr int STAGES = (WROWS == 64) ? 5 : 4;
+    const size_t lds = (size_t)STAGES * (BMB + BNB) * 32 * 2;  // 128 KiB / 120 KiB / 144 KiB
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_set = true;
     }
-    const int grid = (M / 256) * (N / BNB);
+    const int grid = (M / BMB) * (N / BNB);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
 }
 
 static int g_gemm_variant = 0;
+static int g_tile320 = 1;  // allow the 320x256 ping-pong tiling (wise_debug_set_gemm_flags bit 0 turns it off)
+static int g_overlapped = 0;  // the caller is running another stream's kernels beside this one (gemm_set_overlapped)
 static int g_split_m = 1;  // split M between the ping-pong kernel and the 128x128 kernel (bit 29 of the knob: off)
   // 0: 2-stage BK=64 ; 1: ring BK=32 x4 (2 blocks/CU) ; 2: ring BK=64 x4 (1 block/CU) ; 3: ring BK=64 x3
 
@@ -961,6 +976,8 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 41: if (M % 256 == 0 && N % 128 == 0) { launch_pp<MODE, 64>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 42: if (M % 320 == 0 && N % 256 == 0) { launch_pp<MODE, 160>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 30: launch_persist<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 16: launch_ring<MODE, 32, 2, 4>(A, Wt, bias, M, N, K, out, st); break;   // 32 KB LDS: 4 blocks/CU
         case 17: launch_ring<MODE, 32, 3, 3>(A, Wt, bias, M, N, K, out, st); break;   // 48 KB LDS: 3 blocks/CU
@@ -978,7 +995,7 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
 
 static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode,
                        void* out, hipStream_t st) {
-    if (K % 64 != 0 && v != 40) v = 1;
+    if (K % 64 != 0 && v != 40 && v != 42) v = 1;
     else if (N % BN != 0 && v != 1) v = 0;  // N edge is handled by the 128x128 kernels only
     switch (mode) {
         case EPI_BF16: launch_variant<EPI_BF16>(v, A, Wt, bias, M, N, K, out, st); break;
@@ -1003,6 +1020,8 @@ static int auto_variant(int M, int N, int K) {
     return 0;
 }
 
+void gemm_set_overlapped(bool on) { g_overlapped = on ? 1 : 0; }
+
 int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out,
               hipStream_t st) {
     WISE_CHECK_ARG(A && Wt && out, "gemm_bf16: null pointer");
@@ -1013,6 +1032,17 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
     if (v == 100) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);  // force 128x128 (A/B runs)
     if (v != 0) return launch_mode(v, A, Wt, bias, M, N, K, mode, out, st);
 
+    // Tile quantisation decides between the ping-pong tilings: 6400 x 3072 is 300 tiles of 256x256 (two rounds
+    // at 59 %) but 240 tiles of 320x256 (one round at 94 %); measured 694 -> 799 TFLOP/s on that shape.
+    // (not when the caller overlaps two streams: a 144-KiB one-block-per-CU kernel leaves the other stream's
+    // kernels nowhere to run, measured 3.54 -> 3.74 ms per ViT-B/32 step)
+    if (g_tile320 && !g_overlapped && M % 320 == 0 && N % 256 == 0) {
+        const long long t320 = (long long)(M / 320) * (N / 256), t256 = (long long)(M / 256) * (N / 256);
+        const double eff320 = (double)t320 / (double)(((t320 + 255) / 256) * 256);
+        const double eff256 = (M % 256 == 0) ? (double)t256 / (double)(((t256 + 255) / 256) * 256) : 0.0;
+        if (t320 >= 200 && eff320 >= 0.90 && eff320 > eff256 + 0.04)
+            return launch_mode(42, A, Wt, bias, M, N, K, mode, out, st);
+    }
     // The 256x256 ping-pong kernel (one block per CU) has the fastest main loop but no co-resident block to
     // hide its epilogue or its tail.  Give it the rows whose tiles fill whole rounds of the 256 CUs and hand the
     // remaining rows to the two-blocks-per-CU kernels (same stream, so the two launches are ordered).
@@ -1045,6 +1075,11 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
 extern "C" int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, int mode,
                               void* out, void* stream) {
     return wise::gemm_bf16(A, Wt, bias, M, N, K, mode, out, (hipStream_t)stream);
+}
+
+extern "C" int wise_debug_set_gemm_flags(int flags) {
+    wise::g_tile320 = (flags & 1) ? 0 : 1;
+    return 0;
 }
 
 // tuning knob for A/B runs (tools/gemm_bench.py); not part of the stable ABI

@@ -6,6 +6,9 @@ namespace wise {
 
 int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out,
               hipStream_t st);
+// hint for the tile heuristic: the caller is about to enqueue GEMMs on several streams that overlap in time
+// (host-side state; the library is single-threaded by contract)
+void gemm_set_overlapped(bool on);
 int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows, int W, float eps, bf16_t* y,
                        hipStream_t st);
 // head dim 64; causal = query t attends keys <= t (CLIP text tower), otherwise no mask

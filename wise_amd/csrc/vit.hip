@@ -675,6 +675,7 @@ extern "C" int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, 
     for (int i = 0; i < parts && e == hipSuccess; ++i) e = hipStreamWaitEvent(g_side[i], g_ev_fork, 0);
     if (e != hipSuccess) { set_error("vit_forward: fork: %s", hipGetErrorString(e)); return (int)e; }
     size_t base = 0;
+    gemm_set_overlapped(true);
     for (int i = 0; i < parts && !rc; ++i) {
         int lo, hi;
         part_range(batch, parts, i, &lo, &hi);
@@ -682,6 +683,7 @@ extern "C" int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, 
                               out + (size_t)lo * d.D, wsb + base, g_side[i]);
         base += vit_ws(d, hi - lo).total;
     }
+    gemm_set_overlapped(false);
     // always join, even after an error, so the caller's stream never runs ahead of the side streams
     for (int i = 0; i < parts; ++i) {
         hipError_t e2 = hipEventRecord(g_ev_join[i], g_side[i]);
