@@ -55,7 +55,18 @@ __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* lds_tile, int ro
 __device__ __forceinline__ float act_quickgelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
 }
-__device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// erf GELU, 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 — the result is
+// rounded to bf16, 2^-9 relative, right after): one v_rcp_f32 and one v_exp_f32 plus a degree-5 Horner chain,
+// about a third of the instructions of the library erff, which matters because the epilogue applies it to
+// 64-160 values per thread (HTSAT's MLPs and the laion CLIP weights use this activation).
+__device__ __forceinline__ float act_gelu(float x) {
+    const float z = x * 0.70710678118654752f, az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f),
+                                0.254829592f);
+    const float erf_abs = 1.f - poly * __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
+    return 0.5f * x * (1.f + copysignf(erf_abs, z));
+}
 
 // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)][n0 + wn*64 + j*16 + (lane>>4)*4 + r]
 template <int MODE>
@@ -398,7 +409,19 @@ __global__ __launch_bounds__(256, MINB) void gemm_ring_kernel(const bf16_t* __re
         }
         cur = (cur + 1 == STAGES) ? 0 : cur + 1;
     }
-    epilogue<MODE>(acc, bias, out, N, m0, n0, wm, wn, lane);
+    // the ring (>= 64 KiB for the instantiations in use) is dead after the last fragment read: reuse it for the
+    // row-major epilogues (these shapes, K = 96..384 with M in the 10^5s, are bound by their C traffic)
+    constexpr bool RING_FITS = STAGES * SB >= 65536;
+    if (RING_FITS && (MODE == EPI_BF16 || MODE == EPI_QUICKGELU || MODE == EPI_GELU) && (N & 7) == 0 && g_epi_lds) {
+        __syncthreads();
+        epilogue_lds<MODE>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
+    } else if (RING_FITS && (MODE == EPI_RESID || MODE == EPI_F32) && g_epi_lds) {
+        __syncthreads();
+        epilogue_f32_lds_64x64<MODE>(acc, bias, reinterpret_cast<float*>(out), N, m0 + wm * 64, n0 + wn * 64, lane,
+                                     smem + wave * 16384);
+    } else {
+        epilogue<MODE>(acc, bias, out, N, m0, n0, wm, wn, lane);
+    }
 }
 
 template <int MODE, int BKT, int STAGES, int MINB, int ABL = 0>
