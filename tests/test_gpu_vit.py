@@ -24,6 +24,8 @@ def cosine(a, b):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (12800, 768, 768), (1280, 2304, 768),
                                     (640, 768, 3072), (12544, 768, 3072),
+                                    # 256x256 ping-pong (225 tiles) and 320x256 ping-pong (240 tiles) tilings
+                                    (6400, 2304, 768), (6400, 3072, 768),
                                     # HTSAT shapes: N edge (N % 128 != 0) and K % 64 != 0
                                     (256, 288, 96), (128, 96, 384), (384, 192, 96), (256, 576, 192), (128, 36, 32)])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])

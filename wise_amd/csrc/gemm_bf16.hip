@@ -227,6 +227,72 @@ __device__ __forceinline__ void epilogue_f32_lds_64x64(const f32x4 (*acc)[4] /*[
     }
 }
 
+// The same for a (RI*16) x (NJ*16) piece of a wave's accumulators (the 8-wave kernels: NJ = 2, 3 or 4 column
+// tiles, RI <= 4 row tiles per pass so that the image stays within the wave's share of the dead staging LDS).
+// Rows are NJ*64 bytes; chunks are XOR-swizzled when a row has 16 or 8 of them and rotated when it has 12.
+template <int MODE, int RI, int NJ>
+__device__ __forceinline__ void epilogue_f32_lds_piece(const f32x4 (*acc)[NJ], const float* __restrict__ bias,
+                                                       float* __restrict__ out, int N, int row0, int col0, int lane,
+                                                       unsigned char* my) {
+    constexpr int CH = NJ * 4, RB = NJ * 64, ROWS = RI * 16;
+    constexpr int RP = 64 / CH;                       // rows per wave instruction on the row-major walk (4, 5, 8)
+    constexpr int IT = (ROWS + RP - 1) / RP;
+    const int l15 = lane & 15, g = lane >> 4;
+    auto phys = [](int c, int r) { return CH == 12 ? (c + r) % 12 : (c ^ (r & (CH - 1))); };
+    const int wr = lane / CH, wc = lane - wr * CH;    // walk: row within the instruction, chunk
+    const bool lane_on = wr < RP;
+    const int n = col0 + wc * 4;
+    const bool in = lane_on && n + 4 <= N;
+    float4 res[IT];
+    if (MODE == EPI_RESID) {
+#pragma unroll
+        for (int t = 0; t < IT; ++t) {
+            const int r = t * RP + wr;
+            res[t] = (in && r < ROWS) ? *reinterpret_cast<const float4*>(out + (size_t)(row0 + r) * N + n)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int nb = col0 + j * 16 + g * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && nb < N) bv = *reinterpret_cast<const float4*>(bias + nb);
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+            const int r = i * 16 + l15;
+            *reinterpret_cast<float4*>(my + r * RB + (phys(j * 4 + g, r) << 4)) =
+                make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool skip = g_skip_epilogue != 0;
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+        const int r = t * RP + wr;
+        if (!in || r >= ROWS) continue;
+        float4 v = *reinterpret_cast<const float4*>(my + r * RB + (phys(wc, r) << 4));
+        if (skip && v.x != 123456.75f) continue;
+        if (MODE == EPI_RESID) { v.x += res[t].x; v.y += res[t].y; v.z += res[t].z; v.w += res[t].w; }
+        *reinterpret_cast<float4*>(out + (size_t)(row0 + r) * N + n) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// a wave's whole MI x NJ accumulator block through epilogue_f32_lds_piece, four row tiles at a time
+template <int MODE, int MI, int NJ>
+__device__ __forceinline__ void epilogue_f32_lds_wave(const f32x4 (*acc)[NJ], const float* __restrict__ bias,
+                                                      float* __restrict__ out, int N, int row0, int col0, int lane,
+                                                      unsigned char* my) {
+    static_assert(MI == 8 || MI == 10, "row tiles per wave");
+    epilogue_f32_lds_piece<MODE, 4, NJ>(acc, bias, out, N, row0, col0, lane, my);
+    epilogue_f32_lds_piece<MODE, 4, NJ>(acc + 4, bias, out, N, row0 + 64, col0, lane, my);
+    if (MI == 10) epilogue_f32_lds_piece<MODE, 2, NJ>(acc + 8, bias, out, N, row0 + 128, col0, lane, my);
+}
+
 template <int MODE, int ABL = 0>  // ABL (timing-only builds): 1 = no staging in the loop, 2 = no LDS reads / MFMA
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
                                                            const bf16_t* __restrict__ Wt,
@@ -655,7 +721,13 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const bf16_t* __restri
             }
         }
     }
-    epilogue_big<MODE, NT>(acc, bias, out, N, m0, n0, wm, wn, lane);
+    if ((MODE == EPI_RESID || MODE == EPI_F32) && g_epi_lds) {
+        __syncthreads();  // staging buffers are dead; each wave takes SB*2/8 >= 12 KiB of them
+        epilogue_f32_lds_wave<MODE, 8, NT>(acc, bias, reinterpret_cast<float*>(out), N, m0 + wm * 128,
+                                           n0 + wn * (16 * NT), lane, smem + wave * (2 * SB / 8));
+    } else {
+        epilogue_big<MODE, NT>(acc, bias, out, N, m0, n0, wm, wn, lane);
+    }
 }
 
 template <int MODE, int NT, int ABL = 0>
@@ -931,6 +1003,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
         if (BF16OUT && g_epi_lds) {
             __syncthreads();  // both groups are past their last fragment read: the ring is dead
             epilogue_big_lds<MODE, MI>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
+        } else if (!BF16OUT && g_epi_lds) {
+            __syncthreads();  // the ring is dead: 16 KiB (18 KiB) of it per wave
+            epilogue_f32_lds_wave<MODE, MI, NT>(acc, bias, reinterpret_cast<float*>(out), N, m0 + wm * WROWS,
+                                                n0 + wn * 64, lane, smem + wave * 16384);
         } else {
             epilogue_big<MODE, NT, MI>(acc, bias, out, N, m0, n0, wm, wn, lane);
         }
