@@ -61,11 +61,50 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Narrow rows (W <= 128, HTSAT's first stage has W = 96): half a wave per row, so a wave normalises two rows and
+// 24 of every 32 lanes work instead of 24 of 64.  Same two-pass arithmetic; the reductions stay inside 32 lanes.
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ b, int rows, int W, float eps,
+                                                               bf16_t* __restrict__ y) {
+    const int lane = threadIdx.x & 31;
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool live = row < rows;            // both halves of a wave take part in the shuffles
+    const int w4 = W >> 2;
+    const bool on = live && lane < w4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) v = reinterpret_cast<const float4*>(x + (size_t)row * W)[lane];
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)W;
+    float q = 0.f;
+    if (on) {
+        const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+        q = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = rsqrtf(q / (float)W + eps);
+    if (on) {
+        const float4 ww = reinterpret_cast<const float4*>(w)[lane];
+        const float4 bb = reinterpret_cast<const float4*>(b)[lane];
+        uint2 pk;
+        pk.x = pack_bf16x2((v.x - mean) * rstd * ww.x + bb.x, (v.y - mean) * rstd * ww.y + bb.y);
+        pk.y = pack_bf16x2((v.z - mean) * rstd * ww.z + bb.z, (v.w - mean) * rstd * ww.w + bb.w);
+        reinterpret_cast<uint2*>(y + (size_t)row * W)[lane] = pk;
+    }
+}
+
 int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows, int W, float eps, bf16_t* y,
                        hipStream_t st) {
     WISE_CHECK_ARG(x && w && b && y, "layernorm: null pointer");
     WISE_CHECK_ARG(rows >= 0 && W >= 4 && W % 4 == 0 && W <= 4096, "layernorm: W=%d must be a multiple of 4, <= 4096", W);
     if (rows == 0) return WISE_OK;
+    if (W <= 128) {
+        hipLaunchKernelGGL(layernorm_narrow_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, x, w, b, rows, W, eps, y);
+        WISE_LAUNCH_CHECK("layernorm_narrow_kernel");
+        return WISE_OK;
+    }
     const int nv = (W / 4 + 63) / 64;
     const dim3 grid((rows + 3) / 4), block(256);
 #define LN_CASE(n) \
