@@ -315,6 +315,12 @@ def main():
             "batched_nq4_queries_per_s": round(4 * s_steps / sdt4, 2),
             "batched_nq32_queries_per_s": round(32 * s_steps / sdt32, 2),
             "batched_nq32_ms_per_pass": round(sdt32 / s_steps * 1e3, 4),
+            "batched_nq32_roofline": {"kernel": "ip_scan_mfma_kernel", "bound": "hbm",
+                                      "achieved": round(N * d * 4 / world / (sdt32 / s_steps) / 1e9, 1),
+                                      "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": round(N * d * 4 / world / (sdt32 / s_steps) / 1e9 / PEAK_HBM_GBS, 4),
+                                      "note": "whole call (scan + merge) per 32-query pass, per GPU",
+                                      "traffic": load_pmc_traffic("ip_scan_mfma_kernel")},
         }
         del X, local, index
         torch.cuda.empty_cache()
@@ -405,6 +411,7 @@ def main():
                                   "bytes_per_launch": pre_bytes,
                                   "achieved": round(pre_bytes / pre_us / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                   "frac": round(pre_bytes / pre_us / 1e3 / PEAK_HBM_GBS, 4),
+                                  "traffic": load_pmc_traffic("clip_resize_kernel"),
                                   "frames_per_s": round(args.batch / pre_us * 1e6, 0)}}
         del raw, crop
         # f4: the query side — CLIP text tower (ViT-B/32 text), one query at a time and in batches of 256
