@@ -176,10 +176,18 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no HIP device visible; the HIP path is the only path", file=sys.stderr)
         sys.exit(2)
+    # Rehearsal on a one-GPU box (WISE_BENCH_REHEARSAL=1): every rank uses device 0 and the ranks talk over gloo —
+    # it walks the multi-rank code paths (sharding, barriers, max-over-ranks timing); its numbers mean nothing.
+    rehearsal = os.environ.get("WISE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from wise_amd import _lib
     from wise_amd.feature.vit import VitEngine, random_state_dict, spec_for
@@ -419,6 +427,8 @@ def main():
 
         tspec = text_spec_for("ViT-B-32", "openai")
         teng = TextEngine(tspec, random_text_state_dict(tspec, 0), max_batch=256)
+        if world > 1:
+            teng.graph_max_batch = 0   # no graph capture beside a live RCCL communicator; direct launches instead
         trng = np.random.default_rng(11 + rank)
         toks = np.zeros((256, tspec.context), dtype=np.int32)
         for i in range(256):

@@ -177,8 +177,15 @@ class TextEngine:
             self._launch(tok, out)  # warm-up outside the capture (first-call kernel attributes)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._launch(tok, out)
+            try:
+                # thread-local capture mode: other threads of the process (e.g. the RCCL watchdog) may call the
+                # runtime while this thread captures
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._launch(tok, out)
+            except RuntimeError:
+                self.graph_max_batch = 0   # capture not possible here: keep launching directly (same kernels)
+                torch.cuda.synchronize()
+                return None
             hit = (g, tok, out)
             self._graphs[B] = hit
         return hit
@@ -192,10 +199,12 @@ class TextEngine:
         B = t.shape[0]
         self.reserve(B)
         if B <= self.graph_max_batch and not torch.cuda.is_current_stream_capturing():
-            g, tok, gout = self._graph_for(B)
-            tok.copy_(t)
-            g.replay()
-            return gout.clone()
+            hit = self._graph_for(B)
+            if hit is not None:
+                g, tok, gout = hit
+                tok.copy_(t)
+                g.replay()
+                return gout.clone()
         out = torch.empty(B, self.spec.embed_dim, dtype=torch.float32, device=self.device)
         self._launch(t, out)
         return out
