@@ -18,7 +18,7 @@ idx = FlatIPIndex(d).adopt(X, None, id_base=1)
 Q = torch.randn(96, d, device="cuda")
 Q /= Q.norm(dim=1, keepdim=True)
 ref = None
-for rows, bpc in ((4, 0), (4 + 1536, 0)):
+for rows, bpc in ((4, 0), (4 + 512, 0), (4 + 1024, 0)):  # batched kernel: full, no-DMA ablation, no-MFMA ablation
     lib.wise_debug_set_scan(rows, bpc)
     idx._ws = None  # workspace size depends on the grid
     for nq in (1, 32):

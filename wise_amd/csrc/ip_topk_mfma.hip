@@ -7,30 +7,34 @@
 // Roofline: still HBM-bound.  Per 32 rows x 512 dims (64 KB of X) a SIMD issues 256 MFMAs of 64 cycles =
 // 16.4k cycles, against ~27k cycles of HBM time for those bytes at 5.9 TB/s chip-wide.
 //
-// Structure (block = 4 independent waves, one block per CU):
+// Structure (block = 8 independent waves, one block per CU, two waves per SIMD so that one wave's MFMA chain
+// covers the other's wait for its LDS-DMA):
 //   Q [32][d] lives in LDS for the block's lifetime (16-byte chunks XOR-swizzled by query so that the 32
 //   lanes of an MFMA B-operand read hit distinct banks);
-//   each wave streams 32-row x 32-column chunks of X through a private 5-deep LDS ring by 16-byte LDS-DMA
+//   each wave streams 32-row x 32-column chunks of X through a private 2-deep LDS ring by 16-byte LDS-DMA
 //   (lane-linear destination, swizzle on the SOURCE address), waits with a counted vmcnt, reads its A
-//   fragments, re-issues the ring slot, and feeds 16 MFMAs per chunk; no block barrier in the loop;
+//   fragments into registers (a third pipeline stage), re-issues the ring slot, and feeds 16 MFMAs per chunk;
+//   no block barrier in the loop;  at d = 512 the LDS is exactly full: 64 KiB Q + 64 KiB rings + 32 KiB lists;
 //   k-permutation: lane (i, h) holds columns h*16..h*16+15 of row i — the same permutation on the Q side;
 //   selection: after a 32-row group a lane holds, for ITS query, the scores of 16 rows; candidates that beat
 //   the threshold are insertion-sorted into the wave's k-entry list of that query in LDS (the two lanes of a
-//   query take turns).  The threshold is the best k-th key ANY of the block's 4 lists of the query has
+//   query take turns).  The threshold is the best k-th key ANY of the block's 8 lists of the query has
 //   reached (a key below some list's k-th entry is dominated by k keys of the same query, so it cannot be
 //   in the global top-k): inserts, which serialise the wave, fall ~6x against lane-private thresholds.
 //   Measured alternatives that were slower: lists in registers with a branch-free bubble; lists in global
 //   memory with a device-wide atomic threshold (every insert is a chain of dependent global loads that
-//   also drains the LDS-DMA queue: 18-25 ms); 8 waves/block with a 2-deep ring; fragment reads
-//   software-pipelined one chunk ahead (the earlier vmcnt wait costs more than the overlap gains).
-//   10M x 512, 32 queries: 5.4 ms = 3.8 TB/s of X (compute-only 3.9 ms, DMA-only 3.3 ms).
-// The per-wave lists (4 per block and query) are folded by merge_keys_kernel.
+//   also drains the LDS-DMA queue: 18-25 ms); 4 waves/block with a 5-deep ring (5.4 ms: nothing runs under a
+//   wave's DMA wait); fragment reads software-pipelined one chunk ahead (the earlier vmcnt wait costs more
+//   than the overlap gains).
+//   10M x 512, 32 queries: 4.9 ms = 4.2 TB/s of X (MFMA+selection alone 3.1 ms, DMA alone 3.3 ms).
+// The per-wave lists (8 per block and query) are folded by merge_keys_kernel.
 #include "topk_common.h"
 
 namespace wise {
 
 constexpr int CW = 32;          // columns per chunk
-constexpr int RING = 5;         // chunks in flight per wave
+constexpr int RING = 2;         // chunks in flight per wave
+constexpr int WAVES = 8;        // waves per block (two per SIMD: one's MFMA chain covers the other's DMA wait)
 constexpr int CHUNK_BYTES = 32 * CW * 4;  // 4 KiB
 
 __device__ __forceinline__ void glds16_x(const void* gsrc, void* lds_dst) {
@@ -43,7 +47,7 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __restrict__ X, long long N, int d,
+__global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_mfma_kernel(const float* __restrict__ X, long long N, int d,
                                                               const float* __restrict__ qpad, int nq, int k,
                                                               u64* __restrict__ part /*[P][32][k]*/, int abl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -54,11 +58,11 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
     unsigned char* ring = smem + (size_t)32 * d * 4 + (size_t)wave * RING * CHUNK_BYTES;
     // one k-entry descending list per (wave, query): entry e of query j at lists[e*32 + j]; the two lanes
     // (h = 0, 1) that serve a query take turns.  The k-th entries double as the block's shared thresholds.
-    u64* lists_all = reinterpret_cast<u64*>(smem + (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES);
+    u64* lists_all = reinterpret_cast<u64*>(smem + (size_t)32 * d * 4 + (size_t)WAVES * RING * CHUNK_BYTES);
     u64* lists = lists_all + (size_t)wave * MFMA_KL * 32;
 
     // ---- Q -> LDS, chunk c of query j stored at chunk (c & ~15) | ((c & 15) ^ (j & 15))
-    for (int idx = threadIdx.x; idx < 32 * d4; idx += 256) {
+    for (int idx = threadIdx.x; idx < 32 * d4; idx += WAVES * 64) {
         const int j = idx / d4, c = idx - j * d4;
         const float4 v = reinterpret_cast<const float4*>(qpad)[idx];
         const int pc = (c & ~15) | ((c & 15) ^ (j & 15));
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
 
     const int nch = d / CW;
     const long long ngroups = (N + 31) / 32;
-    const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+    const long long gw = (long long)blockIdx.x * WAVES + wave, nw = (long long)gridDim.x * WAVES;
     const long long my_groups = gw < ngroups ? (ngroups - gw + nw - 1) / nw : 0;
     const long long steps = my_groups * nch;
 
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
             cg += nw;
             // adopt the best k-th key any of the block's 4 lists of this query has reached
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < WAVES; ++w) {
                 const u64 t = lists_all[(size_t)w * MFMA_KL * 32 + (k - 1) * 32 + i];
                 tau = t > tau ? t : tau;
             }
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
         }
     }
     // ---- publish: list (block, wave, h) of query i -> part[P_idx][i][0..k)
-    const size_t pidx = (size_t)blockIdx.x * 4 + wave;
+    const size_t pidx = (size_t)blockIdx.x * WAVES + wave;
     u64* dst = part + (pidx * MFMA_QB + i) * k;
     for (int e = h; e < k; e += 2) dst[e] = active ? lists[e * 32 + i] : 0;
 }
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void ip_scan_mfma_kernel(const float* __res
 int g_mfma_abl = 0;  // ablation knob (wise_debug_set_scan): 1 = no DMA, 2 = no MFMA
 
 static int mfma_grid(long long N) {
-    long long need = ((N + 31) / 32 + 3) / 4;
+    long long need = ((N + 31) / 32 + WAVES - 1) / WAVES;
     if (need < 1) need = 1;
     return need < 256 ? (int)need : 256;
 }
@@ -191,18 +195,18 @@ bool mfma_scan_supported(int d, int nq, int k) {
     // Q must fit LDS beside the rings and lists (32*d*4 <= 64 KiB), chunks are 32 columns, lists hold 16
     return nq >= 8 && k <= MFMA_KL && d % CW == 0 && d >= CW && d <= 512;
 }
-int mfma_scan_lists(long long N) { return mfma_grid(N) * 4; }
+int mfma_scan_lists(long long N) { return mfma_grid(N) * WAVES; }
 size_t mfma_scan_part_bytes(long long N, int k) { return (size_t)mfma_scan_lists(N) * MFMA_QB * k * sizeof(u64); }
 
 int mfma_scan_launch(const float* X, long long N, int d, const float* qpad, int nq, int k, u64* part, hipStream_t st) {
-    const size_t lds = (size_t)32 * d * 4 + (size_t)4 * RING * CHUNK_BYTES + (size_t)4 * MFMA_KL * 32 * 8;
+    const size_t lds = (size_t)32 * d * 4 + (size_t)WAVES * RING * CHUNK_BYTES + (size_t)WAVES * MFMA_KL * 32 * 8;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_mfma_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(ip_scan_mfma_kernel, dim3(mfma_grid(N)), dim3(256), lds, st, X, N, d, qpad, nq, k, part,
+    hipLaunchKernelGGL(ip_scan_mfma_kernel, dim3(mfma_grid(N)), dim3(WAVES * 64), lds, st, X, N, d, qpad, nq, k, part,
                        g_mfma_abl);
     WISE_LAUNCH_CHECK("ip_scan_mfma_kernel");
     return WISE_OK;
