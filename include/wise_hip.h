@@ -141,6 +141,9 @@ int wise_htsat_tap(int what, const void* workspace, int batch, int samples, floa
  * (open_clip 2.24.0 state-dict keys without the `visual.` prefix; see wise_amd/feature/text.py)
  * tokens int32 [batch, context] (device): <start_of_text> ... <end_of_text> 0 0 ...; the pooled row is
  * argmax(tokens[b]) as in open_clip (the end-of-text id is the largest id of the vocabulary).
+ * The MS-CLAP caption encoder (src/feature/microsoft_clap.py:53-58: GPT-2 base + msclap Projection) is the same
+ * pipeline with act = 2, pool = 1, head = 1; then wb ends with W1 [1024,W], W2 [1024,1024] and pf with the
+ * Projection's LayerNorm w,b [1024] after ln_f.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct wise_text_config {
     int32_t context;    /* T: 77 */
@@ -149,8 +152,10 @@ typedef struct wise_text_config {
     int32_t layers;     /* L: 12 */
     int32_t heads;      /* H = W/64 */
     int32_t mlp;        /* F = 4W */
-    int32_t embed_dim;  /* D: 512 / 768 */
-    int32_t act;        /* 0 = QuickGELU, 1 = erf GELU */
+    int32_t embed_dim;  /* D: 512 / 768 (1024 with head = 1) */
+    int32_t act;        /* 0 = QuickGELU, 1 = erf GELU, 2 = gelu_new (tanh form, GPT-2) */
+    int32_t pool;       /* pooled row: 0 = first argmax of the ids (open_clip), 1 = last id != 0 (msclap, pad id 0) */
+    int32_t head;       /* 0 = ln_final + linear projection; 1 = ln_f + msclap Projection (W1, GELU, W2, LayerNorm) */
 } wise_text_config;
 int wise_text_layout(const wise_text_config* cfg, int64_t* wb_elems, int64_t* pf_elems);
 size_t wise_text_workspace_bytes(const wise_text_config* cfg, int batch);

@@ -24,7 +24,8 @@ class VitConfig(C.Structure):
 
 
 class TextConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("context", "vocab", "width", "layers", "heads", "mlp", "embed_dim", "act")]
+    _fields_ = [(n, C.c_int32) for n in ("context", "vocab", "width", "layers", "heads", "mlp", "embed_dim", "act",
+                                          "pool", "head")]
 
 
 # every symbol include/wise_hip.h declares: name -> (restype, argtypes)

@@ -18,7 +18,8 @@
 
 namespace wise {
 
-enum : int { EPI_BF16 = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4 };
+enum : int { EPI_BF16 = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4, EPI_GELU_TANH = 5 };
+constexpr bool bf16_out(int mode) { return mode == EPI_BF16 || mode == EPI_QUICKGELU || mode == EPI_GELU || mode == EPI_GELU_TANH; }
 
 __device__ int g_group_m = 0;        // 0 = default; tuning knob (bits 16..23 of wise_debug_set_gemm_variant)
 __device__ int g_epi_lds = 1;        // bf16 epilogue through LDS (bit 30 of the debug knob turns it off)
@@ -67,6 +68,18 @@ __device__ __forceinline__ float act_gelu(float x) {
     const float erf_abs = 1.f - poly * __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
     return 0.5f * x * (1.f + copysignf(erf_abs, z));
 }
+// GPT-2's gelu_new, 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x * sigmoid(2u): one exp2 and one rcp
+__device__ __forceinline__ float act_gelu_tanh(float x) {
+    const float u = 0.7978845608028654f * fmaf(0.044715f * x, x * x, x);
+    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.f * 1.4426950408889634f * u));
+}
+template <int MODE>
+__device__ __forceinline__ float act_apply(float x) {
+    if (MODE == EPI_QUICKGELU) return act_quickgelu(x);
+    if (MODE == EPI_GELU) return act_gelu(x);
+    if (MODE == EPI_GELU_TANH) return act_gelu_tanh(x);
+    return x;
+}
 
 // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)][n0 + wn*64 + j*16 + (lane>>4)*4 + r]
 template <int MODE>
@@ -93,11 +106,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const float* __rest
             } else if (MODE == EPI_F32) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + off) = make_float4(v0, v1, v2, v3);
             } else {
-                if (MODE == EPI_QUICKGELU) {
-                    v0 = act_quickgelu(v0); v1 = act_quickgelu(v1); v2 = act_quickgelu(v2); v3 = act_quickgelu(v3);
-                } else if (MODE == EPI_GELU) {
-                    v0 = act_gelu(v0); v1 = act_gelu(v1); v2 = act_gelu(v2); v3 = act_gelu(v3);
-                }
+                v0 = act_apply<MODE>(v0); v1 = act_apply<MODE>(v1); v2 = act_apply<MODE>(v2); v3 = act_apply<MODE>(v3);
                 uint2 pk;
                 pk.x = pack_bf16x2(v0, v1);
                 pk.y = pack_bf16x2(v2, v3);
@@ -149,11 +158,7 @@ __device__ __forceinline__ void epilogue_lds(f32x4 (&acc)[4][4], const float* __
         for (int i = 0; i < 4; ++i) {
             float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z,
                   v3 = acc[i][j][3] + bv.w;
-            if (MODE == EPI_QUICKGELU) {
-                v0 = act_quickgelu(v0); v1 = act_quickgelu(v1); v2 = act_quickgelu(v2); v3 = act_quickgelu(v3);
-            } else if (MODE == EPI_GELU) {
-                v0 = act_gelu(v0); v1 = act_gelu(v1); v2 = act_gelu(v2); v3 = act_gelu(v3);
-            }
+            v0 = act_apply<MODE>(v0); v1 = act_apply<MODE>(v1); v2 = act_apply<MODE>(v2); v3 = act_apply<MODE>(v3);
             uint2 pk;
             pk.x = pack_bf16x2(v0, v1);
             pk.y = pack_bf16x2(v2, v3);
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
         }
     }
 
-    if ((MODE == EPI_BF16 || MODE == EPI_QUICKGELU || MODE == EPI_GELU) && (N & 7) == 0 && g_epi_lds) {
+    if (bf16_out(MODE) && (N & 7) == 0 && g_epi_lds) {
         __syncthreads();  // staging buffers are dead from here on
         epilogue_lds<MODE>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
     } else if ((MODE == EPI_RESID || MODE == EPI_F32) && g_epi_lds) {
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_ring_kernel(const bf16_t* __re
     // the ring (>= 64 KiB for the instantiations in use) is dead after the last fragment read: reuse it for the
     // row-major epilogues (these shapes, K = 96..384 with M in the 10^5s, are bound by their C traffic)
     constexpr bool RING_FITS = STAGES * SB >= 65536;
-    if (RING_FITS && (MODE == EPI_BF16 || MODE == EPI_QUICKGELU || MODE == EPI_GELU) && (N & 7) == 0 && g_epi_lds) {
+    if (RING_FITS && bf16_out(MODE) && (N & 7) == 0 && g_epi_lds) {
         __syncthreads();
         epilogue_lds<MODE>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
     } else if (RING_FITS && (MODE == EPI_RESID || MODE == EPI_F32) && g_epi_lds) {
@@ -644,11 +649,7 @@ __device__ __forceinline__ void epilogue_big(f32x4 (&acc)[MI][NT], const float* 
             } else if (MODE == EPI_F32) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + off) = make_float4(v0, v1, v2, v3);
             } else {
-                if (MODE == EPI_QUICKGELU) {
-                    v0 = act_quickgelu(v0); v1 = act_quickgelu(v1); v2 = act_quickgelu(v2); v3 = act_quickgelu(v3);
-                } else if (MODE == EPI_GELU) {
-                    v0 = act_gelu(v0); v1 = act_gelu(v1); v2 = act_gelu(v2); v3 = act_gelu(v3);
-                }
+                v0 = act_apply<MODE>(v0); v1 = act_apply<MODE>(v1); v2 = act_apply<MODE>(v2); v3 = act_apply<MODE>(v3);
                 uint2 pk;
                 pk.x = pack_bf16x2(v0, v1);
                 pk.y = pack_bf16x2(v2, v3);
@@ -874,11 +875,7 @@ __device__ __forceinline__ void epilogue_big_lds(f32x4 (&acc)[MI][4], const floa
                 const int i = half * HI + ii;
                 float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z,
                       v3 = acc[i][j][3] + bv.w;
-                if (MODE == EPI_QUICKGELU) {
-                    v0 = act_quickgelu(v0); v1 = act_quickgelu(v1); v2 = act_quickgelu(v2); v3 = act_quickgelu(v3);
-                } else if (MODE == EPI_GELU) {
-                    v0 = act_gelu(v0); v1 = act_gelu(v1); v2 = act_gelu(v2); v3 = act_gelu(v3);
-                }
+                v0 = act_apply<MODE>(v0); v1 = act_apply<MODE>(v1); v2 = act_apply<MODE>(v2); v3 = act_apply<MODE>(v3);
                 uint2 pk;
                 pk.x = pack_bf16x2(v0, v1);
                 pk.y = pack_bf16x2(v2, v3);
@@ -998,7 +995,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
         cur = (cur + 1 == STAGES) ? 0 : cur + 1;
     }
     if (!late) __builtin_amdgcn_s_barrier();
-    constexpr bool BF16OUT = (MODE == EPI_BF16 || MODE == EPI_QUICKGELU || MODE == EPI_GELU);
+    constexpr bool BF16OUT = bf16_out(MODE);
     if constexpr (WROWS != 64) {
         if (BF16OUT && g_epi_lds) {
             __syncthreads();  // both groups are past their last fragment read: the ring is dead
@@ -1100,6 +1097,7 @@ static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bi
         case EPI_BF16: launch_variant<EPI_BF16>(v, A, Wt, bias, M, N, K, out, st); break;
         case EPI_QUICKGELU: launch_variant<EPI_QUICKGELU>(v, A, Wt, bias, M, N, K, out, st); break;
         case EPI_GELU: launch_variant<EPI_GELU>(v, A, Wt, bias, M, N, K, out, st); break;
+        case EPI_GELU_TANH: launch_variant<EPI_GELU_TANH>(v, A, Wt, bias, M, N, K, out, st); break;
         case EPI_RESID: launch_variant<EPI_RESID>(v, A, Wt, bias, M, N, K, out, st); break;
         case EPI_F32: launch_variant<EPI_F32>(v, A, Wt, bias, M, N, K, out, st); break;
         default: set_error("gemm_bf16: unknown mode %d", mode); return WISE_E_INVALID;

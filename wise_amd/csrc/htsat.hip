@@ -548,6 +548,24 @@ __global__ __launch_bounds__(256) void proj_ln_norm_kernel(const float* __restri
     for (int u = 0; u < 16; ++u) out[(size_t)b * OUT + u * 64 + lane] = v[u] / nrm;
 }
 
+}  // namespace htsat
+
+// msclap `Projection` (shared by the audio head and the caption encoder): e1 = lat @ W1^T, e2 = gelu(e1) @ W2^T,
+// out = normalize(LayerNorm(e1 + e2)); three small GEMMs (e fp32 and g bf16 are scratch [Bp,1024], Bp = B
+// rounded up to 128; lat rows past B must be readable) and one wave-per-row kernel.
+int clap_projection(const bf16_t* lat, const bf16_t* W1, const bf16_t* W2, const float* lw, const float* lb, int B,
+                    int d_in, float* e, bf16_t* g, float* out, hipStream_t st) {
+    const int Bp = (B + 127) / 128 * 128;
+    int rc;
+    if ((rc = gemm_bf16(lat, W1, nullptr, Bp, htsat::OUT, d_in, 4, e, st))) return rc;
+    if ((rc = gemm_bf16(lat, W1, nullptr, Bp, htsat::OUT, d_in, 2, g, st))) return rc;
+    if ((rc = gemm_bf16(g, W2, nullptr, Bp, htsat::OUT, htsat::OUT, 3, e, st))) return rc;
+    hipLaunchKernelGGL(htsat::proj_ln_norm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, e, B, lw, lb, out);
+    WISE_LAUNCH_CHECK("proj_ln_norm_kernel");
+    return WISE_OK;
+}
+
+namespace htsat {
 // ------------------------------------------------------------------------------------------------
 // blob layout + workspace
 // ------------------------------------------------------------------------------------------------
@@ -705,19 +723,13 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
             H >>= 1;
         }
     }
-    // head: final LN + token mean -> latent bf16 [Bp,768] (aliases h); Projection as three small GEMMs:
-    // e = lat@W1^T (fp32, aliases qkv), g = gelu(lat@W1^T) (bf16, aliases a), e += g@W2^T; then LN + L2 norm
+    // head: final LN + token mean -> latent bf16 [Bp,768] (aliases h); then the msclap Projection
     {
-        const int Bp = (B + 127) / 128 * 128;
-        float* e = reinterpret_cast<float*>(qkv);
         hipLaunchKernelGGL(latent_kernel, dim3(B), dim3(256), 0, st, x, pf + o.fin_nw, pf + o.fin_nb, h);
         WISE_LAUNCH_CHECK("htsat latent_kernel");
-        if ((rc = gemm_bf16(h, wb + o.pj_w1, nullptr, Bp, OUT, LATENT, 4, e, st))) return rc;
-        if ((rc = gemm_bf16(h, wb + o.pj_w1, nullptr, Bp, OUT, LATENT, 2, a, st))) return rc;
-        if ((rc = gemm_bf16(a, wb + o.pj_w2, nullptr, Bp, OUT, OUT, 3, e, st))) return rc;
-        hipLaunchKernelGGL(proj_ln_norm_kernel, dim3((B + 3) / 4), dim3(256), 0, st, e, B, pf + o.pj_lw, pf + o.pj_lb,
-                           out);
-        WISE_LAUNCH_CHECK("htsat proj_ln_norm_kernel");
+        if ((rc = clap_projection(h, wb + o.pj_w1, wb + o.pj_w2, pf + o.pj_lw, pf + o.pj_lb, B, LATENT,
+                                  reinterpret_cast<float*>(qkv), a, out, st)))
+            return rc;
     }
     return WISE_OK;
 }

@@ -8,6 +8,10 @@
 //   ln_final on the end-of-text row only: row argmax(tokens[b])   (LayerNorm is per row, so normalising just
 //   @ text_projection [W, D] ; L2 normalise                         the pooled row is the same arithmetic)
 // Tokenising is host work (wise_amd/feature/clip_tokenizer.py); this file takes int32 token ids.
+//
+// The same pipeline with three switches is the MS-CLAP caption encoder (src/feature/microsoft_clap.py:53-58:
+// msclap 1.3.3 `TextEncoder` over a GPT-2 base): activation gelu_new (act = 2), pooling at the last token that is
+// not the pad id 0 (pool = 1), and the msclap `Projection` head instead of a linear projection (head = 1).
 #include <algorithm>
 
 #include "transformer.h"
@@ -18,7 +22,8 @@ namespace wise {
 // One wave per token row; wave 0 of each sequence's first row finds the end-of-text position.
 __global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__ tokens, const float* __restrict__ tok_emb,
                                                          const float* __restrict__ pos_emb, int B, int T, int W,
-                                                         int vocab, float* __restrict__ x, int* __restrict__ eot) {
+                                                         int vocab, int pool, float* __restrict__ x,
+                                                         int* __restrict__ eot) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * T) return;
@@ -32,7 +37,14 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__
         const float4 a = e[c], q = p[c];
         xr[c] = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
     }
-    if (t == 0) {
+    if (t == 0 && pool == 1) {
+        // msclap: sequence_lengths = ne(input_ids, 0).sum(-1) - 1 (right-padded with id 0)
+        int cnt = 0;
+        for (int tt = lane; tt < T; tt += 64) cnt += tokens[b * T + tt] != 0 ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (lane == 0) eot[b] = cnt > 0 ? cnt - 1 : T - 1;  // torch indexes -1 from the end when nothing is set
+    } else if (t == 0) {
         // torch.argmax returns the first maximal index; T <= 128: two candidates per lane
         int best = -1, best_t = 0;
         for (int tt = lane; tt < T; tt += 64) {
@@ -49,7 +61,7 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__
 }
 
 struct TextDims {
-    int T, V, W, L, H, F, D;
+    int T, V, W, L, H, F, D, act, pool, head;
 };
 static int text_dims(const wise_text_config* c, TextDims* d) {
     WISE_CHECK_ARG(c, "text: null config");
@@ -61,14 +73,17 @@ static int text_dims(const wise_text_config* c, TextDims* d) {
                    "text: width %d must be heads*64 and a multiple of 128", d->W);
     WISE_CHECK_ARG(d->F > 0 && d->F % 128 == 0, "text: mlp %d must be a multiple of 128", d->F);
     WISE_CHECK_ARG(d->D > 0 && d->D % 4 == 0 && d->L >= 0, "text: bad dims");
-    WISE_CHECK_ARG(c->act == 0 || c->act == 1, "text: act must be 0 (quick_gelu) or 1 (gelu)");
+    WISE_CHECK_ARG(c->act >= 0 && c->act <= 2, "text: act must be 0 (quick_gelu), 1 (gelu) or 2 (gelu_new)");
+    WISE_CHECK_ARG((c->pool == 0 || c->pool == 1) && (c->head == 0 || c->head == 1), "text: pool/head must be 0 or 1");
+    WISE_CHECK_ARG(c->head == 0 || d->D == 1024, "text: the msclap Projection head is 1024 wide");
+    d->act = c->act; d->pool = c->pool; d->head = c->head;
     return WISE_OK;
 }
 
 struct TextOffsets {
-    size_t layer0_b, per_layer_b, in_proj, out_proj, c_fc, c_proj, projT, total_b;                     // bf16 blob
+    size_t layer0_b, per_layer_b, in_proj, out_proj, c_fc, c_proj, projT, proj2, total_b;              // bf16 blob
     size_t tok, pos, layer0_f, per_layer_f, ln1_w, ln1_b, in_b, out_b, ln2_w, ln2_b, fc_b, proj_b, lnf_w, lnf_b,
-        total_f;                                                                                       // fp32 blob
+        pj_lw, pj_lb, total_f;                                                                         // fp32 blob
 };
 static TextOffsets text_offsets(const TextDims& d) {
     TextOffsets o;
@@ -77,13 +92,15 @@ static TextOffsets text_offsets(const TextDims& d) {
     o.in_proj = 0; o.out_proj = 3 * W * W; o.c_fc = o.out_proj + W * W; o.c_proj = o.c_fc + F * W;
     o.per_layer_b = o.c_proj + W * F;
     o.projT = o.per_layer_b * d.L;
-    o.total_b = o.projT + (size_t)d.D * W;
+    o.proj2 = o.projT + (size_t)d.D * W;                       // head 1: W2 [D,D] after W1 [D,W]
+    o.total_b = o.proj2 + (d.head == 1 ? (size_t)d.D * d.D : 0);
     o.tok = 0; o.pos = (size_t)d.V * W; o.layer0_f = o.pos + (size_t)d.T * W;
     o.ln1_w = 0; o.ln1_b = W; o.in_b = 2 * W; o.out_b = 5 * W; o.ln2_w = 6 * W; o.ln2_b = 7 * W; o.fc_b = 8 * W;
     o.proj_b = o.fc_b + F;
     o.per_layer_f = o.proj_b + W;
     o.lnf_w = o.layer0_f + o.per_layer_f * d.L; o.lnf_b = o.lnf_w + W;
-    o.total_f = o.lnf_b + W;
+    o.pj_lw = o.lnf_b + W; o.pj_lb = o.pj_lw + d.D;            // head 1: LayerNorm of the Projection
+    o.total_f = d.head == 1 ? o.pj_lb + d.D : o.pj_lw;
     return o;
 }
 
@@ -100,7 +117,7 @@ static TextWs text_ws(const TextDims& d, int B) {
     // h also holds the pooled rows [Bp, W]; qkv also holds the projected rows fp32 [Bp, D]
     w.h = off; off += align_up(std::max((size_t)w.Mp, Bp) * d.W * 2, 256);
     w.qkv = off; off += align_up(std::max((size_t)w.Mp * 3 * d.W * 2, Bp * d.D * 4), 256);
-    w.a = off; off += align_up((size_t)w.Mp * d.F * 2, 256);
+    w.a = off; off += align_up(std::max((size_t)w.Mp * d.F * 2, Bp * d.D * 2), 256);   // also the head's bf16 scratch
     w.eot = off; off += align_up((size_t)B * 4, 256);
     w.total = off;
     return w;
@@ -150,14 +167,19 @@ extern "C" int wise_text_forward(const wise_text_config* cfg, const uint16_t* wb
     int* eot = reinterpret_cast<int*>(wsb + ws.eot);
 
     hipLaunchKernelGGL(text_embed_kernel, dim3((ws.M + 3) / 4), dim3(256), 0, st, tokens, pf + o.tok, pf + o.pos, batch,
-                       d.T, d.W, d.V, x, eot);
+                       d.T, d.W, d.V, d.pool, x, eot);
     WISE_LAUNCH_CHECK("text_embed_kernel");
     const BlockWeights bw = {wb + o.layer0_b, o.per_layer_b, o.in_proj, o.out_proj, o.c_fc, o.c_proj,
                              pf + o.layer0_f, o.per_layer_f, o.ln1_w, o.ln1_b, o.in_b, o.out_b, o.ln2_w, o.ln2_b,
                              o.fc_b, o.proj_b};
-    if ((rc = transformer_blocks(bw, d.L, d.W, d.H, d.F, cfg->act, batch, d.T, true, x, h, qkv, a, st))) return rc;
-    return pooled_head(x, pf + o.lnf_w, pf + o.lnf_b, wb + o.projT, batch, d.T, d.W, d.D, eot, h,
-                       reinterpret_cast<float*>(qkv), out, st);
+    if ((rc = transformer_blocks(bw, d.L, d.W, d.H, d.F, d.act, batch, d.T, true, x, h, qkv, a, st))) return rc;
+    if (d.head == 0)
+        return pooled_head(x, pf + o.lnf_w, pf + o.lnf_b, wb + o.projT, batch, d.T, d.W, d.D, eot, h,
+                           reinterpret_cast<float*>(qkv), out, st);
+    // msclap: ln_f on the pooled row -> Projection(W1, GELU, W2, LayerNorm(e1 + e2)) -> L2 normalise
+    if ((rc = pooled_ln(x, pf + o.lnf_w, pf + o.lnf_b, batch, d.T, d.W, eot, h, st))) return rc;
+    return clap_projection(h, wb + o.projT, wb + o.proj2, pf + o.pj_lw, pf + o.pj_lb, batch, d.W,
+                           reinterpret_cast<float*>(qkv), a, out, st);
 }
 
 // parity tap: the residual stream x [batch*context, W] after a forward with the same batch

@@ -22,7 +22,14 @@ struct BlockWeights {
 };
 int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int act, int batch, int T, bool causal,
                        float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st);
+// LayerNorm of row pos[b] (or 0) of every sequence -> hb bf16 [batch, W]
+int pooled_ln(const float* x, const float* ln_w, const float* ln_b, int batch, int T, int W, const int* pos,
+              bf16_t* hb, hipStream_t st);
 int pooled_head(const float* x, const float* ln_w, const float* ln_b, const bf16_t* projT, int batch, int T, int W,
                 int D, const int* pos, bf16_t* hb, float* e, float* out, hipStream_t st);
+
+// msclap Projection head (htsat.hip): lat bf16 [Bp, d_in] -> out fp32 [B, 1024], L2-normalised
+int clap_projection(const bf16_t* lat, const bf16_t* W1, const bf16_t* W2, const float* lw, const float* lb, int B,
+                    int d_in, float* e, bf16_t* g, float* out, hipStream_t st);
 
 }  // namespace wise

@@ -460,27 +460,34 @@ int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int a
         if ((rc = attention_bf16(qkv, batch, T, H, h, st, causal))) return rc;
         if ((rc = gemm_bf16(h, lwb + bw.out_proj, lpf + bw.out_b, Mp, W, W, 3, x, st))) return rc;
         if ((rc = layernorm_f32_bf16(x, lpf + bw.ln2_w, lpf + bw.ln2_b, M, W, 1e-5f, h, st))) return rc;
-        if ((rc = gemm_bf16(h, lwb + bw.c_fc, lpf + bw.fc_b, Mp, F, W, act == 0 ? 1 : 2, a, st))) return rc;
+        // act: 0 QuickGELU, 1 erf GELU, 2 gelu_new (tanh) -> epilogue modes 1, 2, 5
+        if ((rc = gemm_bf16(h, lwb + bw.c_fc, lpf + bw.fc_b, Mp, F, W, act == 0 ? 1 : (act == 1 ? 2 : 5), a, st))) return rc;
         if ((rc = gemm_bf16(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, W, F, 3, x, st))) return rc;
     }
     return WISE_OK;
 }
 
 // out[b,:] = normalize( LN(x[b*T + pos[b], :]) @ proj ), projT bf16 [D,W]; hb bf16 [Bp,W] and e fp32 [Bp,D] scratch
-int pooled_head(const float* x, const float* ln_w, const float* ln_b, const bf16_t* projT, int batch, int T, int W,
-                int D, const int* pos, bf16_t* hb, float* e, float* out, hipStream_t st) {
-    const int Bp = (batch + 255) / 256 * 256;
+int pooled_ln(const float* x, const float* ln_w, const float* ln_b, int batch, int T, int W, const int* pos,
+              bf16_t* hb, hipStream_t st) {
     const int nv = (W / 4 + 63) / 64;
     const dim3 grid((batch + 3) / 4), block(256);
 #define CLS_CASE(n) case n: hipLaunchKernelGGL(cls_ln_kernel<n>, grid, block, 0, st, x, ln_w, ln_b, batch, T, W, 1e-5f, \
                                                hb, pos); break;
     switch (nv) {
         CLS_CASE(1) CLS_CASE(2) CLS_CASE(3) CLS_CASE(4) CLS_CASE(5) CLS_CASE(6) CLS_CASE(7) CLS_CASE(8)
-        default: set_error("pooled_head: width %d too large", W); return WISE_E_UNSUPPORTED;
+        default: set_error("pooled_ln: width %d too large", W); return WISE_E_UNSUPPORTED;
     }
 #undef CLS_CASE
     WISE_LAUNCH_CHECK("cls_ln_kernel");
+    return WISE_OK;
+}
+
+int pooled_head(const float* x, const float* ln_w, const float* ln_b, const bf16_t* projT, int batch, int T, int W,
+                int D, const int* pos, bf16_t* hb, float* e, float* out, hipStream_t st) {
+    const int Bp = (batch + 255) / 256 * 256;
     int rc;
+    if ((rc = pooled_ln(x, ln_w, ln_b, batch, T, W, pos, hb, st))) return rc;
     if ((rc = gemm_bf16(hb, projT, nullptr, Bp, D, W, 4, e, st))) return rc;
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, e, batch, D, out);
     WISE_LAUNCH_CHECK("l2norm_rows_kernel");

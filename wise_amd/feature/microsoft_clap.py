@@ -2,7 +2,8 @@
 
 `preprocess_audio` reproduces the reference exactly (transpose when shape[0] > 2, mono mix,
 default_collate([audio])).  `extract_audio_features` drives the HTSAT HIP kernels
-(wise_amd/feature/htsat.py) when they are present.
+(wise_amd/feature/htsat.py); `preprocess_text` / `extract_text_features` drive the caption encoder of the 2023
+model (GPT-2 base + msclap Projection, wise_amd/feature/clap_text.py) on the HIP text-tower kernels.
 """
 from __future__ import annotations
 
@@ -33,10 +34,13 @@ class MicrosoftClap(FeatureExtractor):
         self.DEVICE = "cuda" if torch.cuda.is_available() else "cpu"
         self.output_dim = 1024
         self._engine = None
+        self._text_engine = None
+        self._tokenizer = None
 
     def __getstate__(self):
         st = dict(self.__dict__)
         st["_engine"] = None
+        st["_text_engine"] = None
         return st
 
     def get_output_dim(self):
@@ -51,9 +55,34 @@ class MicrosoftClap(FeatureExtractor):
             audio = torch.mean(audio, 0, keepdim=True)
         return torch.stack([audio], dim=0)  # msclap default_collate([audio]) -> [1,1,N]
 
-    def preprocess_text(self, text: str) -> str:
-        raise NotImplementedError("the CLAP caption encoder (GPT-2 tokenizer + weights) is outside this build's "
-                                  "hot path (SURVEY.md §8 f4)")
+    @property
+    def tokenizer(self):
+        if self._tokenizer is None:
+            if self.version != '2023':
+                raise NotImplementedError(f"caption encoder of CLAP version {self.version} (BERT / clapcap) is not "
+                                          f"built; only the 2023 model's GPT-2 encoder is (SURVEY.md §8 a10)")
+            from .gpt2_tokenizer import Gpt2Tokenizer
+            self._tokenizer = Gpt2Tokenizer.default(77, allow_merge_less=seeded_tag(self.weights_tag) is not None)
+        return self._tokenizer
+
+    def preprocess_text(self, text):
+        """msclap `preprocess_text`: GPT-2 ids of `text + ' <|endoftext|>'`, padded with id 0 to 77 (the reference
+        returns msclap's dict of tensors; here the ids alone, which is all the encoder consumes)."""
+        return self.tokenizer(text)
+
+    def _get_text_engine(self):
+        if self._text_engine is None:
+            from .clap_text import CAPTION_SPEC, pack_caption_weights, random_caption_state_dict
+            from .text import TextEngine
+            seed = seeded_tag(self.weights_tag)
+            if seed is None:
+                from .weights import load_state_dict_file
+                full = load_state_dict_file(f"clap-{self.version}", self.weights_tag)
+                sd = {k[len("caption_encoder."):]: v for k, v in full.items() if k.startswith("caption_encoder.")}
+            else:
+                sd = random_caption_state_dict(CAPTION_SPEC, seed)
+            self._text_engine = TextEngine(CAPTION_SPEC, sd, device="cuda", pack=pack_caption_weights)
+        return self._text_engine
 
     def _get_engine(self):
         if self._engine is None:
@@ -76,4 +105,8 @@ class MicrosoftClap(FeatureExtractor):
         return out.cpu().numpy()
 
     def extract_text_features(self, text: List[str]) -> np.ndarray:
-        raise NotImplementedError("the CLAP caption encoder is outside this build's hot path (SURVEY.md §8 f4)")
+        """caption_encoder + L2 normalise (microsoft_clap.py:53-58) on the HIP text-tower kernels."""
+        tokens = self.preprocess_text(text)
+        if int(tokens.max()) >= self._get_text_engine().spec.vocab:
+            raise RuntimeError("tokenizer vocabulary larger than the model's token embedding")
+        return self._get_text_engine().forward(tokens).cpu().numpy()

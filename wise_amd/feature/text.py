@@ -28,7 +28,9 @@ class TextSpec:
     embed_dim: int
     context: int = 77
     vocab: int = 49408
-    act: str = "quick_gelu"
+    act: str = "quick_gelu"   # 'quick_gelu' | 'gelu' | 'gelu_new' (GPT-2's tanh form)
+    pool: str = "argmax"      # pooled row: 'argmax' of the ids (open_clip) | 'last_nonzero' id (msclap, pad id 0)
+    head: str = "linear"      # 'linear' projection [W,D] | 'clap' = msclap Projection (W1, GELU, W2, LayerNorm)
 
     @property
     def mlp(self) -> int:
@@ -41,7 +43,8 @@ class TextSpec:
 
     def c_config(self) -> _lib.TextConfig:
         return _lib.TextConfig(self.context, self.vocab, self.width, self.layers, self.heads, self.mlp, self.embed_dim,
-                               0 if self.act == "quick_gelu" else 1)
+                               {"quick_gelu": 0, "gelu": 1, "gelu_new": 2}[self.act],
+                               {"argmax": 0, "last_nonzero": 1}[self.pool], {"linear": 0, "clap": 1}[self.head])
 
 
 # text towers of the open_clip models in wise_amd/feature/vit.py:SPECS (open_clip model configs)
@@ -131,14 +134,17 @@ class TextEngine:
     """Device copies of the weight blobs + a workspace; `forward(tokens)` launches the HIP pipeline on the current
     torch stream and returns a device tensor [B, D] fp32 (L2-normalised)."""
 
-    def __init__(self, spec: TextSpec, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 8):
+    def __init__(self, spec: TextSpec, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 8,
+                 pack=None):
+        """`pack(spec, sd) -> (bf16 blob, fp32 blob)` defaults to the open_clip layout (pack_text_weights);
+        the CLAP caption encoder passes its own (clap_text.pack_caption_weights)."""
         self.spec = spec
         self.lib = _lib.lib()
         self.device = torch.device(device)
         self.cfg = spec.c_config()
         nb, nf = C.c_int64(), C.c_int64()
         _lib.check(self.lib.wise_text_layout(C.byref(self.cfg), C.byref(nb), C.byref(nf)), "wise_text_layout")
-        wb, pf = pack_text_weights(spec, sd)
+        wb, pf = (pack or pack_text_weights)(spec, sd)
         if wb.numel() != nb.value or pf.numel() != nf.value:
             raise RuntimeError(f"weight blob size mismatch: packed {wb.numel()}/{pf.numel()}, "
                                f"library expects {nb.value}/{nf.value}")
