@@ -456,6 +456,54 @@ def main():
                                    "[n,512]; seeded weights", "gflop_per_query": round(tspec.flops_per_query() / 1e9, 3)},
             "tflops_batch256": round(256 * t_steps / tdt256 * tspec.flops_per_query() / 1e12, 2)}
         del teng, toks
+        torch.cuda.empty_cache()
+        # f4: IndexIVFFlat at the reference's geometry for 10M rows (nlist = 10 * round(sqrt(N)) = 31620, nprobe 32 =
+        # the REST default, routes.py:902).  The lists are synthesised (equal sizes, rows = list direction + noise,
+        # centroid = normalised list mean): training 31620 cells on 3.2M rows is hours of k-means and is not what
+        # this leg times; recall and exactness are covered by tests/test_gpu_ivf.py.
+        from wise_amd.index.ivf_flat import IVFFlatIPIndex
+
+        nlist, per = 31620, max(1, (args.index_rows // 31620))
+        n_ivf = nlist * per
+        gen = torch.Generator(device="cuda").manual_seed(200 + rank)
+        dirs = torch.randn(nlist, args.dim, generator=gen, device="cuda")
+        Xi = torch.empty(n_ivf, args.dim, dtype=torch.float32, device="cuda")
+        for s0 in range(0, nlist, 1024):
+            e0 = min(nlist, s0 + 1024)
+            blk = dirs[s0:e0, None, :] + 0.7 * torch.randn(e0 - s0, per, args.dim, generator=gen, device="cuda")
+            Xi[s0 * per:e0 * per] = (blk / blk.norm(dim=2, keepdim=True)).reshape(-1, args.dim)
+        cent = Xi.view(nlist, per, args.dim).mean(dim=1)
+        cent = cent / cent.norm(dim=1, keepdim=True)
+        ivf = IVFFlatIPIndex(args.dim, nlist)
+        ivf.set_centroids(cent)
+        ivf.adopt_lists(Xi, torch.arange(n_ivf, device="cuda", dtype=torch.int64) + 1,
+                        torch.arange(nlist + 1, device="cuda", dtype=torch.int64) * per)
+        Qi = Xi[torch.randint(0, n_ivf, (1000,), generator=gen, device="cuda")] + 0.05 * torch.randn(
+            1000, args.dim, generator=gen, device="cuda")
+        ivf_res = {}
+        for nprobe in (32, 1024):
+            ivf.nprobe = nprobe
+
+            def ivf1(i):
+                hold["ivf"] = ivf.search_device(Qi[i % 1000:i % 1000 + 1], args.topk)
+
+            def ivf256(i):
+                hold["ivf"] = ivf.search_device(Qi[:256], args.topk)
+
+            for i in range(3):
+                ivf1(i); ivf256(i)
+            i_steps = max(10, min(args.steps, 50))
+            t1 = timed_region(ivf1, i_steps, world)
+            t256 = timed_region(ivf256, i_steps, world)
+            ivf_res[f"nprobe{nprobe}"] = {"single_query_ms": round(t1 / i_steps * 1e3, 4),
+                                          "queries_per_s_nq1": round(i_steps / t1, 1),
+                                          "queries_per_s_nq256": round(256 * i_steps / t256, 1)}
+        extra["ivf_flat"] = {"value": ivf_res["nprobe32"]["queries_per_s_nq1"], "unit": "queries/s (nq=1, nprobe=32)",
+                             "config": {"workload": f"IndexIVFFlat (inner product), {n_ivf} rows x d={args.dim} in "
+                                                    f"{nlist} synthesised lists of {per} rows per GPU, top-{args.topk}; "
+                                                    f"coarse top-nprobe over the centroids + list scan"},
+                             **ivf_res}
+        del ivf, Xi, dirs, cent
         result["extra"] = extra
 
     # ------------------------------------------------------------------ CPU baselines (rank 0, N=1 only)

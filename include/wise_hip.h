@@ -60,6 +60,25 @@ int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, i
                      const int64_t* ids, int64_t id_base, float* outD, int64_t* outI,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* IndexIVFFlat search, second stage (the first stage — the `nprobe` nearest centroids of each query — is
+ * wise_ip_topk_f32 over the centroid table): scan the probed inverted lists and keep the k best.
+ * Replaces faiss IndexIVFFlat::search as reached through self.index.search at
+ * src/index/feature_search_index.py:113 for indexes built at :53-76 (nprobe set at api/routes.py:899-902).
+ *   X        [N,d] fp32 rows grouped by list (list l occupies rows list_off[l] .. list_off[l+1]-1)
+ *   list_off [nlist+1] int64;  ids [N] int64 external ids in the same order (NULL => the row number)
+ *   probes   [nq,nprobe] int64 list numbers per query, entries < 0 are skipped
+ * outD/outI as wise_ip_topk_f32 (descending scores, (-3.4028235e38, -1) padding).
+ * Ties: the row that comes first in X wins. */
+size_t wise_ivf_scan_workspace_bytes(int nq, int nprobe, int k);
+int wise_ivf_scan_f32(const float* X, int64_t N, int d, const int64_t* list_off, int nlist, const int64_t* ids,
+                      const float* Q, int nq, const int64_t* probes, int nprobe, int k, float* outD, int64_t* outI,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Indices of the k largest entries of each row of scores [rows, n] fp32 (ties: lower index), written in ascending
+ * index order, -1 padding when n < k.  The coarse stage of IndexIVFFlat for large nprobe: scores = Q x centroids^T
+ * (a plain library GEMM on the caller's side), then this selection.  NaN scores are not supported. */
+int wise_select_topk_f32(const float* scores, int rows, int n, int k, int64_t* out, void* stream);
+
 /* Merge `parts` partial top-k lists (e.g. one per GPU after the RCCL all-gather) into one.
  * inD [parts,nq,k] fp32, inI [parts,nq,k] int64 (entries with id -1 are padding) -> outD/outI [nq,k].
  * Ties: lower part index first, then the order within the part.  k <= 2048, parts*k <= 65536. */

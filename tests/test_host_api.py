@@ -238,7 +238,10 @@ def test_search_index_factory_and_file_io(tmp_path):
     Xr, ids = faiss_io.read_idmap_flat_ip(fn)
     assert np.array_equal(np.asarray(Xr), X) and np.array_equal(ids, np.arange(1000) + 1)
     with pytest.raises(NotImplementedError):
-        si.create_index("IndexIVFFlat", overwrite=True)
+        si.create_index("IndexHNSWFlat", overwrite=True)       # not an index type WISE offers
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):                      # k-means and list scan are GPU-only: no CPU fallback
+            si.create_index("IndexIVFFlat", overwrite=True)
     with pytest.raises(RuntimeError):
         faiss_io.read_idmap_flat_ip(idir / "missing.faiss")
     with pytest.raises(ValueError):

@@ -38,6 +38,9 @@ SIGNATURES = {
     "wise_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "wise_ip_topk_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
     "wise_ip_topk_f32": (_i, [_vp, _i64, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "wise_ivf_scan_workspace_bytes": (_sz, [_i, _i, _i]),
+    "wise_ivf_scan_f32": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "wise_select_topk_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "wise_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "wise_reconstruct_batch": (_i, [_vp, _i64, _i, _vp, _i64, _vp, _i, _vp, _vp]),
     "wise_vit_layout": (_i, [C.POINTER(VitConfig), C.POINTER(_i64), C.POINTER(_i64)]),

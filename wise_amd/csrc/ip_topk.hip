@@ -82,15 +82,34 @@ struct WaveList {
 // ------------------------------------------------------------------------------------------------
 // scan kernel: NV = float4 chunks per lane per row (ceil(d/256)), NQ queries, R rows per group
 // ------------------------------------------------------------------------------------------------
-template <int NV, int NQ, int R>
+// SEG = true is the inverted-list form (IndexIVFFlat, wise_ivf_scan_f32): block b serves query b / nprobe and
+// scans only the rows of the list named by probes[b] (X holds the lists back to back, list_off their bounds);
+// its k keys go to part[(b % nprobe) * nq + b / nprobe] so that merge_keys_kernel folds a query's nprobe lists.
+struct SegArgs {
+    const long long* probes;    // [nq][nprobe] list numbers, < 0 = nothing to scan
+    const long long* list_off;  // [nlist + 1]
+    int nprobe, nq;
+};
+
+template <int NV, int NQ, int R, bool SEG = false>
 __global__ __launch_bounds__(256) void ip_scan_kernel(const f32x4* __restrict__ X, long long N, int d4,
                                                       const float* __restrict__ Q, int k, int cap,
-                                                      u64* __restrict__ part /*[grid][NQ][k]*/) {
+                                                      u64* __restrict__ part /*[grid][NQ][k]*/, SegArgs seg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     u64* lds = reinterpret_cast<u64*>(smem);
     // wave w, query q -> lds + (w*NQ + q)*cap
+    long long lo = 0;             // first row of the scanned range; N becomes its end
+    size_t slot = blockIdx.x;     // where the block's keys go
+    if constexpr (SEG) {
+        static_assert(NQ == 1, "one query per block in the inverted-list form");
+        const int qi = blockIdx.x / seg.nprobe, pi = blockIdx.x - qi * seg.nprobe;
+        const long long l = seg.probes[blockIdx.x];
+        if (l >= 0) { lo = seg.list_off[l]; N = seg.list_off[l + 1]; } else { N = 0; }
+        Q += (size_t)qi * d4 * 4;
+        slot = (size_t)pi * seg.nq + qi;
+    }
 
     float4 qv[NQ][NV];
 #pragma unroll
@@ -106,9 +125,9 @@ __global__ __launch_bounds__(256) void ip_scan_kernel(const f32x4* __restrict__ 
 #pragma unroll
     for (int q = 0; q < NQ; ++q) wl[q].init(lds + (size_t)(wave * NQ + q) * cap, cap, k, lane);
 
-    const long long ngroups = (N + R - 1) / R;
-    const long long gw = (long long)blockIdx.x * 4 + wave;
-    const long long nw = (long long)gridDim.x * 4;
+    const long long ngroups = (N - lo + R - 1) / R;
+    const long long gw = SEG ? wave : (long long)blockIdx.x * 4 + wave;
+    const long long nw = SEG ? 4 : (long long)gridDim.x * 4;
 
     // which of the R rows this lane ends up holding after the transpose-reduce
     int myr = 0;
@@ -121,7 +140,7 @@ __global__ __launch_bounds__(256) void ip_scan_kernel(const f32x4* __restrict__ 
     const bool owner = (lane & ((64 >> LOGR) - 1)) == 0;
 
     for (long long g = gw; g < ngroups; g += nw) {
-        const long long row0 = g * R;
+        const long long row0 = lo + g * R;
         f32x4 x[R][NV];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(256) void ip_scan_kernel(const f32x4* __restrict__ 
                 }
             }
             wl[q].compact(lane);
-            u64* dst = part + ((size_t)blockIdx.x * NQ + q) * k;
+            u64* dst = part + (slot * NQ + q) * k;
             for (int i = lane; i < k; i += 64) dst[i] = wl[q].buf[i];
         }
     }
@@ -315,6 +334,78 @@ __global__ void reconstruct_kernel(const float* __restrict__ X, long long N, int
         out[(size_t)i * d + c] = (row >= 0) ? X[row * d + c] : __builtin_nanf("");
 }
 
+// ------------------------------------------------------------------------------------------------
+// select_topk_kernel: indices of the k largest of n scores, one block per row of scores (the coarse stage of
+// IndexIVFFlat when nprobe is large: n = nlist is tens of thousands and k up to 2048, where threshold lists
+// stop filtering).  Radix select on the sortable 32-bit score, most significant byte first (4 histogram passes
+// find the k-th largest value T and how many elements equal to T still belong), then one ordered compaction:
+// everything above T, plus the lowest-indexed ties.  Output: the chosen indices in ascending index order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restrict__ scores, int n, int k,
+                                                           long long* __restrict__ out /*[rows][k]*/) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_remaining;
+    __shared__ unsigned wave_cnt[2][16];
+    __shared__ unsigned base_gt, base_eq;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = scores + (size_t)blockIdx.x * n;
+    long long* dst = out + (size_t)blockIdx.x * k;
+    const int kk = k < n ? k : n;
+    if (tid == 0) { s_prefix = 0; s_remaining = (unsigned)kk; }
+    unsigned mask = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned key = f32_order(row[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned rem = s_remaining, cum = 0;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (cum + hist[b] >= rem) break;
+                cum += hist[b];
+            }
+            s_remaining = rem - cum;          // still to take from bucket b
+            s_prefix = prefix | ((unsigned)b << shift);
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    const unsigned T = s_prefix;              // the k-th largest key
+    const unsigned take_eq = s_remaining;     // how many elements equal to T belong to the result
+    if (tid == 0) { base_gt = 0; base_eq = 0; }
+    __syncthreads();
+    // ordered compaction, 1024 indices at a time: [greater..., then ties] keeps ascending index order within
+    // each class; the two classes are interleaved by position so the output is ascending overall
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const unsigned key = i < n ? f32_order(row[i]) : 0u;
+        const bool gt = i < n && key > T, eq = i < n && key == T;
+        const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+        if (lane == 0) { wave_cnt[0][wave] = __popcll(mg); wave_cnt[1][wave] = __popcll(me); }
+        __syncthreads();
+        unsigned off_g = base_gt, off_e = base_eq, tot_g = 0, tot_e = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) { off_g += wave_cnt[0][w]; off_e += wave_cnt[1][w]; }
+            tot_g += wave_cnt[0][w]; tot_e += wave_cnt[1][w];
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned rank_g = off_g + __popcll(mg & below), rank_e = off_e + __popcll(me & below);
+        // position in the output = (#greater before me) + (#accepted ties before me)
+        if (gt) dst[rank_g + min(rank_e, take_eq)] = i;
+        else if (eq && rank_e < take_eq) dst[rank_g + rank_e] = i;
+        __syncthreads();
+        if (tid == 0) { base_gt += tot_g; base_eq += tot_e; }
+        __syncthreads();
+    }
+    for (int j = kk + tid; j < k; j += 1024) dst[j] = -1;   // fewer than k scores: padding
+}
+
 static int next_pow2(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -359,7 +450,7 @@ static void launch_scan(const ScanPlan& p, const float* X, long long N, int d, c
     if constexpr (NQ == 1 && NV <= 2) {
         if (p.rows == 8) {
             hipLaunchKernelGGL((ip_scan_kernel<NV, NQ, 8>), dim3(p.grid), dim3(256), p.lds, st,
-                               reinterpret_cast<const f32x4*>(X), N, d / 4, Q, k, p.cap, part);
+                               reinterpret_cast<const f32x4*>(X), N, d / 4, Q, k, p.cap, part, SegArgs{});
             return;
         }
     }
@@ -368,7 +459,19 @@ static void launch_scan(const ScanPlan& p, const float* X, long long N, int d, c
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)p.lds);
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds, st, reinterpret_cast<const f32x4*>(X), N, d / 4, Q, k,
-                       p.cap, part);
+                       p.cap, part, SegArgs{});
+}
+
+template <int NV>
+static void launch_seg_scan(const float* X, int d, const float* Q, int k, int cap, u64* part, const SegArgs& seg,
+                            hipStream_t st) {
+    auto kern = ip_scan_kernel<NV, 1, 4, true>;
+    const size_t lds = (size_t)4 * cap * 8;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long long)seg.nq * seg.nprobe)), dim3(256), lds, st,
+                       reinterpret_cast<const f32x4*>(X), 0ll, d / 4, Q, k, cap, part, seg);
 }
 
 template <int NV>
@@ -503,6 +606,64 @@ extern "C" int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q
                            reinterpret_cast<long long*>(outI), q0);
         WISE_LAUNCH_CHECK("merge_keys_kernel");
     }
+    return WISE_OK;
+}
+
+extern "C" size_t wise_ivf_scan_workspace_bytes(int nq, int nprobe, int k) {
+    if (nq < 1 || nprobe < 1 || k < 1 || k > 2048) return 0;
+    return align_up((size_t)nq * nprobe * k * sizeof(u64), 256);
+}
+
+extern "C" int wise_ivf_scan_f32(const float* X, int64_t N, int d, const int64_t* list_off, int nlist,
+                                 const int64_t* ids, const float* Q, int nq, const int64_t* probes, int nprobe, int k,
+                                 float* outD, int64_t* outI, void* workspace, size_t workspace_bytes, void* stream) {
+    WISE_CHECK_ARG(d >= 4 && d <= 2048 && d % 4 == 0, "ivf_scan: d=%d must be a multiple of 4 in [4,2048]", d);
+    WISE_CHECK_ARG(k >= 1 && k <= 2048, "ivf_scan: k=%d out of [1,2048]", k);
+    WISE_CHECK_ARG(nq >= 1 && nprobe >= 1 && nlist >= 1 && (long long)nq * nprobe < (1ll << 31),
+                   "ivf_scan: nq=%d nprobe=%d nlist=%d out of range", nq, nprobe, nlist);
+    WISE_CHECK_ARG(N >= 0 && N < 0xFFFFFFFFll, "ivf_scan: N=%lld out of range", (long long)N);
+    WISE_CHECK_ARG(Q && outD && outI && list_off && probes && (X || N == 0), "ivf_scan: null pointer");
+    WISE_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Q & 15) == 0, "ivf_scan: X and Q must be 16-byte aligned");
+    const size_t need = wise_ivf_scan_workspace_bytes(nq, nprobe, k);
+    if (!workspace || workspace_bytes < need) {
+        set_error("ivf_scan: workspace %zu < %zu bytes", workspace_bytes, need);
+        return WISE_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    u64* part = reinterpret_cast<u64*>(workspace);
+    const int cap = list_cap(k);
+    const SegArgs seg = {reinterpret_cast<const long long*>(probes), reinterpret_cast<const long long*>(list_off), nprobe,
+                         nq};
+    switch ((d / 4 + 63) / 64) {
+        case 1: launch_seg_scan<1>(X, d, Q, k, cap, part, seg, st); break;
+        case 2: launch_seg_scan<2>(X, d, Q, k, cap, part, seg, st); break;
+        case 3: launch_seg_scan<3>(X, d, Q, k, cap, part, seg, st); break;
+        case 4: launch_seg_scan<4>(X, d, Q, k, cap, part, seg, st); break;
+        case 5: launch_seg_scan<5>(X, d, Q, k, cap, part, seg, st); break;
+        case 6: launch_seg_scan<6>(X, d, Q, k, cap, part, seg, st); break;
+        case 7: launch_seg_scan<7>(X, d, Q, k, cap, part, seg, st); break;
+        case 8: launch_seg_scan<8>(X, d, Q, k, cap, part, seg, st); break;
+        default: set_error("ivf_scan: no kernel for d=%d", d); return WISE_E_INVALID;
+    }
+    WISE_LAUNCH_CHECK("ip_scan_kernel<seg>");
+    int mw = 8192 / cap;
+    if (mw < 1) mw = 1;
+    if (mw > 16) mw = 16;
+    const size_t mlds = (size_t)mw * cap * 8;
+    if (mlds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_keys_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds);
+    hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(mw * 64), mlds, st, part, nprobe, nq, k, cap,
+                       reinterpret_cast<const long long*>(ids), 0ll, outD, reinterpret_cast<long long*>(outI), 0);
+    WISE_LAUNCH_CHECK("merge_keys_kernel");
+    return WISE_OK;
+}
+
+extern "C" int wise_select_topk_f32(const float* scores, int rows, int n, int k, int64_t* out, void* stream) {
+    WISE_CHECK_ARG(scores && out && rows >= 1 && n >= 1 && k >= 1, "select_topk: bad argument");
+    hipLaunchKernelGGL(select_topk_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, scores, n, k,
+                       reinterpret_cast<long long*>(out));
+    WISE_LAUNCH_CHECK("select_topk_kernel");
     return WISE_OK;
 }
 

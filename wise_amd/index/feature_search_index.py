@@ -3,8 +3,9 @@ flat inner-product index resident in HBM and searched by the HIP scan+top-k kern
 
 Same constructor contract (asserts on 'features_dir'/'index_dir'), prompts, file naming
 (`{index_dir}/{media_type}-{index_type}.faiss`), skip-if-exists create, `load_index` that also
-builds the FeatureExtractor, and the prompt quirks of `search`.  Only
-`IndexFlatIP` is built; `IndexIVFFlat` (approximate) raises — the flat scan is the hot path here.
+builds the FeatureExtractor, and the prompt quirks of `search`.  Both index types the
+reference offers are built: `IndexFlatIP` (exhaustive, the hot path) and `IndexIVFFlat` (approximate; cell count
+and training-sample size chosen as at feature_search_index.py:55-59, k-means and list scan on the GPU).
 """
 from pathlib import Path
 
@@ -14,6 +15,7 @@ from ..feature.feature_extractor_factory import FeatureExtractorFactory
 from ..feature.store.feature_store_factory import FeatureStoreFactory
 from . import faiss_io
 from .flat_ip import FlatIPIndex
+from .ivf_flat import IVFFlatIPIndex, reference_nlist
 from .search_index import SearchIndex
 
 
@@ -43,9 +45,8 @@ class FeatureSearchIndex(SearchIndex):
         if index_fn.exists() and overwrite is False:
             print(f'{index_type} for {self.media_type} already exists')
             return
-        if index_type != 'IndexFlatIP':
-            raise NotImplementedError(f'{index_type}: only IndexFlatIP is built by the MI355X path '
-                                      f'(exhaustive search is HBM-bound-fast; SURVEY.md §8 f4)')
+        if index_type not in ('IndexFlatIP', 'IndexIVFFlat'):
+            raise NotImplementedError(f'{index_type}: IndexFlatIP and IndexIVFFlat are the index types WISE builds')
         self.index_type = index_type
 
         feature_store = FeatureStoreFactory.load_store(self.media_type, self.features_dir)
@@ -63,7 +64,22 @@ class FeatureSearchIndex(SearchIndex):
             X[n:n + m] = feature_vectors_batch
             ids[n:n + m] = feature_ids_batch
             n += m
-        faiss_io.write_idmap_flat_ip(index_fn, X[:n], ids[:n])
+        if index_type == 'IndexIVFFlat':
+            cell_count = reference_nlist(n)
+            train_count = min(n, 100 * cell_count)
+            # the reference trains on the first train_count vectors of a shard-shuffled pass (:62-69); a seeded
+            # sample of the same size stands in for it
+            sample = np.random.default_rng(1234).permutation(n)[:train_count]
+            sample.sort()
+            print(f'  training {index_type} index with {train_count} features with {cell_count} clusters ...')
+            ivf = IVFFlatIPIndex(feature_dim, cell_count)
+            ivf.train(X[sample])
+            for s0 in range(0, n, 1 << 20):
+                ivf.add_with_ids(X[s0:s0 + (1 << 20)], ids[s0:s0 + (1 << 20)])
+            c, Xs, ids_s, off = ivf.lists_host()
+            faiss_io.write_ivf_flat_ip(index_fn, c, Xs, ids_s, off, nprobe=ivf.nprobe)
+        else:
+            faiss_io.write_idmap_flat_ip(index_fn, X[:n], ids[:n])
         print(f'  saved index to {index_fn}')
 
     def is_index_loaded(self):
@@ -75,10 +91,18 @@ class FeatureSearchIndex(SearchIndex):
             print(f'  index {index_fn} does not exist')
             print(f'  use create-index.py script to create an index')
         # like the reference (App. B.3) a missing file raises from the reader, it does not return False
-        X, ids = faiss_io.read_idmap_flat_ip(index_fn)
-        index = FlatIPIndex(X.shape[1])
-        for s in range(0, X.shape[0], 1 << 20):  # stream the memory-mapped rows into HBM
-            index.add_with_ids(np.ascontiguousarray(X[s:s + (1 << 20)]), ids[s:s + (1 << 20)])
+        if index_fn.exists() and faiss_io.index_fourcc(index_fn) == 'IwFl':
+            import torch
+            f = faiss_io.read_ivf_flat_ip(index_fn)
+            index = IVFFlatIPIndex(f["centroids"].shape[1], f["centroids"].shape[0])
+            index.set_centroids(f["centroids"])
+            index.adopt_lists(torch.from_numpy(f["X"]), torch.from_numpy(f["ids"]), torch.from_numpy(f["list_off"]))
+            index.nprobe = f["nprobe"]
+        else:
+            X, ids = faiss_io.read_idmap_flat_ip(index_fn)
+            index = FlatIPIndex(X.shape[1])
+            for s in range(0, X.shape[0], 1 << 20):  # stream the memory-mapped rows into HBM
+                index.add_with_ids(np.ascontiguousarray(X[s:s + (1 << 20)]), ids[s:s + (1 << 20)])
         self.index = index
         self.feature_extractor = FeatureExtractorFactory(self.feature_extractor_id)
         return True
