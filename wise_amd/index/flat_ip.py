@@ -38,7 +38,11 @@ class FlatIPIndex:
 
     def add_with_ids(self, x, ids) -> None:
         """x [n,d] float32, ids [n] int64 (feature_search_index.py:81)."""
-        x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)) if not torch.is_tensor(x) else x
+        if not torch.is_tensor(x):
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            if not x.flags.writeable:   # e.g. a read-only memory map of an index file: torch wants a writable buffer
+                x = x.copy()
+            x = torch.from_numpy(x)
         ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int64)) if not torch.is_tensor(ids) else ids
         if x.dim() != 2 or x.shape[1] != self.d:
             raise ValueError(f"add_with_ids: expected [n,{self.d}], got {tuple(x.shape)}")
