@@ -20,7 +20,8 @@ def main():
     eng = VitEngine(spec, random_state_dict(spec, 0), max_batch=B)
     x = torch.randn(B, 3, 224, 224, device="cuda")
     ref = None
-    configs = [(1, 0), (2, 0), (1, 1), (2, 1)] * 3   # (streams, gemm flags: bit 0 = no 320-row tiling)
+    # (streams, flags): bit 0 = no 320-row tiling; timing-only ablations: bit 1 = no LayerNorm, bit 2 = no attention
+    configs = [(2, 0), (2, 2), (2, 4), (2, 6), (1, 0), (1, 6)] * 2
     for streams, flags in configs:
         lib.wise_debug_set_vit_streams(streams)
         lib.wise_debug_set_gemm_flags(flags)

@@ -1174,8 +1174,11 @@ extern "C" int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float
     return wise::gemm_bf16(A, Wt, bias, M, N, K, mode, out, (hipStream_t)stream);
 }
 
+namespace wise { int g_ablate = 0; }  // timing-only ablations: bit 1 = skip LayerNorm launches, bit 2 = skip attention
+
 extern "C" int wise_debug_set_gemm_flags(int flags) {
     wise::g_tile320 = (flags & 1) ? 0 : 1;
+    wise::g_ablate = flags & 6;
     return 0;
 }
 

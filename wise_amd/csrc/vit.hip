@@ -14,6 +14,7 @@
 #include "transformer.h"
 
 namespace wise {
+extern int g_ablate;  // timing-only ablation switches (wise_debug_set_gemm_flags)
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row in registers, exact two-pass statistics in fp32
@@ -99,7 +100,7 @@ int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows,
                        hipStream_t st) {
     WISE_CHECK_ARG(x && w && b && y, "layernorm: null pointer");
     WISE_CHECK_ARG(rows >= 0 && W >= 4 && W % 4 == 0 && W <= 4096, "layernorm: W=%d must be a multiple of 4, <= 4096", W);
-    if (rows == 0) return WISE_OK;
+    if (rows == 0 || (g_ablate & 2)) return WISE_OK;
     if (W <= 128) {
         hipLaunchKernelGGL(layernorm_narrow_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, x, w, b, rows, W, eps, y);
         WISE_LAUNCH_CHECK("layernorm_narrow_kernel");
@@ -295,6 +296,7 @@ static int g_attn_qt = 0;  // query tiles (of 16) per wave; 0 = by sequence leng
 
 int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st, bool causal) {
     WISE_CHECK_ARG(qkv && o && B > 0 && T > 0 && H > 0, "attention: bad argument");
+    if (g_ablate & 4) return WISE_OK;
     // 32 queries per wave (126 VGPRs, 4 waves/SIMD) hides latency best when one key block covers T; longer
     // sequences prefer 64 queries per wave (K/V re-read half as often)
     const int qt = g_attn_qt ? (g_attn_qt == 4 ? 4 : 2) : (T <= 64 ? 2 : 4);
