@@ -12,7 +12,14 @@ from wise_amd import _lib  # noqa: E402
 from wise_amd.feature.vit import VitEngine, random_state_dict, spec_for  # noqa: E402
 
 
+ATTN_QT = 0  # 4 forces the per-wave attention kernel with 64 queries per wave (A/B against the shared-K/V kernel)
+
+
 def main():
+    global ATTN_QT
+    if "--qt4" in sys.argv:
+        sys.argv.remove("--qt4")
+        ATTN_QT = 4
     model = sys.argv[1] if len(sys.argv) > 1 else "ViT-B-32"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     lib = _lib.lib()
@@ -23,7 +30,7 @@ def main():
     # (streams, flags): bit 0 = no 320-row tiling; timing-only ablations: bit 1 = no LayerNorm, bit 2 = no attention
     configs = [(2, 0), (2, 2), (2, 4), (2, 6), (1, 0), (1, 6)] * 2
     for streams, flags in configs:
-        lib.wise_debug_set_vit_streams(streams)
+        lib.wise_debug_set_vit_streams(streams | (ATTN_QT << 8))
         lib.wise_debug_set_gemm_flags(flags)
         for _ in range(5):
             o = eng.forward(x)

@@ -129,6 +129,60 @@ int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows,
 constexpr int V_RS = 144;  // bytes per V row in LDS (64 dh bf16 = 128 B + 16 B pad)
 using short4v = __attribute__((ext_vector_type(4))) short;
 
+// One 64-key block of the online softmax for QT query tiles, shared by the attention kernels.  In: sacc = raw
+// scores S^T (this lane: keys kbase + kt*16 + r, query column qt*16 + (lane & 15)).  Out: pf = the exponentiated
+// block as the next MFMA's B operand; oacc / mrun / lrun updated.  The loop around it is bound by these VALU
+// instructions, not by the 64 MFMAs of a block, so they are kept few: the 1/sqrt(64) * log2(e) scale rides in
+// the FMA that subtracts the running maximum, 2^x is the bare v_exp_f32 (arguments are <= 0; results below
+// 2^-126 may flush), and the key-validity compare exists only in the MASK instantiation (the last, partial key
+// block, and causal attention).
+template <int QT, bool MASK>
+__device__ __forceinline__ void softmax_block(f32x4 (&sacc)[4][QT], bf16x8 (&pf)[2][QT], f32x4 (&oacc)[4][QT],
+                                              float (&mrun)[QT], float (&lrun)[QT], int kbase, const int (&klim)[QT]) {
+    const float sc = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (MASK && kbase + kt * 16 + r >= klim[qt]) sacc[kt][qt][r] = -INFINITY;
+                mx = fmaxf(mx, sacc[kt][qt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun[qt], mx * sc);
+        const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+        mrun[qt] = mnew;
+        float ps = 0.f;
+        float p[4][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[kt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kt][qt][r], sc, -mnew));
+                ps += p[kt][r];
+            }
+        lrun[qt] = lrun[qt] * alpha + ps;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha;
+            oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f[r] = (__bf16)p[2 * ks][r];
+                f[4 + r] = (__bf16)p[2 * ks + 1][r];
+            }
+            pf[ks][qt] = f;
+        }
+    }
+}
+
 template <int QT, bool CAUSAL>
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, int B, int T, int H,
                                                         bf16_t* __restrict__ o) {
@@ -165,7 +219,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     float mrun[QT], lrun[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) { mrun[qt] = -INFINITY; lrun[qt] = 0.f; }
-    const float sc = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
 
     // causal (text tower): query t sees keys <= t, so key blocks past the chunk's last query are skipped
     const int q_last = min(T, (qc + 1) * (16 * QT)) - 1;
@@ -207,49 +260,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         }
         // ---- online softmax per query column (qt, l15); this lane holds keys kt*16 + g*4 + r
         bf16x8 pf[2][QT];  // [ks][qt] B operand of the PV product
+        {
+            int klim[QT];  // keys this query sees
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            float mx = -INFINITY;
-            const int key_lim = CAUSAL ? min(T, qc * (16 * QT) + qt * 16 + l15 + 1) : T;  // keys this query sees
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kb * 64 + kt * 16 + g * 4 + r;
-                    float s2 = (key < key_lim) ? sacc[kt][qt][r] * sc : -INFINITY;
-                    sacc[kt][qt][r] = s2;
-                    mx = fmaxf(mx, s2);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(mrun[qt], mx);
-            const float alpha = exp2f(mrun[qt] - mnew);
-            mrun[qt] = mnew;
-            float ps = 0.f;
-            float p[4][4];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p[kt][r] = exp2f(sacc[kt][qt][r] - mnew);
-                    ps += p[kt][r];
-                }
-            lrun[qt] = lrun[qt] * alpha + ps;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha;
-                oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    f[r] = (__bf16)p[2 * ks][r];
-                    f[4 + r] = (__bf16)p[2 * ks + 1][r];
-                }
-                pf[ks][qt] = f;
-            }
+            for (int qt = 0; qt < QT; ++qt) klim[qt] = CAUSAL ? min(T, qc * (16 * QT) + qt * 16 + l15 + 1) : T;
+            if (CAUSAL || kb * 64 + 64 > T)
+                softmax_block<QT, true>(sacc, pf, oacc, mrun, lrun, kb * 64 + g * 4, klim);
+            else
+                softmax_block<QT, false>(sacc, pf, oacc, mrun, lrun, kb * 64 + g * 4, klim);
         }
         // ---- O^T += V^T P^T ; A operand: V^T[dh = dt*16 + l15][slot 8g + j] with
         //      slot j<4 -> key ks*32 + g*4 + j ; j>=4 -> key ks*32 + 16 + g*4 + (j-4)
@@ -297,8 +315,10 @@ static int g_attn_qt = 0;  // query tiles (of 16) per wave; 0 = by sequence leng
 int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st, bool causal) {
     WISE_CHECK_ARG(qkv && o && B > 0 && T > 0 && H > 0, "attention: bad argument");
     if (g_ablate & 4) return WISE_OK;
-    // 32 queries per wave (126 VGPRs, 4 waves/SIMD) hides latency best when one key block covers T; longer
-    // sequences prefer 64 queries per wave (K/V re-read half as often)
+    // 32 queries per wave hides latency best when one key block covers T; longer sequences prefer 64 queries per
+    // wave (K/V re-read half as often).  (Measured and dropped: a block-per-head kernel that stages K/V once in
+    // LDS for all query chunks of a head — at T = 257 it was 5 % slower: the loop is bound by the softmax VALU work
+    // and by latency at 2-3 waves per SIMD, not by the K/V re-reads, which hit L2.)
     const int qt = g_attn_qt ? (g_attn_qt == 4 ? 4 : 2) : (T <= 64 ? 2 : 4);
     const int nqc = (T + 16 * qt - 1) / (16 * qt);
     const long long items = (long long)B * H * nqc;
