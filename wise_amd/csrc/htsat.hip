@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void swin_attention_kernel(const bf16_t* __res
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                p[kt][r] = exp2f(s2[kt][r] - mx);
+                p[kt][r] = __builtin_amdgcn_exp2f(s2[kt][r] - mx);  // arguments <= 0: the bare v_exp_f32
                 ps += p[kt][r];
             }
         ps += __shfl_xor(ps, 16, 64);
