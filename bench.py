@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the CLAP-HTSAT and ViT-L/14 legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget per CPU baseline leg")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="profiling aid: run only the single-stream, event-bracketed ViT pass (the one `roofline` is "
+                         "computed from) so that a rocprofv3 --stats of this command lists exactly those launches")
     return ap.parse_args()
 
 
@@ -211,6 +214,8 @@ def main():
     def vit_step(i):
         out_holder["o"] = eng.forward(x)
 
+    if args.roofline_only:
+        lib.wise_debug_set_vit_streams(1)
     for i in range(args.warmup):
         vit_step(i)
     dt = timed_region(vit_step, args.steps, world)
@@ -242,6 +247,14 @@ def main():
         "end_to_end_frac": round(frames_per_s / world * spec.flops_per_frame() / 1e12 / PEAK_BF16_TFLOPS, 4),
     }
 
+    if args.roofline_only:
+        if rank == 0:
+            print(json.dumps({"roofline_only": True, "single_stream_frames_per_s": round(frames_per_s, 1),
+                              "roofline": roofline}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     result = {
         "metric": METRIC, "value": round(frames_per_s, 1), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),

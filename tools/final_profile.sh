@@ -11,12 +11,18 @@ echo "bench done"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o stats -- python3 bench.py --steps 20 --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1 || exit 1
 python3 tools/prof_top.py $OUT/${TAG}_stats/stats_results.db 40 --csv $OUT/${TAG}_kernel_stats.csv > $OUT/${TAG}_kernel_stats.txt
 echo "stats done"
-timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_fetch.log 2>&1 || exit 1
-echo "fetch pass done"
-timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_write.log 2>&1 || exit 1
-echo "write pass done"
-F=$(find $OUT/${TAG}_pmc_fetch -name "*counter_collection.csv" | head -1)
-W=$(find $OUT/${TAG}_pmc_write -name "*counter_collection.csv" | head -1)
-cp "$F" $OUT/${TAG}_pmc_fetch_counter_collection.csv
-cp "$W" $OUT/${TAG}_pmc_write_counter_collection.csv
+# the single-stream bracketed pass alone: its per-kernel averages are the ones bench.py's roofline object reports
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_roofstats -o roof -- python3 bench.py --steps 20 --roofline-only > $OUT/${TAG}_roofline_only.json 2> $OUT/${TAG}_roofline_only.err || exit 1
+python3 tools/prof_top.py $OUT/${TAG}_roofstats/roof_results.db 12 --csv $OUT/${TAG}_roofline_kernel_stats.csv > $OUT/${TAG}_roofline_kernel_stats.txt
+echo "roofline stats done"
+# PMC passes (one counter per run, kernel-trace only): the headline legs without the extras, so that the per-kernel
+# averages are those of the ViT-B/32 GEMMs and the 10M x 512 scans; the image-transform kernel from its own tool
+for C in FETCH_SIZE WRITE_SIZE; do
+  L=$(echo $C | tr 'A-Z' 'a-z' | cut -d_ -f1)
+  timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$L -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_pmc_$L.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_${L}_pre -- python3 tools/preproc_bench.py 64 > $OUT/${TAG}_pmc_${L}_pre.log 2>&1 || exit 1
+  cp "$(find $OUT/${TAG}_pmc_$L -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_pmc_${L}_counter_collection.csv
+  cp "$(find $OUT/${TAG}_pmc_${L}_pre -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_pmc_${L}_pre_counter_collection.csv
+  echo "$C passes done"
+done
 ls -la $OUT | tail -12

@@ -4,7 +4,8 @@ section prescribes) into profiles/pmc_traffic.json: HBM bytes per launch for the
 Corrections applied exactly as that guide states for gfx950:
   FETCH_SIZE counts 64 B per 128-B request for wide coalesced streaming reads -> doubled;
   WRITE_SIZE is exact for 16-B-per-lane streaming stores.  Both counters are in KiB.
-usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [tag]
+usage: python tools/pmc_traffic.py <fetch csv>[,<fetch csv>...] <write csv>[,<write csv>...]
+(comma-separated lists merge several profiled commands, e.g. bench.py --no-extra and tools/preproc_bench.py)
 """
 import csv
 import json
@@ -13,17 +14,18 @@ from collections import defaultdict
 from pathlib import Path
 
 
-def per_kernel(path, counter):
+def per_kernel(paths, counter):
     acc = defaultdict(lambda: [0.0, 0])
     seen = set()
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
-            continue
-        key = (r["Dispatch_Id"], r["Kernel_Name"])
-        acc[r["Kernel_Name"]][0] += float(r["Counter_Value"])
-        if key not in seen:
-            seen.add(key)
-            acc[r["Kernel_Name"]][1] += 1
+    for path in paths.split(","):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != counter:
+                continue
+            key = (path, r["Dispatch_Id"], r["Kernel_Name"])
+            acc[r["Kernel_Name"]][0] += float(r["Counter_Value"])
+            if key not in seen:
+                seen.add(key)
+                acc[r["Kernel_Name"]][1] += 1
     return {k: (v[0] / max(v[1], 1), v[1]) for k, v in acc.items()}
 
 
@@ -40,7 +42,14 @@ def main():
                       "hbm_bytes_per_launch": round(f * 1024 * 2 + w * 1024)}
     # aggregate keys bench.py looks up
     def agg(prefix):
-        ks = [k for k in out if k.startswith(prefix)]
+        # "ip_scan_kernel" = the flat scan only; its inverted-list instantiation (last template argument true) is
+        # reported as "ivf_scan_kernel"
+        if prefix == "ivf_scan_kernel":
+            ks = [k for k in out if k.startswith("ip_scan_kernel") and k.rstrip().endswith("true>")]
+        elif prefix == "ip_scan_kernel":
+            ks = [k for k in out if k.startswith("ip_scan_kernel") and not k.rstrip().endswith("true>")]
+        else:
+            ks = [k for k in out if k.startswith(prefix)]
         n = sum(out[k]["launches"] for k in ks)
         if not n:
             return None
@@ -50,7 +59,8 @@ def main():
            "per_kernel": out}
     for key, prefix in (("gemm_bf16_kernel", "gemm_"), ("ip_scan_kernel", "ip_scan_kernel"),
                         ("ip_scan_mfma_kernel", "ip_scan_mfma_kernel"), ("clip_resize_kernel", "clip_resize_kernel"),
-                        ("attention_kernel", "attention_kernel"), ("layernorm_kernel", "layernorm_kernel")):
+                        ("ivf_scan_kernel", "ivf_scan_kernel"), ("attention_kernel", "attention_kernel"),
+                        ("layernorm_kernel", "layernorm_kernel")):
         a = agg(prefix)
         if a:
             res[key] = a
