@@ -225,6 +225,10 @@ int wise_preproc_taps(int in_size, int out_size, int* ksize, int* first, int* co
  *       3 -> resid_f32 += acc+bias (in place, fp32 residual stream) ; 4 -> out_f32 = acc+bias */
 int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K,
                    int mode, void* out, void* stream);
+/* LayerNorm fused into the GEMM's A operand: out_bf16[M,N] = epi( LN(x_f32[M,K]; lnw, lnb, eps) @ Wt[N,K]^T + bias ),
+ * for K in {96, 192} (HTSAT stages 1-2), N % 8 == 0, M % 128 == 0, bf16 output modes (0, 1, 2, 5). */
+int wise_gemm_ln_bf16(const float* x, const float* lnw, const float* lnb, const uint16_t* Wt, const float* bias,
+                      int M, int N, int K, float eps, int mode, uint16_t* out, void* stream);
 /* y_bf16[r,:] = (x[r,:]-mean)/sqrt(var+eps)*w+b over W for r < rows. */
 int wise_layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows, int W,
                             float eps, uint16_t* y, void* stream);

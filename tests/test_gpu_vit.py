@@ -175,3 +175,31 @@ def test_vit_b32_batch256_consistency(golden_dir):
     # ragged batch (not a multiple of anything)
     out_r = eng.forward(batch[:37]).cpu()
     assert torch.equal(out_r, out[:37])
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(256, 288, 96, 0), (1024, 384, 96, 2), (128, 576, 192, 0), (256, 768, 192, 2),
+                                        (128, 96, 96, 0), (384, 200, 96, 1), (128, 1024, 192, 5)])
+def test_gemm_with_fused_layernorm(M, N, K, mode):
+    """wise_gemm_ln_bf16 (HTSAT stages 1-2): LayerNorm computed inside the GEMM's A-tile build."""
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(M + N + K + mode)
+    x = torch.randn(M, K, generator=g) * 2 + 0.3
+    lw = 1 + 0.1 * torch.randn(K, generator=g)
+    lb = 0.1 * torch.randn(K, generator=g)
+    W = bf16_round(torch.randn(N, K, generator=g) * K ** -0.5)
+    bias = torch.randn(N, generator=g)
+    h = bf16_round(torch.nn.functional.layer_norm(x, (K,), lw, lb, 1e-5))
+    ref = h.double() @ W.double().t() + bias.double()
+    if mode == 1:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    elif mode == 2:
+        ref = 0.5 * ref * (1 + torch.erf(ref / 2 ** 0.5))
+    elif mode == 5:
+        ref = 0.5 * ref * (1 + torch.tanh(0.7978845608028654 * (ref + 0.044715 * ref ** 3)))
+    xd, lwd, lbd, Wd, bd = x.cuda(), lw.cuda(), lb.cuda(), W.to(torch.bfloat16).cuda(), bias.cuda()
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.wise_gemm_ln_bf16(xd.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), Wd.data_ptr(), bd.data_ptr(), M, N, K,
+                                     1e-5, mode, out.data_ptr(), _lib.stream_ptr()), "gemm_ln")
+    torch.cuda.synchronize()
+    err = (out.float().cpu().double() - ref).abs().max().item()
+    assert err <= 4e-2, err   # one bf16 rounding of the normalised activations and one of O(4) outputs

@@ -10,15 +10,22 @@ from wise_amd.feature.htsat import HtsatEngine, random_htsat_state_dict  # noqa:
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 480000
+from wise_amd import _lib  # noqa: E402
+
 eng = HtsatEngine(random_htsat_state_dict(0), max_batch=B, max_samples=N)
 w = 0.1 * torch.randn(B, N, device="cuda")
-for _ in range(3):
-    o = eng.forward(w)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-n = 10
-for _ in range(n):
-    o = eng.forward(w)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / n
-print(f"HTSAT B={B} N={N}: {dt*1e3:.3f} ms/step  {B/dt:.1f} clips/s  {B/dt*11.82e9/1e12:.1f} TFLOP/s")
+lib = _lib.lib()
+for flags in (0, 1, 0, 1):   # bit 0: LayerNorm-in-GEMM fusion off
+    lib.wise_debug_set_htsat(flags)
+    for _ in range(3):
+        o = eng.forward(w)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        o = eng.forward(w)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"HTSAT B={B} N={N} flags={flags}: {dt*1e3:.3f} ms/step  {B/dt:.1f} clips/s  {B/dt*11.82e9/1e12:.1f} TFLOP/s",
+          flush=True)
+lib.wise_debug_set_htsat(0)

@@ -495,6 +495,119 @@ __global__ __launch_bounds__(256, MINB) void gemm_ring_kernel(const bf16_t* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LayerNorm fused into the GEMM's A operand, for rows short enough that a block holds them whole (K <= 192:
+// HTSAT's first two stages, C = 96 / 192, where activations are 0.5M x 96 and every separate pass is a full trip
+// through HBM).  C[M,N] = epi( LN(x[M,K]; g, b) @ Wt^T + bias ), bf16 output modes only.
+//   1. the block normalises its 128 rows straight from the fp32 residual stream — 8 lanes per row, K/32 float4
+//      per lane, two-pass statistics with 3 cross-lane steps — and writes them as bf16 into the LDS image the
+//      ring kernels' fragment reads expect (K/32 tiles of 128 x 32, 64-byte rows, chunk swizzle);
+//   2. it then walks the column tiles of N itself: the W tile (all of K) arrives by LDS-DMA, K/32 x 16 MFMAs per
+//      wave, and the bf16 C tile leaves row-major through the same LDS region the W tile occupied.
+// x is read once and the normalised activations never exist in HBM.
+// LDS: A image K*256 B + max(W tile K*256 B, 4 x 64 x 144 B epilogue images): 61 KiB at K = 96 (two blocks per CU).
+// ------------------------------------------------------------------------------------------------
+template <int MODE, int NF /* K / 32 */>
+__global__ __launch_bounds__(256, 2) void gemm_ln_kernel(const float* __restrict__ x, const float* __restrict__ lnw,
+                                                         const float* __restrict__ lnb, const bf16_t* __restrict__ Wt,
+                                                         const float* __restrict__ bias, int M, int N, float eps,
+                                                         bf16_t* __restrict__ out) {
+    static_assert(bf16_out(MODE), "bf16 output modes only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int K = NF * 32, TB = 128 * 64;                 // bytes per 128 x 32 bf16 tile
+    constexpr int WREG = (NF * TB > 4 * 64 * 144) ? NF * TB : 4 * 64 * 144;
+    unsigned char* a_img = smem;                              // [NF][128 rows][64 B]
+    unsigned char* w_img = smem + NF * TB;                    // [NF][128 rows][64 B] / epilogue images
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * 128;
+
+    // ---- 1. LayerNorm of rows m0 .. m0+127 into the A image
+    {
+        const int l8 = threadIdx.x & 7;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 32 + (threadIdx.x >> 3);
+            const float4* xr = reinterpret_cast<const float4*>(x + (size_t)(m0 + r) * K);
+            float4 v[NF];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                v[j] = xr[j * 8 + l8];
+                s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            }
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            const float mean = s / (float)K;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+            const float rstd = rsqrtf(q / (float)K + eps);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const float4 g = reinterpret_cast<const float4*>(lnw)[j * 8 + l8];
+                const float4 b = reinterpret_cast<const float4*>(lnb)[j * 8 + l8];
+                uint2 pk;
+                pk.x = pack_bf16x2((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y);
+                pk.y = pack_bf16x2((v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
+                // K-tile j, columns 4*l8 .. 4*l8+3: 16-byte chunk l8 >> 1 (swizzled), half l8 & 1
+                *reinterpret_cast<uint2*>(a_img + j * TB + r * 64 + (swz_chunk<32>(r, l8 >> 1) << 4) + (l8 & 1) * 8) = pk;
+            }
+        }
+    }
+    // ---- 2. column tiles
+    const int tiles_n = (N + 127) / 128;
+    for (int tn = 0; tn < tiles_n; ++tn) {
+        const int n0 = tn * 128;
+        __syncthreads();   // A image complete (first trip) / previous epilogue done with w_img
+#pragma unroll
+        for (int j = 0; j < NF; ++j) stage_tile_ring<32>(Wt, K, n0, j * 32, w_img + j * TB, wave, lane, N - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int chunk = lane >> 4;
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = lds_frag_ring<32>(a_img + j * TB, wm * 64 + i * 16 + (lane & 15), chunk);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) wf[jj] = lds_frag_ring<32>(w_img + j * TB, wn * 64 + jj * 16 + (lane & 15), chunk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj], af[i], acc[i][jj], 0, 0, 0);
+        }
+        __syncthreads();   // every wave is done reading w_img: it becomes the epilogue's scratch
+        epilogue_lds<MODE>(acc, bias, out, N, m0, n0, wm, wn, lane, wave, w_img);
+    }
+    (void)M; (void)WREG;
+}
+
+template <int MODE, int NF>
+static void launch_gemm_ln(const float* x, const float* lnw, const float* lnb, const bf16_t* Wt, const float* bias,
+                           int M, int N, float eps, bf16_t* out, hipStream_t st) {
+    auto kern = gemm_ln_kernel<MODE, NF>;
+    constexpr size_t TBs = 128 * 64;
+    const size_t wreg = (NF * TBs > (size_t)4 * 64 * 144) ? NF * TBs : (size_t)4 * 64 * 144;
+    const size_t lds = NF * TBs + wreg;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), lds, st, x, lnw, lnb, Wt, bias, M, N, eps, out);
+}
+
 template <int MODE, int BKT, int STAGES, int MINB, int ABL = 0>
 static void launch_ring(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
                         hipStream_t st) {
@@ -1119,6 +1232,29 @@ static int auto_variant(int M, int N, int K) {
 
 void gemm_set_overlapped(bool on) { g_overlapped = on ? 1 : 0; }
 
+bool gemm_ln_supported(int N, int K, int mode) { return (K == 96 || K == 192) && N % 8 == 0 && bf16_out(mode); }
+
+// out_bf16[M,N] = epi( LayerNorm(x[M,K]; lnw, lnb, eps) @ Wt^T + bias ); M % 128 == 0 (rows readable), K in {96, 192}
+int gemm_ln_bf16(const float* x, const float* lnw, const float* lnb, const bf16_t* Wt, const float* bias, int M, int N,
+                 int K, float eps, int mode, bf16_t* out, hipStream_t st) {
+    WISE_CHECK_ARG(x && lnw && lnb && Wt && out, "gemm_ln: null pointer");
+    WISE_CHECK_ARG(M > 0 && M % 128 == 0 && gemm_ln_supported(N, K, mode), "gemm_ln: M=%d N=%d K=%d mode=%d unsupported", M,
+                   N, K, mode);
+    ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
+#define LN_CASE(MD)                                                                          \
+    case MD:                                                                                 \
+        if (K == 96) launch_gemm_ln<MD, 3>(x, lnw, lnb, Wt, bias, M, N, eps, out, st);        \
+        else launch_gemm_ln<MD, 6>(x, lnw, lnb, Wt, bias, M, N, eps, out, st);                \
+        break;
+    switch (mode) {
+        LN_CASE(EPI_BF16) LN_CASE(EPI_QUICKGELU) LN_CASE(EPI_GELU) LN_CASE(EPI_GELU_TANH)
+        default: set_error("gemm_ln: mode %d", mode); return WISE_E_INVALID;
+    }
+#undef LN_CASE
+    WISE_LAUNCH_CHECK("gemm_ln_kernel");
+    return WISE_OK;
+}
+
 int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out,
               hipStream_t st) {
     WISE_CHECK_ARG(A && Wt && out, "gemm_bf16: null pointer");
@@ -1168,6 +1304,11 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
 }
 
 }  // namespace wise
+
+extern "C" int wise_gemm_ln_bf16(const float* x, const float* lnw, const float* lnb, const uint16_t* Wt, const float* bias,
+                                 int M, int N, int K, float eps, int mode, uint16_t* out, void* stream) {
+    return wise::gemm_ln_bf16(x, lnw, lnb, Wt, bias, M, N, K, eps, mode, out, (hipStream_t)stream);
+}
 
 extern "C" int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, int mode,
                               void* out, void* stream) {

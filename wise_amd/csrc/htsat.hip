@@ -22,8 +22,13 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
               hipStream_t st);
 int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows, int W, float eps, bf16_t* y,
                        hipStream_t st);
+// LayerNorm fused into the GEMM's A tile (gemm_bf16.hip), for K = 96 / 192
+bool gemm_ln_supported(int N, int K, int mode);
+int gemm_ln_bf16(const float* x, const float* lnw, const float* lnb, const bf16_t* Wt, const float* bias, int M, int N,
+                 int K, float eps, int mode, bf16_t* out, hipStream_t st);
 
 namespace htsat {
+static int g_fuse_ln = 1;  // wise_debug_set_htsat(bit 0 = off): A/B the LayerNorm-in-GEMM fusion
 constexpr int N_FFT = 1024, HOP = 320, N_MELS = 64, MELW = 32, MAXF = 1024;
 constexpr int EMBED = 96, LATENT = 768, OUT = 1024;
 constexpr int DEPTHS[4] = {2, 2, 6, 2};
@@ -694,8 +699,17 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
             const bf16_t* wproj = wq + (size_t)3 * C * C; const bf16_t* wf1 = wproj + (size_t)C * C;
             const bf16_t* wf2 = wf1 + (size_t)4 * C * C;
             const int shift = (j % 2 == 1 && H > 8) ? 4 : 0;
-            if ((rc = layernorm_f32_bf16(x, n1w, n1b, M, C, 1e-5f, h, st))) return rc;
-            if ((rc = gemm_bf16(h, wq, qb, Mp, 3 * C, C, 0, qkv, st))) return rc;
+            // stage 1 (C = 96): a block holds whole rows, so LayerNorm happens inside the GEMM's A-tile build and the
+            // normalised activations never travel through HBM (LN 71 + GEMM 151 us -> 142 us; LN 71 + 200 -> 205).
+            // At C = 192 the fused kernel (one block per CU) loses to LayerNorm + the tuned GEMMs (113 vs 93 us,
+            // 173 vs 140 us), so stage 2 keeps the two-kernel form.
+            const bool fuse_ln = g_fuse_ln && C == 96 && gemm_ln_supported(3 * C, C, 0);
+            if (fuse_ln) {
+                if ((rc = gemm_ln_bf16(x, n1w, n1b, wq, qb, Mp, 3 * C, C, 1e-5f, 0, qkv, st))) return rc;
+            } else {
+                if ((rc = layernorm_f32_bf16(x, n1w, n1b, M, C, 1e-5f, h, st))) return rc;
+                if ((rc = gemm_bf16(h, wq, qb, Mp, 3 * C, C, 0, qkv, st))) return rc;
+            }
             {
                 const long long items = (long long)B * (H / 8) * (H / 8) * heads;
                 hipLaunchKernelGGL(swin_attention_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, B, H,
@@ -703,8 +717,12 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
                 WISE_LAUNCH_CHECK("htsat swin_attention_kernel");
             }
             if ((rc = gemm_bf16(h, wproj, pb, Mp, C, C, 3, x, st))) return rc;
-            if ((rc = layernorm_f32_bf16(x, n2w, n2b, M, C, 1e-5f, h, st))) return rc;
-            if ((rc = gemm_bf16(h, wf1, f1b, Mp, 4 * C, C, 2, a, st))) return rc;
+            if (fuse_ln) {
+                if ((rc = gemm_ln_bf16(x, n2w, n2b, wf1, f1b, Mp, 4 * C, C, 1e-5f, 2, a, st))) return rc;
+            } else {
+                if ((rc = layernorm_f32_bf16(x, n2w, n2b, M, C, 1e-5f, h, st))) return rc;
+                if ((rc = gemm_bf16(h, wf1, f1b, Mp, 4 * C, C, 2, a, st))) return rc;
+            }
             if ((rc = gemm_bf16(a, wf2, f2b, Mp, C, 4 * C, 3, x, st))) return rc;
         }
         if (i < 3) {
@@ -732,6 +750,11 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
             return rc;
     }
     return WISE_OK;
+}
+
+extern "C" int wise_debug_set_htsat(int flags) {
+    wise::htsat::g_fuse_ln = (flags & 1) ? 0 : 1;
+    return 0;
 }
 
 extern "C" int wise_htsat_tap(int what, const void* workspace_ptr, int batch, int samples, float* dst, int64_t count,
