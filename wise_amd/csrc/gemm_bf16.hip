@@ -623,101 +623,6 @@ static void launch_ring(const bf16_t* A, const bf16_t* Wt, const float* bias, in
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, Wt, bias, M, N, K, out);
 }
 
-// Persistent variant of the 128x128 kernel: a fixed grid (2 blocks per CU) walks the tiles; the next
-// tile's first K-step is staged BEFORE the epilogue of the current one, so the epilogue's stores and
-// the prologue's load latency overlap instead of adding up.
-__device__ __forceinline__ void tile_coords_id(int id, int tiles_m, int tiles_n, int group_m, int* tm, int* tn) {
-    const int per_group = group_m * tiles_n;
-    const int gid = id / per_group;
-    const int first_m = gid * group_m;
-    const int gsize = min(tiles_m - first_m, group_m);
-    const int in_group = id - gid * per_group;
-    *tm = first_m + in_group % gsize;
-    *tn = in_group / gsize;
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const bf16_t* __restrict__ A,
-                                                              const bf16_t* __restrict__ Wt,
-                                                              const float* __restrict__ bias, int M, int N, int K,
-                                                              void* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_m = M / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
-    const int gm = g_group_m ? g_group_m : 8;
-    // blocks b, b+8, ... share an XCD: give each XCD a contiguous run of slots
-    const int per_xcd = gridDim.x >> 3;
-    int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int nk = K / BK;
-    int tm, tn;
-    if (tile < ntiles) {
-        tile_coords_id(tile, tiles_m, tiles_n, gm, &tm, &tn);
-        stage_tile(A, K, tm * BM, 0, smem, wave, lane, M - 1);
-        stage_tile(Wt, K, tn * BN, 0, smem + TILE_BYTES, wave, lane, N - 1);
-    }
-    while (tile < ntiles) {
-        const int m0 = tm * BM, n0 = tn * BN;
-        f32x4 acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            __syncthreads();
-            if (kt + 1 < nk) {
-                unsigned char* nb = smem + (cur ^ 1) * 2 * TILE_BYTES;
-                stage_tile(A, K, m0, (kt + 1) * BK, nb, wave, lane, M - 1);
-                stage_tile(Wt, K, n0, (kt + 1) * BK, nb + TILE_BYTES, wave, lane, N - 1);
-            }
-            const unsigned char* At = smem + cur * 2 * TILE_BYTES;
-            const unsigned char* Bt = At + TILE_BYTES;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int chunk = s * 4 + (lane >> 4);
-                bf16x8 af[4], wf[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = lds_frag(At, wm * 64 + i * 16 + (lane & 15), chunk);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wf[j] = lds_frag(Bt, wn * 64 + j * 16 + (lane & 15), chunk);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-            }
-        }
-        __syncthreads();  // every wave is done reading LDS: buffer 0 may take the next tile
-        const int next = tile + gridDim.x;
-        if (next < ntiles) {
-            tile_coords_id(next, tiles_m, tiles_n, gm, &tm, &tn);
-            stage_tile(A, K, tm * BM, 0, smem, wave, lane, M - 1);
-            stage_tile(Wt, K, tn * BN, 0, smem + TILE_BYTES, wave, lane, N - 1);
-        }
-        epilogue<MODE>(acc, bias, out, N, m0, n0, wm, wn, lane);
-        tile = next;
-    }
-}
-
-template <int MODE>
-static void launch_persist(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
-                           hipStream_t st) {
-    auto kern = gemm_persist_kernel<MODE>;
-    const size_t lds = 4 * TILE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_set = true;
-    }
-    const int ntiles = (M / BM) * ((N + BN - 1) / BN);
-    int grid = 512;
-    if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, Wt, bias, M, N, K, out);
-}
-
 template <int MODE, int ABL = 0>
 static void launch_gemm(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
                         hipStream_t st) {
@@ -875,92 +780,6 @@ __device__ __forceinline__ void stage_rows8_ring(const bf16_t* __restrict__ G, i
         const int c = swz_chunk<BKT>(r, lane % CPR);
         glds16(G + (size_t)(row0 + r) * ld + k0 + c * 8, lds_tile + u * 1024);
     }
-}
-
-template <int MODE, int NT, int BKT, int STAGES, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm_bigring_kernel(const bf16_t* __restrict__ A,
-                                                              const bf16_t* __restrict__ Wt,
-                                                              const float* __restrict__ bias, int M, int N, int K,
-                                                              void* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BMB = 256, BNB = 64 * NT, RB = BKT * 2;
-    constexpr int TA = BMB * RB, TBb = BNB * RB, SB = TA + TBb;
-    constexpr int GPS = (TA + TBb) / 1024 / 8;  // glds per thread per K-step
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const int tiles_n = N / BNB;
-    int tm, tn;
-    tile_coords(M / BMB, tiles_n, g_group_m ? g_group_m : 4, &tm, &tn);
-    const int m0 = tm * BMB, n0 = tn * BNB;
-
-    f32x4 acc[8][NT];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / BKT;
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s) {
-        if (s < nk) {
-            stage_rows8_ring<BMB, BKT>(A, K, m0, s * BKT, smem + s * SB, wave, lane);
-            stage_rows8_ring<BNB, BKT>(Wt, K, n0, s * BKT, smem + s * SB + TA, wave, lane);
-        }
-    }
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + STAGES - 2 < nk)
-            wait_vmcnt<(STAGES - 2) * GPS>();
-        else
-            wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        {
-            const int nt = kt + STAGES - 1;
-            if (nt < nk) {
-                int ns = cur + STAGES - 1;
-                if (ns >= STAGES) ns -= STAGES;
-                stage_rows8_ring<BMB, BKT>(A, K, m0, nt * BKT, smem + ns * SB, wave, lane);
-                stage_rows8_ring<BNB, BKT>(Wt, K, n0, nt * BKT, smem + ns * SB + TA, wave, lane);
-            }
-        }
-        const unsigned char* At = smem + cur * SB;
-        const unsigned char* Bt = At + TA;
-        if (ABL == 2) { cur = (cur + 1 == STAGES) ? 0 : cur + 1; continue; }
-#pragma unroll
-        for (int s = 0; s < BKT / 32; ++s) {
-            const int chunk = s * 4 + (lane >> 4);
-            bf16x8 wf[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) wf[j] = lds_frag_ring<BKT>(Bt, wn * (16 * NT) + j * 16 + (lane & 15), chunk);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bf16x8 af = lds_frag_ring<BKT>(At, wm * 128 + i * 16 + (lane & 15), chunk);
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc[i][j], 0, 0, 0);
-            }
-        }
-        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
-    }
-    epilogue_big<MODE, NT>(acc, bias, out, N, m0, n0, wm, wn, lane);
-}
-
-template <int MODE, int NT, int BKT, int STAGES, int ABL = 0>
-static void launch_bigring(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
-                           hipStream_t st) {
-    auto kern = gemm_bigring_kernel<MODE, NT, BKT, STAGES, ABL>;
-    const size_t lds = (size_t)STAGES * (256 + 64 * NT) * BKT * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_set = true;
-    }
-    const int grid = (M / 256) * (N / (64 * NT));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
 }
 
 // bf16 epilogue through LDS for the 8-wave 256x256 tile (wave = 128 rows x 64 columns): same idea as
@@ -1157,44 +976,18 @@ static int g_split_m = 1;  // split M between the ping-pong kernel and the 128x1
 template <int MODE>
 static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K,
                            void* out, hipStream_t st) {
+    // 0: 128x128, two blocks per CU.  1: 128x128 ring with 32-deep K-tiles (K % 64 != 0).  5: 256x192.
+    // 40 / 42: 256x256 / 320x256 ping-pong.  41: 256x128 ping-pong.  8 / 9: timing-only ablations of variant 0.
+    // Shapes a variant cannot tile fall back to variant 0.
     switch (variant) {
         case 1: launch_ring<MODE, 32, 4, 2>(A, Wt, bias, M, N, K, out, st); break;
-        case 2: launch_ring<MODE, 64, 4, 1>(A, Wt, bias, M, N, K, out, st); break;
-        case 3: launch_ring<MODE, 64, 3, 1>(A, Wt, bias, M, N, K, out, st); break;
-        case 4: if (M % 256 == 0 && N % 256 == 0) { launch_big<MODE, 4>(A, Wt, bias, M, N, K, out, st); break; }
-                launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 5: if (M % 256 == 0 && N % 192 == 0) { launch_big<MODE, 3>(A, Wt, bias, M, N, K, out, st); break; }
                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        case 6: if (M % 256 == 0) { launch_big<MODE, 2>(A, Wt, bias, M, N, K, out, st); break; }
-                launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        case 10: if (M % 256 == 0 && N % 256 == 0) { launch_bigring<MODE, 4, 32, 4>(A, Wt, bias, M, N, K, out, st); break; }
-                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        case 11: if (M % 256 == 0) { launch_bigring<MODE, 2, 64, 3>(A, Wt, bias, M, N, K, out, st); break; }
-                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        case 12: if (M % 256 == 0 && N % 192 == 0) { launch_bigring<MODE, 3, 32, 4>(A, Wt, bias, M, N, K, out, st); break; }
-                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        case 13: if (M % 256 == 0 && N % 256 == 0) { launch_bigring<MODE, 4, 32, 3>(A, Wt, bias, M, N, K, out, st); break; }
-                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        case 14: if (M % 256 == 0) { launch_bigring<MODE, 2, 32, 2>(A, Wt, bias, M, N, K, out, st); break; }
-                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        case 15: if (M % 256 == 0) { launch_bigring<MODE, 2, 32, 4>(A, Wt, bias, M, N, K, out, st); break; }
-                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        case 31: if (M % 256 == 0 && N % 256 == 0) { launch_big<MODE, 4, 1>(A, Wt, bias, M, N, K, out, st); break; }
-                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 40: if (M % 256 == 0 && N % 256 == 0) { launch_pp<MODE, 128>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 41: if (M % 256 == 0 && N % 128 == 0) { launch_pp<MODE, 64>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 42: if (M % 320 == 0 && N % 256 == 0) { launch_pp<MODE, 160>(A, Wt, bias, M, N, K, out, st); break; }
-                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        case 30: launch_persist<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        case 16: launch_ring<MODE, 32, 2, 4>(A, Wt, bias, M, N, K, out, st); break;   // 32 KB LDS: 4 blocks/CU
-        case 17: launch_ring<MODE, 32, 3, 3>(A, Wt, bias, M, N, K, out, st); break;   // 48 KB LDS: 3 blocks/CU
-        case 20: launch_ring<MODE, 64, 4, 1, 2>(A, Wt, bias, M, N, K, out, st); break;   // load-only ablations
-        case 21: launch_ring<MODE, 32, 4, 2, 2>(A, Wt, bias, M, N, K, out, st); break;
-        case 22: if (M % 256 == 0 && N % 256 == 0) { launch_bigring<MODE, 4, 32, 4, 2>(A, Wt, bias, M, N, K, out, st); break; }
-                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        case 23: if (M % 256 == 0) { launch_bigring<MODE, 2, 64, 3, 2>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 8: launch_gemm<MODE, 1>(A, Wt, bias, M, N, K, out, st); break;
         case 9: launch_gemm<MODE, 2>(A, Wt, bias, M, N, K, out, st); break;
