@@ -1080,10 +1080,12 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
             return launch_mode(40, A, Wt, bias, M, N, K, mode, out, st);
         // (measured: worth it only when the ping-pong part spans several rounds; at 1-2 rounds the second
         // launch's own tail and the lost overlap cost more than the 128x128 kernel's slower main loop)
-        if (t256 >= 3 * 256 && g_split_m) {
+        // ... or from two rounds when what is left over is small (ViT-L/14 half batch: 129 x 4 tiles = 2 rounds + 4)
+        if (t256 >= 2 * 256 && g_split_m) {
             const int rounds = (int)(t256 / 256);
             const int m_pp = (rounds * 256) / tiles_n;  // m-tiles whose tiles fill `rounds` rounds (within one row)
-            if (m_pp >= 1 && m_pp < tiles_m && (long long)m_pp * tiles_n >= 200) {
+            const bool small_rest = (tiles_m - m_pp) * 8 <= tiles_m;
+            if (m_pp >= 1 && m_pp < tiles_m && (long long)m_pp * tiles_n >= 200 && (t256 >= 3 * 256 || small_rest)) {
                 const int M1 = m_pp * 256, M2 = M - M1;
                 int rc = launch_mode(40, A, Wt, bias, M1, N, K, mode, out, st);
                 if (rc) return rc;
