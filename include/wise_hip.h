@@ -229,6 +229,10 @@ int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int
  * for K in {96, 192} (HTSAT stages 1-2), N % 8 == 0, M % 128 == 0, bf16 output modes (0, 1, 2, 5). */
 int wise_gemm_ln_bf16(const float* x, const float* lnw, const float* lnb, const uint16_t* Wt, const float* bias,
                       int M, int N, int K, float eps, int mode, uint16_t* out, void* stream);
+/* The MLP of a C = 96 Swin block in one kernel (HTSAT stage 1): x_f32[M,96] += fc2(gelu(fc1(LN(x; lnw, lnb, eps)))),
+ * W1 [384,96], b1 [384], W2 [96,384], b2 [96]; M % 128 == 0.  The 384-wide hidden layer never reaches HBM. */
+int wise_mlp96_fused(float* x, const float* lnw, const float* lnb, const uint16_t* W1, const float* b1,
+                     const uint16_t* W2, const float* b2, int M, float eps, void* stream);
 /* y_bf16[r,:] = (x[r,:]-mean)/sqrt(var+eps)*w+b over W for r < rows. */
 int wise_layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows, int W,
                             float eps, uint16_t* y, void* stream);

@@ -203,3 +203,30 @@ def test_gemm_with_fused_layernorm(M, N, K, mode):
     torch.cuda.synchronize()
     err = (out.float().cpu().double() - ref).abs().max().item()
     assert err <= 4e-2, err   # one bf16 rounding of the normalised activations and one of O(4) outputs
+
+
+@pytest.mark.parametrize("M", [128, 1024, 4096])
+def test_fused_mlp96(M):
+    """wise_mlp96_fused (HTSAT stage 1): x += fc2(gelu(fc1(LN(x)))) with the hidden layer kept on chip."""
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(M)
+    C, HID = 96, 384
+    x = torch.randn(M, C, generator=g) * 1.5 + 0.2
+    lw = 1 + 0.1 * torch.randn(C, generator=g)
+    lb = 0.1 * torch.randn(C, generator=g)
+    W1 = bf16_round(torch.randn(HID, C, generator=g) * C ** -0.5)
+    b1 = 0.1 * torch.randn(HID, generator=g)
+    W2 = bf16_round(torch.randn(C, HID, generator=g) * HID ** -0.5)
+    b2 = 0.1 * torch.randn(C, generator=g)
+    h = bf16_round(torch.nn.functional.layer_norm(x, (C,), lw, lb, 1e-5)).double()
+    hid = h @ W1.double().t() + b1.double()
+    hid = bf16_round((0.5 * hid * (1 + torch.erf(hid / 2 ** 0.5))).float()).double()
+    ref = x.double() + hid @ W2.double().t() + b2.double()
+    xd = x.clone().cuda()
+    keep = [t.cuda() for t in (lw, lb, W1.to(torch.bfloat16), b1, W2.to(torch.bfloat16), b2)]
+    _lib.check(lib.wise_mlp96_fused(xd.data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(),
+                                    keep[3].data_ptr(), keep[4].data_ptr(), keep[5].data_ptr(), M, 1e-5,
+                                    _lib.stream_ptr()), "mlp96")
+    torch.cuda.synchronize()
+    err = (xd.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-2, err

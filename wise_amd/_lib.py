@@ -60,6 +60,7 @@ SIGNATURES = {
     "wise_preproc_u8": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "wise_preproc_taps": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i]),
     "wise_gemm_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "wise_mlp96_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
     "wise_gemm_ln_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "wise_layernorm_f32_bf16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "wise_attention_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),

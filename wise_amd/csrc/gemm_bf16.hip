@@ -592,6 +592,136 @@ __global__ __launch_bounds__(256, 2) void gemm_ln_kernel(const float* __restrict
     (void)M; (void)WREG;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The whole MLP of a C = 96 Swin block in one kernel (HTSAT stage 1, 0.5M tokens):
+//     x += fc2( gelu( fc1( LayerNorm(x) ) ) )        fc1: 96 -> 384, fc2: 384 -> 96
+// As two GEMMs the 384-wide hidden activations (403 MB at batch 128) are written and read back once per block;
+// here a workgroup keeps its 128 rows on chip: the normalised rows sit in LDS as the A operand (as in
+// gemm_ln_kernel), the hidden layer is produced 96 columns at a time, activated, rounded to bf16 and parked in LDS in
+// the A-operand layout of the second GEMM, whose 128 x 96 accumulators collect the four chunks.  HBM sees x once
+// in each direction; W1 and W2 (147 KB together) come from L2.
+// LDS: A image 24 KiB + weight tile 24 KiB (W1 chunk, then W2 chunk) + hidden chunk 24 KiB = 72 KiB: two blocks per CU.
+// Wave layout 2 x 2, wave tile 64 x 48 for both GEMMs.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void mlp96_kernel(float* __restrict__ x, const float* __restrict__ lnw,
+                                                       const float* __restrict__ lnb, const bf16_t* __restrict__ W1,
+                                                       const float* __restrict__ b1, const bf16_t* __restrict__ W2,
+                                                       const float* __restrict__ b2, float eps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int C = 96, HID = 384, NF = 3, TB = 128 * 64;
+    unsigned char* a_img = smem;              // LN(x) rows: [3][128][64 B]
+    unsigned char* w_img = smem + NF * TB;    // W1 chunk [96 hidden rows][96 k], then W2 chunk [96 out rows][96 k]
+    unsigned char* h_img = w_img + NF * TB;   // gelu(hidden chunk) [128][96] as an A operand
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 128;
+
+    // ---- LayerNorm of the block's rows into the A image (8 lanes per row)
+    {
+        const int l8 = threadIdx.x & 7;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 32 + (threadIdx.x >> 3);
+            const float4* xr = reinterpret_cast<const float4*>(x + (size_t)(m0 + r) * C);
+            float4 v[NF];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                v[j] = xr[j * 8 + l8];
+                s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            }
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            const float mean = s / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+            const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const float4 gw = reinterpret_cast<const float4*>(lnw)[j * 8 + l8];
+                const float4 gb = reinterpret_cast<const float4*>(lnb)[j * 8 + l8];
+                uint2 pk;
+                pk.x = pack_bf16x2((v[j].x - mean) * rstd * gw.x + gb.x, (v[j].y - mean) * rstd * gw.y + gb.y);
+                pk.y = pack_bf16x2((v[j].z - mean) * rstd * gw.z + gb.z, (v[j].w - mean) * rstd * gw.w + gb.w);
+                *reinterpret_cast<uint2*>(a_img + j * TB + r * 64 + (swz_chunk<32>(r, l8 >> 1) << 4) + (l8 & 1) * 8) = pk;
+            }
+        }
+    }
+    f32x4 acc2[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < HID / 96; ++c) {
+        __syncthreads();   // A image complete (first trip) / GEMM2 of the previous chunk done with w_img and h_img
+        // ---- W1 rows c*96 .. c*96+95 (the tile helper stages 128 rows; the extra ones are never read)
+#pragma unroll
+        for (int t = 0; t < NF; ++t) stage_tile_ring<32>(W1, C, c * 96, t * 32, w_img + t * TB, wave, lane, HID - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x4 acc1[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            bf16x8 af[4], wf[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = lds_frag_ring<32>(a_img + t * TB, wm * 64 + i * 16 + l15, g);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) wf[j] = lds_frag_ring<32>(w_img + t * TB, wn * 48 + j * 16 + l15, g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc1[i][j], 0, 0, 0);
+        }
+        __syncthreads();   // W1 chunk consumed: the weight tile can take W2
+        // ---- W2 rows 0..95 (output columns), k = c*96 .. c*96+95
+#pragma unroll
+        for (int t = 0; t < NF; ++t) stage_tile_ring<32>(W2, HID, 0, c * 96 + t * 32, w_img + t * TB, wave, lane, C - 1);
+        // ---- hidden chunk: bias, GELU, bf16, into the A-operand image of the second GEMM
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int col = wn * 48 + j * 16 + g * 4;                    // column within the chunk
+            const float4 bv = *reinterpret_cast<const float4*>(b1 + c * 96 + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wm * 64 + i * 16 + l15;
+                uint2 pk;
+                pk.x = pack_bf16x2(act_gelu(acc1[i][j][0] + bv.x), act_gelu(acc1[i][j][1] + bv.y));
+                pk.y = pack_bf16x2(act_gelu(acc1[i][j][2] + bv.z), act_gelu(acc1[i][j][3] + bv.w));
+                *reinterpret_cast<uint2*>(h_img + (col >> 5) * TB + r * 64 + (swz_chunk<32>(r, (col & 31) >> 3) << 4) +
+                                          ((col >> 2) & 1) * 8) = pk;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            bf16x8 hf[4], wf[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hf[i] = lds_frag_ring<32>(h_img + t * TB, wm * 64 + i * 16 + l15, g);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) wf[j] = lds_frag_ring<32>(w_img + t * TB, wn * 48 + j * 16 + l15, g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], hf[i], acc2[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();       // all reads of w_img / h_img done: they become the residual epilogue's scratch (4 x 12 KiB)
+    epilogue_f32_lds_piece<EPI_RESID, 4, 3>(acc2, b2, x, C, m0 + wm * 64, wn * 48, lane, w_img + wave * 12288);
+}
+
 template <int MODE, int NF>
 static void launch_gemm_ln(const float* x, const float* lnw, const float* lnb, const bf16_t* Wt, const float* bias,
                            int M, int N, float eps, bf16_t* out, hipStream_t st) {
@@ -1025,6 +1155,23 @@ static int auto_variant(int M, int N, int K) {
 
 void gemm_set_overlapped(bool on) { g_overlapped = on ? 1 : 0; }
 
+// x[M,96] += fc2(gelu(fc1(LN(x)))) in one kernel; M % 128 == 0 (rows readable and writable)
+int mlp96_fused(float* x, const float* lnw, const float* lnb, const bf16_t* W1, const float* b1, const bf16_t* W2,
+                const float* b2, int M, float eps, hipStream_t st) {
+    WISE_CHECK_ARG(x && lnw && lnb && W1 && b1 && W2 && b2 && M > 0 && M % 128 == 0, "mlp96: bad argument (M=%d)", M);
+    ProfScope prof(PROF_GEMM, 4.0 * (double)M * 96.0 * 384.0, st);
+    const size_t lds = (size_t)9 * 128 * 64;  // 72 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp96_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mlp96_kernel, dim3(M / 128), dim3(256), lds, st, x, lnw, lnb, W1, b1, W2, b2, eps);
+    WISE_LAUNCH_CHECK("mlp96_kernel");
+    return WISE_OK;
+}
+
 bool gemm_ln_supported(int N, int K, int mode) { return (K == 96 || K == 192) && N % 8 == 0 && bf16_out(mode); }
 
 // out_bf16[M,N] = epi( LayerNorm(x[M,K]; lnw, lnb, eps) @ Wt^T + bias ); M % 128 == 0 (rows readable), K in {96, 192}
@@ -1099,6 +1246,11 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
 }
 
 }  // namespace wise
+
+extern "C" int wise_mlp96_fused(float* x, const float* lnw, const float* lnb, const uint16_t* W1, const float* b1,
+                                const uint16_t* W2, const float* b2, int M, float eps, void* stream) {
+    return wise::mlp96_fused(x, lnw, lnb, W1, b1, W2, b2, M, eps, (hipStream_t)stream);
+}
 
 extern "C" int wise_gemm_ln_bf16(const float* x, const float* lnw, const float* lnb, const uint16_t* Wt, const float* bias,
                                  int M, int N, int K, float eps, int mode, uint16_t* out, void* stream) {

@@ -26,9 +26,12 @@ int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows,
 bool gemm_ln_supported(int N, int K, int mode);
 int gemm_ln_bf16(const float* x, const float* lnw, const float* lnb, const bf16_t* Wt, const float* bias, int M, int N,
                  int K, float eps, int mode, bf16_t* out, hipStream_t st);
+// x[M,96] += fc2(gelu(fc1(LN(x)))) with the hidden layer kept on chip (gemm_bf16.hip)
+int mlp96_fused(float* x, const float* lnw, const float* lnb, const bf16_t* W1, const float* b1, const bf16_t* W2,
+                const float* b2, int M, float eps, hipStream_t st);
 
 namespace htsat {
-static int g_fuse_ln = 1;  // wise_debug_set_htsat(bit 0 = off): A/B the LayerNorm-in-GEMM fusion
+static int g_fuse_ln = 3;  // bit 0: LayerNorm-in-GEMM fusion, bit 1: fused MLP (stage 1); wise_debug_set_htsat flips them off
 constexpr int N_FFT = 1024, HOP = 320, N_MELS = 64, MELW = 32, MAXF = 1024;
 constexpr int EMBED = 96, LATENT = 768, OUT = 1024;
 constexpr int DEPTHS[4] = {2, 2, 6, 2};
@@ -703,7 +706,7 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
             // normalised activations never travel through HBM (LN 71 + GEMM 151 us -> 142 us; LN 71 + 200 -> 205).
             // At C = 192 the fused kernel (one block per CU) loses to LayerNorm + the tuned GEMMs (113 vs 93 us,
             // 173 vs 140 us), so stage 2 keeps the two-kernel form.
-            const bool fuse_ln = g_fuse_ln && C == 96 && gemm_ln_supported(3 * C, C, 0);
+            const bool fuse_ln = (g_fuse_ln & 1) && C == 96 && gemm_ln_supported(3 * C, C, 0);
             if (fuse_ln) {
                 if ((rc = gemm_ln_bf16(x, n1w, n1b, wq, qb, Mp, 3 * C, C, 1e-5f, 0, qkv, st))) return rc;
             } else {
@@ -717,13 +720,18 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
                 WISE_LAUNCH_CHECK("htsat swin_attention_kernel");
             }
             if ((rc = gemm_bf16(h, wproj, pb, Mp, C, C, 3, x, st))) return rc;
-            if (fuse_ln) {
-                if ((rc = gemm_ln_bf16(x, n2w, n2b, wf1, f1b, Mp, 4 * C, C, 1e-5f, 2, a, st))) return rc;
+            if (C == 96 && (g_fuse_ln & 2)) {
+                // the whole MLP in one kernel: the 384-wide hidden activations (403 MB at batch 128) stay on chip
+                if ((rc = mlp96_fused(x, n2w, n2b, wf1, f1b, wf2, f2b, Mp, 1e-5f, st))) return rc;
             } else {
-                if ((rc = layernorm_f32_bf16(x, n2w, n2b, M, C, 1e-5f, h, st))) return rc;
-                if ((rc = gemm_bf16(h, wf1, f1b, Mp, 4 * C, C, 2, a, st))) return rc;
+                if (fuse_ln) {
+                    if ((rc = gemm_ln_bf16(x, n2w, n2b, wf1, f1b, Mp, 4 * C, C, 1e-5f, 2, a, st))) return rc;
+                } else {
+                    if ((rc = layernorm_f32_bf16(x, n2w, n2b, M, C, 1e-5f, h, st))) return rc;
+                    if ((rc = gemm_bf16(h, wf1, f1b, Mp, 4 * C, C, 2, a, st))) return rc;
+                }
+                if ((rc = gemm_bf16(a, wf2, f2b, Mp, C, 4 * C, 3, x, st))) return rc;
             }
-            if ((rc = gemm_bf16(a, wf2, f2b, Mp, C, 4 * C, 3, x, st))) return rc;
         }
         if (i < 3) {
             const float* mp = pf + o.merge_f[i];
@@ -753,7 +761,7 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
 }
 
 extern "C" int wise_debug_set_htsat(int flags) {
-    wise::htsat::g_fuse_ln = (flags & 1) ? 0 : 1;
+    wise::htsat::g_fuse_ln = 3 & ~flags;   // flags bit 0: no LayerNorm fusion at all, bit 1: no fused MLP
     return 0;
 }
 
