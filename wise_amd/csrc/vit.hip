@@ -183,8 +183,10 @@ __device__ __forceinline__ void softmax_block(f32x4 (&sacc)[4][QT], bf16x8 (&pf)
     }
 }
 
+// (register budget stated explicitly: left alone the compiler spends 200-340 registers on load hoisting and the kernel,
+// which lives on latency hiding, drops to 1-2 waves per SIMD)
 template <int QT, bool CAUSAL>
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, int B, int T, int H,
+__global__ __launch_bounds__(256, QT == 2 ? 4 : 2) void attention_kernel(const bf16_t* __restrict__ qkv, int B, int T, int H,
                                                         bf16_t* __restrict__ o) {
     __shared__ __attribute__((aligned(16))) unsigned char v_all[4][64 * V_RS];
     const int lane = threadIdx.x & 63;
@@ -264,10 +266,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
             int klim[QT];  // keys this query sees
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) klim[qt] = CAUSAL ? min(T, qc * (16 * QT) + qt * 16 + l15 + 1) : T;
-            if (CAUSAL || kb * 64 + 64 > T)
-                softmax_block<QT, true>(sacc, pf, oacc, mrun, lrun, kb * 64 + g * 4, klim);
-            else
-                softmax_block<QT, false>(sacc, pf, oacc, mrun, lrun, kb * 64 + g * 4, klim);
+            // masking is a separate small pass (last, partial key block and causal attention only) so that the
+            // softmax body is instantiated once: with both variants inlined the kernel needed 236 registers
+            // instead of ~130 and lost half its occupancy
+            if (CAUSAL || kb * 64 + 64 > T) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kb * 64 + kt * 16 + g * 4 + r >= klim[qt]) sacc[kt][qt][r] = -INFINITY;
+            }
+            softmax_block<QT, false>(sacc, pf, oacc, mrun, lrun, kb * 64 + g * 4, klim);
         }
         // ---- O^T += V^T P^T ; A operand: V^T[dh = dt*16 + l15][slot 8g + j] with
         //      slot j<4 -> key ks*32 + g*4 + j ; j>=4 -> key ks*32 + 16 + g*4 + (j-4)
