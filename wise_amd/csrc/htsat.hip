@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ me
 // ------------------------------------------------------------------------------------------------
 constexpr int VT_LD = 68;
 
-__global__ __launch_bounds__(256) void swin_attention_kernel(const bf16_t* __restrict__ qkv, int B, int H, int W, int C,
+__global__ __launch_bounds__(256, 4) void swin_attention_kernel(const bf16_t* __restrict__ qkv, int B, int H, int W, int C,
                                                              int heads, int shift,
                                                              const float* __restrict__ bias /*[heads][64][64]*/,
                                                              bf16_t* __restrict__ o) {
