@@ -212,14 +212,28 @@ def main():
     out_holder = {}
 
     def vit_step(i):
+        # one step = one batch of 256 frames through the tower.  Batches arrive in a stream (extract-features.py's
+        # loop), so the engine keeps two of them in flight, each on its own stream and workspace
+        # (VitEngine.forward_pipelined); every step's work is complete when the timed region's final sync returns.
+        out_holder["h"] = eng.forward_pipelined(x)
+
+    def vit_step_serial(i):
         out_holder["o"] = eng.forward(x)
 
     if args.roofline_only:
         lib.wise_debug_set_vit_streams(1)
+        vit_step = vit_step_serial
     for i in range(args.warmup):
         vit_step(i)
     dt = timed_region(vit_step, args.steps, world)
     frames_per_s = world * args.batch * args.steps / dt
+    if "h" in out_holder:
+        out_holder["o"] = out_holder["h"].result()
+    serial_dt = None
+    if not args.roofline_only:   # the same K steps one batch at a time (wise_vit_forward: two half batches on two streams)
+        for i in range(2):
+            vit_step_serial(i)
+        serial_dt = timed_region(vit_step_serial, args.steps, world)
     norms = out_holder["o"].norm(dim=1)
     assert bool(torch.isfinite(norms).all()) and abs(float(norms.mean()) - 1.0) < 1e-3, "embeddings not unit-norm"
 
@@ -229,8 +243,8 @@ def main():
     n_gemm_per_fwd = 4 * (4 * spec.layers + 2)  # capacity (split launches, patch embed, projection)
     lib.wise_debug_set_vit_streams(1)
     for i in range(2):
-        vit_step(i)
-    prof = prof_pass(lib, vit_step, args.steps, args.steps * n_gemm_per_fwd + 8)
+        vit_step_serial(i)
+    prof = prof_pass(lib, vit_step_serial, args.steps, args.steps * n_gemm_per_fwd + 8)
     lib.wise_debug_set_vit_streams(2)
     g_ms, g_n, g_flop = prof[0]
     gemm_tflops = (g_flop / g_n) / (g_ms / g_n * 1e-3) / 1e12 if g_n else 0.0
@@ -262,6 +276,9 @@ def main():
         "config": {"workload": "OpenCLIP ViT-B/32 image tower (encode_image + L2 normalise), bs=256 frames per GPU, "
                                "fp32 normalised frames resident in HBM -> [256,512] fp32 unit vectors; "
                                "seeded random weights (no checkpoints offline)",
+                   "batches_in_flight": 2,
+                   "one_batch_at_a_time_frames_per_s": (round(world * args.batch * args.steps / serial_dt, 1)
+                                                        if serial_dt else None),
                    "global_batch": world * args.batch, "frames_per_gpu": args.batch, "parallelism": f"dp{world}",
                    "gflop_per_frame": round(spec.flops_per_frame() / 1e9, 4), "device": dev_name},
         "roofline": roofline,
@@ -400,16 +417,24 @@ def main():
         raw = torch.randint(0, 256, (args.batch, 3, fh, fw), dtype=torch.uint8, device="cuda",
                             generator=torch.Generator(device="cuda").manual_seed(7 + rank))
         pre = ClipPreprocessor(spec.image_size)
-        crop = torch.empty((args.batch, 3, spec.image_size, spec.image_size), dtype=torch.uint8, device="cuda")
+        crops = [torch.empty((args.batch, 3, spec.image_size, spec.image_size), dtype=torch.uint8, device="cuda")
+                 for _ in range(3)]   # a crop buffer is reused only after the forward that read it has long finished
+        crop = crops[0]
+
+        crop_users = [None, None, None]
 
         def u8_step(i):
-            pre(raw, crop)
-            hold["u"] = eng.forward(crop)
+            c = crops[i % 3]
+            if crop_users[i % 3] is not None:
+                crop_users[i % 3].result()     # stream-order: the batch that read this buffer is done (no host sync)
+            pre(raw, c)
+            hold["uh"] = crop_users[i % 3] = eng.forward_pipelined(c)
 
         for i in range(3):
             u8_step(i)
         u_steps = max(5, min(args.steps, 20))
         udt = timed_region(u8_step, u_steps, world)
+        hold["u"] = hold["uh"].result()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(20):
@@ -434,7 +459,7 @@ def main():
                                   "frac": round(pre_bytes / pre_us / 1e3 / PEAK_HBM_GBS, 4),
                                   "traffic": load_pmc_traffic("clip_resize_kernel"),
                                   "frames_per_s": round(args.batch / pre_us * 1e6, 0)}}
-        del raw, crop
+        del raw, crop, crops
         # f4: the query side — CLIP text tower (ViT-B/32 text), one query at a time and in batches of 256
         from wise_amd.feature.text import EOT_TOKEN, SOT_TOKEN, TextEngine, random_text_state_dict, text_spec_for
 

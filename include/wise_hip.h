@@ -124,6 +124,11 @@ size_t wise_vit_workspace_bytes(const wise_vit_config* cfg, int batch);
 int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, const float* pf,
                      const void* images, int in_kind, int batch, float* out, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* The same forward kept entirely on `stream` (wise_vit_forward splits a batch of >= 64 images into two halves on two
+ * internal streams).  For callers that pipeline whole batches themselves — two in flight, each with its own stream and
+ * workspace; workspace_bytes as reported by wise_vit_workspace_bytes. */
+int wise_vit_forward_single(const wise_vit_config* cfg, const uint16_t* wb, const float* pf, const void* images,
+                            int in_kind, int batch, float* out, void* workspace, size_t workspace_bytes, void* stream);
 /* Debug/parity tap: copy the residual stream x [B*T, W] fp32 as it stands after `after_layer`
  * blocks (0 = after ln_pre) from the workspace of the LAST forward into dst. */
 int wise_vit_tap_residual(const wise_vit_config* cfg, int batch, const void* workspace, float* dst,

@@ -230,3 +230,23 @@ def test_fused_mlp96(M):
     torch.cuda.synchronize()
     err = (xd.cpu().double() - ref).abs().max().item()
     assert err <= 2e-2, err
+
+
+def test_pipelined_batches_equal_one_at_a_time():
+    """VitEngine.forward_pipelined (two batches in flight, each on its own stream and workspace) must return exactly
+    what forward() returns, for every batch, whatever order the results are collected in."""
+    spec = spec_for("ViT-B-32", "openai")
+    eng = VitEngine(spec, random_state_dict(spec, 0), max_batch=96)
+    g = torch.Generator().manual_seed(5)
+    batches = [torch.randn(n, 3, 224, 224, generator=g).cuda() for n in (96, 64, 96, 33, 96)]
+    want = [eng.forward(b).clone() for b in batches]
+    torch.cuda.synchronize()
+    handles = [eng.forward_pipelined(b) for b in batches]
+    got = [h.result() for h in reversed(handles)][::-1]
+    torch.cuda.synchronize()
+    for w, o in zip(want, got):
+        assert torch.equal(w, o)
+    u8 = (torch.rand(70, 3, 224, 224, generator=g) * 255).to(torch.uint8).cuda()
+    assert torch.equal(eng.forward_pipelined(u8).result(), eng.forward(u8))
+    with pytest.raises(ValueError):
+        eng.forward_pipelined(torch.zeros(2, 3, 32, 32, device="cuda"))

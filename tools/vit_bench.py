@@ -37,8 +37,12 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n = 20 if model == "ViT-B-32" else 5
-        for _ in range(n):
-            o = eng.forward(x)
+        if "--pipe" in sys.argv:   # two whole batches in flight (VitEngine.forward_pipelined)
+            hs = [eng.forward_pipelined(x) for _ in range(n)]
+            o = hs[-1].result()
+        else:
+            for _ in range(n):
+                o = eng.forward(x)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         if ref is None:

@@ -46,6 +46,7 @@ SIGNATURES = {
     "wise_vit_layout": (_i, [C.POINTER(VitConfig), C.POINTER(_i64), C.POINTER(_i64)]),
     "wise_vit_workspace_bytes": (_sz, [C.POINTER(VitConfig), _i]),
     "wise_vit_forward": (_i, [C.POINTER(VitConfig), _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "wise_vit_forward_single": (_i, [C.POINTER(VitConfig), _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "wise_vit_tap_residual": (_i, [C.POINTER(VitConfig), _i, _vp, _vp, _vp]),
     "wise_htsat_layout": (_i, [C.POINTER(_i64), C.POINTER(_i64)]),
     "wise_htsat_workspace_bytes": (_sz, [_i, _i]),

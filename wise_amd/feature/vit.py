@@ -148,6 +148,18 @@ def pack_weights(spec: VitSpec, sd: Dict[str, torch.Tensor]):
     return wb_t, pf_t
 
 
+class PendingEmbeddings:
+    """Handle of a batch enqueued by VitEngine.forward_pipelined."""
+
+    def __init__(self, out: torch.Tensor, done: "torch.cuda.Event"):
+        self._out, self._done = out, done
+
+    def result(self) -> torch.Tensor:
+        """The embeddings [B, D], ordered after the batch on the caller's current stream (no host sync)."""
+        torch.cuda.current_stream(self._out.device).wait_event(self._done)
+        return self._out
+
+
 class VitEngine:
     """Owns the device copies of the two weight blobs and a workspace; `forward` launches the HIP
     pipeline on the current torch stream and returns a device tensor [B, D] fp32 (L2-normalised)."""
@@ -196,6 +208,48 @@ class VitEngine:
                                        out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "wise_vit_forward")
         return out
+
+    # -- two whole batches in flight ---------------------------------------------------------------
+    def forward_pipelined(self, images: torch.Tensor) -> "PendingEmbeddings":
+        """Enqueue one batch and return at once; `.result()` of the returned handle gives the embeddings.
+
+        Successive calls alternate between two slots, each with its own stream and workspace, so the GPU always
+        holds two whole batches: a batch runs with full-batch GEMM shapes (which tile the chip better than the
+        half batches of `forward`) and the other batch's kernels fill its LayerNorm / attention phases and tails.
+        Use it where batches arrive in a stream (extract-features style loops) and a result is consumed one batch
+        later; `forward` stays the call for a single batch."""
+        S = self.spec.image_size
+        if images.dim() != 4 or tuple(images.shape[1:]) != (3, S, S):
+            raise ValueError(f"expected [B,3,{S},{S}], got {tuple(images.shape)}")
+        if images.dtype == torch.uint8:
+            kind = _lib.WISE_VIT_IN_U8
+        elif images.dtype == torch.float32:
+            kind = _lib.WISE_VIT_IN_F32
+        else:
+            raise ValueError(f"images must be float32 or uint8, got {images.dtype}")
+        x = images.to(self.device).contiguous()
+        B = x.shape[0]
+        if not hasattr(self, "_slots"):
+            self._slots, self._next_slot = [], 0
+        need = self.lib.wise_vit_workspace_bytes(C.byref(self.cfg), B)
+        while len(self._slots) < 2:
+            self._slots.append({"stream": torch.cuda.Stream(device=self.device), "ws": None})
+        slot = self._slots[self._next_slot]
+        self._next_slot ^= 1
+        if slot["ws"] is None or slot["ws"].numel() < need:
+            slot["ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        slot["stream"].wait_stream(cur)              # the batch was produced on the caller's stream
+        out = torch.empty(B, self.spec.embed_dim, dtype=torch.float32, device=self.device)
+        x.record_stream(slot["stream"])
+        out.record_stream(slot["stream"])
+        rc = self.lib.wise_vit_forward_single(C.byref(self.cfg), self.wb.data_ptr(), self.pf.data_ptr(), x.data_ptr(),
+                                              kind, B, out.data_ptr(), slot["ws"].data_ptr(), slot["ws"].numel(),
+                                              slot["stream"].cuda_stream)
+        _lib.check(rc, "wise_vit_forward_single")
+        done = torch.cuda.Event()
+        done.record(slot["stream"])
+        return PendingEmbeddings(out, done)
 
     def residual(self, batch: int) -> torch.Tensor:
         """Residual stream [B*T, W] fp32 left by the last forward (parity tap)."""
