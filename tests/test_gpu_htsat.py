@@ -86,3 +86,75 @@ def test_microsoft_clap_plugin_surface(waves, golden_dir):
     # the reference's own test feeds 408700 samples and checks the dim only (test_feature_extractor.py:37-41)
     long = fx.extract_audio_features(fx.preprocess_audio(torch.rand(1, 408700)))
     assert long.shape == (1, 1024)
+
+
+def test_two_batches_in_flight_equal_serial():
+    """HtsatEngine.forward_pipelined: two forwards overlapping on two streams return what one forward returns alone,
+    bit for bit, every time (the STFT kernel once did not: see the note at the top of csrc/htsat_frontend.hip)."""
+    B, N = 16, 480000
+    eng = HtsatEngine(random_htsat_state_dict(0), max_batch=B, max_samples=N)
+    w = 0.1 * torch.randn(B, N, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    ref = eng.forward(w).clone()
+    for _ in range(6):
+        pending = [eng.forward_pipelined(w) for _ in range(4)]
+        for p in pending:
+            assert torch.equal(p.result(), ref)
+
+
+def test_frontend_beside_matrix_kernels():
+    """The log-mel front end run while another stream keeps the matrix cores busy (the fused HTSAT MLP, and a bare
+    MFMA loop sized to share compute units with it) is bit-identical to the front end run alone."""
+    import ctypes
+
+    from wise_amd import _lib
+    lib = _lib.lib()
+    lib.wise_debug_neighbour.restype = ctypes.c_int
+    lib.wise_debug_neighbour.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3
+    B, N, Fc = 16, 480000, 1024
+    eng = HtsatEngine(random_htsat_state_dict(0), max_batch=B, max_samples=N)
+    w = 0.1 * torch.randn(B, N, device="cuda", generator=torch.Generator("cuda").manual_seed(5))
+    need = lib.wise_htsat_workspace_bytes(B, N)
+    wss = [torch.empty(need, dtype=torch.uint8, device="cuda") for _ in range(8)]
+    out = torch.empty(B, 1024, device="cuda")
+    s_front, s_other = torch.cuda.Stream(), torch.cuda.Stream()
+    M = 131072
+    x = torch.randn(M, 96, device="cuda")
+    lnw, lnb = torch.ones(96, device="cuda"), torch.zeros(96, device="cuda")
+    W1 = (0.05 * torch.randn(384, 96, device="cuda")).bfloat16(); b1 = torch.zeros(384, device="cuda")
+    W2 = (0.05 * torch.randn(96, 384, device="cuda")).bfloat16(); b2 = torch.zeros(96, device="cuda")
+    src = torch.zeros(1024, dtype=torch.int32, device="cuda"); sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+    P = lambda t: t.data_ptr()
+    neighbours = {
+        "fused MLP": lambda: lib.wise_mlp96_fused(P(x), P(lnw), P(lnb), P(W1), P(b1), P(W2), P(b2), M, 1e-5,
+                                                  s_other.cuda_stream),
+        "MFMA loop": lambda: lib.wise_debug_neighbour(3, 2048, 61440, 64, P(src), P(sink), s_other.cuda_stream),
+    }
+
+    def front(ws):
+        _lib.check(lib.wise_htsat_forward(eng.wb.data_ptr(), eng.pf.data_ptr(), w.data_ptr(), B, N, out.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), s_front.cuda_stream), "front end")
+
+    def mel_of(ws):
+        mel = torch.empty(B * Fc, 64, device="cuda")
+        _lib.check(lib.wise_htsat_tap(0, ws.data_ptr(), B, N, mel.data_ptr(), mel.numel(), _lib.stream_ptr()), "tap")
+        torch.cuda.synchronize()
+        return mel
+
+    lib.wise_debug_set_htsat(8)   # stop after the front end
+    try:
+        torch.cuda.synchronize()
+        front(wss[0]); torch.cuda.synchronize()
+        alone = mel_of(wss[0])
+        for name, fn in neighbours.items():
+            for ws in wss:
+                ws[:B * Fc * 256].zero_()
+            torch.cuda.synchronize()
+            for ws in wss:
+                for _ in range(3):
+                    _lib.check(fn(), name)
+                front(ws)
+            torch.cuda.synchronize()
+            wrong = sum(0 if torch.equal(mel_of(ws), alone) else 1 for ws in wss)
+            assert wrong == 0, f"{wrong} of {len(wss)} front ends differ beside {name}"
+    finally:
+        lib.wise_debug_set_htsat(0)

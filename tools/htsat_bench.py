@@ -29,3 +29,14 @@ for flags in (0, 2, 1, 0, 2, 1):   # bit 0: no LayerNorm fusion at all, bit 1: n
     print(f"HTSAT B={B} N={N} flags={flags}: {dt*1e3:.3f} ms/step  {B/dt:.1f} clips/s  {B/dt*11.82e9/1e12:.1f} TFLOP/s",
           flush=True)
 lib.wise_debug_set_htsat(0)
+o = eng.forward(w).clone()
+torch.cuda.synchronize()
+for rep in range(2):
+    hs = [eng.forward_pipelined(w) for _ in range(3)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hs = [eng.forward_pipelined(w) for _ in range(10)]
+    o2 = hs[-1].result()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    print(f"HTSAT B={B} N={N} two batches in flight: {dt*1e3:.3f} ms/step  {B/dt:.1f} clips/s  same={torch.equal(o, o2)}", flush=True)

@@ -16,8 +16,10 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libwise_hip.so"
-HIP_SOURCES = ["common.hip", "ip_topk.hip", "ip_topk_mfma.hip", "gemm_bf16.hip", "vit.hip", "htsat.hip", "preprocess.hip", "text.hip"]
+HIP_SOURCES = ["common.hip", "ip_topk.hip", "ip_topk_mfma.hip", "gemm_bf16.hip", "vit.hip", "htsat.hip", "htsat_frontend.hip", "preprocess.hip", "text.hip", "debug_probe.hip"]
 ARCH = "gfx950"
+# per-file flags; htsat_frontend.hip: see the note at the top of that file
+FILE_FLAGS = {"htsat_frontend.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(target: Path, deps) -> bool:
@@ -49,7 +51,7 @@ def build_hip(force: bool = False, verbose: bool = False, extra_flags=()) -> Pat
         objs.append(o)
         if force or _newer(o, [s] + list(CSRC.glob("*.h")) + [ROOT / "include" / "wise_hip.h"]):
             cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(s), "-o", str(o),
-                   *extra_flags]
+                   *FILE_FLAGS.get(s.name, ()), *extra_flags]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

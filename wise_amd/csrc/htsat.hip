@@ -31,178 +31,16 @@ int mlp96_fused(float* x, const float* lnw, const float* lnb, const bf16_t* W1, 
                 const float* b2, int M, float eps, hipStream_t st);
 
 namespace htsat {
+// htsat_frontend.hip
+int frontend(const float* wave, int B, int samples, int Fc, const float* hann, const float* mel_start,
+             const float* mel_len, const float* mel_wt, const float* bn_scale, const float* bn_shift, float* melbn,
+             hipStream_t st);
+static int g_frontend_only = 0;  // (debug) stop after the front end: concurrency tests tap the log-mel
 static int g_fuse_ln = 3;  // bit 0: LayerNorm-in-GEMM fusion, bit 1: fused MLP (stage 1); wise_debug_set_htsat flips them off
 constexpr int N_FFT = 1024, HOP = 320, N_MELS = 64, MELW = 32, MAXF = 1024;
 constexpr int EMBED = 96, LATENT = 768, OUT = 1024;
 constexpr int DEPTHS[4] = {2, 2, 6, 2};
 constexpr int HEADS[4] = {4, 8, 16, 32};
-
-// ------------------------------------------------------------------------------------------------
-// frontend: a wave computes one STFT frame at a time and loops over frames (persistent grid)
-//
-// 1024-point radix-2 decimation-in-time FFT, butterflies in exactly the textbook order, but each lane keeps 16
-// points in registers and runs 4 + 4 + 2 stages there; only the two regroupings between them go through LDS:
-//   group 1 (stages 1-4):  lane L owns the contiguous points 16L .. 16L+15 of the bit-reversed sequence.  It
-//                          loads them straight from global memory: x[brev4(e)*64 + brev6(L)] — for a fixed e
-//                          the wave reads one contiguous 256-byte window;
-//   exchange 1:            64 x 16 transpose through a pitch-17 image;
-//   group 2 (stages 5-8):  lane (blk, r) owns points blk*256 + r + 16q, q < 16;
-//   exchange 2:            natural order, 16 points of padding per 256 so the four blk groups use both
-//                          halves of the banks;
-//   group 3 (stages 9-10): lane owns points lane + 64u + 256q', u, q' < 4; |X|^2 of bins 0..512 go to LDS
-//                          for the mel filterbank.
-// Twiddles tw[half + j] = exp(-i*pi*j/half) come from a table built once per process (fft_twiddle_kernel);
-// every per-lane twiddle, the lane's Hann taps and its mel weights are loaded once, before the frame loop.
-// ------------------------------------------------------------------------------------------------
-__device__ float2 g_fft_tw[1024];
-
-__global__ void fft_twiddle_kernel() {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 1024) return;
-    const int half = idx ? (1 << (31 - __clz(idx))) : 1;
-    const int j = idx - half;
-    float s, c;
-    sincospif(idx ? (float)j / (float)half : 0.f, &s, &c);
-    g_fft_tw[idx] = make_float2(c, -s);
-}
-
-// one radix-2 butterfly, the arithmetic of the stage loop it replaces
-__device__ __forceinline__ void bfly(float2& a, float2& q, const float2 t) {
-    const float tr = t.x * q.x - t.y * q.y, ti = t.x * q.y + t.y * q.x;
-    const float2 a0 = a;
-    a = make_float2(a0.x + tr, a0.y + ti);
-    q = make_float2(a0.x - tr, a0.y - ti);
-}
-
-constexpr int FFT_LDS = 1088;  // float2 per wave: max(64 * 17, 1024 + 3 * 16)
-
-__global__ __launch_bounds__(256, 2) void frontend_kernel(const float* __restrict__ wave, int B, int N, int Fc,
-                                                          const float* __restrict__ hann,
-                                                          const float* __restrict__ mel_start,
-                                                          const float* __restrict__ mel_len,
-                                                          const float* __restrict__ mel_wt /*[MELW][64]*/,
-                                                          const float* __restrict__ bn_scale,
-                                                          const float* __restrict__ bn_shift,
-                                                          float* __restrict__ melbn /*[B,Fc,64]*/) {
-    __shared__ float2 bufs[4][FFT_LDS];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float2* buf = bufs[wv];
-    const float2* __restrict__ tw = g_fft_tw;
-    const int brev6 = (int)(__brev((unsigned)lane) >> 26);
-    const int blk = lane >> 4, r = lane & 15;
-
-    // ---- per-lane constants
-    float hw[16];            // Hann taps of the lane's 16 input samples
-#pragma unroll
-    for (int e = 0; e < 16; ++e) hw[e] = hann[(int)(__brev((unsigned)e) >> 28) * 64 + brev6];
-    float2 t2[15];           // group 2: stage 5 -> t2[0], stage 6 -> t2[1..2], stage 7 -> t2[3..6], stage 8 -> t2[7..14]
-#pragma unroll
-    for (int sg = 0; sg < 4; ++sg)
-#pragma unroll
-        for (int jl = 0; jl < (1 << sg); ++jl) t2[(1 << sg) - 1 + jl] = tw[(16 << sg) + r + 16 * jl];
-    float2 t9[4], t10[8];    // group 3: stage 9 twiddle per u, stage 10 per (u, pair)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        t9[u] = tw[256 + lane + 64 * u];
-        t10[2 * u] = tw[512 + lane + 64 * u];
-        t10[2 * u + 1] = tw[512 + lane + 64 * u + 256];
-    }
-    const int mst = (int)mel_start[lane], mln = (int)mel_len[lane];
-    float mw[MELW];
-#pragma unroll
-    for (int j = 0; j < MELW; ++j) mw[j] = (j < mln) ? mel_wt[j * 64 + lane] : 0.f;
-    const float bsc = bn_scale[lane], bsh = bn_shift[lane];
-
-    const long long total = (long long)B * Fc;
-    for (long long fid = (long long)blockIdx.x * 4 + wv; fid < total; fid += (long long)gridDim.x * 4) {
-        const int b = (int)(fid / Fc), f = (int)(fid % Fc);
-        const float* w = wave + (size_t)b * N;
-        float2 v[16];
-        // ---- group 1: bit-reversed points 16*lane + e  <-  sample brev4(e)*64 + brev6(lane), reflect padded
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int n = (int)(__brev((unsigned)e) >> 28) * 64 + brev6;
-            int s = f * HOP - N_FFT / 2 + n;
-            if (s < 0) s = -s;
-            if (s >= N) s = 2 * (N - 1) - s;
-            v[e] = make_float2(w[s] * hw[e], 0.f);
-        }
-#pragma unroll
-        for (int st = 1; st <= 4; ++st) {
-            const int half = 1 << (st - 1);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int j = k & (half - 1);
-                const int i0 = ((k >> (st - 1)) << st) + j;
-                bfly(v[i0], v[i0 + half], tw[half + j]);   // wave-uniform table entries
-            }
-        }
-        // ---- exchange 1: (L1 = point >> 4, e = point & 15) kept at L1*17 + e
-#pragma unroll
-        for (int e = 0; e < 16; ++e) buf[lane * 17 + e] = v[e];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = buf[(blk * 16 + q) * 17 + r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- group 2: stages 5-8 on points blk*256 + r + 16q
-#pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
-            const int hq = 1 << sg;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int jl = k & (hq - 1);
-                const int q0 = ((k >> sg) << (sg + 1)) + jl;
-                bfly(v[q0], v[q0 + hq], t2[hq - 1 + jl]);
-            }
-        }
-        // ---- exchange 2: point p kept at p + (p >> 8) * 16
-#pragma unroll
-        for (int q = 0; q < 16; ++q) buf[blk * 272 + r + 16 * q] = v[q];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[qq * 4 + u] = buf[qq * 272 + lane + 64 * u];   // point lane + 64u + 256qq
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- group 3: stage 9 pairs (q' = 0,1), (2,3); stage 10 pairs (0,2), (1,3)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            bfly(v[0 * 4 + u], v[1 * 4 + u], t9[u]);
-            bfly(v[2 * 4 + u], v[3 * 4 + u], t9[u]);
-            bfly(v[0 * 4 + u], v[2 * 4 + u], t10[2 * u]);
-            bfly(v[1 * 4 + u], v[3 * 4 + u], t10[2 * u + 1]);
-        }
-        // ---- power of bins 0..512 -> LDS (float view of the wave's buffer)
-        float* pw = reinterpret_cast<float*>(buf);
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float2 x = v[qq * 4 + u];
-                pw[qq * 256 + lane + 64 * u] = x.x * x.x + x.y * x.y;
-            }
-        if (lane == 0) pw[512] = v[8].x * v[8].x + v[8].y * v[8].y;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < MELW; ++j) acc = fmaf(mw[j], pw[min(mst + j, 512)], acc);
-        const float db = 10.f * log10f(fmaxf(acc, 1e-10f));
-        melbn[((size_t)b * Fc + f) * 64 + lane] = db * bsc + bsh;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // embed: wave per token (b, i, j) of the 64x64 grid
@@ -671,19 +509,10 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
     const int B = batch, Fc = ws.Fc;
     int rc;
 
-    {
-        static bool twiddles_ready = false;  // the table lives in a __device__ array: build it on first use
-        if (!twiddles_ready) {
-            hipLaunchKernelGGL(fft_twiddle_kernel, dim3(4), dim3(256), 0, st);
-            WISE_LAUNCH_CHECK("htsat fft_twiddle_kernel");
-            twiddles_ready = true;
-        }
-        const long long fblocks = ((long long)B * Fc + 3) / 4;
-        hipLaunchKernelGGL(frontend_kernel, dim3((unsigned)(fblocks < 512 ? fblocks : 512)), dim3(256), 0, st, wave, B,
-                           samples, Fc, pf + o.hann, pf + o.mel_start, pf + o.mel_len, pf + o.mel_wt, pf + o.bn_scale,
-                           pf + o.bn_shift, mel);
-    }
-    WISE_LAUNCH_CHECK("htsat frontend_kernel");
+    if ((rc = frontend(wave, B, samples, Fc, pf + o.hann, pf + o.mel_start, pf + o.mel_len, pf + o.mel_wt, pf + o.bn_scale,
+                       pf + o.bn_shift, mel, st)))
+        return rc;
+    if (g_frontend_only) return WISE_OK;
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)(B * 64)), dim3(256), 0, st, mel, B, Fc,
                        pf + o.pe_w, pf + o.pe_b, pf + o.pe_nw, pf + o.pe_nb, x);
     WISE_LAUNCH_CHECK("htsat embed_kernel");
@@ -762,6 +591,7 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
 
 extern "C" int wise_debug_set_htsat(int flags) {
     wise::htsat::g_fuse_ln = 3 & ~flags;   // flags bit 0: no LayerNorm fusion at all, bit 1: no fused MLP
+    wise::htsat::g_frontend_only = (flags >> 3) & 1;   // bit 3: front end only
     return 0;
 }
 

@@ -128,6 +128,36 @@ class HtsatEngine:
         self._last = (B, N)
         return out
 
+    def forward_pipelined(self, wave: torch.Tensor):
+        """Enqueue one batch of clips and return a handle at once (`.result()` -> embeddings): successive calls
+        alternate between two slots, each with its own stream and workspace, so two batches are in flight (same
+        scheme and same caveats as VitEngine.forward_pipelined)."""
+        from .vit import PendingEmbeddings
+        if wave.dim() != 2:
+            raise ValueError(f"expected [B, samples], got {tuple(wave.shape)}")
+        x = wave.to(self.device, torch.float32).contiguous()
+        B, N = x.shape
+        if N < N_FFT // 2 + 1:
+            raise ValueError(f"audio too short for a reflect-padded STFT: {N} samples")
+        if not hasattr(self, "_slots"):
+            self._slots, self._next_slot = [{"stream": torch.cuda.Stream(device=self.device), "ws": None}
+                                            for _ in range(2)], 0
+        need = self.lib.wise_htsat_workspace_bytes(B, N)
+        slot = self._slots[self._next_slot]
+        self._next_slot ^= 1
+        if slot["ws"] is None or slot["ws"].numel() < need:
+            slot["ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        slot["stream"].wait_stream(torch.cuda.current_stream(self.device))
+        out = torch.empty(B, OUT_DIM, dtype=torch.float32, device=self.device)
+        x.record_stream(slot["stream"])
+        out.record_stream(slot["stream"])
+        rc = self.lib.wise_htsat_forward(self.wb.data_ptr(), self.pf.data_ptr(), x.data_ptr(), B, N, out.data_ptr(),
+                                         slot["ws"].data_ptr(), slot["ws"].numel(), slot["stream"].cuda_stream)
+        _lib.check(rc, "wise_htsat_forward")
+        done = torch.cuda.Event()
+        done.record(slot["stream"])
+        return PendingEmbeddings(out, done)
+
     def tap(self, what: int, rows: int, cols: int) -> torch.Tensor:
         """parity taps: 0 = log-mel+bn [B*frames,64] fp32, 1 = residual stream x fp32 [rows, cols]."""
         out = torch.empty(rows, cols, dtype=torch.float32, device=self.device)
