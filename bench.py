@@ -333,6 +333,15 @@ def main():
         for i in range(3):
             search32(i)
         sdt32 = timed_region(search32, s_steps, world)
+
+        def search256(i):  # cfg-3's nq=256 point: eight 32-query passes per call
+            j = (256 * i) % 744
+            res["DI256"] = index.search_device(Q[j:j + 256], k)
+
+        for i in range(2):
+            search256(i)
+        s256 = max(4, s_steps // 5)
+        sdt256 = timed_region(search256, s256, world)
         D32, I32 = index.search_device(Q[:32], k)
         D1, I1 = index.search_device(Q[:1], k)
         # the two kernels sum the d products in different orders: same ids, scores to the tested 2e-5
@@ -353,6 +362,7 @@ def main():
             "batched_nq4_queries_per_s": round(4 * s_steps / sdt4, 2),
             "batched_nq32_queries_per_s": round(32 * s_steps / sdt32, 2),
             "batched_nq32_ms_per_pass": round(sdt32 / s_steps * 1e3, 4),
+            "batched_nq256_queries_per_s": round(256 * s256 / sdt256, 2),
             "batched_nq32_roofline": {"kernel": "ip_scan_mfma_kernel", "bound": "hbm",
                                       "achieved": round(N * d * 4 / world / (sdt32 / s_steps) / 1e9, 1),
                                       "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -375,16 +385,26 @@ def main():
                                 device="cuda")
         hold = {}
 
-        def clap_step(i):
+        def clap_step_serial(i):
             hold["o"] = heng.forward(wav)
 
+        def clap_step(i):  # two batches in flight, like the headline leg
+            hold["p"] = heng.forward_pipelined(wav)
+
+        for i in range(2):
+            clap_step_serial(i)
+        a_steps = max(4, min(args.steps, 10))
+        adt_serial = timed_region(clap_step_serial, a_steps, world)
         for i in range(2):
             clap_step(i)
-        a_steps = max(3, min(args.steps, 10))
+        torch.cuda.synchronize()
         adt = timed_region(clap_step, a_steps, world)
         assert abs(float(hold["o"].norm(dim=1).mean()) - 1.0) < 1e-3
+        assert torch.equal(hold["p"].result(), hold["o"]), "HTSAT: in-flight and serial embeddings differ"
         extra["clap_htsat"] = {"value": round(world * ab * a_steps / adt, 1), "unit": "clips/s",
                                "ms_per_step": round(adt / a_steps * 1e3, 3), "steps": a_steps,
+                               "batches_in_flight": 2,
+                               "one_batch_at_a_time_clips_per_s": round(world * ab * a_steps / adt_serial, 1),
                                "config": {"workload": "MS-CLAP 2023 HTSAT audio encoder + projection, 10-s clips "
                                                       "(480000 samples @48 kHz), bs=128 per GPU", "dtype": "bf16",
                                           "gflop_per_clip": 11.82},
@@ -396,15 +416,25 @@ def main():
         leng = VitEngine(lspec, random_state_dict(lspec, 0), max_batch=args.batch)
 
         def l14_step(i):
-            hold["l"] = leng.forward(x)
+            hold["l"] = leng.forward_pipelined(x)
 
+        def l14_step_serial(i):
+            hold["ls"] = leng.forward(x)
+
+        l_steps = max(4, min(args.steps, 6))
+        for i in range(2):
+            l14_step_serial(i)
+        ldt_serial = timed_region(l14_step_serial, l_steps, world)
         for i in range(2):
             l14_step(i)
-        l_steps = max(3, min(args.steps, 5))
+        torch.cuda.synchronize()
         ldt = timed_region(l14_step, l_steps, world)
+        assert torch.equal(hold["l"].result(), hold["ls"]), "ViT-L/14: in-flight and serial embeddings differ"
         lfps = world * args.batch * l_steps / ldt
         extra["vit_l14"] = {"value": round(lfps, 1), "unit": "frames/s", "ms_per_step": round(ldt / l_steps * 1e3, 3),
-                            "steps": l_steps, "config": {"workload": "OpenCLIP ViT-L/14 image tower, bs=256 per GPU",
+                            "steps": l_steps, "batches_in_flight": 2,
+                            "one_batch_at_a_time_frames_per_s": round(world * args.batch * l_steps / ldt_serial, 1),
+                            "config": {"workload": "OpenCLIP ViT-L/14 image tower, bs=256 per GPU",
                                                          "gflop_per_frame": round(lspec.flops_per_frame() / 1e9, 2)},
                             "tflops": round(lfps / world * lspec.flops_per_frame() / 1e12, 2),
                             "frac_of_bf16_peak": round(lfps / world * lspec.flops_per_frame() / 1e12 / PEAK_BF16_TFLOPS, 4)}
