@@ -161,3 +161,25 @@ def test_batched_path_matches_single_query_path_and_ties():
         Ds, Is = idx.search(Q[q:q + 1], 10)
         assert np.array_equal(Is[0], Ib[q]), q
         assert np.allclose(Ds[0], Db[q], atol=2e-6)
+
+
+def test_batched_split_candidates_resolve_near_ties():
+    """The batched scan ranks candidates by split-bf16 scores (error <= 1.6e-5) and re-scores the best 16 in f32:
+    a cluster of 14 rows whose scores differ by ~1e-5 must still come back in exact f32 order."""
+    N, d, k = 40000, 512, 10
+    X = unit_rows(N, d, 41)
+    q = unit_rows(1, d, 42)[0]
+    rng = np.random.default_rng(43)
+    cluster = rng.choice(N, size=14, replace=False)
+    for c in cluster:
+        v = q + 3e-3 * rng.standard_normal(d).astype(np.float32)
+        X[c] = v / np.linalg.norm(v)
+    Q = np.concatenate([q[None], unit_rows(15, d, 44)], axis=0)
+    ids = np.arange(N, dtype=np.int64) + 1
+    idx = FlatIPIndex(d)
+    idx.add_with_ids(X, ids)
+    D, I = idx.search(Q, k)
+    check_against_oracle(X, Q, k, ids, D, I)
+    assert set(I[0]) <= set(cluster + 1)
+    Ds, Is = idx.search(Q[:1], k)          # the single-query (VALU) path agrees
+    assert np.array_equal(Is[0], I[0])

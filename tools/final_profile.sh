@@ -25,4 +25,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
   cp "$(find $OUT/${TAG}_pmc_${L}_pre -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_pmc_${L}_pre_counter_collection.csv
   echo "$C passes done"
 done
+# matrix-core utilisation of the GEMM launches: busy cycles of the MFMA pipes over the launch's cycles (own pass)
+timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_mfma -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --roofline-only > $OUT/${TAG}_pmc_mfma.log 2>&1 || exit 1
+cp "$(find $OUT/${TAG}_pmc_mfma -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_pmc_mfma_counter_collection.csv
+echo "MFMA pass done"
 ls -la $OUT | tail -12

@@ -1,0 +1,30 @@
+"""batched flat scan (10M x 512, top-10): the variants behind wise_debug_set_scan, timed and cross-checked"""
+import sys, time
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from wise_amd import _lib
+from wise_amd.index.flat_ip import FlatIPIndex
+lib = _lib.lib()
+N, d = 10_000_000, 512
+X = torch.nn.functional.normalize(torch.randn(N, d, device="cuda"), dim=1)
+idx = FlatIPIndex(d).adopt(X)
+Q = torch.nn.functional.normalize(torch.randn(256, d, device="cuda"), dim=1)
+variants = [("f32 MFMA, DMA ring", 1 << 11), ("split-bf16, DMA ring", 8 << 12), ("split regs x4, no sample", (4 << 12) | (1 << 16)),
+            ("split regs x4, sample 32K", (4 << 12) | (2 << 17)), ("split regs x4, sample 128K", (4 << 12) | (8 << 17)),
+            ("split regs x4, sample 512K", (4 << 12) | (32 << 17)), ("split regs x3, sample 128K", (3 << 12) | (8 << 17))]
+ref = None
+for name, flags in variants * 2:
+    lib.wise_debug_set_scan(4 | flags, 0)
+    for nq in (32, 256):
+        for _ in range(2): D, I = idx.search_device(Q[:nq], 10)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        n = 6 if nq == 32 else 2
+        for _ in range(n): D, I = idx.search_device(Q[:nq], 10)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+        msg = f"{name:28s} nq={nq:3d}: {dt * 1e3 / (nq // 32):.3f} ms/pass  {nq / dt:.0f} q/s"
+        if nq == 256:
+            if ref is None: ref = (D.clone(), I.clone())
+            msg += f"  ids equal to first: {bool(torch.equal(I, ref[1]))}  max |dscore| {float((D - ref[0]).abs().max()):.2e}"
+        print(msg, flush=True)
+lib.wise_debug_set_scan(4, 0)

@@ -25,7 +25,17 @@ constexpr int MFMA_KL = 16;   // per-lane list length: the path serves k <= 16
 bool mfma_scan_supported(int d, int nq, int k);
 int mfma_scan_lists(long long N);                    // P: partial lists per query the scan leaves
 size_t mfma_scan_part_bytes(long long N, int k);     // P * MFMA_QB * k keys
+constexpr int MFMA_KC = 12;   // largest k the split-bf16 candidate scan serves (16 candidates, exact re-scoring)
+bool mfma_split_supported(int d, int nq, int k);
 int mfma_scan_launch(const float* X, long long N, int d, const float* qpad /*[32][d], zero rows past nq*/, int nq,
-                     int k, u64* part, hipStream_t st);
+                     int k, u64* part, bool split, hipStream_t st);
+// the register-queue split scan over a row range, and the sample-pass threshold (ip_topk_mfma.hip)
+int split_scan_launch(const float* X, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
+                      const u64* tau0, hipStream_t st);
+bool split_direct_enabled();
+int sample_threshold_launch(const float* cand_scores, const long long* cand_rows, u64* tau0, hipStream_t st);
+// exact f32 scores of cand_rows [nq][MFMA_KL], ordered, first k -> outD/outI [nq][k]
+int rescore_launch(const float* X, int d, const float* Q, const long long* cand_rows, int nq, int k, const long long* ids,
+                   long long id_base, float* outD, long long* outI, hipStream_t st);
 
 }  // namespace wise
