@@ -326,7 +326,7 @@ def main():
             search4(i)
         sdt4 = timed_region(search4, s_steps, world)
 
-        def search32(i):  # the batched form: 32 queries share one pass on the fp32 matrix cores
+        def search32(i):  # the batched form: 32 queries share one pass over X (matrix cores)
             j = (32 * i) % 960
             res["DI32"] = index.search_device(Q[j:j + 32], k)
 
@@ -363,12 +363,20 @@ def main():
             "batched_nq32_queries_per_s": round(32 * s_steps / sdt32, 2),
             "batched_nq32_ms_per_pass": round(sdt32 / s_steps * 1e3, 4),
             "batched_nq256_queries_per_s": round(256 * s256 / sdt256, 2),
-            "batched_nq32_roofline": {"kernel": "ip_scan_mfma_kernel", "bound": "hbm",
+            "batched_nq256_roofline": {"kernel": "ip_scan_split64_kernel", "bound": "hbm",
+                                       "achieved": round(N * d * 4 / world / (sdt256 / s256 / 4) / 1e9, 1),
+                                       "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                       "frac": round(N * d * 4 / world / (sdt256 / s256 / 4) / 1e9 / PEAK_HBM_GBS, 4),
+                                       "note": "whole call / 4 passes of 64 queries (sample pass, scan, merge, exact "
+                                               "re-scoring), per GPU",
+                                       "traffic": load_pmc_traffic("ip_scan_split64_kernel")},
+            "batched_nq32_roofline": {"kernel": "ip_scan_split_direct_kernel", "bound": "hbm",
                                       "achieved": round(N * d * 4 / world / (sdt32 / s_steps) / 1e9, 1),
                                       "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": round(N * d * 4 / world / (sdt32 / s_steps) / 1e9 / PEAK_HBM_GBS, 4),
-                                      "note": "whole call (scan + merge) per 32-query pass, per GPU",
-                                      "traffic": load_pmc_traffic("ip_scan_mfma_kernel")},
+                                      "note": "whole call (sample pass, scan, merge, exact re-scoring) per 32-query "
+                                              "pass, per GPU",
+                                      "traffic": load_pmc_traffic("ip_scan_split_direct_kernel")},
         }
         del X, local, index
         torch.cuda.empty_cache()

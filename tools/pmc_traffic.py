@@ -41,7 +41,7 @@ def main():
                       "hbm_read_bytes_per_launch": round(f * 1024 * 2), "hbm_write_bytes_per_launch": round(w * 1024),
                       "hbm_bytes_per_launch": round(f * 1024 * 2 + w * 1024)}
     # aggregate keys bench.py looks up
-    def agg(prefix):
+    def agg(prefix, per=1):
         # "ip_scan_kernel" = the flat scan only; its inverted-list instantiation (last template argument true) is
         # reported as "ivf_scan_kernel"
         if prefix == "ivf_scan_kernel":
@@ -53,20 +53,23 @@ def main():
         n = sum(out[k]["launches"] for k in ks)
         if not n:
             return None
-        return {"launches": n, "hbm_bytes_per_launch": round(sum(out[k]["hbm_bytes_per_launch"] * out[k]["launches"]
-                                                               for k in ks) / n), "kernels": ks}
+        # per = 2: a pass is two launches of the kernel (the sample pass over the first rows, then the rest)
+        return {"launches": n // per, "hbm_bytes_per_launch": round(sum(out[k]["hbm_bytes_per_launch"] * out[k]["launches"]
+                                                                      for k in ks) / (n // per)), "kernels": ks}
     res = {"_note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request); KiB units",
            "per_kernel": out}
-    for key, prefix in (("gemm_bf16_kernel", "gemm_"), ("ip_scan_kernel", "ip_scan_kernel"),
-                        ("ip_scan_mfma_kernel", "ip_scan_mfma_kernel"), ("clip_resize_kernel", "clip_resize_kernel"),
-                        ("ivf_scan_kernel", "ivf_scan_kernel"), ("attention_kernel", "attention_kernel"),
-                        ("layernorm_kernel", "layernorm_kernel")):
-        a = agg(prefix)
+    for key, prefix, per in (("gemm_bf16_kernel", "gemm_", 1), ("ip_scan_kernel", "ip_scan_kernel", 1),
+                             ("ip_scan_mfma_kernel", "ip_scan_mfma_kernel", 1),
+                             ("ip_scan_split_direct_kernel", "ip_scan_split_direct_kernel", 2),
+                             ("ip_scan_split64_kernel", "ip_scan_split64_kernel", 2),
+                             ("clip_resize_kernel", "clip_resize_kernel", 1), ("ivf_scan_kernel", "ivf_scan_kernel", 1),
+                             ("attention_kernel", "attention_kernel", 1), ("layernorm_kernel", "layernorm_kernel", 1)):
+        a = agg(prefix, per)
         if a:
             res[key] = a
     dst = Path(__file__).resolve().parent.parent / "profiles" / "pmc_traffic.json"
     dst.write_text(json.dumps(res, indent=1))
-    for k in ("gemm_bf16_kernel", "ip_scan_kernel", "ip_scan_mfma_kernel", "clip_resize_kernel"):
+    for k in ("gemm_bf16_kernel", "ip_scan_kernel", "ip_scan_split_direct_kernel", "ip_scan_split64_kernel", "clip_resize_kernel"):
         if k in res:
             print(k, res[k]["hbm_bytes_per_launch"] / 1e6, "MB/launch over", res[k]["launches"], "launches")
     for k, v in out.items():

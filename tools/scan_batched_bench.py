@@ -10,19 +10,17 @@ N, d = 10_000_000, 512
 X = torch.nn.functional.normalize(torch.randn(N, d, device="cuda"), dim=1)
 idx = FlatIPIndex(d).adopt(X)
 Q = torch.nn.functional.normalize(torch.randn(256, d, device="cuda"), dim=1)
-variants = [("f32 MFMA, DMA ring", 1 << 11), ("split-bf16, DMA ring", 8 << 12), ("split regs x4, no sample", (4 << 12) | (1 << 16)),
-            ("split regs x4, sample 32K", (4 << 12) | (2 << 17)), ("split regs x4, sample 128K", (4 << 12) | (8 << 17)),
-            ("split regs x4, sample 512K", (4 << 12) | (32 << 17)), ("split regs x3, sample 128K", (3 << 12) | (8 << 17))]
+variants = [("f32 MFMA, DMA ring", 1 << 11), ("split regs x4, 32/pass", (4 << 12) | (1 << 25)), ("split regs x4, 64/pass", 4 << 12)]
 ref = None
 for name, flags in variants * 2:
     lib.wise_debug_set_scan(4 | flags, 0)
-    for nq in (32, 256):
+    for nq in (32, 64, 256):
         for _ in range(2): D, I = idx.search_device(Q[:nq], 10)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         n = 6 if nq == 32 else 2
         for _ in range(n): D, I = idx.search_device(Q[:nq], 10)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-        msg = f"{name:28s} nq={nq:3d}: {dt * 1e3 / (nq // 32):.3f} ms/pass  {nq / dt:.0f} q/s"
+        msg = f"{name:28s} nq={nq:3d}: {dt * 1e3:.3f} ms/call  {nq / dt:.0f} q/s"
         if nq == 256:
             if ref is None: ref = (D.clone(), I.clone())
             msg += f"  ids equal to first: {bool(torch.equal(I, ref[1]))}  max |dscore| {float((D - ref[0]).abs().max()):.2e}"

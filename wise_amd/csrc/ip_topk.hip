@@ -422,6 +422,7 @@ struct ScanPlan {
 static int g_scan_rows = 4, g_scan_blocks_per_cu = 0;  // tuning knobs (wise_debug_set_scan)
 static int g_use_mfma = 1;                              // batched queries on the matrix cores
 static long long g_scan_sample = 32768;                  // rows of the split scan's sample pass (0 = none)
+static int g_use_qb64 = 1;                               // 64 queries per pass when more than 32 are waiting
 static int g_use_split = 1;                             // ... as split-bf16 candidates + exact re-scoring (k <= MFMA_KC)
 extern int g_mfma_abl, g_split_direct;
 
@@ -503,6 +504,7 @@ extern "C" int wise_debug_set_scan(int rows, int blocks_per_cu) {
     g_use_split = (rows >> 11) & 1 ? 0 : 1;
     g_split_direct = (rows >> 12) & 15 ? ((rows >> 12) & 15) % 8 : 4;   // bits 12-15: queue depth 3/4/6; 8 = DMA ring
     if (((rows >> 12) & 15) == 8) g_split_direct = 0;
+    g_use_qb64 = (rows >> 25) & 1 ? 0 : 1;   // bit 25: never 64 queries per pass
     g_scan_sample = (rows >> 16) & 1 ? 0 : ((rows >> 17) & 0xFF ? (long long)((rows >> 17) & 0xFF) * 16384 : 32768);  // bit 16: no sample pass; bits 17-24: sample rows / 16384  // bit 11: f32 matrix-core scan instead of the split-bf16 candidates
     return 0;
 }
@@ -516,8 +518,8 @@ extern "C" size_t wise_ip_topk_workspace_bytes(int64_t N, int d, int nq, int k) 
     if (g_use_mfma && mfma_scan_supported(d, nq, k)) {
         // the split path keeps MFMA_KL keys per list and a candidate block [32][MFMA_KL] of (score, row)
         // (lists of the sample pass and of the main pass, a 32-key threshold block)
-        size_t mf = align_up(2 * mfma_scan_part_bytes(N, MFMA_KL), 256) + align_up((size_t)MFMA_QB * d * sizeof(float), 256) +
-                    align_up((size_t)MFMA_QB * MFMA_KL * 12, 256) + 256 + 256;
+        size_t mf = align_up(2 * mfma_scan_part_bytes(N, MFMA_KL), 256) + align_up((size_t)MFMA_QB2 * d * sizeof(float), 256) +
+                    align_up((size_t)MFMA_QB2 * MFMA_KL * 12, 256) + 512 + 256;
         if (mf > valu) valu = mf;
     }
     return valu;
@@ -539,49 +541,56 @@ extern "C" int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q
     }
     hipStream_t st = (hipStream_t)stream;
     if (g_use_mfma && N > 0 && mfma_scan_supported(d, nq, k)) {
-        // batched path: 32 queries share one pass over X on the matrix cores
+        // batched path: 32 or 64 queries share one pass over X on the matrix cores
         const bool split = g_use_split && mfma_split_supported(d, nq, k);
+        const bool direct = split && split_direct_enabled();
         const int kl = split ? MFMA_KL : k;
         unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
         u64* mpart = reinterpret_cast<u64*>(wsb);
         size_t off = align_up(2 * mfma_scan_part_bytes(N, MFMA_KL), 256);
         float* mq = reinterpret_cast<float*>(wsb + off);
-        off += align_up((size_t)MFMA_QB * d * sizeof(float), 256);
+        off += align_up((size_t)MFMA_QB2 * d * sizeof(float), 256);
         long long* cand_rows = reinterpret_cast<long long*>(wsb + off);
-        float* cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)MFMA_QB * MFMA_KL * 8);
-        off += align_up((size_t)MFMA_QB * MFMA_KL * 12, 256);
+        float* cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)MFMA_QB2 * MFMA_KL * 8);
+        off += align_up((size_t)MFMA_QB2 * MFMA_KL * 12, 256);
         u64* tau0 = reinterpret_cast<u64*>(wsb + off);
         const int cap = list_cap(kl);
         int mwv = 8192 / cap;
         if (mwv < 1) mwv = 1;
         if (mwv > 16) mwv = 16;
-        for (int q0 = 0; q0 < nq; q0 += MFMA_QB) {
-            const int nqa = (nq - q0 < MFMA_QB) ? nq - q0 : MFMA_QB;
+        for (int q0 = 0; q0 < nq;) {
+            // 64 at a time while more than 32 remain (d <= 512 keeps both bf16 images of 64 queries in LDS)
+            const int qb = (direct && g_use_qb64 && split64_supported(d) && nq - q0 > MFMA_QB) ? MFMA_QB2 : MFMA_QB;
+            const int nqa = (nq - q0 < qb) ? nq - q0 : qb;
             hipError_t e = hipSuccess;
-            if (nqa < MFMA_QB) e = hipMemsetAsync(mq, 0, (size_t)MFMA_QB * d * sizeof(float), st);
+            if (nqa < qb) e = hipMemsetAsync(mq, 0, (size_t)qb * d * sizeof(float), st);
             if (e == hipSuccess)
                 e = hipMemcpyAsync(mq, Q + (size_t)q0 * d, (size_t)nqa * d * sizeof(float), hipMemcpyDeviceToDevice, st);
             if (e != hipSuccess) { set_error("ip_topk: query staging: %s", hipGetErrorString(e)); return (int)e; }
             int nlists = mfma_scan_lists(N);
-            if (split && split_direct_enabled()) {
+            if (direct) {
                 // sample pass over the first rows: its MFMA_KL-th candidate of a query is a threshold nothing in the
                 // final top MFMA_KL can fall below, so the main pass (the other rows) hardly ever touches its lists
                 const long long ns = (g_scan_sample && N >= 8ll * g_scan_sample) ? g_scan_sample : 0;
+                auto scan = [&](const float* Xp, long long n, long long row_off, u64* dst, const u64* t0) {
+                    return qb == MFMA_QB2 ? split64_scan_launch(Xp, n, row_off, d, mq, nqa, dst, t0, st)
+                                          : split_scan_launch(Xp, n, row_off, d, mq, nqa, dst, t0, st);
+                };
+                auto lists_of = [&](long long n) { return qb == MFMA_QB2 ? split64_lists(n) : mfma_scan_lists(n); };
                 int p1 = 0;
                 ProfScope prof(PROF_SCAN, (double)N * d * 4.0, st);
                 if (ns > 0) {
-                    int rc = split_scan_launch(X, ns, 0, d, mq, nqa, mpart, nullptr, st);
+                    int rc = scan(X, ns, 0, mpart, nullptr);
                     if (rc) return rc;
-                    p1 = mfma_scan_lists(ns);
-                    hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart, p1,
-                                       MFMA_QB, kl, cap, (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
+                    p1 = lists_of(ns);
+                    hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart, p1, qb,
+                                       kl, cap, (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
                     WISE_LAUNCH_CHECK("merge_keys_kernel");
                     if ((rc = sample_threshold_launch(cand_scores, cand_rows, tau0, st))) return rc;
                 }
-                int rc = split_scan_launch(X + (size_t)ns * d, N - ns, ns, d, mq, nqa, mpart + (size_t)p1 * MFMA_QB * kl,
-                                           ns > 0 ? tau0 : nullptr, st);
+                int rc = scan(X + (size_t)ns * d, N - ns, ns, mpart + (size_t)p1 * qb * kl, ns > 0 ? tau0 : nullptr);
                 if (rc) return rc;
-                nlists = p1 + mfma_scan_lists(N - ns);
+                nlists = p1 + lists_of(N - ns);
             } else {
                 ProfScope prof(PROF_SCAN, (double)N * d * 4.0, st);
                 int rc = mfma_scan_launch(X, N, d, mq, nqa, k, mpart, split, st);
@@ -589,8 +598,8 @@ extern "C" int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q
             }
             if (split) {
                 // best MFMA_KL candidates per query by approximate score (rows, not ids), then their exact scores
-                hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart, nlists,
-                                   MFMA_QB, kl, cap, (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
+                hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart, nlists, qb,
+                                   kl, cap, (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
                 WISE_LAUNCH_CHECK("merge_keys_kernel");
                 int rc = rescore_launch(X, d, mq, cand_rows, nqa, k, reinterpret_cast<const long long*>(ids),
                                         (long long)id_base, outD + (size_t)q0 * k,
@@ -602,6 +611,7 @@ extern "C" int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q
                                    (long long)id_base, outD, reinterpret_cast<long long*>(outI), q0);
                 WISE_LAUNCH_CHECK("merge_keys_kernel");
             }
+            q0 += nqa;
         }
         return WISE_OK;
     }

@@ -1,33 +1,44 @@
-// HP-2, batched queries: brute-force inner-product scan for up to 32 queries per pass on the fp32
-// matrix cores (v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulate — a serial fmaf chain per output, no reduced precision),
-// so that a batch of queries shares ONE pass over the database.  Serves the batched form of the search
-// the reference issues one query at a time (src/index/feature_search_index.py:113; the 3842 sequential
-// queries of docs/Retrieval-Evaluation.md:36-45) — SURVEY.md §8 f3.
+// HP-2, batched queries: brute-force inner-product scan for 32 or 64 queries per pass over the database, on the
+// matrix cores, so that a batch of queries shares ONE pass over X.  Serves the batched form of the search the
+// reference issues one query at a time (src/index/feature_search_index.py:113; the 3842 sequential queries of
+// docs/Retrieval-Evaluation.md:36-45) — SURVEY.md §8 f3.  Still an HBM-bound path: the kernels are judged against
+// N*d*4 bytes per pass.
 //
-// Roofline: still HBM-bound.  Per 32 rows x 512 dims (64 KB of X) a SIMD issues 256 MFMAs of 64 cycles =
-// 16.4k cycles, against ~27k cycles of HBM time for those bytes at 5.9 TB/s chip-wide.
+// Three kernels, newest last (wise_ip_topk_f32 in ip_topk.hip picks; wise_debug_set_scan can force each):
+//   ip_scan_mfma_kernel<false>   f32 operands on v_mfma_f32_32x32x2_f32, X through a per-wave LDS-DMA ring, lists of
+//                                k <= 16 entries per (wave, query); scores final.  4.9 ms per 32 queries at 10M x 512:
+//                                256 MFMAs of 64 cycles per 32 rows x 512 columns on a SIMD are two thirds of the HBM
+//                                time, and loads and MFMAs do not overlap well with one 4 KiB chunk in flight per wave.
+//                                Serves 12 < k <= 16.
+//   ip_scan_split_direct_kernel  (k <= 12) candidate generation + exact re-scoring.  Operands are split into bf16
+//                                halves, x*q ~ hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (error of a dot
+//                                product <= 2^-16 sum|x_c q_c| <= 1.6e-5 for unit rows): 6 MFMAs of 32 cycles per 4 KiB
+//                                chunk instead of 16 of 64.  X goes straight into a 4-deep register queue (12 KiB in
+//                                flight per wave, no ring).  A sample pass over the first 32K rows gives each query a
+//                                threshold that 16 rows already beat, so the main pass over the other rows almost
+//                                never touches its lists (selection fell from ~1.1 ms to noise).  Lists always keep
+//                                MFMA_KL = 16 candidates; rescore_topk_kernel recomputes their scores in f32, orders
+//                                them and returns the first k: ids and scores are f32-exact as long as fewer than
+//                                16 - k rows sit within the candidate error of the k-th score.  3.64 ms per 32 queries
+//                                (5.6 TB/s of X).
+//   ip_scan_split64_kernel       the same for 64 queries per pass: with inserts rare, the block's eight waves share one
+//                                list per query behind a spin lock, which frees the LDS for the hi/lo images of 64
+//                                queries (128 KiB at d = 512).  4.2 ms per 64 queries: 15.2k queries/s at 10M x 512.
 //
-// Structure (block = 8 independent waves, one block per CU, two waves per SIMD so that one wave's MFMA chain
-// covers the other's wait for its LDS-DMA):
-//   Q [32][d] lives in LDS for the block's lifetime (16-byte chunks XOR-swizzled by query so that the 32
-//   lanes of an MFMA B-operand read hit distinct banks);
-//   each wave streams 32-row x 32-column chunks of X through a private 2-deep LDS ring by 16-byte LDS-DMA
-//   (lane-linear destination, swizzle on the SOURCE address), waits with a counted vmcnt, reads its A
-//   fragments into registers (a third pipeline stage), re-issues the ring slot, and feeds 16 MFMAs per chunk;
-//   no block barrier in the loop;  at d = 512 the LDS is exactly full: 64 KiB Q + 64 KiB rings + 32 KiB lists;
-//   k-permutation: lane (i, h) holds columns h*16..h*16+15 of row i — the same permutation on the Q side;
-//   selection: after a 32-row group a lane holds, for ITS query, the scores of 16 rows; candidates that beat
-//   the threshold are insertion-sorted into the wave's k-entry list of that query in LDS (the two lanes of a
-//   query take turns).  The threshold is the best k-th key ANY of the block's 8 lists of the query has
-//   reached (a key below some list's k-th entry is dominated by k keys of the same query, so it cannot be
-//   in the global top-k): inserts, which serialise the wave, fall ~6x against lane-private thresholds.
-//   Measured alternatives that were slower: lists in registers with a branch-free bubble; lists in global
-//   memory with a device-wide atomic threshold (every insert is a chain of dependent global loads that
-//   also drains the LDS-DMA queue: 18-25 ms); 4 waves/block with a 5-deep ring (5.4 ms: nothing runs under a
-//   wave's DMA wait); fragment reads software-pipelined one chunk ahead (the earlier vmcnt wait costs more
-//   than the overlap gains).
-//   10M x 512, 32 queries: 4.9 ms = 4.2 TB/s of X (MFMA+selection alone 3.1 ms, DMA alone 3.3 ms).
-// The per-wave lists (8 per block and query) are folded by merge_keys_kernel.
+// Structure shared by all three (block = 8 independent waves, one block per CU, two waves per SIMD):
+//   Q lives in LDS for the block's lifetime (16-byte chunks XOR-swizzled by query so that the 32 lanes of an MFMA
+//   B-operand read hit distinct banks); no block barrier in the loop;
+//   k-permutation: lane (i, h) holds columns h*16..h*16+15 of row i of a 32-column chunk — the same permutation on
+//   the Q side;
+//   selection: after a 32-row group a lane holds, for ITS query, the scores of 16 rows; candidates that beat the
+//   threshold are insertion-sorted into the query's list in LDS (the two lanes of a query take turns).  In the ring
+//   kernel the threshold is the best k-th key ANY of the block's 8 lists of the query has reached (a key below some
+//   list's k-th entry is dominated by k keys of the same query, so it cannot be in the global top-k).
+//   Measured alternatives that were slower: lists in registers with a branch-free bubble; lists in global memory with
+//   a device-wide atomic threshold (every insert is a chain of dependent global loads: 18-25 ms); 4 waves/block with a
+//   5-deep ring (5.4 ms); fragment reads software-pipelined one chunk ahead; the split products on the DMA ring
+//   (4.7 ms: the ring, not the matrix cores, was the limit).
+// The per-list results (part) are folded by merge_keys_kernel.
 #include "topk_common.h"
 
 namespace wise {
@@ -422,6 +433,196 @@ int mfma_scan_launch(const float* X, long long N, int d, const float* qpad, int 
     return WISE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 64 queries per pass.  With the sample-pass threshold a list insert is a rare event, so the eight waves of a
+// block can share ONE list per query behind a spin lock (LDS: 16 x 64 keys = 8 KiB instead of 8 x that), which
+// leaves room for the hi/lo images of 64 queries (128 KiB at d = 512): a pass over X serves twice the queries
+// and the loads are still the bound (12 MFMAs of 32 cycles per 4 KiB chunk and wave).
+//   lock discipline: a lane that wins the compare-and-swap runs its critical section inside that same loop
+//   trip and releases before the wave's next trip, so no lane holds a lock while a wave-mate spins (no
+//   hold-and-wait); the two lanes (i, 0), (i, 1) that serve a query in a wave go in two phases as above.
+// part [gridDim][64][MFMA_KL].
+// ------------------------------------------------------------------------------------------------
+constexpr int QB2 = 64;
+
+__device__ __forceinline__ void select_group_shared(f32x16& acc, u64& tau, u64* lists /*[kl][QB2]*/, int* locks, int q,
+                                                    int h, bool active, long long row0, long long N,
+                                                    long long row_offset) {
+    constexpr int kl = MFMA_KL;
+    {
+        const u64 t = lists[(kl - 1) * QB2 + q];   // the block's current MFMA_KL-th key of this query
+        tau = t > tau ? t : tau;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const u64 key = make_key(acc[r], (unsigned)(row + row_offset));
+        const bool pass = active && row < N && key > tau;
+        if (__ballot(pass) != 0) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                bool todo = pass && h == hh;
+                while (__ballot(todo) != 0) {
+                    if (todo && __hip_atomic_exchange(&locks[q], 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+                        const u64 kth = lists[(kl - 1) * QB2 + q];
+                        if (key > kth) {
+                            int pos = kl - 1;
+                            while (pos > 0) {
+                                const u64 prev = lists[(pos - 1) * QB2 + q];
+                                if (prev >= key) break;
+                                lists[pos * QB2 + q] = prev;
+                                --pos;
+                            }
+                            lists[pos * QB2 + q] = key;
+                        }
+                        const u64 nk = lists[(kl - 1) * QB2 + q];
+                        tau = nk > tau ? nk : tau;
+                        __hip_atomic_store(&locks[q], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        todo = false;
+                    }
+                }
+            }
+        }
+        acc[r] = 0.f;
+    }
+}
+
+template <int PF>
+__global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_split64_kernel(const float* __restrict__ X, long long N, int d,
+                                                                 const float* __restrict__ qpad /*[64][d]*/, int nq,
+                                                                 u64* __restrict__ part /*[grid][64][MFMA_KL]*/,
+                                                                 long long row_offset,
+                                                                 const u64* __restrict__ tau0 /*[64] or null*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int d4 = d >> 2, d8 = d >> 3;
+    unsigned char* Qh = smem;
+    unsigned char* Ql = smem + (size_t)QB2 * d * 2;
+    u64* lists = reinterpret_cast<u64*>(smem + (size_t)QB2 * d * 4);
+    int* locks = reinterpret_cast<int*>(lists + MFMA_KL * QB2);
+    constexpr int kl = MFMA_KL;
+
+    for (int idx = threadIdx.x; idx < QB2 * d4; idx += WAVES * 64) {
+        const int j = idx / d4, c = idx - j * d4;
+        const float4 v = reinterpret_cast<const float4*>(qpad)[idx];
+        const unsigned h01 = pack_bf16x2(v.x, v.y), h23 = pack_bf16x2(v.z, v.w);
+        const unsigned l01 = pack_bf16x2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xFFFF0000u));
+        const unsigned l23 = pack_bf16x2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xFFFF0000u));
+        const int c8 = c >> 1;
+        const size_t off = ((size_t)j * d8 + ((c8 & ~15) | ((c8 & 15) ^ (j & 15)))) * 16 + (c & 1) * 8;
+        *reinterpret_cast<uint2*>(Qh + off) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(Ql + off) = make_uint2(l01, l23);
+    }
+    for (int e = threadIdx.x; e < MFMA_KL * QB2; e += WAVES * 64) lists[e] = 0;
+    if (threadIdx.x < QB2) locks[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int nch = d / CW;
+    const long long ngroups = (N + 31) / 32;
+    const long long gw = (long long)blockIdx.x * WAVES + wave, nw = (long long)gridDim.x * WAVES;
+    const long long my_groups = gw < ngroups ? (ngroups - gw + nw - 1) / nw : 0;
+    const long long steps = my_groups * nch;
+
+    float4 xq[PF][4];
+    long long pg = gw, issued = 0;
+    int pc = 0;
+    auto prefetch = [&](float4 (&dst)[4]) {
+        long long grow = pg * 32 + i;
+        if (grow >= N) grow = N - 1;
+        const float4* src = reinterpret_cast<const float4*>(X + grow * d + pc * CW + h * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst[t] = src[t];
+        if (issued + 1 < steps) {
+            ++issued;
+            if (++pc == nch) { pc = 0; pg += nw; }
+        }
+    };
+    if (steps > 0) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) prefetch(xq[p]);
+    }
+
+    f32x16 acc0, acc1;   // queries i and 32 + i (named, not an array: the accumulators must stay in registers)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    u64 tau_a = tau0 ? tau0[i] : 0, tau_b = tau0 ? tau0[32 + i] : 0;
+    const bool active_a = i < nq, active_b = 32 + i < nq;
+    long long cg = gw;
+    int cc = 0;
+    for (long long s0 = 0; s0 < steps; s0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            {   // nch % PF == 0 (host check): steps is a multiple of PF and a group ends on the last slot
+                const int c0 = (cc + p) * CW;
+                bf16x8 qha0, qha1, qla0, qla1, qhb0, qhb1, qlb0, qlb1, xh0, xh1, xl0, xl1;
+                {
+                    const int c8 = (c0 >> 3) + h * 2;
+                    const size_t ra = (size_t)i * d8, rb = (size_t)(32 + i) * d8;
+                    const size_t o0 = (size_t)((c8 & ~15) | ((c8 & 15) ^ (i & 15))) * 16;
+                    const size_t o1 = (size_t)(((c8 + 1) & ~15) | (((c8 + 1) & 15) ^ (i & 15))) * 16;
+                    qha0 = *reinterpret_cast<const bf16x8*>(Qh + ra * 16 + o0);
+                    qla0 = *reinterpret_cast<const bf16x8*>(Ql + ra * 16 + o0);
+                    qha1 = *reinterpret_cast<const bf16x8*>(Qh + ra * 16 + o1);
+                    qla1 = *reinterpret_cast<const bf16x8*>(Ql + ra * 16 + o1);
+                    qhb0 = *reinterpret_cast<const bf16x8*>(Qh + rb * 16 + o0);
+                    qlb0 = *reinterpret_cast<const bf16x8*>(Ql + rb * 16 + o0);
+                    qhb1 = *reinterpret_cast<const bf16x8*>(Qh + rb * 16 + o1);
+                    qlb1 = *reinterpret_cast<const bf16x8*>(Ql + rb * 16 + o1);
+                }
+                split_bf16x8(xq[p][0], xq[p][1], xh0, xl0);
+                split_bf16x8(xq[p][2], xq[p][3], xh1, xl1);
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch(xq[p]);
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl0, qha0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl0, qhb0, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, qla0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, qlb0, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, qha0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh0, qhb0, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl1, qha1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl1, qhb1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, qla1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, qlb1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, qha1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh1, qhb1, acc1, 0, 0, 0);
+            }
+        }
+        cc += PF;
+        if (cc == nch) {
+            cc = 0;
+            const long long row0 = cg * 32;
+            cg += nw;
+            select_group_shared(acc0, tau_a, lists, locks, i, h, active_a, row0, N, row_offset);
+            select_group_shared(acc1, tau_b, lists, locks, 32 + i, h, active_b, row0, N, row_offset);
+        }
+    }
+    __syncthreads();
+    u64* dst = part + (size_t)blockIdx.x * QB2 * kl;
+    for (int e = threadIdx.x; e < QB2 * kl; e += WAVES * 64) {
+        const int q = e / kl, r = e - q * kl;
+        dst[e] = q < nq ? lists[r * QB2 + q] : 0;
+    }
+}
+
+int split64_lists(long long N) { return mfma_grid(N); }
+bool split64_supported(int d) { return d % (4 * CW) == 0 && d <= 512; }   // whole groups per trip of the 4-deep queue
+int split64_scan_launch(const float* X, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
+                        const u64* tau0, hipStream_t st) {
+    const size_t dl = (size_t)QB2 * d * 4 + (size_t)MFMA_KL * QB2 * 8 + QB2 * 4;
+    static bool dattr = false;
+    if (!dattr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_split64_kernel<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        dattr = true;
+    }
+    hipLaunchKernelGGL(ip_scan_split64_kernel<4>, dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, X, N, d, qpad, nq, part,
+                       row_offset, tau0);
+    WISE_LAUNCH_CHECK("ip_scan_split64_kernel");
+    return WISE_OK;
+}
+
 // the register-queue scan over rows [row_offset, row_offset + N) of the database (X points at the first of them);
 // lists go to part[0 .. mfma_scan_lists(N))
 int split_scan_launch(const float* X, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
@@ -449,8 +650,7 @@ bool split_direct_enabled() { return g_split_direct != 0; }
 // tau0[q] = the key of the last of the MFMA_KL sample candidates of query q (0 while the sample holds fewer)
 __global__ void sample_threshold_kernel(const float* __restrict__ cand_scores, const long long* __restrict__ cand_rows,
                                         u64* __restrict__ tau0) {
-    const int q = threadIdx.x;
-    if (q >= MFMA_QB) return;
+    const int q = threadIdx.x;   // launched with 64 threads: the candidate block is sized for 64 queries
     const long long row = cand_rows[(size_t)q * MFMA_KL + MFMA_KL - 1];
     tau0[q] = row >= 0 ? make_key(cand_scores[(size_t)q * MFMA_KL + MFMA_KL - 1], (unsigned)row) : 0;
 }

@@ -33,6 +33,12 @@ int mfma_scan_launch(const float* X, long long N, int d, const float* qpad /*[32
 int split_scan_launch(const float* X, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
                       const u64* tau0, hipStream_t st);
 bool split_direct_enabled();
+// 64 queries per pass, one list per (block, query): part [split64_lists(N)][64][MFMA_KL]
+constexpr int MFMA_QB2 = 64;
+int split64_lists(long long N);
+bool split64_supported(int d);
+int split64_scan_launch(const float* X, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
+                        const u64* tau0, hipStream_t st);
 int sample_threshold_launch(const float* cand_scores, const long long* cand_rows, u64* tau0, hipStream_t st);
 // exact f32 scores of cand_rows [nq][MFMA_KL], ordered, first k -> outD/outI [nq][k]
 int rescore_launch(const float* X, int d, const float* Q, const long long* cand_rows, int nq, int k, const long long* ids,
