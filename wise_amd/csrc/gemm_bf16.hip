@@ -24,6 +24,7 @@ constexpr bool bf16_out(int mode) { return mode == EPI_BF16 || mode == EPI_QUICK
 __device__ int g_group_m = 0;        // 0 = default; tuning knob (bits 16..23 of wise_debug_set_gemm_variant)
 __device__ int g_epi_lds = 1;        // bf16 epilogue through LDS (bit 30 of the debug knob turns it off)
 __device__ int g_dephase = 0;        // tuning knob (bits 24..27): initial s_sleep units for the second block per CU
+__device__ int g_store_nt = 0;       // (experiment) non-temporal stores in the bf16 epilogue of the 256-row tiles
 __device__ int g_skip_epilogue = 0;  // timing-only ablation (tools/gemm_bench.py), set via wise_debug_set_gemm_variant
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -952,7 +953,13 @@ __device__ __forceinline__ void epilogue_big_lds(f32x4 (&acc)[MI][4], const floa
             const int row = t * 8 + (lane >> 3);
             const uint4 v = *reinterpret_cast<const uint4*>(my + row * RS + chunk * 16);
             if (skip && v.x != 0x12345678u) continue;
-            *reinterpret_cast<uint4*>(out + (size_t)(m0 + wm * (MI * 16) + half * HROWS + row) * N + ncol) = v;
+            uint4* gdst = reinterpret_cast<uint4*>(out + (size_t)(m0 + wm * (MI * 16) + half * HROWS + row) * N + ncol);
+            if (g_store_nt) {
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(gdst));
+            } else {
+                *gdst = v;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1276,6 +1283,8 @@ extern "C" int wise_debug_set_gemm_variant(int v) {
     wise::g_split_m = ((v >> 29) & 1) ? 0 : 1;
     int skip = (v >> 8) & 1;  // bit 8: skip epilogue stores (timing-only ablation)
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_skip_epilogue), &skip, sizeof(int));
+    int nt = (v >> 9) & 1;   // bit 9: non-temporal epilogue stores
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_store_nt), &nt, sizeof(int));
     int el = ((v >> 30) & 1) ? 0 : 1;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_epi_lds), &el, sizeof(int));
     int dp = (v >> 24) & 0x3F;
