@@ -232,10 +232,11 @@ class VitEngine:
         if not hasattr(self, "_slots"):
             self._slots, self._next_slot = [], 0
         need = self.lib.wise_vit_workspace_bytes(C.byref(self.cfg), B)
-        while len(self._slots) < 2:
+        nslots = getattr(self, "pipeline_depth", 2)
+        while len(self._slots) < nslots:
             self._slots.append({"stream": torch.cuda.Stream(device=self.device), "ws": None})
         slot = self._slots[self._next_slot]
-        self._next_slot ^= 1
+        self._next_slot = (self._next_slot + 1) % nslots
         if slot["ws"] is None or slot["ws"].numel() < need:
             slot["ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
         cur = torch.cuda.current_stream(self.device)
