@@ -236,10 +236,11 @@ __device__ __forceinline__ void epilogue_f32_lds_64x64(const f32x4 (*acc)[4] /*[
 // The same for a (RI*16) x (NJ*16) piece of a wave's accumulators (the 8-wave kernels: NJ = 2, 3 or 4 column
 // tiles, RI <= 4 row tiles per pass so that the image stays within the wave's share of the dead staging LDS).
 // Rows are NJ*64 bytes; chunks are XOR-swizzled when a row has 16 or 8 of them and rotated when it has 12.
+// `pre` (optional): the residual values of this piece loaded earlier by prefetch_resid_piece with the same arguments.
 template <int MODE, int RI, int NJ>
 __device__ __forceinline__ void epilogue_f32_lds_piece(const f32x4 (*acc)[NJ], const float* __restrict__ bias,
                                                        float* __restrict__ out, int N, int row0, int col0, int lane,
-                                                       unsigned char* my) {
+                                                       unsigned char* my, const float4* pre = nullptr) {
     constexpr int CH = NJ * 4, RB = NJ * 64, ROWS = RI * 16;
     constexpr int RP = 64 / CH;                       // rows per wave instruction on the row-major walk (4, 5, 8)
     constexpr int IT = (ROWS + RP - 1) / RP;
@@ -254,8 +255,10 @@ __device__ __forceinline__ void epilogue_f32_lds_piece(const f32x4 (*acc)[NJ], c
 #pragma unroll
         for (int t = 0; t < IT; ++t) {
             const int r = t * RP + wr;
-            res[t] = (in && r < ROWS) ? *reinterpret_cast<const float4*>(out + (size_t)(row0 + r) * N + n)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pre) res[t] = pre[t];
+            else
+                res[t] = (in && r < ROWS) ? *reinterpret_cast<const float4*>(out + (size_t)(row0 + r) * N + n)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 #pragma unroll
@@ -286,6 +289,23 @@ __device__ __forceinline__ void epilogue_f32_lds_piece(const f32x4 (*acc)[NJ], c
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// residual values of a (RI*16) x (NJ*16) piece in the lane order epilogue_f32_lds_piece adds them: issued at the top of
+// a kernel, the 200 KB a 256x192 tile reads back arrive under the main loop instead of in front of the store burst
+template <int RI, int NJ>
+__device__ __forceinline__ void prefetch_resid_piece(const float* __restrict__ out, int N, int row0, int col0, int lane,
+                                                     float4* res) {
+    constexpr int CH = NJ * 4, ROWS = RI * 16, RP = 64 / CH, IT = (ROWS + RP - 1) / RP;
+    const int wr = lane / CH, wc = lane - wr * CH;
+    const int n = col0 + wc * 4;
+    const bool in = wr < RP && n + 4 <= N;
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+        const int r = t * RP + wr;
+        res[t] = (in && r < ROWS) ? *reinterpret_cast<const float4*>(out + (size_t)(row0 + r) * N + n)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 // a wave's whole MI x NJ accumulator block through epilogue_f32_lds_piece, four row tiles at a time
@@ -821,10 +841,13 @@ __device__ __forceinline__ void stage_rows8(const bf16_t* __restrict__ G, int ld
     }
 }
 
-template <int MODE, int NT, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
-                                                          const float* __restrict__ bias, int M, int N, int K,
-                                                          void* __restrict__ out) {
+// PRE (residual mode): the tile's residual values are loaded into registers before the main loop (one block per CU:
+// 96 accumulator + 104 residual registers per lane)
+template <int MODE, int NT, int ABL = 0, bool PRE = false>
+__global__ __launch_bounds__(512, PRE ? 1 : 2) void gemm_big_kernel(const bf16_t* __restrict__ A,
+                                                                    const bf16_t* __restrict__ Wt,
+                                                                    const float* __restrict__ bias, int M, int N, int K,
+                                                                    void* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BMB = 256, BNB = 64 * NT;
     constexpr int TA = BMB * 128, TBb = BNB * 128, SB = TA + TBb;
@@ -846,6 +869,13 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const bf16_t* __restri
     const int nk = K / 64;
     stage_rows8<BMB>(A, K, m0, 0, smem, wave, lane);
     stage_rows8<BNB>(Wt, K, n0, 0, smem + TA, wave, lane);
+    constexpr int PIT = (64 + 64 / (NT * 4) - 1) / (64 / (NT * 4));   // residual float4 per lane and 64-row piece
+    float4 pre0[PRE ? PIT : 1], pre1[PRE ? PIT : 1];
+    if (PRE) {
+        prefetch_resid_piece<4, NT>(reinterpret_cast<const float*>(out), N, m0 + wm * 128, n0 + wn * (16 * NT), lane, pre0);
+        prefetch_resid_piece<4, NT>(reinterpret_cast<const float*>(out), N, m0 + wm * 128 + 64, n0 + wn * (16 * NT), lane,
+                                    pre1);
+    }
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         __syncthreads();
@@ -871,12 +901,36 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const bf16_t* __restri
             }
         }
     }
-    if ((MODE == EPI_RESID || MODE == EPI_F32) && g_epi_lds) {
+    if (PRE) {
+        __syncthreads();
+        unsigned char* my = smem + wave * (2 * SB / 8);
+        epilogue_f32_lds_piece<MODE, 4, NT>(acc, bias, reinterpret_cast<float*>(out), N, m0 + wm * 128, n0 + wn * (16 * NT),
+                                            lane, my, pre0);
+        epilogue_f32_lds_piece<MODE, 4, NT>(acc + 4, bias, reinterpret_cast<float*>(out), N, m0 + wm * 128 + 64,
+                                            n0 + wn * (16 * NT), lane, my, pre1);
+    } else if ((MODE == EPI_RESID || MODE == EPI_F32) && g_epi_lds) {
         __syncthreads();  // staging buffers are dead; each wave takes SB*2/8 >= 12 KiB of them
         epilogue_f32_lds_wave<MODE, 8, NT>(acc, bias, reinterpret_cast<float*>(out), N, m0 + wm * 128,
                                            n0 + wn * (16 * NT), lane, smem + wave * (2 * SB / 8));
     } else {
         epilogue_big<MODE, NT>(acc, bias, out, N, m0, n0, wm, wn, lane);
+    }
+}
+
+template <int MODE, int NT>
+static void launch_big_pre(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
+                           hipStream_t st) {
+    if constexpr (MODE == EPI_RESID) {
+        auto kern = gemm_big_kernel<MODE, NT, 0, true>;
+        const size_t lds = (size_t)2 * (256 + 64 * NT) * 128;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            attr_set = true;
+        }
+        const int grid = (M / 256) * (N / (64 * NT));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
     }
 }
 
@@ -989,7 +1043,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
                                                          void* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BKT = 32, NT = 4, MI = WROWS / 16;
-    constexpr int BMB = (WROWS == 64) ? 256 : 2 * WROWS;
+    constexpr int BMB = (WROWS == 64) ? 256 : (WROWS == 80) ? 320 : 2 * WROWS;   // 80: 320 x 128, four wave rows
     constexpr int WM_WAVES = BMB / WROWS, WN_WAVES = 8 / WM_WAVES, BNB = WN_WAVES * 64;
     constexpr int STAGES = (WROWS == 64) ? 5 : 4;
     constexpr int TA = BMB * BKT * 2, TBt = BNB * BKT * 2, SB = TA + TBt;
@@ -1065,7 +1119,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
     }
     if (!late) __builtin_amdgcn_s_barrier();
     constexpr bool BF16OUT = bf16_out(MODE);
-    if constexpr (WROWS != 64) {
+    if constexpr (WROWS == 80) {
+        if (!BF16OUT && g_epi_lds) {
+            __syncthreads();  // the ring (112 KiB) is dead: 14 KiB of it per wave, pieces of 32 rows x 256 B
+            unsigned char* my = smem + wave * 14336;
+            float* o = reinterpret_cast<float*>(out);
+            epilogue_f32_lds_piece<MODE, 2, NT>(acc, bias, o, N, m0 + wm * WROWS, n0 + wn * 64, lane, my);
+            epilogue_f32_lds_piece<MODE, 2, NT>(acc + 2, bias, o, N, m0 + wm * WROWS + 32, n0 + wn * 64, lane, my);
+            epilogue_f32_lds_piece<MODE, 1, NT>(acc + 4, bias, o, N, m0 + wm * WROWS + 64, n0 + wn * 64, lane, my);
+        } else {
+            epilogue_big<MODE, NT, MI>(acc, bias, out, N, m0, n0, wm, wn, lane);
+        }
+    } else if constexpr (WROWS != 64) {
         if (BF16OUT && g_epi_lds) {
             __syncthreads();  // both groups are past their last fragment read: the ring is dead
             epilogue_big_lds<MODE, MI>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
@@ -1090,8 +1155,8 @@ template <int MODE, int WROWS>
 static void launch_pp(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
                       hipStream_t st) {
     auto kern = gemm_pp_kernel<MODE, WROWS>;
-    constexpr int BNB = (WROWS == 64) ? 128 : 256;
-    constexpr int BMB = (WROWS == 64) ? 256 : 2 * WROWS;
+    constexpr int BNB = (WROWS == 64 || WROWS == 80) ? 128 : 256;
+    constexpr int BMB = (WROWS == 64) ? 256 : (WROWS == 80) ? 320 : 2 * WROWS;
     constexpr int STAGES = (WROWS == 64) ? 5 : 4;
     const size_t lds = (size_t)STAGES * (BMB + BNB) * 32 * 2;  // 128 KiB / 120 KiB / 144 KiB
     static bool attr_set = false;
@@ -1120,7 +1185,11 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
         case 1: launch_ring<MODE, 32, 4, 2>(A, Wt, bias, M, N, K, out, st); break;
         case 5: if (M % 256 == 0 && N % 192 == 0) { launch_big<MODE, 3>(A, Wt, bias, M, N, K, out, st); break; }
                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 6: if (MODE == EPI_RESID && M % 256 == 0 && N % 192 == 0) { launch_big_pre<MODE, 3>(A, Wt, bias, M, N, K, out, st); break; }
+                launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 40: if (M % 256 == 0 && N % 256 == 0) { launch_pp<MODE, 128>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 44: if (M % 320 == 0 && N % 128 == 0) { launch_pp<MODE, 80>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 41: if (M % 256 == 0 && N % 128 == 0) { launch_pp<MODE, 64>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
@@ -1222,6 +1291,14 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
         const double eff256 = (M % 256 == 0) ? (double)t256 / (double)(((t256 + 255) / 256) * 256) : 0.0;
         if (t320 >= 200 && eff320 >= 0.90 && eff320 > eff256 + 0.04)
             return launch_mode(42, A, Wt, bias, M, N, K, mode, out, st);
+    }
+    // fp32-output GEMMs with a narrow N (the two residual GEMMs of a ViT-B block, N = 768): 320 x 128 tiles of the
+    // ping-pong kernel when they fill the chip's 256 CUs almost exactly (12800 x 768: 240 tiles, against 200 tiles of
+    // 256 x 192 with a quarter more work each): 12800 x 768 x 3072 77 -> 70 us, x 768 32.6 -> 30.7 us
+    if ((mode == EPI_RESID || mode == EPI_F32) && g_tile320 && !g_overlapped && M % 320 == 0 && N % 128 == 0 && K >= 128) {
+        const long long t = (long long)(M / 320) * (N / 128);
+        const double eff = (double)t / (double)(((t + 255) / 256) * 256);
+        if (t >= 200 && t <= 256 && eff >= 0.90) return launch_mode(44, A, Wt, bias, M, N, K, mode, out, st);
     }
     // The 256x256 ping-pong kernel (one block per CU) has the fastest main loop but no co-resident block to
     // hide its epilogue or its tail.  Give it the rows whose tiles fill whole rounds of the 256 CUs and hand the
