@@ -51,14 +51,31 @@ int wise_prof_end(double* ms_sum, int64_t* launches, double* work_sum);
  * Ties: the row with the lower position wins (faiss leaves tie order unspecified).
  * Limits: d % 4 == 0, 4 <= d <= 2048, 1 <= k <= 2048, 1 <= nq <= 1024, X 16-byte aligned.
  * Batches: nq < 8 (or k > 16, d > 512, d % 32 != 0) runs the single-pass VALU scan per group of up to 4
- * queries; nq >= 8 runs passes of 32 queries on the fp32 matrix cores, one pass over X per 32 queries.
- * Both paths accumulate in fp32 (different summation orders: scores agree to ~1e-6 relative, ids agree
- * wherever neighbouring scores differ by more than that).
+ * queries; nq >= 8 runs passes of 32 (or 64) queries on the matrix cores, one pass over X per pass: for k <= 12
+ * candidates are ranked by split-bf16 products (error <= 2^-16 sum|x_c q_c|) and the best 16 per query are
+ * re-scored in fp32, for 12 < k <= 16 the products themselves are fp32.
+ * Every returned score is an fp32 dot product (different summation orders between paths: scores agree to ~1e-6
+ * relative, ids agree wherever neighbouring scores differ by more than that).
  * ---------------------------------------------------------------------------------------------- */
 size_t wise_ip_topk_workspace_bytes(int64_t N, int d, int nq, int k);
 int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, int k,
                      const int64_t* ids, int64_t id_base, float* outD, int64_t* outI,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same search for ONE query (the reference's call shape, feature_search_index.py:113) in two stages over a bf16
+ * shadow copy of the rows, exact by construction:
+ *   wise_ip_shadow_bf16   Xb [N,d] bf16 (round-to-nearest-even copy of X) and *max_norm = max_r |X[r,:]| (device float)
+ *   wise_ip_topk_shadow_f32   (1) scan Xb (half the bytes of X) for the 64 best approximate scores, (2) recompute those
+ *       64 from the fp32 rows, order them, write the first k, (3) certify: a row outside the 64 has approximate score
+ *       <= t (the 64th), so exact score <= t + 2^-8 |q| max_norm (+ accumulation slack); if the k-th exact score is
+ *       above that bound the result is the exact top-k, (4) otherwise the fp32 scan queued behind (it returns at once
+ *       when the certificate held) recomputes the query.  All on the stream, no host round trip.
+ * Same outputs, ties and padding as wise_ip_topk_f32 with nq = 1.  Limits: d % 8 == 0, 8 <= d <= 1024, k <= 16, N >= 1. */
+int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* Xb, float* max_norm, void* stream);
+size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int k);
+int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* max_norm, int64_t N, int d, const float* q,
+                            int k, const int64_t* ids, int64_t id_base, float* outD, int64_t* outI, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* IndexIVFFlat search, second stage (the first stage — the `nprobe` nearest centroids of each query — is
  * wise_ip_topk_f32 over the centroid table): scan the probed inverted lists and keep the k best.

@@ -183,3 +183,65 @@ def test_batched_split_candidates_resolve_near_ties():
     assert set(I[0]) <= set(cluster + 1)
     Ds, Is = idx.search(Q[:1], k)          # the single-query (VALU) path agrees
     assert np.array_equal(Is[0], I[0])
+
+
+def _shadow_stats():
+    import ctypes
+
+    from wise_amd import _lib
+    lib = _lib.lib()
+    lib.wise_debug_shadow_stats.restype = ctypes.c_int
+    lib.wise_debug_shadow_stats.argtypes = [ctypes.c_void_p]
+    out = (ctypes.c_int * 2)()
+    _lib.check(lib.wise_debug_shadow_stats(out), "shadow_stats")
+    return out[0], out[1]
+
+
+@pytest.mark.parametrize("N,d,k", [(50000, 512, 10), (4097, 512, 1), (33333, 768, 16), (40, 512, 10), (200000, 256, 5),
+                                   (64, 64, 16), (65, 128, 3)])
+def test_single_query_two_stage_search_is_exact(N, d, k):
+    """nq = 1, k <= 16 on an index with a bf16 shadow: candidates from the bf16 rows, exact fp32 scores, a certificate,
+    the fp32 scan behind it.  Whatever the certificate says, the result is the oracle's."""
+    X = unit_rows(N, d, 500 + N % 97)
+    ids = np.arange(N, dtype=np.int64) * 3 + 11
+    idx = FlatIPIndex(d, shadow=True)
+    idx.add_with_ids(X, ids)
+    ref = FlatIPIndex(d, shadow=False)
+    ref.add_with_ids(X, ids)
+    _shadow_stats()
+    for seed in range(4):
+        Q = unit_rows(1, d, 900 + seed)
+        D, I = idx.search(Q, k)
+        check_against_oracle(X, Q, k, ids, D, I)
+        Dr, Ir = ref.search(Q, k)
+        assert np.array_equal(I, Ir) and np.allclose(D, Dr, atol=2e-6)
+    certified, fallback = _shadow_stats()
+    assert certified + fallback == 4
+
+
+def test_two_stage_search_falls_back_when_it_cannot_certify():
+    """80 rows within 1e-3 of the query: more near-ties than the 64 candidates kept and closer together than the bf16
+    error bound, so the certificate must fail and the fp32 scan must give the answer."""
+    N, d, k = 30000, 512, 10
+    X = unit_rows(N, d, 61)
+    q = unit_rows(1, d, 62)[0]
+    rng = np.random.default_rng(63)
+    cluster = rng.choice(N, size=80, replace=False)
+    for c in cluster:
+        v = q + 1e-3 * rng.standard_normal(d).astype(np.float32)
+        X[c] = v / np.linalg.norm(v)
+    ids = np.arange(N, dtype=np.int64) + 1
+    idx = FlatIPIndex(d, shadow=True)
+    idx.add_with_ids(X, ids)
+    _shadow_stats()
+    D, I = idx.search(q[None], k)
+    certified, fallback = _shadow_stats()
+    assert (certified, fallback) == (0, 1)
+    check_against_oracle(X, q[None], k, ids, D, I)
+    ref = FlatIPIndex(d, shadow=False)
+    ref.add_with_ids(X, ids)
+    Dr, Ir = ref.search(q[None], k)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)     # the fallback IS the f32 path
+    # and an ordinary query on the same index is certified
+    D2, I2 = idx.search(unit_rows(1, d, 64), k)
+    assert _shadow_stats() == (1, 0)

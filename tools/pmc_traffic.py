@@ -60,6 +60,7 @@ def main():
            "per_kernel": out}
     for key, prefix, per in (("gemm_bf16_kernel", "gemm_", 1), ("ip_scan_kernel", "ip_scan_kernel", 1),
                              ("ip_scan_mfma_kernel", "ip_scan_mfma_kernel", 1),
+                             ("ip_scan_bf16_kernel", "ip_scan_bf16_kernel", 1),
                              ("ip_scan_split_direct_kernel", "ip_scan_split_direct_kernel", 2),
                              ("ip_scan_split64_kernel", "ip_scan_split64_kernel", 2),
                              ("clip_resize_kernel", "clip_resize_kernel", 1), ("ivf_scan_kernel", "ivf_scan_kernel", 1),
@@ -69,7 +70,7 @@ def main():
             res[key] = a
     dst = Path(__file__).resolve().parent.parent / "profiles" / "pmc_traffic.json"
     dst.write_text(json.dumps(res, indent=1))
-    for k in ("gemm_bf16_kernel", "ip_scan_kernel", "ip_scan_split_direct_kernel", "ip_scan_split64_kernel", "clip_resize_kernel"):
+    for k in ("gemm_bf16_kernel", "ip_scan_kernel", "ip_scan_bf16_kernel", "ip_scan_split_direct_kernel", "ip_scan_split64_kernel", "clip_resize_kernel"):
         if k in res:
             print(k, res[k]["hbm_bytes_per_launch"] / 1e6, "MB/launch over", res[k]["launches"], "launches")
     for k, v in out.items():

@@ -89,6 +89,7 @@ struct SegArgs {
     const long long* probes;    // [nq][nprobe] list numbers, < 0 = nothing to scan
     const long long* list_off;  // [nlist + 1]
     int nprobe, nq;
+    const int* gate;            // optional: the launch does nothing unless *gate != 0 (two-stage search fallback)
 };
 
 template <int NV, int NQ, int R, bool SEG = false>
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void ip_scan_kernel(const f32x4* __restrict__ 
                                                       const float* __restrict__ Q, int k, int cap,
                                                       u64* __restrict__ part /*[grid][NQ][k]*/, SegArgs seg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (seg.gate && *seg.gate == 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     u64* lds = reinterpret_cast<u64*>(smem);
@@ -224,8 +226,10 @@ __global__ __launch_bounds__(256) void ip_scan_kernel(const f32x4* __restrict__ 
 __global__ __launch_bounds__(1024) void merge_keys_kernel(const u64* __restrict__ part, int P, int qstride,
                                                           int k, int cap, const long long* __restrict__ ids,
                                                           long long id_base, float* __restrict__ outD,
-                                                          long long* __restrict__ outI, int q_off) {
+                                                          long long* __restrict__ outI, int q_off,
+                                                          const int* __restrict__ gate = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (gate && *gate == 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
@@ -406,6 +410,215 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restri
     for (int j = kk + tid; j < k; j += 1024) dst[j] = -1;   // fewer than k scores: padding
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-stage exact search over a bf16 shadow of the index (nq = 1, k <= 16), wise_ip_topk_shadow_f32:
+//   1. ip_scan_bf16_kernel streams Xb [N,d] bf16 (half the bytes of X) against the f32 query and keeps the
+//      SHADOW_C = 64 best approximate scores per wave (same selection machinery as ip_scan_kernel);
+//   2. merge_keys_kernel folds them into the 64 best candidates of the query;
+//   3. rescore_certify_kernel recomputes the candidates' scores from the f32 rows, orders them, writes the first k,
+//      and checks a certificate: every row outside the candidate set has approximate score <= t (the 64th
+//      candidate's), hence exact score <= t + eps with eps = 2^-8 |q| max|x| (bf16 rounding of x, Cauchy-Schwarz) plus
+//      f32 accumulation slack; if the k-th exact score is above t + eps the answer is the exact top-k;
+//   4. otherwise *gate = 1 and the f32 scan + merge queued behind (which return at once when *gate == 0) recompute
+//      the query exactly.  No host round trip either way.
+// ------------------------------------------------------------------------------------------------
+constexpr int SHADOW_C = 64;
+
+__global__ __launch_bounds__(256) void shadow_bf16_kernel(const float* __restrict__ X, long long N, int d,
+                                                          bf16_t* __restrict__ Xb, float* __restrict__ max_norm) {
+    // one wave per row: bf16 (RNE) copy and the largest row norm (non-negative floats order like their bit patterns)
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float4* xr = reinterpret_cast<const float4*>(X + row * d);
+    uint2* br = reinterpret_cast<uint2*>(Xb + row * d);
+    float ss = 0.f;
+    for (int c = lane; c < (d >> 2); c += 64) {
+        const float4 v = xr[c];
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        br[c] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(max_norm), __float_as_uint(sqrtf(ss)));
+}
+
+// NV8 = 16-byte chunks (8 bf16) per lane per row, R rows per group, one query
+template <int NV8, int R>
+__global__ __launch_bounds__(256) void ip_scan_bf16_kernel(const uint4* __restrict__ Xb, long long N, int d8,
+                                                           const float* __restrict__ Q, int kl, int cap,
+                                                           u64* __restrict__ part /*[grid][kl]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    u64* lds = reinterpret_cast<u64*>(smem);
+    float qv[NV8][8];
+#pragma unroll
+    for (int v = 0; v < NV8; ++v) {
+        const int c = v * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[v][e] = (c < d8) ? Q[c * 8 + e] : 0.f;
+    }
+    WaveList wl;
+    wl.init(lds + (size_t)wave * cap, cap, kl, lane);
+
+    const long long ngroups = (N + R - 1) / R;
+    const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+    int myr = 0;
+    {
+        int bit = 5;
+#pragma unroll
+        for (int h = R / 2; h >= 1; h >>= 1, --bit) myr += ((lane >> bit) & 1) * h;
+    }
+    constexpr int LOGR = (R == 8) ? 3 : (R == 4) ? 2 : (R == 2) ? 1 : 0;
+    const bool owner = (lane & ((64 >> LOGR) - 1)) == 0;
+
+    for (long long g = gw; g < ngroups; g += nw) {
+        const long long row0 = g * R;
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t x[R][NV8];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            long long row = row0 + r;
+            if (row >= N) row = N - 1;
+#pragma unroll
+            for (int v = 0; v < NV8; ++v) {
+                const int c = v * 64 + lane;
+                if (NV8 * 64 == d8 || c < d8)
+                    x[r][v] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(Xb) + row * d8 + c);
+                else
+                    x[r][v] = u32x4_t{0u, 0u, 0u, 0u};
+            }
+        }
+        float a[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV8; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned u = x[r][v][e];
+                    s = fmaf(__uint_as_float(u << 16), qv[v][2 * e], s);
+                    s = fmaf(__uint_as_float(u & 0xFFFF0000u), qv[v][2 * e + 1], s);
+                }
+            a[r] = s;
+        }
+        int bit = 5;
+#pragma unroll
+        for (int h = R / 2; h >= 1; h >>= 1, --bit) {
+            const int m = 1 << bit;
+            const bool up = (lane >> bit) & 1;
+#pragma unroll
+            for (int i = 0; i < h; ++i) {
+                float send = up ? a[i] : a[i + h];
+                float keep = up ? a[i + h] : a[i];
+                a[i] = keep + __shfl_xor(send, m, 64);
+            }
+        }
+        float s = a[0];
+#pragma unroll
+        for (int m = (32 >> LOGR); m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        const long long row = row0 + myr;
+        const u64 key = make_key(s, (unsigned)row);
+        const bool pass = owner && (row < N) && (key > wl.tau);
+        wl.offer(pass, key, lane, R);
+    }
+    wl.compact(lane);
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < 4; ++w) {
+            const u64* other = lds + (size_t)w * cap;
+            for (int i0 = 0; i0 < kl; i0 += 64) {
+                const int i = i0 + lane;
+                const u64 key = (i < kl) ? other[i] : 0;
+                const bool pass = (key != 0) && (key > wl.tau);
+                wl.offer(pass, key, lane, 64);
+            }
+        }
+        wl.compact(lane);
+        u64* dst = part + (size_t)blockIdx.x * kl;
+        for (int i = lane; i < kl; i += 64) dst[i] = wl.buf[i];
+    }
+}
+
+// exact scores of the SHADOW_C candidates (16 waves, four candidates each, all their loads in flight at once), then
+// wave 0 orders them, writes the first k, and evaluates the certificate -> *gate
+__global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __restrict__ X, int d, const float* __restrict__ Q,
+                                                               const float* __restrict__ cand_scores,
+                                                               const long long* __restrict__ cand_rows, int k,
+                                                               const long long* __restrict__ ids, long long id_base,
+                                                               const float* __restrict__ max_norm,
+                                                               float* __restrict__ outD, long long* __restrict__ outI,
+                                                               int* __restrict__ gate, int* __restrict__ stats) {
+    __shared__ float exact[SHADOW_C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d4 = d >> 2;
+    const float4* qv = reinterpret_cast<const float4*>(Q);
+    {
+        constexpr int PER = SHADOW_C / 16;
+        long long rows[PER];
+        float p[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { rows[u] = cand_rows[wave * PER + u]; p[u] = 0.f; }
+        for (int j = lane; j < d4; j += 64) {
+            const float4 b = qv[j];
+            float4 a[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u)
+                a[u] = rows[u] >= 0 ? reinterpret_cast<const float4*>(X + (size_t)rows[u] * d)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                p[u] = fmaf(a[u].x, b.x, p[u]); p[u] = fmaf(a[u].y, b.y, p[u]);
+                p[u] = fmaf(a[u].z, b.z, p[u]); p[u] = fmaf(a[u].w, b.w, p[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) p[u] += __shfl_xor(p[u], o, 64);
+            if (lane == 0) exact[wave * PER + u] = p[u];
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const long long my_row = cand_rows[lane];
+    const float my_score = exact[lane];
+    float qq = 0.f;
+    for (int j = lane; j < d4; j += 64) {
+        const float4 b = qv[j];
+        qq += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    const u64 my_key = my_row >= 0 ? make_key(my_score, (unsigned)my_row) : 0;
+    int rank = 0, valid = 0;
+    for (int c = 0; c < SHADOW_C; ++c) {
+        const u64 other = __shfl(my_key, c, 64);
+        rank += other > my_key;
+        valid += other != 0;
+    }
+    if (my_key != 0 && rank < k) {
+        outD[rank] = my_score;
+        outI[rank] = ids ? ids[my_row] : id_base + my_row;
+    }
+    if (lane < k && lane >= valid) {
+        outD[lane] = -3.4028234663852886e38f;
+        outI[lane] = -1;
+    }
+    // certificate: the k-th exact score (held by the lane of rank k-1) against the bound on everything not kept
+    const float t = cand_scores[SHADOW_C - 1];                       // lowest approximate score kept
+    const float eps = (0.00390625f + 4e-5f) * sqrtf(qq) * max_norm[0];  // 2^-8 (bf16 RNE) + f32 accumulation slack
+    const bool holder = my_key != 0 && rank == k - 1;
+    const bool ok_lane = holder && (my_score > t + eps);
+    const bool certified = valid < SHADOW_C || (valid >= k && __ballot(ok_lane) != 0);
+    if (lane == 0) {
+        *gate = certified ? 0 : 1;
+        atomicAdd(stats + (certified ? 0 : 1), 1);
+    }
+}
+
+
 static int next_pow2(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -449,11 +662,13 @@ static ScanPlan plan_scan(long long N, int d, int nq, int k) {
 
 template <int NV, int NQ>
 static void launch_scan(const ScanPlan& p, const float* X, long long N, int d, const float* Q, int k, u64* part,
-                        hipStream_t st) {
+                        hipStream_t st, const int* gate = nullptr) {
+    SegArgs sa{};
+    sa.gate = gate;
     if constexpr (NQ == 1 && NV <= 2) {
         if (p.rows == 8) {
             hipLaunchKernelGGL((ip_scan_kernel<NV, NQ, 8>), dim3(p.grid), dim3(256), p.lds, st,
-                               reinterpret_cast<const f32x4*>(X), N, d / 4, Q, k, p.cap, part, SegArgs{});
+                               reinterpret_cast<const f32x4*>(X), N, d / 4, Q, k, p.cap, part, sa);
             return;
         }
     }
@@ -462,7 +677,7 @@ static void launch_scan(const ScanPlan& p, const float* X, long long N, int d, c
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)p.lds);
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds, st, reinterpret_cast<const f32x4*>(X), N, d / 4, Q, k,
-                       p.cap, part, SegArgs{});
+                       p.cap, part, sa);
 }
 
 template <int NV>
@@ -714,6 +929,121 @@ extern "C" int wise_ivf_scan_f32(const float* X, int64_t N, int d, const int64_t
     hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(mw * 64), mlds, st, part, nprobe, nq, k, cap,
                        reinterpret_cast<const long long*>(ids), 0ll, outD, reinterpret_cast<long long*>(outI), 0);
     WISE_LAUNCH_CHECK("merge_keys_kernel");
+    return WISE_OK;
+}
+
+// ---- two-stage exact search over a bf16 shadow (see the kernels above)
+namespace wise {
+__device__ int g_shadow_stats[2];   // certified, fell back (debug / tests)
+static int shadow_grid(long long N) {
+    long long need = ((N + 7) / 8 + 3) / 4;
+    if (need < 1) need = 1;
+    return need < 1024 ? (int)need : 1024;
+}
+static bool shadow_supported(int d, int k) { return d % 8 == 0 && d >= 8 && d <= 1024 && k >= 1 && k <= 16; }
+}  // namespace wise
+
+extern "C" int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* Xb, float* max_norm, void* stream) {
+    WISE_CHECK_ARG(d >= 8 && d % 8 == 0 && N >= 0 && (X && Xb || N == 0) && max_norm, "ip_shadow_bf16: bad argument");
+    WISE_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Xb & 15) == 0, "ip_shadow_bf16: X and Xb must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(max_norm, 0, sizeof(float), st);
+    if (e != hipSuccess) { set_error("ip_shadow_bf16: %s", hipGetErrorString(e)); return (int)e; }
+    if (N > 0) {
+        hipLaunchKernelGGL(shadow_bf16_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, X, (long long)N, d, Xb,
+                           max_norm);
+        WISE_LAUNCH_CHECK("shadow_bf16_kernel");
+    }
+    return WISE_OK;
+}
+
+extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int k) {
+    if (N < 0 || !shadow_supported(d, k)) return 0;
+    const ScanPlan p = plan_scan(N, d, 1, k);
+    return align_up((size_t)shadow_grid(N) * SHADOW_C * sizeof(u64), 256) + align_up((size_t)SHADOW_C * 12, 256) + 256 +
+           align_up((size_t)p.grid * k * sizeof(u64), 256);
+}
+
+extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* max_norm, int64_t N, int d,
+                                       const float* q, int k, const int64_t* ids, int64_t id_base, float* outD,
+                                       int64_t* outI, void* workspace, size_t workspace_bytes, void* stream) {
+    WISE_CHECK_ARG(shadow_supported(d, k), "ip_topk_shadow: d=%d must be a multiple of 8 in [8,1024], k=%d in [1,16]", d, k);
+    WISE_CHECK_ARG(N > 0 && N < 0xFFFFFFFFll, "ip_topk_shadow: N=%lld out of range", (long long)N);
+    WISE_CHECK_ARG(X && Xb && max_norm && q && outD && outI, "ip_topk_shadow: null pointer");
+    WISE_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Xb & 15) == 0 && ((uintptr_t)q & 15) == 0,
+                   "ip_topk_shadow: X, Xb and q must be 16-byte aligned");
+    const size_t need = wise_ip_topk_shadow_workspace_bytes(N, d, k);
+    if (!workspace || workspace_bytes < need) {
+        set_error("ip_topk_shadow: workspace %zu < %zu bytes", workspace_bytes, need);
+        return WISE_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+    const int sgrid = shadow_grid(N);
+    u64* spart = reinterpret_cast<u64*>(wsb);
+    size_t off = align_up((size_t)sgrid * SHADOW_C * sizeof(u64), 256);
+    long long* cand_rows = reinterpret_cast<long long*>(wsb + off);
+    float* cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)SHADOW_C * 8);
+    off += align_up((size_t)SHADOW_C * 12, 256);
+    int* gate = reinterpret_cast<int*>(wsb + off);
+    off += 256;
+    u64* epart = reinterpret_cast<u64*>(wsb + off);
+    const int scap = list_cap(SHADOW_C);
+    int* stats = nullptr;
+    (void)hipGetSymbolAddress(reinterpret_cast<void**>(&stats), HIP_SYMBOL(wise::g_shadow_stats));
+    // 1. candidates from the bf16 rows
+    {
+        ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
+        const int d8 = d / 8;
+        const size_t lds = (size_t)4 * scap * 8;
+        const uint4* xb = reinterpret_cast<const uint4*>(Xb);
+        switch ((d8 + 63) / 64) {
+            case 1: hipLaunchKernelGGL((ip_scan_bf16_kernel<1, 8>), dim3(sgrid), dim3(256), lds, st, xb, (long long)N, d8, q,
+                                       SHADOW_C, scap, spart); break;
+            case 2: hipLaunchKernelGGL((ip_scan_bf16_kernel<2, 8>), dim3(sgrid), dim3(256), lds, st, xb, (long long)N, d8, q,
+                                       SHADOW_C, scap, spart); break;
+            default: set_error("ip_topk_shadow: no kernel for d=%d", d); return WISE_E_INVALID;
+        }
+        WISE_LAUNCH_CHECK("ip_scan_bf16_kernel");
+    }
+    int mw = 8192 / scap;
+    if (mw > 16) mw = 16;
+    hipLaunchKernelGGL(merge_keys_kernel, dim3(1), dim3(mw * 64), (size_t)mw * scap * 8, st, spart, sgrid, 1, SHADOW_C, scap,
+                       (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
+    WISE_LAUNCH_CHECK("merge_keys_kernel");
+    // 2. exact scores of the candidates, the answer, and the certificate
+    hipLaunchKernelGGL(rescore_certify_kernel, dim3(1), dim3(1024), 0, st, X, d, q, cand_scores, cand_rows, k,
+                       reinterpret_cast<const long long*>(ids), (long long)id_base, max_norm, outD,
+                       reinterpret_cast<long long*>(outI), gate, stats);
+    WISE_LAUNCH_CHECK("rescore_certify_kernel");
+    // 3. the f32 scan, which returns at once unless the certificate failed
+    const ScanPlan p = plan_scan(N, d, 1, k);
+    const int nv = (d / 4 + 63) / 64;
+    switch (nv) {
+        case 1: launch_scan<1, 1>(p, X, N, d, q, k, epart, st, gate); break;
+        case 2: launch_scan<2, 1>(p, X, N, d, q, k, epart, st, gate); break;
+        case 3: launch_scan<3, 1>(p, X, N, d, q, k, epart, st, gate); break;
+        case 4: launch_scan<4, 1>(p, X, N, d, q, k, epart, st, gate); break;
+        default: set_error("ip_topk_shadow: no kernel for d=%d", d); return WISE_E_INVALID;
+    }
+    WISE_LAUNCH_CHECK("ip_scan_kernel (gated)");
+    int emw = 8192 / p.cap;
+    if (emw < 1) emw = 1;
+    if (emw > 16) emw = 16;
+    hipLaunchKernelGGL(merge_keys_kernel, dim3(1), dim3(emw * 64), (size_t)emw * p.cap * 8, st, epart, p.grid, 1, k, p.cap,
+                       reinterpret_cast<const long long*>(ids), (long long)id_base, outD,
+                       reinterpret_cast<long long*>(outI), 0, gate);
+    WISE_LAUNCH_CHECK("merge_keys_kernel (gated)");
+    return WISE_OK;
+}
+
+// debug / tests: how many two-stage searches were certified / fell back since the last call (counters reset)
+extern "C" int wise_debug_shadow_stats(int* certified_and_fallback /*[2], host*/) {
+    int* stats = nullptr;
+    hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&stats), HIP_SYMBOL(wise::g_shadow_stats));
+    if (e == hipSuccess) e = hipMemcpy(certified_and_fallback, stats, 2 * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemset(stats, 0, 2 * sizeof(int));
+    if (e != hipSuccess) { set_error("shadow_stats: %s", hipGetErrorString(e)); return (int)e; }
     return WISE_OK;
 }
 

@@ -8,6 +8,7 @@ both with hasattr/try).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -17,11 +18,20 @@ from .. import _lib
 
 
 class FlatIPIndex:
-    def __init__(self, d: int, device: str = "cuda"):
+    def __init__(self, d: int, device: str = "cuda", shadow: Optional[bool] = None):
+        """shadow: keep a bf16 copy of the rows (+50 % memory) so that single-query searches with k <= 16 scan half the
+        bytes and verify in fp32 (wise_ip_topk_shadow_f32: same results, certified or recomputed).  None = on unless
+        WISE_FLAT_SHADOW=0."""
         if d < 4 or d % 4 != 0 or d > 2048:
             raise ValueError(f"FlatIPIndex: d={d} must be a multiple of 4 in [4, 2048]")
         self.d = int(d)
         self.device = torch.device(device)
+        if shadow is None:
+            shadow = os.environ.get("WISE_FLAT_SHADOW", "1") != "0"
+        self.shadow = bool(shadow) and d % 8 == 0 and d <= 1024
+        self._Xb: Optional[torch.Tensor] = None      # [N,d] bf16 bits (int16) on device
+        self._max_norm: Optional[torch.Tensor] = None
+        self._sws: Optional[torch.Tensor] = None
         self._chunks: List[torch.Tensor] = []
         self._id_chunks: List[torch.Tensor] = []
         self._X: Optional[torch.Tensor] = None  # [N,d] fp32 on device
@@ -60,6 +70,7 @@ class FlatIPIndex:
             raise ValueError("adopt: ids must be int64 [N]")
         self._chunks, self._id_chunks = [], []
         self._X, self._ids, self.id_base, self._n = X, ids, int(id_base), X.shape[0]
+        self._Xb = None
         return self
 
     def _finalize(self):
@@ -72,6 +83,7 @@ class FlatIPIndex:
             self._X = torch.cat(parts, dim=0).contiguous()
             self._ids = torch.cat(idp, dim=0).contiguous()
             self._chunks, self._id_chunks = [], []
+            self._Xb = None
         if self._X is None:
             self._X = torch.empty(0, self.d, dtype=torch.float32, device=self.device)
             self._ids = torch.empty(0, dtype=torch.int64, device=self.device)
@@ -89,6 +101,16 @@ class FlatIPIndex:
         I = torch.empty(nq, k, dtype=torch.int64, device=self.device)
         if nq == 0:
             return D, I
+        if self.shadow and nq == 1 and 1 <= k <= 16 and self._n >= 1:
+            self._ensure_shadow(lib)
+            need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, k)
+            if self._sws is None or self._sws.numel() < need:
+                self._sws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            rc = lib.wise_ip_topk_shadow_f32(self._X.data_ptr(), self._Xb.data_ptr(), self._max_norm.data_ptr(), self._n,
+                                             self.d, q.data_ptr(), k, _lib.ptr(self._ids), self.id_base, D.data_ptr(),
+                                             I.data_ptr(), self._sws.data_ptr(), self._sws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "wise_ip_topk_shadow_f32")
+            return D, I
         need = lib.wise_ip_topk_workspace_bytes(self._n, self.d, nq, k)
         if need == 0:
             raise ValueError(f"search: unsupported shape N={self._n} d={self.d} nq={nq} k={k}")
@@ -99,6 +121,15 @@ class FlatIPIndex:
                                   _lib.stream_ptr())
         _lib.check(rc, "wise_ip_topk_f32")
         return D, I
+
+    def _ensure_shadow(self, lib) -> None:
+        if self._Xb is not None and self._Xb.shape[0] == self._n:
+            return
+        self._Xb = torch.empty(self._n, self.d, dtype=torch.int16, device=self.device)
+        self._max_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        rc = lib.wise_ip_shadow_bf16(self._X.data_ptr(), self._n, self.d, self._Xb.data_ptr(), self._max_norm.data_ptr(),
+                                     _lib.stream_ptr())
+        _lib.check(rc, "wise_ip_shadow_bf16")
 
     def search(self, x, k: int):
         """faiss signature: x np.ndarray [nq,d] float32 -> (D, I) numpy (feature_search_index.py:113)."""
