@@ -308,26 +308,20 @@ def main():
             res["DI"] = index.search_device(Q[j:j + 1], k)
 
         s_steps = max(args.steps, 20)
-        import ctypes as _C
-        lib.wise_debug_shadow_stats.restype = _C.c_int
-        lib.wise_debug_shadow_stats.argtypes = [_C.c_void_p]
-        shadow_stats = (_C.c_int * 2)()
         # the fp32 scan alone (what the two-stage search falls back to), for reference
-        for sh in index.shards if hasattr(index, "shards") else [getattr(index, "local", index)]:
-            if hasattr(sh, "shadow"):
-                sh.shadow = False
+        flat = getattr(index, "local", index)
+        flat.shadow = False
         for i in range(3):
             search_step(i)
         qps_f32 = s_steps / timed_region(search_step, s_steps, world)
-        for sh in index.shards if hasattr(index, "shards") else [getattr(index, "local", index)]:
-            if hasattr(sh, "shadow"):
-                sh.shadow = True
+        flat.shadow = True
         for i in range(max(args.warmup, 3)):
             search_step(i)
-        lib.wise_debug_shadow_stats(shadow_stats)
+        c0 = flat.shadow_counts()
         sdt = timed_region(search_step, s_steps, world)
         qps = s_steps / sdt
-        lib.wise_debug_shadow_stats(shadow_stats)
+        c1 = flat.shadow_counts()
+        shadow_stats = (c1[0] - c0[0], c1[1] - c0[1])
         D, I = res["DI"]
         assert bool((D[:, :-1] >= D[:, 1:]).all()) and bool((I >= 1).all())
         sprof = prof_pass(lib, search_step, s_steps, s_steps + 8)

@@ -76,6 +76,10 @@ size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int k);
 int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* max_norm, int64_t N, int d, const float* q,
                             int k, const int64_t* ids, int64_t id_base, float* outD, int64_t* outI, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* Process-wide counters of two-stage searches: out[0] certified, out[1] recomputed by the fp32 scan, since the previous
+ * call (which resets them).  Synchronises the device.  A caller whose data defeats the certificate most of the time
+ * should call wise_ip_topk_f32 instead (FlatIPIndex does that by itself). */
+int wise_ip_shadow_stats(int* certified_and_fallback);
 
 /* IndexIVFFlat search, second stage (the first stage — the `nprobe` nearest centroids of each query — is
  * wise_ip_topk_f32 over the centroid table): scan the probed inverted lists and keep the k best.

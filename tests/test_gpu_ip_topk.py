@@ -190,10 +190,10 @@ def _shadow_stats():
 
     from wise_amd import _lib
     lib = _lib.lib()
-    lib.wise_debug_shadow_stats.restype = ctypes.c_int
-    lib.wise_debug_shadow_stats.argtypes = [ctypes.c_void_p]
+    lib.wise_ip_shadow_stats.restype = ctypes.c_int
+    lib.wise_ip_shadow_stats.argtypes = [ctypes.c_void_p]
     out = (ctypes.c_int * 2)()
-    _lib.check(lib.wise_debug_shadow_stats(out), "shadow_stats")
+    _lib.check(lib.wise_ip_shadow_stats(out), "shadow_stats")
     return out[0], out[1]
 
 

@@ -1037,8 +1037,9 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
     return WISE_OK;
 }
 
-// debug / tests: how many two-stage searches were certified / fell back since the last call (counters reset)
-extern "C" int wise_debug_shadow_stats(int* certified_and_fallback /*[2], host*/) {
+// how many two-stage searches of this process were certified / fell back since the last call (counters reset); a
+// caller whose data defeats the certificate most of the time should search the f32 rows directly
+extern "C" int wise_ip_shadow_stats(int* certified_and_fallback /*[2], host*/) {
     int* stats = nullptr;
     hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&stats), HIP_SYMBOL(wise::g_shadow_stats));
     if (e == hipSuccess) e = hipMemcpy(certified_and_fallback, stats, 2 * sizeof(int), hipMemcpyDeviceToHost);

@@ -32,6 +32,8 @@ class FlatIPIndex:
         self._Xb: Optional[torch.Tensor] = None      # [N,d] bf16 bits (int16) on device
         self._max_norm: Optional[torch.Tensor] = None
         self._sws: Optional[torch.Tensor] = None
+        self._shadow_calls = 0
+        self.shadow_certified = self.shadow_fallback = 0
         self._chunks: List[torch.Tensor] = []
         self._id_chunks: List[torch.Tensor] = []
         self._X: Optional[torch.Tensor] = None  # [N,d] fp32 on device
@@ -110,6 +112,9 @@ class FlatIPIndex:
                                              self.d, q.data_ptr(), k, _lib.ptr(self._ids), self.id_base, D.data_ptr(),
                                              I.data_ptr(), self._sws.data_ptr(), self._sws.numel(), _lib.stream_ptr())
             _lib.check(rc, "wise_ip_topk_shadow_f32")
+            self._shadow_calls += 1
+            if self._shadow_calls % 64 == 0:
+                self._review_shadow(lib)
             return D, I
         need = lib.wise_ip_topk_workspace_bytes(self._n, self.d, nq, k)
         if need == 0:
@@ -130,6 +135,23 @@ class FlatIPIndex:
         rc = lib.wise_ip_shadow_bf16(self._X.data_ptr(), self._n, self.d, self._Xb.data_ptr(), self._max_norm.data_ptr(),
                                      _lib.stream_ptr())
         _lib.check(rc, "wise_ip_shadow_bf16")
+
+    def _review_shadow(self, lib) -> None:
+        """Every 64 two-stage searches: if the fp32 scan had to redo most of them (data whose neighbours sit closer
+        together than the bf16 error bound), stop paying for the first stage."""
+        import ctypes
+        st = (ctypes.c_int * 2)()
+        _lib.check(lib.wise_ip_shadow_stats(st), "wise_ip_shadow_stats")
+        self.shadow_certified += st[0]
+        self.shadow_fallback += st[1]
+        if st[1] > st[0]:
+            self.shadow = False
+            self._Xb = self._sws = None
+
+    def shadow_counts(self):
+        """(certified, recomputed by the fp32 scan) over this process's two-stage searches seen by this index so far."""
+        self._review_shadow(_lib.lib())
+        return self.shadow_certified, self.shadow_fallback
 
     def search(self, x, k: int):
         """faiss signature: x np.ndarray [nq,d] float32 -> (D, I) numpy (feature_search_index.py:113)."""
