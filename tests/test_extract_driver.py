@@ -115,6 +115,10 @@ def test_batched_driver_reproduces_reference_loop_gpu(tmp_path):
         def extract_image_features(self, x):
             return self.e.forward(x).cpu().numpy()
 
+        def extract_image_features_async(self, x):   # the driver's overlapped path (two batches in flight)
+            from wise_amd.feature.mlfoundation_openclip import _AsyncFeatures
+            return _AsyncFeatures(self.e.forward_pipelined(x))
+
     clap = FeatureExtractorFactory("microsoft/clap/2023/seeded-0")
     global synthetic_loader
     orig = synthetic_loader

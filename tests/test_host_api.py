@@ -119,7 +119,7 @@ def test_openclip_preprocess_matches_reference_transform():
     x = fx.preprocess_image(imgs)
     assert x.shape == (8, 3, 224, 224) and x.dtype == torch.float32
     black = torch.tensor([-m / s for m, s in zip(CLIP_MEAN, CLIP_STD)])
-    assert torch.allclose(x[0, :, 0, 0], black, atol=1e-6)
+    assert torch.allclose(x[0, :, 0, 0].cpu(), black, atol=1e-6)   # x sits on fx.DEVICE, as in the reference
     # tensor input (decoder output: uint8 [n,3,H,W]), shorter side resized to 224 then centre crop
     frames = torch.randint(0, 256, (2, 3, 240, 320), dtype=torch.uint8)
     y = fx.preprocess_image(frames)
@@ -127,14 +127,14 @@ def test_openclip_preprocess_matches_reference_transform():
     ref = Image.fromarray(frames[0].permute(1, 2, 0).numpy()).resize((298, 224), Image.BICUBIC).crop((37, 0, 261, 224))
     ref = (torch.from_numpy(np.asarray(ref)).permute(2, 0, 1).float() / 255 -
            torch.tensor(CLIP_MEAN).view(3, 1, 1)) / torch.tensor(CLIP_STD).view(3, 1, 1)
-    assert torch.allclose(y[0], ref, atol=1e-6)
+    assert torch.allclose(y[0].cpu(), ref, atol=1e-6)
     with pytest.raises(ValueError):
         fx.preprocess_image("not an image")
     with pytest.raises(ValueError):
         fx.extract_image_features([1, 2, 3])
     # picklable for DataLoader workers (extract-features.py:302-308)
     fx2 = pickle.loads(pickle.dumps(fx))
-    assert torch.equal(fx2.preprocess_image(imgs[:1]), x[:1])
+    assert torch.equal(fx2.preprocess_image(imgs[:1]).cpu(), x[:1].cpu())
 
 
 def test_clap_preprocess_audio_quirks():

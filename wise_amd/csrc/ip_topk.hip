@@ -417,8 +417,8 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restri
 //   2. merge_keys_kernel folds them into the 64 best candidates of the query;
 //   3. rescore_certify_kernel recomputes the candidates' scores from the f32 rows, orders them, writes the first k,
 //      and checks a certificate: every row outside the candidate set has approximate score <= t (the 64th
-//      candidate's), hence exact score <= t + eps with eps = 2^-8 |q| max|x| (bf16 rounding of x, Cauchy-Schwarz) plus
-//      f32 accumulation slack; if the k-th exact score is above t + eps the answer is the exact top-k;
+//      candidate's), hence exact score <= t + eps with eps = (2^-8 + d 2^-23) |q| max|x| (bf16 rounding of x and the
+//      f32 accumulation error of both dot products, Cauchy-Schwarz); if the k-th exact score is above t + eps the answer is the exact top-k;
 //   4. otherwise *gate = 1 and the f32 scan + merge queued behind (which return at once when *gate == 0) recompute
 //      the query exactly.  No host round trip either way.
 // ------------------------------------------------------------------------------------------------
@@ -608,7 +608,8 @@ __global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __re
     }
     // certificate: the k-th exact score (held by the lane of rank k-1) against the bound on everything not kept
     const float t = cand_scores[SHADOW_C - 1];                       // lowest approximate score kept
-    const float eps = (0.00390625f + 4e-5f) * sqrtf(qq) * max_norm[0];  // 2^-8 (bf16 RNE) + f32 accumulation slack
+    // 2^-8: bf16 round-to-nearest of every x_c; d * 2^-23: worst-case f32 accumulation error of the two dot products
+    const float eps = (0.00390625f + (float)d * 1.1920929e-7f) * 1.0001f * sqrtf(qq) * max_norm[0];
     const bool holder = my_key != 0 && rank == k - 1;
     const bool ok_lane = holder && (my_score > t + eps);
     const bool certified = valid < SHADOW_C || (valid >= k && __ballot(ok_lane) != 0);

@@ -8,6 +8,10 @@ the extractor runs once per `video_batch` frames / `audio_batch` segments.  Embe
 the batch a frame sits in (tests/test_gpu_vit.py::test_vit_b32_batch256_consistency), so the stores come
 out identical to the reference loop's.
 
+When an extractor offers `extract_*_features_async` (the HIP extractors do) a batch is only SUBMITTED when it is
+full; its vectors go to the store when the next batch has been submitted (or at flush), so the GPU works on one
+batch while the host writes the previous one.  Store order is unchanged: results are drained first in, first out.
+
 `create_vector(modality, media_id, timestamp, end_timestamp) -> int` stands where VectorRepo.create
 stands (extract-features.py:348-357,364-372); SQLite itself is outside this build.
 """
@@ -33,6 +37,7 @@ class BatchedExtractionDriver:
         self.audio_samples_per_chunk = audio_samples_per_chunk
         self._queue: Dict[str, List[Tuple[torch.Tensor, List[int]]]] = {m: [] for m in feature_extractors}
         self._rows: Dict[str, int] = {m: 0 for m in feature_extractors}
+        self._pending: Dict[str, list] = {m: [] for m in feature_extractors}   # submitted, not yet written
         self.vectors_written = 0
 
     def feed(self, mid, chunks: Dict[str, object]) -> None:
@@ -66,28 +71,47 @@ class BatchedExtractionDriver:
             by_len: Dict[int, List[int]] = {}
             for n, (t, _) in enumerate(items):
                 by_len.setdefault(t.shape[2], []).append(n)
-            feats: List[Optional[np.ndarray]] = [None] * len(items)
+            submit = getattr(fx, "extract_audio_features_async", None)
+            groups = []
             for _, idxs in by_len.items():
-                out = fx.extract_audio_features(torch.cat([items[n][0] for n in idxs], dim=0))
+                batch = torch.cat([items[n][0] for n in idxs], dim=0)
+                groups.append((idxs, submit(batch) if submit else fx.extract_audio_features(batch)))
+            self._pending[media_type].append(("audio", items, groups))
+        else:
+            batch = torch.cat([t for t, _ in items], dim=0)
+            submit = getattr(fx, "extract_image_features_async", None)
+            self._pending[media_type].append(("frames", items, submit(batch) if submit else fx.extract_image_features(batch)))
+        self._queue[media_type] = []
+        self._rows[media_type] = 0
+        while len(self._pending[media_type]) > 1:      # keep one batch in flight, write the older ones
+            self._drain_one(media_type)
+
+    def _drain_one(self, media_type: str) -> None:
+        kind, items, res = self._pending[media_type].pop(0)
+        store = self.stores[media_type]
+        if kind == "audio":
+            feats: List[Optional[np.ndarray]] = [None] * len(items)
+            for idxs, out in res:
+                out = out.result() if hasattr(out, "result") else out
                 for r, n in enumerate(idxs):
                     feats[n] = out[r:r + 1]
             for (t, ids), f in zip(items, feats):
-                self.stores[media_type].add(ids[0], f)                       # whole segment, [1, D]
+                store.add(ids[0], f)                                         # whole segment, [1, D]
                 self.vectors_written += 1
         else:
-            out = fx.extract_image_features(torch.cat([t for t, _ in items], dim=0))
+            out = res.result() if hasattr(res, "result") else res
             row = 0
             for t, ids in items:
                 for i, vid in enumerate(ids):
-                    self.stores[media_type].add(vid, np.expand_dims(out[row + i], axis=0))
+                    store.add(vid, np.expand_dims(out[row + i], axis=0))
                     self.vectors_written += 1
                 row += t.shape[0]
-        self._queue[media_type] = []
-        self._rows[media_type] = 0
 
     def flush(self) -> None:
         for media_type in self.extractors:
             self._run(media_type)
+            while self._pending[media_type]:
+                self._drain_one(media_type)
 
     def close(self) -> None:
         self.flush()

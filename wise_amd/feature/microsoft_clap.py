@@ -104,6 +104,12 @@ class MicrosoftClap(FeatureExtractor):
         out = self._get_engine().forward(x)
         return out.cpu().numpy()
 
+    def extract_audio_features_async(self, preprocessed_audio: torch.Tensor):
+        """Handle whose `.result()` is what `extract_audio_features` returns; two batches in flight on the GPU."""
+        from .mlfoundation_openclip import _AsyncFeatures
+        x = preprocessed_audio.reshape(preprocessed_audio.shape[0], preprocessed_audio.shape[2])
+        return _AsyncFeatures(self._get_engine().forward_pipelined(x))
+
     def extract_text_features(self, text: List[str]) -> np.ndarray:
         """caption_encoder + L2 normalise (microsoft_clap.py:53-58) on the HIP text-tower kernels."""
         tokens = self.preprocess_text(text)

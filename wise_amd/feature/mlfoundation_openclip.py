@@ -74,6 +74,27 @@ def to_pil_image(pic: torch.Tensor) -> Image.Image:
     return Image.fromarray(arr, mode="RGB")
 
 
+class _AsyncFeatures:
+    """Embeddings on their way to the host: copy queued behind the forward on a side stream, `.result()` waits for it."""
+    _copy_stream = None
+
+    def __init__(self, pending):
+        dev = pending.device
+        if _AsyncFeatures._copy_stream is None:
+            _AsyncFeatures._copy_stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(_AsyncFeatures._copy_stream):
+            out = pending.result()                     # orders the copy stream after the forward
+            self._host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+            self._host.copy_(out, non_blocking=True)
+            out.record_stream(_AsyncFeatures._copy_stream)
+            self._done = torch.cuda.Event()
+            self._done.record(_AsyncFeatures._copy_stream)
+
+    def result(self) -> np.ndarray:
+        self._done.synchronize()
+        return self._host.numpy()
+
+
 class MlfoundationOpenClip(FeatureExtractor):
     ID_PREFIX = 'mlfoundations/open_clip/'
     DESCRIPTION = 'OpenCLIP image tower as MI355X HIP kernels; see https://github.com/mlfoundations/open_clip'
@@ -158,6 +179,16 @@ class MlfoundationOpenClip(FeatureExtractor):
             raise ValueError('input to extract_features() must be an instance of torch.Tensor')
         out = self._get_engine().forward(images.to(torch.float32) if images.dtype != torch.uint8 else images)
         return out.cpu().numpy()
+
+    def extract_image_features_async(self, images: torch.Tensor):
+        """Enqueue the batch and return a handle whose `.result()` is what `extract_image_features` returns.  Two
+        batches are kept in flight on the GPU (VitEngine.forward_pipelined) and the device-to-host copy goes into
+        pinned memory behind the forward, so a caller that collects a batch's result after submitting the next one
+        never waits on an idle GPU (wise_amd/extract.py does)."""
+        if not isinstance(images, torch.Tensor):
+            raise ValueError('input to extract_features() must be an instance of torch.Tensor')
+        pending = self._get_engine().forward_pipelined(images.to(torch.float32) if images.dtype != torch.uint8 else images)
+        return _AsyncFeatures(pending)
 
     @property
     def tokenizer(self) -> ClipTokenizer:

@@ -154,6 +154,10 @@ class PendingEmbeddings:
     def __init__(self, out: torch.Tensor, done: "torch.cuda.Event"):
         self._out, self._done = out, done
 
+    @property
+    def device(self) -> torch.device:
+        return self._out.device
+
     def result(self) -> torch.Tensor:
         """The embeddings [B, D], ordered after the batch on the caller's current stream (no host sync)."""
         torch.cuda.current_stream(self._out.device).wait_event(self._done)
