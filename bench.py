@@ -381,20 +381,22 @@ def main():
             "batched_nq32_queries_per_s": round(32 * s_steps / sdt32, 2),
             "batched_nq32_ms_per_pass": round(sdt32 / s_steps * 1e3, 4),
             "batched_nq256_queries_per_s": round(256 * s256 / sdt256, 2),
-            "batched_nq256_roofline": {"kernel": "ip_scan_split64_kernel", "bound": "hbm",
-                                       "achieved": round(N * d * 4 / world / (sdt256 / s256 / 4) / 1e9, 1),
+            "batched_nq256_roofline": {"kernel": "ip_scan_shadow64_kernel (stage 1 of the batched two-stage search)",
+                                       "bound": "hbm",
+                                       "achieved": round(N * d * 2 / world / (sdt256 / s256 / 4) / 1e9, 1),
                                        "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": round(N * d * 4 / world / (sdt256 / s256 / 4) / 1e9 / PEAK_HBM_GBS, 4),
-                                       "note": "whole call / 4 passes of 64 queries (sample pass, scan, merge, exact "
-                                               "re-scoring), per GPU",
-                                       "traffic": load_pmc_traffic("ip_scan_split64_kernel")},
-            "batched_nq32_roofline": {"kernel": "ip_scan_split_direct_kernel", "bound": "hbm",
-                                      "achieved": round(N * d * 4 / world / (sdt32 / s_steps) / 1e9, 1),
+                                       "frac": round(N * d * 2 / world / (sdt256 / s256 / 4) / 1e9 / PEAK_HBM_GBS, 4),
+                                       "note": "bf16 shadow rows (N*d*2 bytes) per pass of 64 queries; whole call / 4 passes "
+                                               "(threshold pass, two scan ranges, merges, fp32 re-scoring + certificates, "
+                                               "gated fallback launches), per GPU",
+                                       "traffic": load_pmc_traffic("ip_scan_shadow64_kernel")},
+            "batched_nq32_roofline": {"kernel": "ip_scan_shadow64_kernel (one pass, half its 64 query slots used)",
+                                      "bound": "hbm",
+                                      "achieved": round(N * d * 2 / world / (sdt32 / s_steps) / 1e9, 1),
                                       "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                      "frac": round(N * d * 4 / world / (sdt32 / s_steps) / 1e9 / PEAK_HBM_GBS, 4),
-                                      "note": "whole call (sample pass, scan, merge, exact re-scoring) per 32-query "
-                                              "pass, per GPU",
-                                      "traffic": load_pmc_traffic("ip_scan_split_direct_kernel")},
+                                      "frac": round(N * d * 2 / world / (sdt32 / s_steps) / 1e9 / PEAK_HBM_GBS, 4),
+                                      "note": "bf16 shadow rows (N*d*2 bytes) per call; whole call, per GPU",
+                                      "traffic": load_pmc_traffic("ip_scan_shadow64_kernel")},
         }
         del X, local, index
         torch.cuda.empty_cache()

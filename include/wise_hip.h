@@ -62,7 +62,8 @@ int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, i
                      const int64_t* ids, int64_t id_base, float* outD, int64_t* outI,
                      void* workspace, size_t workspace_bytes, void* stream);
 
-/* The same search for ONE query (the reference's call shape, feature_search_index.py:113) in two stages over a bf16
+/* The same search in two stages over a bf16 shadow copy of the rows — first of all for ONE query, the reference's call
+ * shape (feature_search_index.py:113) —, exact by construction; described for one query: bf16
  * shadow copy of the rows, exact by construction:
  *   wise_ip_shadow_bf16   Xb [N,d] bf16 (round-to-nearest-even copy of X) and *max_norm = max_r |X[r,:]| (device float)
  *   wise_ip_topk_shadow_f32   (1) scan Xb (half the bytes of X) for the 64 best approximate scores, (2) recompute those
@@ -70,12 +71,15 @@ int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, i
  *       <= t (the 64th), so exact score <= t + 2^-8 |q| max_norm (+ accumulation slack); if the k-th exact score is
  *       above that bound the result is the exact top-k, (4) otherwise the fp32 scan queued behind (it returns at once
  *       when the certificate held) recomputes the query.  All on the stream, no host round trip.
- * Same outputs, ties and padding as wise_ip_topk_f32 with nq = 1.  Limits: d % 8 == 0, 8 <= d <= 1024, k <= 16, N >= 1. */
+ * Batches (nq >= 8, k <= 12, d = 256 or 512) run the same scheme 64 queries at a time on the matrix cores: the bf16 rows
+ * are MFMA operands as loaded, 48 candidates per query, per-query certificates, and the split-bf16 scan of the fp32 rows
+ * (wise_ip_topk_f32's batched path) queued behind as the gated fallback of the pass.  Other nq: one query at a time.
+ * Same outputs, ties and padding as wise_ip_topk_f32.  Limits: d % 8 == 0, 8 <= d <= 1024, k <= 16, N >= 1, nq <= 1024. */
 int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* Xb, float* max_norm, void* stream);
-size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int k);
-int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* max_norm, int64_t N, int d, const float* q,
-                            int k, const int64_t* ids, int64_t id_base, float* outD, int64_t* outI, void* workspace,
-                            size_t workspace_bytes, void* stream);
+size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, int k);
+int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* max_norm, int64_t N, int d, const float* Q,
+                            int nq, int k, const int64_t* ids, int64_t id_base, float* outD, int64_t* outI,
+                            void* workspace, size_t workspace_bytes, void* stream);
 /* Process-wide counters of two-stage searches: out[0] certified, out[1] recomputed by the fp32 scan, since the previous
  * call (which resets them).  Synchronises the device.  A caller whose data defeats the certificate most of the time
  * should call wise_ip_topk_f32 instead (FlatIPIndex does that by itself). */

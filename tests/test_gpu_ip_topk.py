@@ -245,3 +245,44 @@ def test_two_stage_search_falls_back_when_it_cannot_certify():
     # and an ordinary query on the same index is certified
     D2, I2 = idx.search(unit_rows(1, d, 64), k)
     assert _shadow_stats() == (1, 0)
+
+
+def test_batched_two_stage_search_certifies_or_falls_back():
+    """A batch of 40 queries on an index with a bf16 shadow: ordinary queries are certified from the bf16 pass; one query
+    with 80 near-duplicate neighbours cannot be, and the pass is redone from the f32 rows.  Either way: the oracle's."""
+    N, d, k = 60000, 512, 10
+    X = unit_rows(N, d, 71)
+    Q = unit_rows(40, d, 72)
+    ids = np.arange(N, dtype=np.int64) + 5
+    idx = FlatIPIndex(d, shadow=True)
+    idx.add_with_ids(X, ids)
+    _shadow_stats()
+    D, I = idx.search(Q, k)
+    assert _shadow_stats() == (40, 0)
+    check_against_oracle(X, Q, k, ids, D, I)
+    rng = np.random.default_rng(73)
+    for c in rng.choice(N, size=80, replace=False):
+        v = Q[7] + 1e-3 * rng.standard_normal(d).astype(np.float32)
+        X[c] = v / np.linalg.norm(v)
+    idx2 = FlatIPIndex(d, shadow=True)
+    idx2.add_with_ids(X, ids)
+    D2, I2 = idx2.search(Q, k)
+    certified, fallback = _shadow_stats()
+    assert fallback >= 1 and certified + fallback == 40
+    check_against_oracle(X, Q, k, ids, D2, I2)
+
+
+def test_batched_two_stage_search_with_threshold_passes():
+    """Large enough (N >= 8 x 32768) for the threshold pass of the batched bf16 scan: scores of the first 32K rows dumped,
+    the 48th best per query picked by radix select, the rest scanned under it."""
+    N, d, k = 300000, 256, 10
+    X = unit_rows(N, d, 81)
+    Q = unit_rows(70, d, 82)
+    ids = np.arange(N, dtype=np.int64) + 1
+    idx = FlatIPIndex(d, shadow=True)
+    idx.add_with_ids(X, ids)
+    _shadow_stats()
+    D, I = idx.search(Q, k)
+    certified, fallback = _shadow_stats()
+    assert certified + fallback == 70
+    check_against_oracle(X, Q, k, ids, D, I)

@@ -63,6 +63,7 @@ def main():
                              ("ip_scan_bf16_kernel", "ip_scan_bf16_kernel", 1),
                              ("ip_scan_split_direct_kernel", "ip_scan_split_direct_kernel", 2),
                              ("ip_scan_split64_kernel", "ip_scan_split64_kernel", 2),
+                             ("ip_scan_shadow64_kernel", "ip_scan_shadow64_kernel", 3),
                              ("clip_resize_kernel", "clip_resize_kernel", 1), ("ivf_scan_kernel", "ivf_scan_kernel", 1),
                              ("attention_kernel", "attention_kernel", 1), ("layernorm_kernel", "layernorm_kernel", 1)):
         a = agg(prefix, per)

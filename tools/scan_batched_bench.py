@@ -8,17 +8,20 @@ from wise_amd.index.flat_ip import FlatIPIndex
 lib = _lib.lib()
 N, d = 10_000_000, 512
 X = torch.nn.functional.normalize(torch.randn(N, d, device="cuda"), dim=1)
-idx = FlatIPIndex(d).adopt(X)
+idx = FlatIPIndex(d, shadow=False).adopt(X)
+idx_shadow = FlatIPIndex(d, shadow=True).adopt(X)
 Q = torch.nn.functional.normalize(torch.randn(256, d, device="cuda"), dim=1)
-variants = [("f32 MFMA, DMA ring", 1 << 11), ("split regs x4, 32/pass", (4 << 12) | (1 << 25)), ("split regs x4, 64/pass", 4 << 12)]
+variants = [("f32 MFMA, DMA ring", 1 << 11), ("split regs x4, 32/pass", (4 << 12) | (1 << 25)), ("split regs x4, 64/pass", 4 << 12),
+            ("two-stage, bf16 shadow 64/pass", -1)]
 ref = None
 for name, flags in variants * 2:
-    lib.wise_debug_set_scan(4 | flags, 0)
+    lib.wise_debug_set_scan(4 | max(flags, 0), 0)
+    use = idx_shadow if flags < 0 else idx
     for nq in (32, 64, 256):
-        for _ in range(2): D, I = idx.search_device(Q[:nq], 10)
+        for _ in range(2): D, I = use.search_device(Q[:nq], 10)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         n = 6 if nq == 32 else 2
-        for _ in range(n): D, I = idx.search_device(Q[:nq], 10)
+        for _ in range(n): D, I = use.search_device(Q[:nq], 10)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
         msg = f"{name:28s} nq={nq:3d}: {dt * 1e3:.3f} ms/call  {nq / dt:.0f} q/s"
         if nq == 256:

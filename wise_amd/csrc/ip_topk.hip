@@ -426,21 +426,25 @@ constexpr int SHADOW_C = 64;
 
 __global__ __launch_bounds__(256) void shadow_bf16_kernel(const float* __restrict__ X, long long N, int d,
                                                           bf16_t* __restrict__ Xb, float* __restrict__ max_norm) {
-    // one wave per row: bf16 (RNE) copy and the largest row norm (non-negative floats order like their bit patterns)
+    // a wave per row, waves stride over the rows: bf16 (RNE) copy and the largest row norm (non-negative floats order
+    // like their bit patterns; one atomic per wave at the end)
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= N) return;
-    const float4* xr = reinterpret_cast<const float4*>(X + row * d);
-    uint2* br = reinterpret_cast<uint2*>(Xb + row * d);
-    float ss = 0.f;
-    for (int c = lane; c < (d >> 2); c += 64) {
-        const float4 v = xr[c];
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        br[c] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-    }
+    const long long w0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    float best = 0.f;
+    for (long long row = w0; row < N; row += nw) {
+        const float4* xr = reinterpret_cast<const float4*>(X + row * d);
+        uint2* br = reinterpret_cast<uint2*>(Xb + row * d);
+        float ss = 0.f;
+        for (int c = lane; c < (d >> 2); c += 64) {
+            const float4 v = xr[c];
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            br[c] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(max_norm), __float_as_uint(sqrtf(ss)));
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        best = ss > best ? ss : best;
+    }
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(max_norm), __float_as_uint(sqrtf(best)));
 }
 
 // NV8 = 16-byte chunks (8 bf16) per lane per row, R rows per group, one query
@@ -542,25 +546,35 @@ __global__ __launch_bounds__(256) void ip_scan_bf16_kernel(const uint4* __restri
     }
 }
 
-// exact scores of the SHADOW_C candidates (16 waves, four candidates each, all their loads in flight at once), then
-// wave 0 orders them, writes the first k, and evaluates the certificate -> *gate
+// exact scores of a query's C <= 64 candidates (16 waves, up to four candidates each, all their loads in flight at once),
+// then wave 0 orders them, writes the first k, and evaluates the certificate; block q = query q of the pass.
+// *gate is raised (never cleared here) when a query cannot be certified.
 __global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __restrict__ X, int d, const float* __restrict__ Q,
                                                                const float* __restrict__ cand_scores,
-                                                               const long long* __restrict__ cand_rows, int k,
+                                                               const long long* __restrict__ cand_rows, int C, int k,
                                                                const long long* __restrict__ ids, long long id_base,
                                                                const float* __restrict__ max_norm,
                                                                float* __restrict__ outD, long long* __restrict__ outI,
                                                                int* __restrict__ gate, int* __restrict__ stats) {
-    __shared__ float exact[SHADOW_C];
+    __shared__ float exact[64];
+    const int q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d4 = d >> 2;
-    const float4* qv = reinterpret_cast<const float4*>(Q);
+    const float4* qv = reinterpret_cast<const float4*>(Q + (size_t)q * d);
+    cand_scores += (size_t)q * C;
+    cand_rows += (size_t)q * C;
+    outD += (size_t)q * k;
+    outI += (size_t)q * k;
     {
-        constexpr int PER = SHADOW_C / 16;
+        constexpr int PER = 4;
         long long rows[PER];
         float p[PER];
 #pragma unroll
-        for (int u = 0; u < PER; ++u) { rows[u] = cand_rows[wave * PER + u]; p[u] = 0.f; }
+        for (int u = 0; u < PER; ++u) {
+            const int c = wave * PER + u;
+            rows[u] = c < C ? cand_rows[c] : -1;
+            p[u] = 0.f;
+        }
         for (int j = lane; j < d4; j += 64) {
             const float4 b = qv[j];
             float4 a[PER];
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __re
     }
     __syncthreads();
     if (wave != 0) return;
-    const long long my_row = cand_rows[lane];
+    const long long my_row = lane < C ? cand_rows[lane] : -1;
     const float my_score = exact[lane];
     float qq = 0.f;
     for (int j = lane; j < d4; j += 64) {
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __re
     for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
     const u64 my_key = my_row >= 0 ? make_key(my_score, (unsigned)my_row) : 0;
     int rank = 0, valid = 0;
-    for (int c = 0; c < SHADOW_C; ++c) {
+    for (int c = 0; c < 64; ++c) {
         const u64 other = __shfl(my_key, c, 64);
         rank += other > my_key;
         valid += other != 0;
@@ -607,18 +621,17 @@ __global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __re
         outI[lane] = -1;
     }
     // certificate: the k-th exact score (held by the lane of rank k-1) against the bound on everything not kept
-    const float t = cand_scores[SHADOW_C - 1];                       // lowest approximate score kept
+    const float t = cand_scores[C - 1];                              // lowest approximate score kept
     // 2^-8: bf16 round-to-nearest of every x_c; d * 2^-23: worst-case f32 accumulation error of the two dot products
     const float eps = (0.00390625f + (float)d * 1.1920929e-7f) * 1.0001f * sqrtf(qq) * max_norm[0];
     const bool holder = my_key != 0 && rank == k - 1;
     const bool ok_lane = holder && (my_score > t + eps);
-    const bool certified = valid < SHADOW_C || (valid >= k && __ballot(ok_lane) != 0);
+    const bool certified = valid < C || (valid >= k && __ballot(ok_lane) != 0);
     if (lane == 0) {
-        *gate = certified ? 0 : 1;
+        if (!certified) atomicOr(gate, 1);
         atomicAdd(stats + (certified ? 0 : 1), 1);
     }
 }
-
 
 static int next_pow2(int v) {
     int p = 1;
@@ -951,35 +964,54 @@ extern "C" int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* X
     hipError_t e = hipMemsetAsync(max_norm, 0, sizeof(float), st);
     if (e != hipSuccess) { set_error("ip_shadow_bf16: %s", hipGetErrorString(e)); return (int)e; }
     if (N > 0) {
-        hipLaunchKernelGGL(shadow_bf16_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, X, (long long)N, d, Xb,
-                           max_norm);
+        const long long want = (N + 3) / 4;
+        hipLaunchKernelGGL(shadow_bf16_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, st, X, (long long)N, d,
+                           Xb, max_norm);
         WISE_LAUNCH_CHECK("shadow_bf16_kernel");
     }
     return WISE_OK;
 }
 
-extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int k) {
-    if (N < 0 || !shadow_supported(d, k)) return 0;
+extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, int k) {
+    if (N < 0 || nq < 1 || !shadow_supported(d, k)) return 0;
     const ScanPlan p = plan_scan(N, d, 1, k);
-    return align_up((size_t)shadow_grid(N) * SHADOW_C * sizeof(u64), 256) + align_up((size_t)SHADOW_C * 12, 256) + 256 +
-           align_up((size_t)p.grid * k * sizeof(u64), 256);
+    // single query: candidate lists of the bf16 scan | candidates | gate | lists of the gated f32 scan
+    size_t one = align_up((size_t)shadow_grid(N) * SHADOW_C * sizeof(u64), 256) + align_up((size_t)SHADOW_C * 12, 256) + 256 +
+                 align_up((size_t)p.grid * k * sizeof(u64), 256);
+    // batches: lists of both passes of either scan | 64 padded queries | candidates | thresholds | gate
+    size_t many = align_up((size_t)3 * split64_lists(N) * MFMA_QB2 * SHADOW_KL * sizeof(u64), 256) +
+                  align_up((size_t)MFMA_QB2 * d * sizeof(float), 256) + align_up((size_t)MFMA_QB2 * SHADOW_KL * 12, 256) +
+                  512 + 256 + align_up((size_t)MFMA_QB2 * g_scan_sample * sizeof(float), 256) +
+                  align_up((size_t)MFMA_QB2 * SHADOW_KL * sizeof(long long), 256);
+    return one > many ? one : many;
 }
 
-extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* max_norm, int64_t N, int d,
-                                       const float* q, int k, const int64_t* ids, int64_t id_base, float* outD,
-                                       int64_t* outI, void* workspace, size_t workspace_bytes, void* stream) {
-    WISE_CHECK_ARG(shadow_supported(d, k), "ip_topk_shadow: d=%d must be a multiple of 8 in [8,1024], k=%d in [1,16]", d, k);
-    WISE_CHECK_ARG(N > 0 && N < 0xFFFFFFFFll, "ip_topk_shadow: N=%lld out of range", (long long)N);
-    WISE_CHECK_ARG(X && Xb && max_norm && q && outD && outI, "ip_topk_shadow: null pointer");
-    WISE_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Xb & 15) == 0 && ((uintptr_t)q & 15) == 0,
-                   "ip_topk_shadow: X, Xb and q must be 16-byte aligned");
-    const size_t need = wise_ip_topk_shadow_workspace_bytes(N, d, k);
-    if (!workspace || workspace_bytes < need) {
-        set_error("ip_topk_shadow: workspace %zu < %zu bytes", workspace_bytes, need);
-        return WISE_E_WORKSPACE;
+namespace wise {
+// tau0[q] = the smallest key a score equal to the lowest of query q's `kl` selected sample scores can have: at least kl
+// rows reach that score, so nothing below it can be among the best kl of the whole index
+__global__ void tau_from_selected_kernel(const float* __restrict__ scores, long long n, const long long* __restrict__ sel,
+                                         int kl, u64* __restrict__ tau0) {
+    const int q = threadIdx.x;
+    float lo = 3.4028234663852886e38f;
+    for (int e = 0; e < kl; ++e) {
+        const long long j = sel[(size_t)q * kl + e];
+        if (j < 0) { lo = -3.4028234663852886e38f; break; }
+        const float v = scores[(size_t)q * n + j];
+        lo = v < lo ? v : lo;
     }
-    hipStream_t st = (hipStream_t)stream;
-    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+    tau0[q] = lo == -3.4028234663852886e38f ? 0 : ((u64)f32_order(lo) << 32);
+}
+
+static int* shadow_stats_ptr() {
+    static int* stats = nullptr;
+    if (!stats) (void)hipGetSymbolAddress(reinterpret_cast<void**>(&stats), HIP_SYMBOL(wise::g_shadow_stats));
+    return stats;
+}
+
+// one query: bf16 scan -> 64 candidates -> exact scores + certificate -> gated f32 scan
+static int shadow_search_one(const float* X, const bf16_t* Xb, const float* max_norm, long long N, int d, const float* q,
+                             int k, const long long* ids, long long id_base, float* outD, long long* outI,
+                             unsigned char* wsb, hipStream_t st) {
     const int sgrid = shadow_grid(N);
     u64* spart = reinterpret_cast<u64*>(wsb);
     size_t off = align_up((size_t)sgrid * SHADOW_C * sizeof(u64), 256);
@@ -990,19 +1022,18 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
     off += 256;
     u64* epart = reinterpret_cast<u64*>(wsb + off);
     const int scap = list_cap(SHADOW_C);
-    int* stats = nullptr;
-    (void)hipGetSymbolAddress(reinterpret_cast<void**>(&stats), HIP_SYMBOL(wise::g_shadow_stats));
-    // 1. candidates from the bf16 rows
+    hipError_t e = hipMemsetAsync(gate, 0, sizeof(int), st);
+    if (e != hipSuccess) { set_error("ip_topk_shadow: %s", hipGetErrorString(e)); return (int)e; }
     {
         ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
         const int d8 = d / 8;
         const size_t lds = (size_t)4 * scap * 8;
         const uint4* xb = reinterpret_cast<const uint4*>(Xb);
         switch ((d8 + 63) / 64) {
-            case 1: hipLaunchKernelGGL((ip_scan_bf16_kernel<1, 8>), dim3(sgrid), dim3(256), lds, st, xb, (long long)N, d8, q,
-                                       SHADOW_C, scap, spart); break;
-            case 2: hipLaunchKernelGGL((ip_scan_bf16_kernel<2, 8>), dim3(sgrid), dim3(256), lds, st, xb, (long long)N, d8, q,
-                                       SHADOW_C, scap, spart); break;
+            case 1: hipLaunchKernelGGL((ip_scan_bf16_kernel<1, 8>), dim3(sgrid), dim3(256), lds, st, xb, N, d8, q, SHADOW_C,
+                                       scap, spart); break;
+            case 2: hipLaunchKernelGGL((ip_scan_bf16_kernel<2, 8>), dim3(sgrid), dim3(256), lds, st, xb, N, d8, q, SHADOW_C,
+                                       scap, spart); break;
             default: set_error("ip_topk_shadow: no kernel for d=%d", d); return WISE_E_INVALID;
         }
         WISE_LAUNCH_CHECK("ip_scan_bf16_kernel");
@@ -1012,15 +1043,12 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
     hipLaunchKernelGGL(merge_keys_kernel, dim3(1), dim3(mw * 64), (size_t)mw * scap * 8, st, spart, sgrid, 1, SHADOW_C, scap,
                        (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
     WISE_LAUNCH_CHECK("merge_keys_kernel");
-    // 2. exact scores of the candidates, the answer, and the certificate
-    hipLaunchKernelGGL(rescore_certify_kernel, dim3(1), dim3(1024), 0, st, X, d, q, cand_scores, cand_rows, k,
-                       reinterpret_cast<const long long*>(ids), (long long)id_base, max_norm, outD,
-                       reinterpret_cast<long long*>(outI), gate, stats);
+    hipLaunchKernelGGL(rescore_certify_kernel, dim3(1), dim3(1024), 0, st, X, d, q, cand_scores, cand_rows, SHADOW_C, k, ids,
+                       id_base, max_norm, outD, outI, gate, shadow_stats_ptr());
     WISE_LAUNCH_CHECK("rescore_certify_kernel");
-    // 3. the f32 scan, which returns at once unless the certificate failed
+    // the f32 scan, which returns at once unless the certificate failed
     const ScanPlan p = plan_scan(N, d, 1, k);
-    const int nv = (d / 4 + 63) / 64;
-    switch (nv) {
+    switch ((d / 4 + 63) / 64) {
         case 1: launch_scan<1, 1>(p, X, N, d, q, k, epart, st, gate); break;
         case 2: launch_scan<2, 1>(p, X, N, d, q, k, epart, st, gate); break;
         case 3: launch_scan<3, 1>(p, X, N, d, q, k, epart, st, gate); break;
@@ -1032,17 +1060,154 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
     if (emw < 1) emw = 1;
     if (emw > 16) emw = 16;
     hipLaunchKernelGGL(merge_keys_kernel, dim3(1), dim3(emw * 64), (size_t)emw * p.cap * 8, st, epart, p.grid, 1, k, p.cap,
-                       reinterpret_cast<const long long*>(ids), (long long)id_base, outD,
-                       reinterpret_cast<long long*>(outI), 0, gate);
+                       ids, id_base, outD, outI, 0, gate);
     WISE_LAUNCH_CHECK("merge_keys_kernel (gated)");
+    return WISE_OK;
+}
+
+// up to 64 queries: bf16 MFMA scan (sample pass + main pass) -> SHADOW_KL candidates per query -> exact scores +
+// certificates -> if any failed, the split-bf16 scan of the f32 rows (candidates exact to 2^-16) and its re-scoring, gated
+static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max_norm, long long N, int d, const float* Q,
+                              int nqa, int k, const long long* ids, long long id_base, float* outD, long long* outI,
+                              unsigned char* wsb, hipStream_t st) {
+    constexpr int QB = MFMA_QB2;
+    u64* mpart = reinterpret_cast<u64*>(wsb);
+    size_t off = align_up((size_t)3 * split64_lists(N) * QB * SHADOW_KL * sizeof(u64), 256);
+    float* mq = reinterpret_cast<float*>(wsb + off);
+    off += align_up((size_t)QB * d * sizeof(float), 256);
+    long long* cand_rows = reinterpret_cast<long long*>(wsb + off);
+    float* cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)QB * SHADOW_KL * 8);
+    off += align_up((size_t)QB * SHADOW_KL * 12, 256);
+    u64* tau0 = reinterpret_cast<u64*>(wsb + off);
+    off += 512;
+    int* gate = reinterpret_cast<int*>(wsb + off);
+    off += 256;
+    float* dump = reinterpret_cast<float*>(wsb + off);
+    off += align_up((size_t)QB * g_scan_sample * sizeof(float), 256);
+    long long* sel = reinterpret_cast<long long*>(wsb + off);
+    hipError_t e = hipMemsetAsync(gate, 0, sizeof(int), st);
+    if (e == hipSuccess && nqa < QB) e = hipMemsetAsync(mq, 0, (size_t)QB * d * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemcpyAsync(mq, Q, (size_t)nqa * d * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { set_error("ip_topk_shadow: query staging: %s", hipGetErrorString(e)); return (int)e; }
+    const long long ns = (g_scan_sample && N >= 8ll * g_scan_sample) ? g_scan_sample : 0;
+    int rc;
+    // ---- stage 1 over the bf16 rows, in growing row ranges: each range runs under the threshold the ranges before it
+    // established (the candidate lists of a block only know that block's rows; without a good threshold a block
+    // inserts thousands of keys into 48-entry lists), and all ranges' lists are merged at the end
+    {
+        const int kl = SHADOW_KL, cap = list_cap(kl);
+        int mwv = 8192 / cap;
+        if (mwv < 1) mwv = 1;
+        if (mwv > 16) mwv = 16;
+        // ranges: [0, ns) scored only (threshold pass: scores dumped, the kl-th best per query selected by radix select),
+        // then [0, 32 ns) under that threshold, then the rest under the threshold the second range established
+        long long bounds[3] = {0, 0, 0};
+        int nb = 0;
+        if (ns > 0 && N >= 8 * 32 * ns) bounds[++nb] = 32 * ns;
+        bounds[++nb] = N;
+        int plists = 0;
+        {
+            ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
+            if (ns > 0) {
+                if ((rc = shadow64_scan_launch(Xb, ns, 0, d, mq, QB, nullptr, nullptr, st, dump))) return rc;
+                hipLaunchKernelGGL(select_topk_kernel, dim3(QB), dim3(1024), 0, st, dump, (int)ns, kl, sel);
+                WISE_LAUNCH_CHECK("select_topk_kernel");
+                hipLaunchKernelGGL(tau_from_selected_kernel, dim3(1), dim3(QB), 0, st, dump, ns, sel, kl, tau0);
+                WISE_LAUNCH_CHECK("tau_from_selected_kernel");
+            }
+            for (int r = 0; r < nb; ++r) {
+                const long long lo = bounds[r], hi = bounds[r + 1];
+                if ((rc = shadow64_scan_launch(Xb + (size_t)lo * d, hi - lo, lo, d, mq, nqa, mpart + (size_t)plists * QB * kl,
+                                               (ns > 0) ? tau0 : nullptr, st)))
+                    return rc;
+                plists += split64_lists(hi - lo);
+                if (r + 1 < nb) {
+                    hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart, plists,
+                                       QB, kl, cap, (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
+                    WISE_LAUNCH_CHECK("merge_keys_kernel");
+                    if ((rc = sample_threshold_launch(cand_scores, cand_rows, tau0, st, kl))) return rc;
+                }
+            }
+        }
+        hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart, plists, QB, kl, cap,
+                           (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
+        WISE_LAUNCH_CHECK("merge_keys_kernel");
+        hipLaunchKernelGGL(rescore_certify_kernel, dim3(nqa), dim3(1024), 0, st, X, d, mq, cand_scores, cand_rows, kl, k, ids,
+                           id_base, max_norm, outD, outI, gate, shadow_stats_ptr());
+        WISE_LAUNCH_CHECK("rescore_certify_kernel");
+    }
+    // ---- gated fallback over the f32 rows: every launch returns at once while *gate == 0
+    {
+        const int kl = MFMA_KL, cap = list_cap(kl);
+        int mwv = 8192 / cap;
+        if (mwv < 1) mwv = 1;
+        if (mwv > 16) mwv = 16;
+        int p1 = 0;
+        if (ns > 0) {
+            if ((rc = split64_scan_launch(X, ns, 0, d, mq, nqa, mpart, nullptr, st, gate))) return rc;
+            p1 = split64_lists(ns);
+            hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart, p1, QB, kl, cap,
+                               (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0, gate);
+            WISE_LAUNCH_CHECK("merge_keys_kernel (gated)");
+            if ((rc = sample_threshold_launch(cand_scores, cand_rows, tau0, st, kl, gate))) return rc;
+        }
+        if ((rc = split64_scan_launch(X + (size_t)ns * d, N - ns, ns, d, mq, nqa, mpart + (size_t)p1 * QB * kl,
+                                      ns > 0 ? tau0 : nullptr, st, gate)))
+            return rc;
+        hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart,
+                           p1 + split64_lists(N - ns), QB, kl, cap, (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0,
+                           gate);
+        WISE_LAUNCH_CHECK("merge_keys_kernel (gated)");
+        if ((rc = rescore_launch(X, d, mq, cand_rows, nqa, k, ids, id_base, outD, outI, st, gate))) return rc;
+    }
+    return WISE_OK;
+}
+}  // namespace wise
+
+extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* max_norm, int64_t N, int d,
+                                       const float* Q, int nq, int k, const int64_t* ids, int64_t id_base, float* outD,
+                                       int64_t* outI, void* workspace, size_t workspace_bytes, void* stream) {
+    WISE_CHECK_ARG(shadow_supported(d, k), "ip_topk_shadow: d=%d must be a multiple of 8 in [8,1024], k=%d in [1,16]", d, k);
+    WISE_CHECK_ARG(N > 0 && N < 0xFFFFFFFFll, "ip_topk_shadow: N=%lld out of range", (long long)N);
+    WISE_CHECK_ARG(nq >= 1 && nq <= 1024, "ip_topk_shadow: nq=%d out of [1,1024]", nq);
+    WISE_CHECK_ARG(X && Xb && max_norm && Q && outD && outI, "ip_topk_shadow: null pointer");
+    WISE_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Xb & 15) == 0 && ((uintptr_t)Q & 15) == 0,
+                   "ip_topk_shadow: X, Xb and Q must be 16-byte aligned");
+    const size_t need = wise_ip_topk_shadow_workspace_bytes(N, d, nq, k);
+    if (!workspace || workspace_bytes < need) {
+        set_error("ip_topk_shadow: workspace %zu < %zu bytes", workspace_bytes, need);
+        return WISE_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+    const long long* lids = reinterpret_cast<const long long*>(ids);
+    long long* lI = reinterpret_cast<long long*>(outI);
+    // batches on the matrix cores where the 64-query kernels apply (k <= 12: the fallback keeps 16 candidates), else
+    // one query at a time
+    const bool batched = nq >= 8 && k <= MFMA_KC && shadow64_supported(d) && mfma_split_supported(d, nq, k) &&
+                         split64_supported(d) && split_direct_enabled();
+    if (batched) {
+        for (int q0 = 0; q0 < nq; q0 += MFMA_QB2) {
+            const int nqa = nq - q0 < MFMA_QB2 ? nq - q0 : MFMA_QB2;
+            int rc = shadow_search_pass(X, Xb, max_norm, N, d, Q + (size_t)q0 * d, nqa, k, lids, (long long)id_base,
+                                        outD + (size_t)q0 * k, lI + (size_t)q0 * k, wsb, st);
+            if (rc) return rc;
+        }
+        return WISE_OK;
+    }
+    for (int q = 0; q < nq; ++q) {
+        int rc = shadow_search_one(X, Xb, max_norm, N, d, Q + (size_t)q * d, k, lids, (long long)id_base, outD + (size_t)q * k,
+                                   lI + (size_t)q * k, wsb, st);
+        if (rc) return rc;
+    }
     return WISE_OK;
 }
 
 // how many two-stage searches of this process were certified / fell back since the last call (counters reset); a
 // caller whose data defeats the certificate most of the time should search the f32 rows directly
 extern "C" int wise_ip_shadow_stats(int* certified_and_fallback /*[2], host*/) {
-    int* stats = nullptr;
-    hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&stats), HIP_SYMBOL(wise::g_shadow_stats));
+    int* stats = shadow_stats_ptr();
+    hipError_t e = stats ? hipSuccess : hipErrorNotFound;
     if (e == hipSuccess) e = hipMemcpy(certified_and_fallback, stats, 2 * sizeof(int), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemset(stats, 0, 2 * sizeof(int));
     if (e != hipSuccess) { set_error("shadow_stats: %s", hipGetErrorString(e)); return (int)e; }

@@ -445,10 +445,11 @@ int mfma_scan_launch(const float* X, long long N, int d, const float* qpad, int 
 // ------------------------------------------------------------------------------------------------
 constexpr int QB2 = 64;
 
+template <int KLS = MFMA_KL>
 __device__ __forceinline__ void select_group_shared(f32x16& acc, u64& tau, u64* lists /*[kl][QB2]*/, int* locks, int q,
                                                     int h, bool active, long long row0, long long N,
                                                     long long row_offset) {
-    constexpr int kl = MFMA_KL;
+    constexpr int kl = KLS;
     {
         const u64 t = lists[(kl - 1) * QB2 + q];   // the block's current MFMA_KL-th key of this query
         tau = t > tau ? t : tau;
@@ -492,8 +493,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_split64_kernel(const fl
                                                                  const float* __restrict__ qpad /*[64][d]*/, int nq,
                                                                  u64* __restrict__ part /*[grid][64][MFMA_KL]*/,
                                                                  long long row_offset,
-                                                                 const u64* __restrict__ tau0 /*[64] or null*/) {
+                                                                 const u64* __restrict__ tau0 /*[64] or null*/,
+                                                                 const int* __restrict__ gate /*null, or run only if != 0*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (gate && *gate == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int d4 = d >> 2, d8 = d >> 3;
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_split64_kernel(const fl
 int split64_lists(long long N) { return mfma_grid(N); }
 bool split64_supported(int d) { return d % (4 * CW) == 0 && d <= 512; }   // whole groups per trip of the 4-deep queue
 int split64_scan_launch(const float* X, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
-                        const u64* tau0, hipStream_t st) {
+                        const u64* tau0, hipStream_t st, const int* gate) {
     const size_t dl = (size_t)QB2 * d * 4 + (size_t)MFMA_KL * QB2 * 8 + QB2 * 4;
     static bool dattr = false;
     if (!dattr) {
@@ -618,8 +621,172 @@ int split64_scan_launch(const float* X, long long N, long long row_offset, int d
         dattr = true;
     }
     hipLaunchKernelGGL(ip_scan_split64_kernel<4>, dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, X, N, d, qpad, nq, part,
-                       row_offset, tau0);
+                       row_offset, tau0, gate);
     WISE_LAUNCH_CHECK("ip_scan_split64_kernel");
+    return WISE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 64 queries per pass over the bf16 SHADOW of the index (wise_ip_topk_shadow_f32, nq >= 8): stage 1 of the batched
+// two-stage exact search.  The rows arrive as bf16, so they are MFMA A-operands as loaded (no split, no VALU work):
+// a lane's four 16-byte loads cover 32 columns of a 64-column chunk, and a product is x*(q_hi + q_lo): 16 MFMAs per
+// 4 KiB chunk and wave for the 64 queries.  Half the bytes of the f32 rows per pass; the approximate scores carry the
+// bf16 rounding of x (<= 2^-8 |x||q|), which the certificate of rescore_certify_kernel accounts for.  Lists hold
+// SHADOW_KL = 48 candidates per query (block-shared, locked, as in ip_scan_split64_kernel): LDS 128 KiB of Q images
+// + 24 KiB of lists at d = 512.  part [grid][64][SHADOW_KL].
+// ------------------------------------------------------------------------------------------------
+constexpr int CW2 = 64;   // columns per chunk of the bf16 scan
+
+template <int PF>
+__global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const bf16_t* __restrict__ Xb, long long N, int d,
+                                                                  const float* __restrict__ qpad /*[64][d]*/, int nq,
+                                                                  u64* __restrict__ part /*[grid][64][SHADOW_KL]*/,
+                                                                  long long row_offset,
+                                                                  const u64* __restrict__ tau0 /*[64] or null*/,
+                                                                  float* __restrict__ dump /*[64][N] or null*/, int abl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int d4 = d >> 2, d8 = d >> 3;
+    unsigned char* Qh = smem;
+    unsigned char* Ql = smem + (size_t)QB2 * d * 2;
+    u64* lists = reinterpret_cast<u64*>(smem + (size_t)QB2 * d * 4);
+    int* locks = reinterpret_cast<int*>(lists + SHADOW_KL * QB2);
+    constexpr int kl = SHADOW_KL;
+
+    for (int idx = threadIdx.x; idx < QB2 * d4; idx += WAVES * 64) {
+        const int j = idx / d4, c = idx - j * d4;
+        const float4 v = reinterpret_cast<const float4*>(qpad)[idx];
+        const unsigned h01 = pack_bf16x2(v.x, v.y), h23 = pack_bf16x2(v.z, v.w);
+        const unsigned l01 = pack_bf16x2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xFFFF0000u));
+        const unsigned l23 = pack_bf16x2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xFFFF0000u));
+        const int c8 = c >> 1;
+        const size_t off = ((size_t)j * d8 + ((c8 & ~15) | ((c8 & 15) ^ (j & 15)))) * 16 + (c & 1) * 8;
+        *reinterpret_cast<uint2*>(Qh + off) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(Ql + off) = make_uint2(l01, l23);
+    }
+    for (int e = threadIdx.x; e < kl * QB2; e += WAVES * 64) lists[e] = 0;
+    if (threadIdx.x < QB2) locks[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int nch = d / CW2;
+    const long long ngroups = (N + 31) / 32;
+    const long long gw = (long long)blockIdx.x * WAVES + wave, nw = (long long)gridDim.x * WAVES;
+    const long long my_groups = gw < ngroups ? (ngroups - gw + nw - 1) / nw : 0;
+    const long long steps = my_groups * nch;
+
+    bf16x8 xq[PF][4];
+    long long pg = gw, issued = 0;
+    int pc = 0;
+    auto prefetch = [&](bf16x8 (&dst)[4]) {
+        long long grow = pg * 32 + i;
+        if (grow >= N) grow = N - 1;
+        const bf16x8* src = reinterpret_cast<const bf16x8*>(Xb + grow * d + pc * CW2 + h * 32);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst[t] = src[t];
+        if (issued + 1 < steps) {
+            ++issued;
+            if (++pc == nch) { pc = 0; pg += nw; }
+        }
+    };
+    if (steps > 0) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) prefetch(xq[p]);
+    }
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    u64 tau_a = tau0 ? tau0[i] : 0, tau_b = tau0 ? tau0[32 + i] : 0;
+    const bool active_a = i < nq, active_b = 32 + i < nq;
+    long long cg = gw;
+    int cc = 0;
+    const size_t ra = (size_t)i * d8 * 16, rb = (size_t)(32 + i) * d8 * 16;
+    for (long long s0 = 0; s0 < steps; s0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            // nch % PF == 0 (host check): a group ends on the last slot of a trip
+            const int c8 = ((cc + p) * CW2 >> 3) + h * 4;
+            bf16x8 x0 = xq[p][0], x1 = xq[p][1], x2 = xq[p][2], x3 = xq[p][3];
+            bf16x8 qa[4], la[4], qb[4], lb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t o = (size_t)(((c8 + j) & ~15) | (((c8 + j) & 15) ^ (i & 15))) * 16;
+                qa[j] = *reinterpret_cast<const bf16x8*>(Qh + ra + o);
+                la[j] = *reinterpret_cast<const bf16x8*>(Ql + ra + o);
+                qb[j] = *reinterpret_cast<const bf16x8*>(Qh + rb + o);
+                lb[j] = *reinterpret_cast<const bf16x8*>(Ql + rb + o);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch(xq[p]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (abl & 2) { acc0[0] += (float)x0[0] + (float)x1[1] + (float)x2[2] + (float)x3[3] + (float)qa[0][0] + (float)la[1][0] + (float)qb[2][0] + (float)lb[3][0] + (float)qa[1][0] + (float)qa[2][0] + (float)qa[3][0] + (float)la[0][0] + (float)la[2][0] + (float)la[3][0] + (float)qb[0][0] + (float)qb[1][0] + (float)qb[3][0] + (float)lb[0][0] + (float)lb[1][0] + (float)lb[2][0]; continue; }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, la[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, lb[0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, qa[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, qb[0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, la[1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, lb[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, qa[1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, qb[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, la[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, lb[2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, qa[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, qb[2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, la[3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, lb[3], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, qa[3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, qb[3], acc1, 0, 0, 0);
+        }
+        cc += PF;
+        if (cc == nch) {
+            cc = 0;
+            const long long row0 = cg * 32;
+            cg += nw;
+            if (dump) {
+                // threshold pass: no lists, the scores of this row range go to dump[q][row] for a per-query selection
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < N) {
+                        dump[(size_t)i * N + row] = acc0[r];
+                        dump[(size_t)(32 + i) * N + row] = acc1[r];
+                    }
+                    acc0[r] = 0.f; acc1[r] = 0.f;
+                }
+            } else if (abl & 1) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { t += acc0[r] + acc1[r]; acc0[r] = 0.f; acc1[r] = 0.f; }
+                if (t == 1.2345e-30f) lists[i] = 1;
+            } else {
+            select_group_shared<SHADOW_KL>(acc0, tau_a, lists, locks, i, h, active_a, row0, N, row_offset);
+            select_group_shared<SHADOW_KL>(acc1, tau_b, lists, locks, 32 + i, h, active_b, row0, N, row_offset);
+            }
+        }
+    }
+    if (dump) return;   // threshold pass: nothing to publish
+    __syncthreads();
+    u64* dst = part + (size_t)blockIdx.x * QB2 * kl;
+    for (int e = threadIdx.x; e < QB2 * kl; e += WAVES * 64) {
+        const int q = e / kl, r = e - q * kl;
+        dst[e] = q < nq ? lists[r * QB2 + q] : 0;
+    }
+}
+
+bool shadow64_supported(int d) { return d % (4 * CW2) == 0 && d <= 512; }
+int shadow64_scan_launch(const bf16_t* Xb, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
+                         const u64* tau0, hipStream_t st, float* dump) {
+    const size_t dl = (size_t)QB2 * d * 4 + (size_t)SHADOW_KL * QB2 * 8 + QB2 * 4;
+    static bool dattr = false;
+    if (!dattr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        dattr = true;
+    }
+    hipLaunchKernelGGL(ip_scan_shadow64_kernel<4>, dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, Xb, N, d, qpad, nq, part,
+                       row_offset, tau0, dump, g_mfma_abl);
+    WISE_LAUNCH_CHECK("ip_scan_shadow64_kernel");
     return WISE_OK;
 }
 
@@ -649,13 +816,15 @@ bool split_direct_enabled() { return g_split_direct != 0; }
 
 // tau0[q] = the key of the last of the MFMA_KL sample candidates of query q (0 while the sample holds fewer)
 __global__ void sample_threshold_kernel(const float* __restrict__ cand_scores, const long long* __restrict__ cand_rows,
-                                        u64* __restrict__ tau0) {
+                                        u64* __restrict__ tau0, int kl, const int* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     const int q = threadIdx.x;   // launched with 64 threads: the candidate block is sized for 64 queries
-    const long long row = cand_rows[(size_t)q * MFMA_KL + MFMA_KL - 1];
-    tau0[q] = row >= 0 ? make_key(cand_scores[(size_t)q * MFMA_KL + MFMA_KL - 1], (unsigned)row) : 0;
+    const long long row = cand_rows[(size_t)q * kl + kl - 1];
+    tau0[q] = row >= 0 ? make_key(cand_scores[(size_t)q * kl + kl - 1], (unsigned)row) : 0;
 }
-int sample_threshold_launch(const float* cand_scores, const long long* cand_rows, u64* tau0, hipStream_t st) {
-    hipLaunchKernelGGL(sample_threshold_kernel, dim3(1), dim3(64), 0, st, cand_scores, cand_rows, tau0);
+int sample_threshold_launch(const float* cand_scores, const long long* cand_rows, u64* tau0, hipStream_t st, int kl,
+                            const int* gate) {
+    hipLaunchKernelGGL(sample_threshold_kernel, dim3(1), dim3(64), 0, st, cand_scores, cand_rows, tau0, kl, gate);
     WISE_LAUNCH_CHECK("sample_threshold_kernel");
     return WISE_OK;
 }
@@ -668,7 +837,9 @@ int sample_threshold_launch(const float* cand_scores, const long long* cand_rows
 __global__ __launch_bounds__(64) void rescore_topk_kernel(const float* __restrict__ X, int d, const float* __restrict__ Q,
                                                           const long long* __restrict__ cand_rows, int k,
                                                           const long long* __restrict__ ids, long long id_base,
-                                                          float* __restrict__ outD, long long* __restrict__ outI) {
+                                                          float* __restrict__ outD, long long* __restrict__ outI,
+                                                          const int* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     const int q = blockIdx.x, lane = threadIdx.x;
     const int d4 = d >> 2;
     const float4* qv = reinterpret_cast<const float4*>(Q + (size_t)q * d);
@@ -705,8 +876,9 @@ __global__ __launch_bounds__(64) void rescore_topk_kernel(const float* __restric
 }
 
 int rescore_launch(const float* X, int d, const float* Q, const long long* cand_rows, int nq, int k, const long long* ids,
-                   long long id_base, float* outD, long long* outI, hipStream_t st) {
-    hipLaunchKernelGGL(rescore_topk_kernel, dim3(nq), dim3(64), 0, st, X, d, Q, cand_rows, k, ids, id_base, outD, outI);
+                   long long id_base, float* outD, long long* outI, hipStream_t st, const int* gate) {
+    hipLaunchKernelGGL(rescore_topk_kernel, dim3(nq), dim3(64), 0, st, X, d, Q, cand_rows, k, ids, id_base, outD, outI,
+                       gate);
     WISE_LAUNCH_CHECK("rescore_topk_kernel");
     return WISE_OK;
 }

@@ -38,10 +38,17 @@ constexpr int MFMA_QB2 = 64;
 int split64_lists(long long N);
 bool split64_supported(int d);
 int split64_scan_launch(const float* X, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
-                        const u64* tau0, hipStream_t st);
-int sample_threshold_launch(const float* cand_scores, const long long* cand_rows, u64* tau0, hipStream_t st);
+                        const u64* tau0, hipStream_t st, const int* gate = nullptr);
+// the same over the bf16 shadow rows, SHADOW_KL candidates per query: part [split64_lists(N)][64][SHADOW_KL]
+constexpr int SHADOW_KL = 48;
+bool shadow64_supported(int d);
+// dump != null: threshold pass — no lists; the scores of the N rows go to dump [64][N]
+int shadow64_scan_launch(const bf16_t* Xb, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
+                         const u64* tau0, hipStream_t st, float* dump = nullptr);
+int sample_threshold_launch(const float* cand_scores, const long long* cand_rows, u64* tau0, hipStream_t st,
+                            int kl = MFMA_KL, const int* gate = nullptr);
 // exact f32 scores of cand_rows [nq][MFMA_KL], ordered, first k -> outD/outI [nq][k]
 int rescore_launch(const float* X, int d, const float* Q, const long long* cand_rows, int nq, int k, const long long* ids,
-                   long long id_base, float* outD, long long* outI, hipStream_t st);
+                   long long id_base, float* outD, long long* outI, hipStream_t st, const int* gate = nullptr);
 
 }  // namespace wise

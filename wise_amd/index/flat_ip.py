@@ -103,13 +103,16 @@ class FlatIPIndex:
         I = torch.empty(nq, k, dtype=torch.int64, device=self.device)
         if nq == 0:
             return D, I
-        if self.shadow and nq == 1 and 1 <= k <= 16 and self._n >= 1:
+        # one query (the reference's shape) or a batch the 64-query matrix-core kernels serve (k <= 12, d = 256 / 512)
+        two_stage = self.shadow and self._n >= 1 and ((nq == 1 and 1 <= k <= 16) or
+                                                     (nq >= 8 and 1 <= k <= 12 and self.d in (256, 512)))
+        if two_stage:
             self._ensure_shadow(lib)
-            need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, k)
+            need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k)
             if self._sws is None or self._sws.numel() < need:
                 self._sws = torch.empty(need, dtype=torch.uint8, device=self.device)
             rc = lib.wise_ip_topk_shadow_f32(self._X.data_ptr(), self._Xb.data_ptr(), self._max_norm.data_ptr(), self._n,
-                                             self.d, q.data_ptr(), k, _lib.ptr(self._ids), self.id_base, D.data_ptr(),
+                                             self.d, q.data_ptr(), nq, k, _lib.ptr(self._ids), self.id_base, D.data_ptr(),
                                              I.data_ptr(), self._sws.data_ptr(), self._sws.numel(), _lib.stream_ptr())
             _lib.check(rc, "wise_ip_topk_shadow_f32")
             self._shadow_calls += 1
