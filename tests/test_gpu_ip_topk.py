@@ -273,9 +273,9 @@ def test_batched_two_stage_search_certifies_or_falls_back():
 
 
 def test_batched_two_stage_search_with_threshold_passes():
-    """Large enough (N >= 8 x 32768) for the threshold pass of the batched bf16 scan: scores of the first 32K rows dumped,
+    """Large enough (N >= 16 x 32768) for the threshold pass of the batched bf16 scan: scores of the first 64K rows dumped,
     the 48th best per query picked by radix select, the rest scanned under it."""
-    N, d, k = 300000, 256, 10
+    N, d, k = 600000, 256, 10
     X = unit_rows(N, d, 81)
     Q = unit_rows(70, d, 82)
     ids = np.arange(N, dtype=np.int64) + 1

@@ -649,6 +649,7 @@ struct ScanPlan {
 static int g_scan_rows = 4, g_scan_blocks_per_cu = 0;  // tuning knobs (wise_debug_set_scan)
 static int g_use_mfma = 1;                              // batched queries on the matrix cores
 static long long g_scan_sample = 32768;                  // rows of the split scan's sample pass (0 = none)
+static int g_stage2_factor = 8;                          // batched bf16 scan: second row range = factor x the threshold sample
 static int g_use_qb64 = 1;                               // 64 queries per pass when more than 32 are waiting
 static int g_use_split = 1;                             // ... as split-bf16 candidates + exact re-scoring (k <= MFMA_KC)
 extern int g_mfma_abl, g_split_direct;
@@ -727,7 +728,8 @@ using namespace wise;
 
 extern "C" int wise_debug_set_scan(int rows, int blocks_per_cu) {
     g_scan_rows = rows & 0xFF;
-    g_scan_blocks_per_cu = blocks_per_cu;
+    g_scan_blocks_per_cu = blocks_per_cu & 0xFF;
+    g_stage2_factor = (blocks_per_cu >> 8) & 0xFFF ? (blocks_per_cu >> 8) & 0xFFF : 8;
     g_use_mfma = (rows >> 8) & 1 ? 0 : 1;  // bit 8: force the VALU kernel for batched queries
     g_mfma_abl = (rows >> 9) & 3;
     g_use_split = (rows >> 11) & 1 ? 0 : 1;
@@ -981,7 +983,7 @@ extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, 
     // batches: lists of both passes of either scan | 64 padded queries | candidates | thresholds | gate
     size_t many = align_up((size_t)3 * split64_lists(N) * MFMA_QB2 * SHADOW_KL * sizeof(u64), 256) +
                   align_up((size_t)MFMA_QB2 * d * sizeof(float), 256) + align_up((size_t)MFMA_QB2 * SHADOW_KL * 12, 256) +
-                  512 + 256 + align_up((size_t)MFMA_QB2 * g_scan_sample * sizeof(float), 256) +
+                  512 + 256 + align_up((size_t)MFMA_QB2 * 2 * g_scan_sample * sizeof(float), 256) +
                   align_up((size_t)MFMA_QB2 * SHADOW_KL * sizeof(long long), 256);
     return one > many ? one : many;
 }
@@ -1083,13 +1085,15 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max
     int* gate = reinterpret_cast<int*>(wsb + off);
     off += 256;
     float* dump = reinterpret_cast<float*>(wsb + off);
-    off += align_up((size_t)QB * g_scan_sample * sizeof(float), 256);
+    off += align_up((size_t)QB * 2 * g_scan_sample * sizeof(float), 256);
     long long* sel = reinterpret_cast<long long*>(wsb + off);
     hipError_t e = hipMemsetAsync(gate, 0, sizeof(int), st);
     if (e == hipSuccess && nqa < QB) e = hipMemsetAsync(mq, 0, (size_t)QB * d * sizeof(float), st);
     if (e == hipSuccess) e = hipMemcpyAsync(mq, Q, (size_t)nqa * d * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) { set_error("ip_topk_shadow: query staging: %s", hipGetErrorString(e)); return (int)e; }
-    const long long ns = (g_scan_sample && N >= 8ll * g_scan_sample) ? g_scan_sample : 0;
+    // threshold sample of the bf16 pass: 64K rows (twice the split scan's), second range 8 x that (tools: 2.34 ms per pass
+    // against 2.53 at 32K / x32)
+    const long long ns = (g_scan_sample && N >= 16ll * g_scan_sample) ? 2 * g_scan_sample : 0;
     int rc;
     // ---- stage 1 over the bf16 rows, in growing row ranges: each range runs under the threshold the ranges before it
     // established (the candidate lists of a block only know that block's rows; without a good threshold a block
@@ -1103,7 +1107,7 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max
         // then [0, 32 ns) under that threshold, then the rest under the threshold the second range established
         long long bounds[3] = {0, 0, 0};
         int nb = 0;
-        if (ns > 0 && N >= 8 * 32 * ns) bounds[++nb] = 32 * ns;
+        if (ns > 0 && N >= 8ll * g_stage2_factor * ns) bounds[++nb] = (long long)g_stage2_factor * ns;
         bounds[++nb] = N;
         int plists = 0;
         {

@@ -4,7 +4,8 @@
 // docs/Retrieval-Evaluation.md:36-45) — SURVEY.md §8 f3.  Still an HBM-bound path: the kernels are judged against
 // N*d*4 bytes per pass.
 //
-// Three kernels, newest last (wise_ip_topk_f32 in ip_topk.hip picks; wise_debug_set_scan can force each):
+// Four kernels, newest last (wise_ip_topk_f32 / wise_ip_topk_shadow_f32 in ip_topk.hip pick; wise_debug_set_scan can
+// force each of the first three):
 //   ip_scan_mfma_kernel<false>   f32 operands on v_mfma_f32_32x32x2_f32, X through a per-wave LDS-DMA ring, lists of
 //                                k <= 16 entries per (wave, query); scores final.  4.9 ms per 32 queries at 10M x 512:
 //                                256 MFMAs of 64 cycles per 32 rows x 512 columns on a SIMD are two thirds of the HBM
@@ -24,6 +25,10 @@
 //   ip_scan_split64_kernel       the same for 64 queries per pass: with inserts rare, the block's eight waves share one
 //                                list per query behind a spin lock, which frees the LDS for the hi/lo images of 64
 //                                queries (128 KiB at d = 512).  4.2 ms per 64 queries: 15.2k queries/s at 10M x 512.
+//   ip_scan_shadow64_kernel      stage 1 of the batched two-stage search (wise_ip_topk_shadow_f32): the same 64-query
+//                                structure over the bf16 SHADOW rows — MFMA operands as loaded, x*(q_hi + q_lo), 48
+//                                candidates per query, a dump mode for the threshold pass.  2.5 ms per 64 queries
+//                                end to end (25k queries/s); the kernels above are its gated fallback.
 //
 // Structure shared by all three (block = 8 independent waves, one block per CU, two waves per SIMD):
 //   Q lives in LDS for the block's lifetime (16-byte chunks XOR-swizzled by query so that the 32 lanes of an MFMA
