@@ -83,6 +83,10 @@ def load(path: Path | None = None):
         raise RuntimeError(
             f"{p} is missing: build it with `python -m wise_amd.build` (hipcc --offload-arch=gfx950). "
             "wise_amd has no CPU fallback.")
+    # torch first: it brings its own libamdhip64, and the library must bind to THAT runtime (the one whose streams and
+    # allocations it is handed) — dlopen before `import torch` would pull in the system copy and leave two HIP runtimes
+    # in the process ("no ROCm-capable device" at the first launch)
+    import torch  # noqa: F401
     lib = C.CDLL(str(p))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
