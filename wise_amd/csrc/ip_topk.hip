@@ -422,7 +422,8 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restri
 //   4. otherwise *gate = 1 and the f32 scan + merge queued behind (which return at once when *gate == 0) recompute
 //      the query exactly.  No host round trip either way.
 // ------------------------------------------------------------------------------------------------
-constexpr int SHADOW_C = 64;
+constexpr int SHADOW_C = 64;   // candidates re-scored per query
+constexpr int SHADOW_L = 16;   // candidates a scan block keeps (its last key bounds what it dropped)
 
 __global__ __launch_bounds__(256) void shadow_bf16_kernel(const float* __restrict__ X, long long N, int d,
                                                           bf16_t* __restrict__ Xb, float* __restrict__ max_norm) {
@@ -555,7 +556,9 @@ __global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __re
                                                                const long long* __restrict__ ids, long long id_base,
                                                                const float* __restrict__ max_norm,
                                                                float* __restrict__ outD, long long* __restrict__ outI,
-                                                               int* __restrict__ gate, int* __restrict__ stats) {
+                                                               int* __restrict__ gate, int* __restrict__ stats,
+                                                               const u64* __restrict__ block_lists = nullptr,
+                                                               int nblocks = 0, int per_block = 0) {
     __shared__ float exact[64];
     const int q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -621,7 +624,24 @@ __global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __re
         outI[lane] = -1;
     }
     // certificate: the k-th exact score (held by the lane of rank k-1) against the bound on everything not kept
-    const float t = cand_scores[C - 1];                              // lowest approximate score kept
+    float t = cand_scores[C - 1];                                    // lowest approximate score the merge kept
+    if (block_lists) {
+        // scan blocks kept only their `per_block` best: a row a block dropped scores at most that block's last key
+        u64 worst = 0;
+        for (int b = lane; b < nblocks; b += 64) {
+            const u64 kb = block_lists[(size_t)b * per_block + per_block - 1];
+            worst = kb > worst ? kb : worst;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const u64 other = __shfl_xor(worst, o, 64);
+            worst = other > worst ? other : worst;
+        }
+        if (worst != 0) {
+            const float tb = f32_unorder((unsigned)(worst >> 32));
+            t = tb > t ? tb : t;
+        }
+    }
     // 2^-8: bf16 round-to-nearest of every x_c; d * 2^-23: worst-case f32 accumulation error of the two dot products
     const float eps = (0.00390625f + (float)d * 1.1920929e-7f) * 1.0001f * sqrtf(qq) * max_norm[0];
     const bool holder = my_key != 0 && rank == k - 1;
@@ -953,7 +973,8 @@ namespace wise {
 __device__ int g_shadow_stats[2];   // certified, fell back (debug / tests)
 static int shadow_grid(long long N) {
     long long need = ((N + 7) / 8 + 3) / 4;
-    if (need < 1) need = 1;
+    if (need < 4) need = 4;
+    need = (need + 3) / 4 * 4;   // a multiple of 4: four block lists of SHADOW_L keys read as one list of SHADOW_C
     return need < 1024 ? (int)need : 1024;
 }
 static bool shadow_supported(int d, int k) { return d % 8 == 0 && d >= 8 && d <= 1024 && k >= 1 && k <= 16; }
@@ -978,7 +999,7 @@ extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, 
     if (N < 0 || nq < 1 || !shadow_supported(d, k)) return 0;
     const ScanPlan p = plan_scan(N, d, 1, k);
     // single query: candidate lists of the bf16 scan | candidates | gate | lists of the gated f32 scan
-    size_t one = align_up((size_t)shadow_grid(N) * SHADOW_C * sizeof(u64), 256) + align_up((size_t)SHADOW_C * 12, 256) + 256 +
+    size_t one = align_up((size_t)shadow_grid(N) * SHADOW_L * sizeof(u64), 256) + align_up((size_t)SHADOW_C * 12, 256) + 256 +
                  align_up((size_t)p.grid * k * sizeof(u64), 256);
     // batches: lists of both passes of either scan | 64 padded queries | candidates | thresholds | gate
     size_t many = align_up((size_t)3 * split64_lists(N) * MFMA_QB2 * SHADOW_KL * sizeof(u64), 256) +
@@ -1016,14 +1037,14 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* max_
                              unsigned char* wsb, hipStream_t st) {
     const int sgrid = shadow_grid(N);
     u64* spart = reinterpret_cast<u64*>(wsb);
-    size_t off = align_up((size_t)sgrid * SHADOW_C * sizeof(u64), 256);
+    size_t off = align_up((size_t)sgrid * SHADOW_L * sizeof(u64), 256);
     long long* cand_rows = reinterpret_cast<long long*>(wsb + off);
     float* cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)SHADOW_C * 8);
     off += align_up((size_t)SHADOW_C * 12, 256);
     int* gate = reinterpret_cast<int*>(wsb + off);
     off += 256;
     u64* epart = reinterpret_cast<u64*>(wsb + off);
-    const int scap = list_cap(SHADOW_C);
+    const int scap = list_cap(SHADOW_L), mcap = list_cap(SHADOW_C);
     hipError_t e = hipMemsetAsync(gate, 0, sizeof(int), st);
     if (e != hipSuccess) { set_error("ip_topk_shadow: %s", hipGetErrorString(e)); return (int)e; }
     {
@@ -1032,21 +1053,22 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* max_
         const size_t lds = (size_t)4 * scap * 8;
         const uint4* xb = reinterpret_cast<const uint4*>(Xb);
         switch ((d8 + 63) / 64) {
-            case 1: hipLaunchKernelGGL((ip_scan_bf16_kernel<1, 8>), dim3(sgrid), dim3(256), lds, st, xb, N, d8, q, SHADOW_C,
+            case 1: hipLaunchKernelGGL((ip_scan_bf16_kernel<1, 8>), dim3(sgrid), dim3(256), lds, st, xb, N, d8, q, SHADOW_L,
                                        scap, spart); break;
-            case 2: hipLaunchKernelGGL((ip_scan_bf16_kernel<2, 8>), dim3(sgrid), dim3(256), lds, st, xb, N, d8, q, SHADOW_C,
+            case 2: hipLaunchKernelGGL((ip_scan_bf16_kernel<2, 8>), dim3(sgrid), dim3(256), lds, st, xb, N, d8, q, SHADOW_L,
                                        scap, spart); break;
             default: set_error("ip_topk_shadow: no kernel for d=%d", d); return WISE_E_INVALID;
         }
         WISE_LAUNCH_CHECK("ip_scan_bf16_kernel");
     }
-    int mw = 8192 / scap;
+    // the sgrid lists of SHADOW_L keys are read as sgrid * SHADOW_L / SHADOW_C lists of SHADOW_C (sgrid is a multiple of 4)
+    int mw = 8192 / mcap;
     if (mw > 16) mw = 16;
-    hipLaunchKernelGGL(merge_keys_kernel, dim3(1), dim3(mw * 64), (size_t)mw * scap * 8, st, spart, sgrid, 1, SHADOW_C, scap,
-                       (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
+    hipLaunchKernelGGL(merge_keys_kernel, dim3(1), dim3(mw * 64), (size_t)mw * mcap * 8, st, spart,
+                       sgrid * SHADOW_L / SHADOW_C, 1, SHADOW_C, mcap, (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
     WISE_LAUNCH_CHECK("merge_keys_kernel");
     hipLaunchKernelGGL(rescore_certify_kernel, dim3(1), dim3(1024), 0, st, X, d, q, cand_scores, cand_rows, SHADOW_C, k, ids,
-                       id_base, max_norm, outD, outI, gate, shadow_stats_ptr());
+                       id_base, max_norm, outD, outI, gate, shadow_stats_ptr(), spart, sgrid, SHADOW_L);
     WISE_LAUNCH_CHECK("rescore_certify_kernel");
     // the f32 scan, which returns at once unless the certificate failed
     const ScanPlan p = plan_scan(N, d, 1, k);
