@@ -68,7 +68,7 @@ int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, i
  *   wise_ip_shadow_bf16   Xb [N,d] bf16 (round-to-nearest-even copy of X) and *max_norm = max_r |X[r,:]| (device float)
  *   wise_ip_topk_shadow_f32   (1) scan Xb (half the bytes of X) for the 64 best approximate scores, (2) recompute those
  *       64 from the fp32 rows, order them, write the first k, (3) certify: a row outside the 64 has approximate score
- *       <= t (the 64th), so exact score <= t + 2^-8 |q| max_norm (+ accumulation slack); if the k-th exact score is
+ *       <= t (the 64th candidate's, or the last key of a scan block's full list if larger), so exact score <= t + 2^-8 |q| max_norm (+ accumulation slack); if the k-th exact score is
  *       above that bound the result is the exact top-k, (4) otherwise the fp32 scan queued behind (it returns at once
  *       when the certificate held) recomputes the query.  All on the stream, no host round trip.
  * Batches (nq >= 8, k <= 12, d = 256 or 512) run the same scheme 64 queries at a time on the matrix cores: the bf16 rows
