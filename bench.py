@@ -204,11 +204,13 @@ def main():
     spec = spec_for("ViT-B-32", "openai")
     sd = random_state_dict(spec, 0)
     eng = VitEngine(spec, sd, max_batch=args.batch)
-    from oracle import vit_ref  # only normalize_u8 (input synthesis) and the cpu_baseline leg use the oracle
+    from wise_amd.feature.mlfoundation_openclip import CLIP_MEAN, CLIP_STD   # (the oracle is used by the cpu_baseline leg only)
 
     frames = torch.from_numpy(
         np.random.default_rng(1 + rank).integers(0, 256, size=(args.batch, 3, 224, 224), dtype=np.uint8))
-    x = vit_ref.normalize_u8(frames).cuda()  # what preprocess_image hands over: fp32 [B,3,224,224], resident
+    # what preprocess_image hands over: ToTensor + Normalize of the decoded frames, fp32 [B,3,224,224], resident
+    x = ((frames.to(torch.float32) / 255.0 - torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)) /
+         torch.tensor(CLIP_STD).view(1, 3, 1, 1)).cuda()
     out_holder = {}
 
     def vit_step(i):
