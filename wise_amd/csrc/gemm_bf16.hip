@@ -24,7 +24,8 @@ constexpr bool bf16_out(int mode) { return mode == EPI_BF16 || mode == EPI_QUICK
 __device__ int g_group_m = 0;        // 0 = default; tuning knob (bits 16..23 of wise_debug_set_gemm_variant)
 __device__ int g_epi_lds = 1;        // bf16 epilogue through LDS (bit 30 of the debug knob turns it off)
 __device__ int g_dephase = 0;        // tuning knob (bits 24..27): initial s_sleep units for the second block per CU
-__device__ int g_store_nt = 0;       // (experiment) non-temporal stores in the bf16 epilogue of the 256-row tiles
+__device__ int g_store_nt = 1;       // non-temporal stores in the bf16 epilogue of the 256-row tiles: the C tile is read by a
+                                     // later kernel, not by this one (ViT-L/14 +1.5 % end to end, ViT-B/32 unchanged)
 __device__ int g_skip_epilogue = 0;  // timing-only ablation (tools/gemm_bench.py), set via wise_debug_set_gemm_variant
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -1360,7 +1361,7 @@ extern "C" int wise_debug_set_gemm_variant(int v) {
     wise::g_split_m = ((v >> 29) & 1) ? 0 : 1;
     int skip = (v >> 8) & 1;  // bit 8: skip epilogue stores (timing-only ablation)
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_skip_epilogue), &skip, sizeof(int));
-    int nt = (v >> 9) & 1;   // bit 9: non-temporal epilogue stores
+    int nt = (v >> 9) & 1 ? 0 : 1;   // bit 9: plain (temporal) epilogue stores
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_store_nt), &nt, sizeof(int));
     int el = ((v >> 30) & 1) ? 0 : 1;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_epi_lds), &el, sizeof(int));
