@@ -1010,19 +1010,38 @@ extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, 
 }
 
 namespace wise {
-// tau0[q] = the smallest key a score equal to the lowest of query q's `kl` selected sample scores can have: at least kl
-// rows reach that score, so nothing below it can be among the best kl of the whole index
-__global__ void tau_from_selected_kernel(const float* __restrict__ scores, long long n, const long long* __restrict__ sel,
-                                         int kl, u64* __restrict__ tau0) {
-    const int q = threadIdx.x;
-    float lo = 3.4028234663852886e38f;
-    for (int e = 0; e < kl; ++e) {
-        const long long j = sel[(size_t)q * kl + e];
-        if (j < 0) { lo = -3.4028234663852886e38f; break; }
-        const float v = scores[(size_t)q * n + j];
-        lo = v < lo ? v : lo;
+// Threshold of query q from its n dumped sample scores: thread t takes the maximum of elements t, t + 1024, ... (1024
+// disjoint segments, each maximum a different row), the block sorts the 1024 maxima, and tau0[q] is the smallest key a
+// score equal to the kl-th largest maximum can have.  At least kl rows reach that score, so nothing below it can be
+// among the best kl of the whole index; with n = 64K it is within a hair of the exact kl-th best of the sample (the top
+// scores rarely share a segment) at a tenth of the cost of selecting it (radix select: 176 us, this: ~15 us).
+__global__ __launch_bounds__(1024) void segmax_threshold_kernel(const float* __restrict__ scores, long long n, int kl,
+                                                                u64* __restrict__ tau0) {
+    __shared__ float mx[1024];
+    const int q = blockIdx.x, t = threadIdx.x;
+    const float* sq = scores + (size_t)q * n;
+    float m = -3.4028234663852886e38f;
+    for (long long j = t; j < n; j += 1024) {
+        const float v = sq[j];
+        m = v > m ? v : m;
     }
-    tau0[q] = lo == -3.4028234663852886e38f ? 0 : ((u64)f32_order(lo) << 32);
+    mx[t] = m;
+    __syncthreads();
+    for (int size = 2; size <= 1024; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int pos = ((t / stride) * (stride << 1)) + (t % stride);
+            if (t < 512) {
+                const int par = pos + stride;
+                const bool desc = (pos & size) == 0;
+                const float a = mx[pos], b2 = mx[par];
+                if (desc ? (a < b2) : (a > b2)) { mx[pos] = b2; mx[par] = a; }
+            }
+            __syncthreads();
+        }
+    if (t == 0) {
+        const float lo = mx[kl - 1];   // n >= 1024 * 1 here (host check), so every segment holds a row
+        tau0[q] = ((u64)f32_order(lo) << 32);
+    }
 }
 
 static int* shadow_stats_ptr() {
@@ -1108,7 +1127,7 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max
     off += 256;
     float* dump = reinterpret_cast<float*>(wsb + off);
     off += align_up((size_t)QB * 2 * g_scan_sample * sizeof(float), 256);
-    long long* sel = reinterpret_cast<long long*>(wsb + off);
+    (void)off;   // (the rest of the workspace is spare)
     hipError_t e = hipMemsetAsync(gate, 0, sizeof(int), st);
     if (e == hipSuccess && nqa < QB) e = hipMemsetAsync(mq, 0, (size_t)QB * d * sizeof(float), st);
     if (e == hipSuccess) e = hipMemcpyAsync(mq, Q, (size_t)nqa * d * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -1125,7 +1144,7 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max
         int mwv = 8192 / cap;
         if (mwv < 1) mwv = 1;
         if (mwv > 16) mwv = 16;
-        // ranges: [0, ns) scored only (threshold pass: scores dumped, the kl-th best per query selected by radix select),
+        // ranges: [0, ns) scored only (threshold pass: scores dumped, a per-query threshold from 1024 segment maxima),
         // then [0, 32 ns) under that threshold, then the rest under the threshold the second range established
         long long bounds[3] = {0, 0, 0};
         int nb = 0;
@@ -1136,10 +1155,8 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max
             ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
             if (ns > 0) {
                 if ((rc = shadow64_scan_launch(Xb, ns, 0, d, mq, QB, nullptr, nullptr, st, dump))) return rc;
-                hipLaunchKernelGGL(select_topk_kernel, dim3(QB), dim3(1024), 0, st, dump, (int)ns, kl, sel);
-                WISE_LAUNCH_CHECK("select_topk_kernel");
-                hipLaunchKernelGGL(tau_from_selected_kernel, dim3(1), dim3(QB), 0, st, dump, ns, sel, kl, tau0);
-                WISE_LAUNCH_CHECK("tau_from_selected_kernel");
+                hipLaunchKernelGGL(segmax_threshold_kernel, dim3(QB), dim3(1024), 0, st, dump, ns, kl, tau0);
+                WISE_LAUNCH_CHECK("segmax_threshold_kernel");
             }
             for (int r = 0; r < nb; ++r) {
                 const long long lo = bounds[r], hi = bounds[r + 1];
