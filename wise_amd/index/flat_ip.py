@@ -106,8 +106,7 @@ class FlatIPIndex:
         # one query (the reference's shape) or a batch the 64-query matrix-core kernels serve (k <= 12, d = 256 / 512)
         two_stage = self.shadow and self._n >= 1 and ((nq == 1 and 1 <= k <= 16) or
                                                      (nq >= 8 and 1 <= k <= 12 and self.d in (256, 512)))
-        if two_stage:
-            self._ensure_shadow(lib)
+        if two_stage and self._ensure_shadow(lib):
             need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k)
             if self._sws is None or self._sws.numel() < need:
                 self._sws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -130,14 +129,21 @@ class FlatIPIndex:
         _lib.check(rc, "wise_ip_topk_f32")
         return D, I
 
-    def _ensure_shadow(self, lib) -> None:
+    def _ensure_shadow(self, lib) -> bool:
+        """Build the bf16 copy if it is not there; False (and the shadow switched off) when HBM has no room for it."""
         if self._Xb is not None and self._Xb.shape[0] == self._n:
-            return
+            return True
+        need = self._n * self.d * 2
+        free, _ = torch.cuda.mem_get_info(self.device)
+        if free < need + (2 << 30):          # keep 2 GiB for workspaces and the caller
+            self.shadow = False
+            return False
         self._Xb = torch.empty(self._n, self.d, dtype=torch.int16, device=self.device)
         self._max_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
         rc = lib.wise_ip_shadow_bf16(self._X.data_ptr(), self._n, self.d, self._Xb.data_ptr(), self._max_norm.data_ptr(),
                                      _lib.stream_ptr())
         _lib.check(rc, "wise_ip_shadow_bf16")
+        return True
 
     def _review_shadow(self, lib) -> None:
         """Every 64 two-stage searches: if the fp32 scan had to redo most of them (data whose neighbours sit closer
