@@ -286,3 +286,34 @@ def test_batched_two_stage_search_with_threshold_passes():
     certified, fallback = _shadow_stats()
     assert certified + fallback == 70
     check_against_oracle(X, Q, k, ids, D, I)
+
+
+def test_full_size_two_stage_against_the_f32_scan():
+    """BASELINE cfg-3 size (10M x 512): the two-stage searches (one query; batches of 64 on the matrix cores, with
+    the threshold pass and both row ranges) return exactly what the f32 scans of the same index return, and what
+    torch's own f32 matmul + topk returns; scores scale linearly with the query."""
+    N, d, k = 10_000_000, 512, 10
+    g = torch.Generator(device="cuda").manual_seed(12)
+    X = torch.randn(N, d, generator=g, device="cuda")
+    X /= X.norm(dim=1, keepdim=True)
+    Q = torch.randn(96, d, generator=g, device="cuda")
+    Q /= Q.norm(dim=1, keepdim=True)
+    Q[0] = X[N - 1]                       # a planted neighbour in the last row
+    two = FlatIPIndex(d, shadow=True).adopt(X, None, id_base=1)
+    f32 = FlatIPIndex(d, shadow=False).adopt(X, None, id_base=1)
+    _shadow_stats()
+    Db, Ib = two.search_device(Q, k)       # batched two-stage: 64 + 32
+    Dr, Ir = f32.search_device(Q, k)       # split-bf16 candidates of the f32 rows + exact re-scoring
+    assert torch.equal(Ib, Ir) and torch.allclose(Db, Dr, atol=2e-6)
+    assert Ib[0, 0].item() == N and abs(Db[0, 0].item() - 1.0) < 1e-5
+    for q in (0, 1, 17, 95):               # one query at a time: bf16 scan + certificate vs the f32 VALU scan
+        D1, I1 = two.search_device(Q[q:q + 1], k)
+        D0, I0 = f32.search_device(Q[q:q + 1], k)
+        assert torch.equal(I1, I0) and torch.allclose(D1, D0, atol=2e-6)
+        assert torch.equal(I1[0], Ib[q])
+    certified, fallback = _shadow_stats()
+    assert certified + fallback == 96 + 4
+    Dt, It = torch.topk(Q[:8] @ X.T, k, dim=1)
+    assert torch.equal(Ib[:8], It + 1) and torch.allclose(Db[:8], Dt, atol=2e-5)
+    D2, I2 = two.search_device(2.0 * Q[:40], k)
+    assert torch.equal(I2, Ib[:40]) and torch.allclose(D2, 2 * Db[:40], atol=2e-5)
