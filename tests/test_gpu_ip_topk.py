@@ -317,3 +317,25 @@ def test_full_size_two_stage_against_the_f32_scan():
     assert torch.equal(Ib[:8], It + 1) and torch.allclose(Db[:8], Dt, atol=2e-5)
     D2, I2 = two.search_device(2.0 * Q[:40], k)
     assert torch.equal(I2, Ib[:40]) and torch.allclose(D2, 2 * Db[:40], atol=2e-5)
+
+
+@pytest.mark.parametrize("N,d,nq,k", [(50000, 512, 4, 10), (33333, 512, 7, 16), (20000, 768, 3, 5), (70, 256, 6, 10),
+                                      (40000, 1024, 2, 10)])
+def test_few_queries_through_the_two_stage_search(N, d, nq, k):
+    """2-7 queries: one 64-query matrix-core pass over the bf16 rows where those kernels apply (k <= 12, d = 256 / 512),
+    else one query at a time (2-3 queries) or the f32 batch kernels; each certified or recomputed from the f32 rows."""
+    X = unit_rows(N, d, 600 + N % 53)
+    Q = unit_rows(nq, d, 31)
+    ids = np.arange(N, dtype=np.int64) * 2 + 3
+    idx = FlatIPIndex(d, shadow=True)
+    idx.add_with_ids(X, ids)
+    _shadow_stats()
+    D, I = idx.search(Q, k)
+    certified, fallback = _shadow_stats()
+    two_stage = (k <= 12 and d in (256, 512)) or nq <= 3
+    assert certified + fallback == (nq if two_stage else 0)
+    check_against_oracle(X, Q, k, ids, D, I)
+    ref = FlatIPIndex(d, shadow=False)
+    ref.add_with_ids(X, ids)
+    Dr, Ir = ref.search(Q, k)
+    assert np.array_equal(I, Ir) and np.allclose(D, Dr, atol=2e-6)

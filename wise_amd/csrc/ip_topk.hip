@@ -227,9 +227,10 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(const u64* __restrict_
                                                           int k, int cap, const long long* __restrict__ ids,
                                                           long long id_base, float* __restrict__ outD,
                                                           long long* __restrict__ outI, int q_off,
-                                                          const int* __restrict__ gate = nullptr) {
+                                                          const int* __restrict__ gate = nullptr, int k_in = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (gate && *gate == 0) return;
+    const int kin = k_in > 0 ? k_in : k;   // keys per input list (the lists may be shorter than the k kept)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
@@ -240,13 +241,13 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(const u64* __restrict_
     wl.init(lds + (size_t)wave * cap, cap, k, lane);
     // the P lists of this query hold P*k keys in all: every offer carries 64 of them (one per lane), whatever k
     // is; waves take 64-key chunks round-robin
-    const long long total = (long long)P * k;
+    const long long total = (long long)P * kin;
     for (long long c0 = (long long)wave * 64; c0 < total; c0 += (long long)nwaves * 64) {
         const long long i = c0 + lane;
         u64 key = 0;
         if (i < total) {
-            const int p = (int)(i / k), j = (int)(i - (long long)p * k);
-            key = part[((size_t)p * qstride + q) * k + j];
+            const int p = (int)(i / kin), j = (int)(i - (long long)p * kin);
+            key = part[((size_t)p * qstride + q) * kin + j];
         }
         const bool pass = (key != 0) && (key > wl.tau);
         wl.offer(pass, key, lane, 64);
@@ -449,23 +450,26 @@ __global__ __launch_bounds__(256) void shadow_bf16_kernel(const float* __restric
 }
 
 // NV8 = 16-byte chunks (8 bf16) per lane per row, R rows per group, one query
-template <int NV8, int R>
+template <int NV8, int NQ, int R>
 __global__ __launch_bounds__(256) void ip_scan_bf16_kernel(const uint4* __restrict__ Xb, long long N, int d8,
-                                                           const float* __restrict__ Q, int kl, int cap,
-                                                           u64* __restrict__ part /*[grid][kl]*/) {
+                                                           const float* __restrict__ Q /*[NQ][d]*/, int kl, int cap,
+                                                           u64* __restrict__ part /*[grid][NQ][kl]*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    u64* lds = reinterpret_cast<u64*>(smem);
-    float qv[NV8][8];
+    u64* lds = reinterpret_cast<u64*>(smem);   // wave w, query q -> lds + (w*NQ + q)*cap
+    float qv[NQ][NV8][8];
 #pragma unroll
-    for (int v = 0; v < NV8; ++v) {
-        const int c = v * 64 + lane;
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qv[v][e] = (c < d8) ? Q[c * 8 + e] : 0.f;
-    }
-    WaveList wl;
-    wl.init(lds + (size_t)wave * cap, cap, kl, lane);
+        for (int v = 0; v < NV8; ++v) {
+            const int c = v * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[q][v][e] = (c < d8) ? Q[(size_t)q * d8 * 8 + c * 8 + e] : 0.f;
+        }
+    WaveList wl[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) wl[q].init(lds + (size_t)(wave * NQ + q) * cap, cap, kl, lane);
 
     const long long ngroups = (N + R - 1) / R;
     const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
@@ -495,55 +499,62 @@ __global__ __launch_bounds__(256) void ip_scan_bf16_kernel(const uint4* __restri
                     x[r][v] = u32x4_t{0u, 0u, 0u, 0u};
             }
         }
-        float a[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float s = 0.f;
+        for (int q = 0; q < NQ; ++q) {
+            float a[R];
 #pragma unroll
-            for (int v = 0; v < NV8; ++v)
+            for (int r = 0; r < R; ++r) {
+                float s = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned u = x[r][v][e];
-                    s = fmaf(__uint_as_float(u << 16), qv[v][2 * e], s);
-                    s = fmaf(__uint_as_float(u & 0xFFFF0000u), qv[v][2 * e + 1], s);
-                }
-            a[r] = s;
-        }
-        int bit = 5;
+                for (int v = 0; v < NV8; ++v)
 #pragma unroll
-        for (int h = R / 2; h >= 1; h >>= 1, --bit) {
-            const int m = 1 << bit;
-            const bool up = (lane >> bit) & 1;
-#pragma unroll
-            for (int i = 0; i < h; ++i) {
-                float send = up ? a[i] : a[i + h];
-                float keep = up ? a[i + h] : a[i];
-                a[i] = keep + __shfl_xor(send, m, 64);
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned u = x[r][v][e];
+                        s = fmaf(__uint_as_float(u << 16), qv[q][v][2 * e], s);
+                        s = fmaf(__uint_as_float(u & 0xFFFF0000u), qv[q][v][2 * e + 1], s);
+                    }
+                a[r] = s;
             }
-        }
-        float s = a[0];
+            int bit = 5;
 #pragma unroll
-        for (int m = (32 >> LOGR); m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        const long long row = row0 + myr;
-        const u64 key = make_key(s, (unsigned)row);
-        const bool pass = owner && (row < N) && (key > wl.tau);
-        wl.offer(pass, key, lane, R);
+            for (int h = R / 2; h >= 1; h >>= 1, --bit) {
+                const int m = 1 << bit;
+                const bool up = (lane >> bit) & 1;
+#pragma unroll
+                for (int i = 0; i < h; ++i) {
+                    float send = up ? a[i] : a[i + h];
+                    float keep = up ? a[i + h] : a[i];
+                    a[i] = keep + __shfl_xor(send, m, 64);
+                }
+            }
+            float s = a[0];
+#pragma unroll
+            for (int m = (32 >> LOGR); m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+            const long long row = row0 + myr;
+            const u64 key = make_key(s, (unsigned)row);
+            const bool pass = owner && (row < N) && (key > wl[q].tau);
+            wl[q].offer(pass, key, lane, R);
+        }
     }
-    wl.compact(lane);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) wl[q].compact(lane);
     __syncthreads();
     if (wave == 0) {
-        for (int w = 1; w < 4; ++w) {
-            const u64* other = lds + (size_t)w * cap;
-            for (int i0 = 0; i0 < kl; i0 += 64) {
-                const int i = i0 + lane;
-                const u64 key = (i < kl) ? other[i] : 0;
-                const bool pass = (key != 0) && (key > wl.tau);
-                wl.offer(pass, key, lane, 64);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            for (int w = 1; w < 4; ++w) {
+                const u64* other = lds + (size_t)(w * NQ + q) * cap;
+                for (int i0 = 0; i0 < kl; i0 += 64) {
+                    const int i = i0 + lane;
+                    const u64 key = (i < kl) ? other[i] : 0;
+                    const bool pass = (key != 0) && (key > wl[q].tau);
+                    wl[q].offer(pass, key, lane, 64);
+                }
             }
+            wl[q].compact(lane);
+            u64* dst = part + ((size_t)blockIdx.x * NQ + q) * kl;
+            for (int i = lane; i < kl; i += 64) dst[i] = wl[q].buf[i];
         }
-        wl.compact(lane);
-        u64* dst = part + (size_t)blockIdx.x * kl;
-        for (int i = lane; i < kl; i += 64) dst[i] = wl.buf[i];
     }
 }
 
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __re
                                                                float* __restrict__ outD, long long* __restrict__ outI,
                                                                int* __restrict__ gate, int* __restrict__ stats,
                                                                const u64* __restrict__ block_lists = nullptr,
-                                                               int nblocks = 0, int per_block = 0) {
+                                                               int nblocks = 0, int per_block = 0, int nq_lists = 1) {
     __shared__ float exact[64];
     const int q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -629,7 +640,7 @@ __global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __re
         // scan blocks kept only their `per_block` best: a row a block dropped scores at most that block's last key
         u64 worst = 0;
         for (int b = lane; b < nblocks; b += 64) {
-            const u64 kb = block_lists[(size_t)b * per_block + per_block - 1];
+            const u64 kb = block_lists[((size_t)b * nq_lists + q) * per_block + per_block - 1];
             worst = kb > worst ? kb : worst;
         }
 #pragma unroll
@@ -997,10 +1008,14 @@ extern "C" int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* X
 
 extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, int k) {
     if (N < 0 || nq < 1 || !shadow_supported(d, k)) return 0;
-    const ScanPlan p = plan_scan(N, d, 1, k);
-    // single query: candidate lists of the bf16 scan | candidates | gate | lists of the gated f32 scan
-    size_t one = align_up((size_t)shadow_grid(N) * SHADOW_L * sizeof(u64), 256) + align_up((size_t)SHADOW_C * 12, 256) + 256 +
-                 align_up((size_t)p.grid * k * sizeof(u64), 256);
+    ScanPlan p = plan_scan(N, d, 1, k);
+    for (int m = 2; m <= 4; m *= 2) {   // the gated f32 scan of 2 or 4 queries may plan a larger grid
+        const ScanPlan pm = plan_scan(N, d, m, k);
+        if (pm.grid > p.grid) p.grid = pm.grid;
+    }
+    // few queries: candidate lists of the bf16 scan | candidates | gate | lists of the gated f32 scan
+    size_t one = align_up((size_t)shadow_grid(N) * 4 * SHADOW_L * sizeof(u64), 256) + align_up((size_t)4 * SHADOW_C * 12, 256) +
+                 256 + align_up((size_t)p.grid * 4 * k * sizeof(u64), 256);
     // batches: lists of both passes of either scan | 64 padded queries | candidates | thresholds | gate
     size_t many = align_up((size_t)3 * split64_lists(N) * MFMA_QB2 * SHADOW_KL * sizeof(u64), 256) +
                   align_up((size_t)MFMA_QB2 * d * sizeof(float), 256) + align_up((size_t)MFMA_QB2 * SHADOW_KL * 12, 256) +
@@ -1050,16 +1065,19 @@ static int* shadow_stats_ptr() {
     return stats;
 }
 
-// one query: bf16 scan -> 64 candidates -> exact scores + certificate -> gated f32 scan
-static int shadow_search_one(const float* X, const bf16_t* Xb, const float* max_norm, long long N, int d, const float* q,
+// 1, 2 or 4 queries in one pass over the bf16 rows (VALU scan, the queries in registers): per-block lists of SHADOW_L
+// candidates per query -> the 64 best per query -> exact scores + certificates -> the f32 scan of the same queries,
+// gated on "some certificate failed"
+template <int NQ>
+static int shadow_search_few(const float* X, const bf16_t* Xb, const float* max_norm, long long N, int d, const float* q,
                              int k, const long long* ids, long long id_base, float* outD, long long* outI,
                              unsigned char* wsb, hipStream_t st) {
     const int sgrid = shadow_grid(N);
     u64* spart = reinterpret_cast<u64*>(wsb);
-    size_t off = align_up((size_t)sgrid * SHADOW_L * sizeof(u64), 256);
+    size_t off = align_up((size_t)sgrid * 4 * SHADOW_L * sizeof(u64), 256);
     long long* cand_rows = reinterpret_cast<long long*>(wsb + off);
-    float* cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)SHADOW_C * 8);
-    off += align_up((size_t)SHADOW_C * 12, 256);
+    float* cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)4 * SHADOW_C * 8);
+    off += align_up((size_t)4 * SHADOW_C * 12, 256);
     int* gate = reinterpret_cast<int*>(wsb + off);
     off += 256;
     u64* epart = reinterpret_cast<u64*>(wsb + off);
@@ -1069,40 +1087,46 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* max_
     {
         ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
         const int d8 = d / 8;
-        const size_t lds = (size_t)4 * scap * 8;
+        const size_t lds = (size_t)4 * NQ * scap * 8;
         const uint4* xb = reinterpret_cast<const uint4*>(Xb);
         switch ((d8 + 63) / 64) {
-            case 1: hipLaunchKernelGGL((ip_scan_bf16_kernel<1, 8>), dim3(sgrid), dim3(256), lds, st, xb, N, d8, q, SHADOW_L,
-                                       scap, spart); break;
-            case 2: hipLaunchKernelGGL((ip_scan_bf16_kernel<2, 8>), dim3(sgrid), dim3(256), lds, st, xb, N, d8, q, SHADOW_L,
-                                       scap, spart); break;
+            case 1: hipLaunchKernelGGL((ip_scan_bf16_kernel<1, NQ, 8>), dim3(sgrid), dim3(256), lds, st, xb, N, d8, q,
+                                       SHADOW_L, scap, spart); break;
+            case 2:
+                if constexpr (NQ <= 2) {
+                    hipLaunchKernelGGL((ip_scan_bf16_kernel<2, NQ, 8>), dim3(sgrid), dim3(256), lds, st, xb, N, d8, q,
+                                       SHADOW_L, scap, spart);
+                    break;
+                }
+                set_error("ip_topk_shadow: no %d-query kernel for d=%d", NQ, d); return WISE_E_INVALID;
             default: set_error("ip_topk_shadow: no kernel for d=%d", d); return WISE_E_INVALID;
         }
         WISE_LAUNCH_CHECK("ip_scan_bf16_kernel");
     }
-    // the sgrid lists of SHADOW_L keys are read as sgrid * SHADOW_L / SHADOW_C lists of SHADOW_C (sgrid is a multiple of 4)
     int mw = 8192 / mcap;
     if (mw > 16) mw = 16;
-    hipLaunchKernelGGL(merge_keys_kernel, dim3(1), dim3(mw * 64), (size_t)mw * mcap * 8, st, spart,
-                       sgrid * SHADOW_L / SHADOW_C, 1, SHADOW_C, mcap, (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
+    // lists of SHADOW_L keys in, the SHADOW_C best out
+    hipLaunchKernelGGL(merge_keys_kernel, dim3(NQ), dim3(mw * 64), (size_t)mw * mcap * 8, st, spart, sgrid, NQ, SHADOW_C, mcap,
+                       (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0, (const int*)nullptr, SHADOW_L);
     WISE_LAUNCH_CHECK("merge_keys_kernel");
-    hipLaunchKernelGGL(rescore_certify_kernel, dim3(1), dim3(1024), 0, st, X, d, q, cand_scores, cand_rows, SHADOW_C, k, ids,
-                       id_base, max_norm, outD, outI, gate, shadow_stats_ptr(), spart, sgrid, SHADOW_L);
+    hipLaunchKernelGGL(rescore_certify_kernel, dim3(NQ), dim3(1024), 0, st, X, d, q, cand_scores, cand_rows, SHADOW_C, k, ids,
+                       id_base, max_norm, outD, outI, gate, shadow_stats_ptr(), spart, sgrid, SHADOW_L, NQ);
     WISE_LAUNCH_CHECK("rescore_certify_kernel");
-    // the f32 scan, which returns at once unless the certificate failed
-    const ScanPlan p = plan_scan(N, d, 1, k);
-    switch ((d / 4 + 63) / 64) {
-        case 1: launch_scan<1, 1>(p, X, N, d, q, k, epart, st, gate); break;
-        case 2: launch_scan<2, 1>(p, X, N, d, q, k, epart, st, gate); break;
-        case 3: launch_scan<3, 1>(p, X, N, d, q, k, epart, st, gate); break;
-        case 4: launch_scan<4, 1>(p, X, N, d, q, k, epart, st, gate); break;
-        default: set_error("ip_topk_shadow: no kernel for d=%d", d); return WISE_E_INVALID;
-    }
+    // the f32 scan of the same queries, which returns at once unless a certificate failed
+    ScanPlan p = plan_scan(N, d, NQ, k);
+    if (p.nq_per_pass != NQ) { set_error("ip_topk_shadow: f32 plan serves %d queries per pass, not %d", p.nq_per_pass, NQ); return WISE_E_INVALID; }
+    const int nv = (d / 4 + 63) / 64;
+    bool launched = false;
+    if constexpr (NQ * 1 <= 8) if (nv == 1) { launch_scan<1, NQ>(p, X, N, d, q, k, epart, st, gate); launched = true; }
+    if constexpr (NQ * 2 <= 8) if (nv == 2) { launch_scan<2, NQ>(p, X, N, d, q, k, epart, st, gate); launched = true; }
+    if constexpr (NQ * 3 <= 8) if (nv == 3) { launch_scan<3, NQ>(p, X, N, d, q, k, epart, st, gate); launched = true; }
+    if constexpr (NQ * 4 <= 8) if (nv == 4) { launch_scan<4, NQ>(p, X, N, d, q, k, epart, st, gate); launched = true; }
+    if (!launched) { set_error("ip_topk_shadow: no f32 kernel for d=%d with %d queries", d, NQ); return WISE_E_INVALID; }
     WISE_LAUNCH_CHECK("ip_scan_kernel (gated)");
     int emw = 8192 / p.cap;
     if (emw < 1) emw = 1;
     if (emw > 16) emw = 16;
-    hipLaunchKernelGGL(merge_keys_kernel, dim3(1), dim3(emw * 64), (size_t)emw * p.cap * 8, st, epart, p.grid, 1, k, p.cap,
+    hipLaunchKernelGGL(merge_keys_kernel, dim3(NQ), dim3(emw * 64), (size_t)emw * p.cap * 8, st, epart, p.grid, NQ, k, p.cap,
                        ids, id_base, outD, outI, 0, gate);
     WISE_LAUNCH_CHECK("merge_keys_kernel (gated)");
     return WISE_OK;
@@ -1225,9 +1249,11 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
     unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
     const long long* lids = reinterpret_cast<const long long*>(ids);
     long long* lI = reinterpret_cast<long long*>(outI);
-    // batches on the matrix cores where the 64-query kernels apply (k <= 12: the fallback keeps 16 candidates), else
-    // one query at a time
-    const bool batched = nq >= 8 && k <= MFMA_KC && shadow64_supported(d) && mfma_split_supported(d, nq, k) &&
+    // two or more queries on the matrix cores where the 64-query kernels apply (k <= 12: the fallback keeps 16
+    // candidates), else one query at a time
+    // (from two queries on: a 64-query pass costs 2.2 ms at 10M x 512 whatever it carries, two single-query searches
+    // 3.4 ms; the VALU scan with 2 or 4 queries in registers is bound by its cross-lane reductions, 3.9 / 6.7 ms)
+    const bool batched = nq >= 2 && k <= MFMA_KC && shadow64_supported(d) && mfma_split_supported(d, 8, k) &&
                          split64_supported(d) && split_direct_enabled();
     if (batched) {
         for (int q0 = 0; q0 < nq; q0 += MFMA_QB2) {
@@ -1238,9 +1264,11 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
         }
         return WISE_OK;
     }
+    // otherwise one query per pass of the VALU scan (shadow_search_few<2> / <4> exist and are exact, but their
+    // cross-lane reductions make them no faster than separate passes)
     for (int q = 0; q < nq; ++q) {
-        int rc = shadow_search_one(X, Xb, max_norm, N, d, Q + (size_t)q * d, k, lids, (long long)id_base, outD + (size_t)q * k,
-                                   lI + (size_t)q * k, wsb, st);
+        int rc = shadow_search_few<1>(X, Xb, max_norm, N, d, Q + (size_t)q * d, k, lids, (long long)id_base,
+                                      outD + (size_t)q * k, lI + (size_t)q * k, wsb, st);
         if (rc) return rc;
     }
     return WISE_OK;

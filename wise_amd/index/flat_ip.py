@@ -103,9 +103,11 @@ class FlatIPIndex:
         I = torch.empty(nq, k, dtype=torch.int64, device=self.device)
         if nq == 0:
             return D, I
-        # one query (the reference's shape) or a batch the 64-query matrix-core kernels serve (k <= 12, d = 256 / 512)
+        # one query (the reference's shape), or two and more where the 64-query matrix-core kernels apply (k <= 12,
+        # d = 256 / 512); a few queries outside those limits go one at a time when that beats the f32 batch kernels
         two_stage = self.shadow and self._n >= 1 and ((nq == 1 and 1 <= k <= 16) or
-                                                     (nq >= 8 and 1 <= k <= 12 and self.d in (256, 512)))
+                                                     (nq >= 2 and 1 <= k <= 12 and self.d in (256, 512)) or
+                                                     (2 <= nq <= 3 and 1 <= k <= 16))
         if two_stage and self._ensure_shadow(lib):
             need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k)
             if self._sws is None or self._sws.numel() < need:
