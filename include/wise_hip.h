@@ -71,7 +71,8 @@ int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, i
  *       <= t (the 64th candidate's, or the last key of a scan block's full list if larger), so exact score <= t + 2^-8 |q| max_norm (+ accumulation slack); if the k-th exact score is
  *       above that bound the result is the exact top-k, (4) otherwise the fp32 scan queued behind (it returns at once
  *       when the certificate held) recomputes the query.  All on the stream, no host round trip.
- * Two or more queries (k <= 12, d = 256 or 512) run the same scheme 64 queries at a time on the matrix cores: the bf16 rows
+ * Two or more queries (k <= 12, d = 256 or 512; three or more with k <= 16 for d = 768 or 1024, 32 at a time with the
+ * fp32 VALU scan as the gated fallback) run the same scheme 64 queries at a time on the matrix cores: the bf16 rows
  * are MFMA operands as loaded, 48 candidates per query, per-query certificates, and the split-bf16 scan of the fp32 rows
  * (wise_ip_topk_f32's batched path) queued behind as the gated fallback of the pass.  Otherwise: one query at a time.
  * Same outputs, ties and padding as wise_ip_topk_f32.  Limits: d % 8 == 0, 8 <= d <= 1024, k <= 16, N >= 1, nq <= 1024. */

@@ -339,3 +339,37 @@ def test_few_queries_through_the_two_stage_search(N, d, nq, k):
     ref.add_with_ids(X, ids)
     Dr, Ir = ref.search(Q, k)
     assert np.array_equal(I, Ir) and np.allclose(D, Dr, atol=2e-6)
+
+
+@pytest.mark.parametrize("N,d,nq,k", [(40000, 768, 40, 10), (30000, 1024, 5, 16), (600000, 768, 33, 10)])
+def test_batched_two_stage_search_for_wide_rows(N, d, nq, k):
+    """512 < d <= 1024 (768 is the ViT-L/14 dimension): 32 queries per pass over the bf16 rows on the matrix cores, the
+    f32 VALU scan as the gated fallback."""
+    X = unit_rows(N, d, 700 + N % 31)
+    Q = unit_rows(nq, d, 33)
+    ids = np.arange(N, dtype=np.int64) + 9
+    idx = FlatIPIndex(d, shadow=True)
+    idx.add_with_ids(X, ids)
+    _shadow_stats()
+    D, I = idx.search(Q, k)
+    certified, fallback = _shadow_stats()
+    assert certified + fallback == nq
+    check_against_oracle(X, Q, k, ids, D, I)
+
+
+def test_wide_row_batch_falls_back_to_the_f32_scan():
+    N, d, k = 30000, 768, 10
+    X = unit_rows(N, d, 91)
+    Q = unit_rows(12, d, 92)
+    rng = np.random.default_rng(93)
+    for c in rng.choice(N, size=80, replace=False):
+        v = Q[5] + 1e-3 * rng.standard_normal(d).astype(np.float32)
+        X[c] = v / np.linalg.norm(v)
+    ids = np.arange(N, dtype=np.int64) + 1
+    idx = FlatIPIndex(d, shadow=True)
+    idx.add_with_ids(X, ids)
+    _shadow_stats()
+    D, I = idx.search(Q, k)
+    certified, fallback = _shadow_stats()
+    assert fallback >= 1 and certified + fallback == 12
+    check_against_oracle(X, Q, k, ids, D, I)

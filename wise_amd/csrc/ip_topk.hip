@@ -1136,21 +1136,20 @@ static int shadow_search_few(const float* X, const bf16_t* Xb, const float* max_
 // certificates -> if any failed, the split-bf16 scan of the f32 rows (candidates exact to 2^-16) and its re-scoring, gated
 static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max_norm, long long N, int d, const float* Q,
                               int nqa, int k, const long long* ids, long long id_base, float* outD, long long* outI,
-                              unsigned char* wsb, hipStream_t st) {
-    constexpr int QB = MFMA_QB2;
+                              unsigned char* wsb, hipStream_t st, int QB /*64, or 32 for 512 < d <= 1024*/) {
     u64* mpart = reinterpret_cast<u64*>(wsb);
-    size_t off = align_up((size_t)3 * split64_lists(N) * QB * SHADOW_KL * sizeof(u64), 256);
+    size_t off = align_up((size_t)3 * split64_lists(N) * MFMA_QB2 * SHADOW_KL * sizeof(u64), 256);
     float* mq = reinterpret_cast<float*>(wsb + off);
-    off += align_up((size_t)QB * d * sizeof(float), 256);
+    off += align_up((size_t)MFMA_QB2 * d * sizeof(float), 256);
     long long* cand_rows = reinterpret_cast<long long*>(wsb + off);
-    float* cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)QB * SHADOW_KL * 8);
-    off += align_up((size_t)QB * SHADOW_KL * 12, 256);
+    float* cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)MFMA_QB2 * SHADOW_KL * 8);
+    off += align_up((size_t)MFMA_QB2 * SHADOW_KL * 12, 256);
     u64* tau0 = reinterpret_cast<u64*>(wsb + off);
     off += 512;
     int* gate = reinterpret_cast<int*>(wsb + off);
     off += 256;
     float* dump = reinterpret_cast<float*>(wsb + off);
-    off += align_up((size_t)QB * 2 * g_scan_sample * sizeof(float), 256);
+    off += align_up((size_t)MFMA_QB2 * 2 * g_scan_sample * sizeof(float), 256);
     (void)off;   // (the rest of the workspace is spare)
     hipError_t e = hipMemsetAsync(gate, 0, sizeof(int), st);
     if (e == hipSuccess && nqa < QB) e = hipMemsetAsync(mq, 0, (size_t)QB * d * sizeof(float), st);
@@ -1178,14 +1177,14 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max
         {
             ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
             if (ns > 0) {
-                if ((rc = shadow64_scan_launch(Xb, ns, 0, d, mq, QB, nullptr, nullptr, st, dump))) return rc;
+                if ((rc = shadow64_scan_launch(Xb, ns, 0, d, mq, QB, nullptr, nullptr, st, dump, QB))) return rc;
                 hipLaunchKernelGGL(segmax_threshold_kernel, dim3(QB), dim3(1024), 0, st, dump, ns, kl, tau0);
                 WISE_LAUNCH_CHECK("segmax_threshold_kernel");
             }
             for (int r = 0; r < nb; ++r) {
                 const long long lo = bounds[r], hi = bounds[r + 1];
                 if ((rc = shadow64_scan_launch(Xb + (size_t)lo * d, hi - lo, lo, d, mq, nqa, mpart + (size_t)plists * QB * kl,
-                                               (ns > 0) ? tau0 : nullptr, st)))
+                                               (ns > 0) ? tau0 : nullptr, st, nullptr, QB)))
                     return rc;
                 plists += split64_lists(hi - lo);
                 if (r + 1 < nb) {
@@ -1204,6 +1203,33 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max
         WISE_LAUNCH_CHECK("rescore_certify_kernel");
     }
     // ---- gated fallback over the f32 rows: every launch returns at once while *gate == 0
+    if (QB != MFMA_QB2) {
+        // d > 512: the split-bf16 kernels do not reach; the f32 VALU scan redoes the pass, two queries per launch
+        const ScanPlan p = plan_scan(N, d, 2, k);
+        const int nv = (d / 4 + 63) / 64;
+        u64* epart = mpart;          // the stage-1 lists are dead by now
+        int emw = 8192 / p.cap;
+        if (emw < 1) emw = 1;
+        if (emw > 16) emw = 16;
+        for (int q0 = 0; q0 < nqa; q0 += p.nq_per_pass) {
+            const int nqp = nqa - q0 < p.nq_per_pass ? nqa - q0 : p.nq_per_pass;   // mq is zero-padded to QB rows
+            const float* qq = mq + (size_t)q0 * d;
+            bool ok = false;
+            if (p.nq_per_pass == 2) {
+                if (nv == 3) { launch_scan<3, 2>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
+                if (nv == 4) { launch_scan<4, 2>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
+            } else if (p.nq_per_pass == 1) {
+                if (nv == 3) { launch_scan<3, 1>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
+                if (nv == 4) { launch_scan<4, 1>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
+            }
+            if (!ok) { set_error("ip_topk_shadow: no f32 fallback kernel for d=%d", d); return WISE_E_INVALID; }
+            WISE_LAUNCH_CHECK("ip_scan_kernel (gated)");
+            hipLaunchKernelGGL(merge_keys_kernel, dim3(nqp), dim3(emw * 64), (size_t)emw * p.cap * 8, st, epart, p.grid,
+                               p.nq_per_pass, k, p.cap, ids, id_base, outD, outI, q0, gate);
+            WISE_LAUNCH_CHECK("merge_keys_kernel (gated)");
+        }
+        return WISE_OK;
+    }
     {
         const int kl = MFMA_KL, cap = list_cap(kl);
         int mwv = 8192 / cap;
@@ -1255,11 +1281,15 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
     // 3.4 ms; the VALU scan with 2 or 4 queries in registers is bound by its cross-lane reductions, 3.9 / 6.7 ms)
     const bool batched = nq >= 2 && k <= MFMA_KC && shadow64_supported(d) && mfma_split_supported(d, 8, k) &&
                          split64_supported(d) && split_direct_enabled();
-    if (batched) {
-        for (int q0 = 0; q0 < nq; q0 += MFMA_QB2) {
-            const int nqa = nq - q0 < MFMA_QB2 ? nq - q0 : MFMA_QB2;
+    // 512 < d <= 1024 (768: the ViT-L/14 dimension): 32 queries per pass, the f32 VALU scan as the gated fallback;
+    // worth it from 3 queries on (a pass moves the bf16 rows once: 2.7 ms at 10M x 768, a single query 2.4 ms)
+    const bool batched32 = !batched && nq >= 3 && k <= 16 && d > 512 && shadow32_supported(d);
+    if (batched || batched32) {
+        const int qb = batched ? MFMA_QB2 : MFMA_QB;
+        for (int q0 = 0; q0 < nq; q0 += qb) {
+            const int nqa = nq - q0 < qb ? nq - q0 : qb;
             int rc = shadow_search_pass(X, Xb, max_norm, N, d, Q + (size_t)q0 * d, nqa, k, lids, (long long)id_base,
-                                        outD + (size_t)q0 * k, lI + (size_t)q0 * k, wsb, st);
+                                        outD + (size_t)q0 * k, lI + (size_t)q0 * k, wsb, st, qb);
             if (rc) return rc;
         }
         return WISE_OK;

@@ -450,13 +450,13 @@ int mfma_scan_launch(const float* X, long long N, int d, const float* qpad, int 
 // ------------------------------------------------------------------------------------------------
 constexpr int QB2 = 64;
 
-template <int KLS = MFMA_KL>
-__device__ __forceinline__ void select_group_shared(f32x16& acc, u64& tau, u64* lists /*[kl][QB2]*/, int* locks, int q,
+template <int KLS = MFMA_KL, int QBS = 64>
+__device__ __forceinline__ void select_group_shared(f32x16& acc, u64& tau, u64* lists /*[kl][QBS]*/, int* locks, int q,
                                                     int h, bool active, long long row0, long long N,
                                                     long long row_offset) {
     constexpr int kl = KLS;
     {
-        const u64 t = lists[(kl - 1) * QB2 + q];   // the block's current MFMA_KL-th key of this query
+        const u64 t = lists[(kl - 1) * QBS + q];   // the block's current MFMA_KL-th key of this query
         tau = t > tau ? t : tau;
     }
 #pragma unroll
@@ -470,18 +470,18 @@ __device__ __forceinline__ void select_group_shared(f32x16& acc, u64& tau, u64* 
                 bool todo = pass && h == hh;
                 while (__ballot(todo) != 0) {
                     if (todo && __hip_atomic_exchange(&locks[q], 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
-                        const u64 kth = lists[(kl - 1) * QB2 + q];
+                        const u64 kth = lists[(kl - 1) * QBS + q];
                         if (key > kth) {
                             int pos = kl - 1;
                             while (pos > 0) {
-                                const u64 prev = lists[(pos - 1) * QB2 + q];
+                                const u64 prev = lists[(pos - 1) * QBS + q];
                                 if (prev >= key) break;
-                                lists[pos * QB2 + q] = prev;
+                                lists[pos * QBS + q] = prev;
                                 --pos;
                             }
-                            lists[pos * QB2 + q] = key;
+                            lists[pos * QBS + q] = key;
                         }
-                        const u64 nk = lists[(kl - 1) * QB2 + q];
+                        const u64 nk = lists[(kl - 1) * QBS + q];
                         tau = nk > tau ? nk : tau;
                         __hip_atomic_store(&locks[q], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         todo = false;
@@ -642,7 +642,7 @@ int split64_scan_launch(const float* X, long long N, long long row_offset, int d
 // ------------------------------------------------------------------------------------------------
 constexpr int CW2 = 64;   // columns per chunk of the bf16 scan
 
-template <int PF>
+template <int PF, int QB>
 __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const bf16_t* __restrict__ Xb, long long N, int d,
                                                                   const float* __restrict__ qpad /*[64][d]*/, int nq,
                                                                   u64* __restrict__ part /*[grid][64][SHADOW_KL]*/,
@@ -654,12 +654,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
     const int i = lane & 31, h = lane >> 5;
     const int d4 = d >> 2, d8 = d >> 3;
     unsigned char* Qh = smem;
-    unsigned char* Ql = smem + (size_t)QB2 * d * 2;
-    u64* lists = reinterpret_cast<u64*>(smem + (size_t)QB2 * d * 4);
-    int* locks = reinterpret_cast<int*>(lists + SHADOW_KL * QB2);
+    unsigned char* Ql = smem + (size_t)QB * d * 2;
+    u64* lists = reinterpret_cast<u64*>(smem + (size_t)QB * d * 4);
+    int* locks = reinterpret_cast<int*>(lists + SHADOW_KL * QB);
     constexpr int kl = SHADOW_KL;
 
-    for (int idx = threadIdx.x; idx < QB2 * d4; idx += WAVES * 64) {
+    for (int idx = threadIdx.x; idx < QB * d4; idx += WAVES * 64) {
         const int j = idx / d4, c = idx - j * d4;
         const float4 v = reinterpret_cast<const float4*>(qpad)[idx];
         const unsigned h01 = pack_bf16x2(v.x, v.y), h23 = pack_bf16x2(v.z, v.w);
@@ -670,8 +670,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
         *reinterpret_cast<uint2*>(Qh + off) = make_uint2(h01, h23);
         *reinterpret_cast<uint2*>(Ql + off) = make_uint2(l01, l23);
     }
-    for (int e = threadIdx.x; e < kl * QB2; e += WAVES * 64) lists[e] = 0;
-    if (threadIdx.x < QB2) locks[threadIdx.x] = 0;
+    for (int e = threadIdx.x; e < kl * QB; e += WAVES * 64) lists[e] = 0;
+    if (threadIdx.x < QB) locks[threadIdx.x] = 0;
     __syncthreads();
 
     const int nch = d / CW2;
@@ -702,11 +702,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    u64 tau_a = tau0 ? tau0[i] : 0, tau_b = tau0 ? tau0[32 + i] : 0;
-    const bool active_a = i < nq, active_b = 32 + i < nq;
+    u64 tau_a = tau0 ? tau0[i] : 0, tau_b = (tau0 && QB == 64) ? tau0[32 + i] : 0;
+    const bool active_a = i < nq, active_b = QB == 64 && 32 + i < nq;
     long long cg = gw;
     int cc = 0;
-    const size_t ra = (size_t)i * d8 * 16, rb = (size_t)(32 + i) * d8 * 16;
+    const size_t ra = (size_t)i * d8 * 16, rb = (size_t)((QB == 64 ? 32 : 0) + i) * d8 * 16;
     for (long long s0 = 0; s0 < steps; s0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
@@ -719,29 +719,31 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
                 const size_t o = (size_t)(((c8 + j) & ~15) | (((c8 + j) & 15) ^ (i & 15))) * 16;
                 qa[j] = *reinterpret_cast<const bf16x8*>(Qh + ra + o);
                 la[j] = *reinterpret_cast<const bf16x8*>(Ql + ra + o);
-                qb[j] = *reinterpret_cast<const bf16x8*>(Qh + rb + o);
-                lb[j] = *reinterpret_cast<const bf16x8*>(Ql + rb + o);
+                if constexpr (QB == 64) {
+                    qb[j] = *reinterpret_cast<const bf16x8*>(Qh + rb + o);
+                    lb[j] = *reinterpret_cast<const bf16x8*>(Ql + rb + o);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             prefetch(xq[p]);
             __builtin_amdgcn_sched_barrier(0);
             if (abl & 2) { acc0[0] += (float)x0[0] + (float)x1[1] + (float)x2[2] + (float)x3[3] + (float)qa[0][0] + (float)la[1][0] + (float)qb[2][0] + (float)lb[3][0] + (float)qa[1][0] + (float)qa[2][0] + (float)qa[3][0] + (float)la[0][0] + (float)la[2][0] + (float)la[3][0] + (float)qb[0][0] + (float)qb[1][0] + (float)qb[3][0] + (float)lb[0][0] + (float)lb[1][0] + (float)lb[2][0]; continue; }
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, la[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, lb[0], acc1, 0, 0, 0);
+            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, lb[0], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, qa[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, qb[0], acc1, 0, 0, 0);
+            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, qb[0], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, la[1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, lb[1], acc1, 0, 0, 0);
+            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, lb[1], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, qa[1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, qb[1], acc1, 0, 0, 0);
+            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, qb[1], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, la[2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, lb[2], acc1, 0, 0, 0);
+            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, lb[2], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, qa[2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, qb[2], acc1, 0, 0, 0);
+            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, qb[2], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, la[3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, lb[3], acc1, 0, 0, 0);
+            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, lb[3], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, qa[3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, qb[3], acc1, 0, 0, 0);
+            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, qb[3], acc1, 0, 0, 0);
         }
         cc += PF;
         if (cc == nch) {
@@ -755,7 +757,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
                     const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (row < N) {
                         dump[(size_t)i * N + row] = acc0[r];
-                        dump[(size_t)(32 + i) * N + row] = acc1[r];
+                        if constexpr (QB == 64) dump[(size_t)(32 + i) * N + row] = acc1[r];
                     }
                     acc0[r] = 0.f; acc1[r] = 0.f;
                 }
@@ -765,32 +767,41 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
                 for (int r = 0; r < 16; ++r) { t += acc0[r] + acc1[r]; acc0[r] = 0.f; acc1[r] = 0.f; }
                 if (t == 1.2345e-30f) lists[i] = 1;
             } else {
-            select_group_shared<SHADOW_KL>(acc0, tau_a, lists, locks, i, h, active_a, row0, N, row_offset);
-            select_group_shared<SHADOW_KL>(acc1, tau_b, lists, locks, 32 + i, h, active_b, row0, N, row_offset);
+            select_group_shared<SHADOW_KL, QB>(acc0, tau_a, lists, locks, i, h, active_a, row0, N, row_offset);
+            if constexpr (QB == 64)
+                select_group_shared<SHADOW_KL, QB>(acc1, tau_b, lists, locks, 32 + i, h, active_b, row0, N, row_offset);
             }
         }
     }
     if (dump) return;   // threshold pass: nothing to publish
     __syncthreads();
-    u64* dst = part + (size_t)blockIdx.x * QB2 * kl;
-    for (int e = threadIdx.x; e < QB2 * kl; e += WAVES * 64) {
+    u64* dst = part + (size_t)blockIdx.x * QB * kl;
+    for (int e = threadIdx.x; e < QB * kl; e += WAVES * 64) {
         const int q = e / kl, r = e - q * kl;
-        dst[e] = q < nq ? lists[r * QB2 + q] : 0;
+        dst[e] = q < nq ? lists[r * QB + q] : 0;
     }
 }
 
 bool shadow64_supported(int d) { return d % (4 * CW2) == 0 && d <= 512; }
+// 32 queries per pass: the Q images of 32 queries fit up to d = 1024 (the L/14 dimension, 768, included)
+bool shadow32_supported(int d) { return d % (4 * CW2) == 0 && d <= 1024; }
 int shadow64_scan_launch(const bf16_t* Xb, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
-                         const u64* tau0, hipStream_t st, float* dump) {
-    const size_t dl = (size_t)QB2 * d * 4 + (size_t)SHADOW_KL * QB2 * 8 + QB2 * 4;
+                         const u64* tau0, hipStream_t st, float* dump, int qb) {
+    const size_t dl = (size_t)qb * d * 4 + (size_t)SHADOW_KL * qb * 8 + qb * 4;
     static bool dattr = false;
     if (!dattr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 32>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         dattr = true;
     }
-    hipLaunchKernelGGL(ip_scan_shadow64_kernel<4>, dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, Xb, N, d, qpad, nq, part,
-                       row_offset, tau0, dump, g_mfma_abl);
+    if (qb == 64)
+        hipLaunchKernelGGL((ip_scan_shadow64_kernel<4, 64>), dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, Xb, N, d, qpad, nq,
+                           part, row_offset, tau0, dump, g_mfma_abl);
+    else
+        hipLaunchKernelGGL((ip_scan_shadow64_kernel<4, 32>), dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, Xb, N, d, qpad, nq,
+                           part, row_offset, tau0, dump, g_mfma_abl);
     WISE_LAUNCH_CHECK("ip_scan_shadow64_kernel");
     return WISE_OK;
 }

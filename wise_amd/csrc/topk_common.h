@@ -43,8 +43,10 @@ int split64_scan_launch(const float* X, long long N, long long row_offset, int d
 constexpr int SHADOW_KL = 48;
 bool shadow64_supported(int d);
 // dump != null: threshold pass — no lists; the scores of the N rows go to dump [64][N]
+// qb = 64 or 32 queries per pass (32: d up to 1024): part [split64_lists(N)][qb][SHADOW_KL], dump [qb][N]
+bool shadow32_supported(int d);
 int shadow64_scan_launch(const bf16_t* Xb, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
-                         const u64* tau0, hipStream_t st, float* dump = nullptr);
+                         const u64* tau0, hipStream_t st, float* dump = nullptr, int qb = 64);
 int sample_threshold_launch(const float* cand_scores, const long long* cand_rows, u64* tau0, hipStream_t st,
                             int kl = MFMA_KL, const int* gate = nullptr);
 // exact f32 scores of cand_rows [nq][MFMA_KL], ordered, first k -> outD/outI [nq][k]

@@ -104,9 +104,11 @@ class FlatIPIndex:
         if nq == 0:
             return D, I
         # one query (the reference's shape), or two and more where the 64-query matrix-core kernels apply (k <= 12,
-        # d = 256 / 512); a few queries outside those limits go one at a time when that beats the f32 batch kernels
+        # d = 256 / 512; 32-query passes for d = 768 / 1024, k <= 16); a few queries outside those limits go one at a
+        # time when that beats the f32 batch kernels
         two_stage = self.shadow and self._n >= 1 and ((nq == 1 and 1 <= k <= 16) or
                                                      (nq >= 2 and 1 <= k <= 12 and self.d in (256, 512)) or
+                                                     (nq >= 3 and 1 <= k <= 16 and self.d in (768, 1024)) or
                                                      (2 <= nq <= 3 and 1 <= k <= 16))
         if two_stage and self._ensure_shadow(lib):
             need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k)
