@@ -989,7 +989,9 @@ static int shadow_grid(long long N) {
     long long need = ((N + 7) / 8 + 3) / 4;
     if (need < 4) need = 4;
     need = (need + 3) / 4 * 4;   // a multiple of 4: four block lists of SHADOW_L keys read as one list of SHADOW_C
-    return need < 1024 ? (int)need : 1024;
+    // two blocks per CU: as fast as four (1.65 vs 1.69 ms at 10M x 512) and half the lists to merge
+    const long long cap = g_scan_blocks_per_cu > 0 ? 256ll * g_scan_blocks_per_cu : 512;
+    return need < cap ? (int)need : (int)cap;
 }
 static bool shadow_supported(int d, int k) { return d % 8 == 0 && d >= 8 && d <= 1024 && k >= 1 && k <= 16; }
 }  // namespace wise
