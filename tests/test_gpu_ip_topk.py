@@ -373,3 +373,32 @@ def test_wide_row_batch_falls_back_to_the_f32_scan():
     certified, fallback = _shadow_stats()
     assert fallback >= 1 and certified + fallback == 12
     check_against_oracle(X, Q, k, ids, D, I)
+
+
+def test_searches_beside_matrix_kernels_of_another_stream():
+    """The two-stage searches (one query; a batch of 32) run while another stream keeps the matrix cores busy return
+    what they return alone, bit for bit, every time.  (Built with packed f32 VALU math the candidate re-scoring kernel
+    returned dot products off by up to 5e-2 in about one call of four — see wise_amd/build.py.)"""
+    import ctypes
+
+    from wise_amd import _lib
+    lib = _lib.lib()
+    lib.wise_debug_neighbour.restype = ctypes.c_int
+    lib.wise_debug_neighbour.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3
+    other = torch.cuda.Stream()
+    g = torch.Generator("cuda").manual_seed(1)
+    X = torch.nn.functional.normalize(torch.randn(1_000_000, 512, device="cuda", generator=g), dim=1)
+    idx = FlatIPIndex(512, shadow=True).adopt(X)
+    src = torch.zeros(1024, dtype=torch.int32, device="cuda")
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+    for q in (X[100:132] + 0.01, X[7:8] + 0.01):
+        D0, I0 = idx.search_device(q, 10)
+        torch.cuda.synchronize()
+        for _ in range(12):
+            for _ in range(4):
+                lib.wise_debug_neighbour(3, 2048, 1024, 64, src.data_ptr(), sink.data_ptr(), other.cuda_stream)
+            D1, I1 = idx.search_device(q, 10)
+            for _ in range(2):
+                lib.wise_debug_neighbour(3, 2048, 1024, 64, src.data_ptr(), sink.data_ptr(), other.cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(I1, I0) and torch.equal(D1, D0)

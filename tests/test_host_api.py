@@ -268,3 +268,37 @@ def test_shard_range_partition():
         assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 3, 3)
+
+
+def test_no_packed_f32_math_in_the_product_kernels(tmp_path):
+    """wise_amd/build.py compiles every product file without packed f32 VALU math (kernels using v_pk_{fma,mul,add}_f32
+    returned wrong values beside MFMA-issuing kernels of another stream: DESIGN.md).  Disassemble the device code of
+    each object and hold the build to that."""
+    import shutil
+    import subprocess
+
+    from wise_amd import build
+
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    if not (llvm / "llvm-objdump").exists() or shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists():
+        pytest.skip("ROCm LLVM tools not available")
+    build.build_hip()
+    checked = 0
+    for src in build.HIP_SOURCES:
+        if src == "debug_probe.hip":          # the probes emit those instructions on purpose
+            continue
+        obj = build.LIBDIR / "obj" / (Path(src).stem + ".o")
+        assert obj.exists(), obj
+        fat, co = tmp_path / "fat.bin", tmp_path / "dev.co"
+        r = subprocess.run([str(llvm / "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", str(obj)],
+                           capture_output=True, text=True)
+        if r.returncode != 0:                 # a file without kernels has no device code section
+            assert "not found" in r.stderr or "section" in r.stderr, r.stderr
+            continue
+        subprocess.run([str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        asm = subprocess.run([str(llvm / "llvm-objdump"), "-d", str(co)], check=True, capture_output=True, text=True).stdout
+        packed = [l for l in asm.splitlines() if "v_pk_fma_f32" in l or "v_pk_mul_f32" in l or "v_pk_add_f32" in l]
+        assert not packed, f"{src}: {len(packed)} packed f32 instructions, e.g. {packed[0].strip()}"
+        checked += 1
+    assert checked >= 8

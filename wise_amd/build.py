@@ -18,8 +18,18 @@ LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libwise_hip.so"
 HIP_SOURCES = ["common.hip", "ip_topk.hip", "ip_topk_mfma.hip", "gemm_bf16.hip", "vit.hip", "htsat.hip", "htsat_frontend.hip", "preprocess.hip", "text.hip", "debug_probe.hip"]
 ARCH = "gfx950"
-# per-file flags; htsat_frontend.hip: see the note at the top of that file
-FILE_FLAGS = {"htsat_frontend.hip": ["-fno-slp-vectorize"]}
+# No packed f32 VALU math in the product kernels.  Kernels that use v_pk_{fma,mul,add}_f32 have twice been caught
+# returning wrong values — only while another stream's MFMA-issuing kernel shared the GPU, never alone: the HTSAT front
+# end (see csrc/htsat_frontend.hip) and the candidate re-scoring kernel of the two-stage search (exact dot products off
+# by up to 5e-2 in ~1 call of 4 beside a bare MFMA loop; tools/concurrency_sweep.py).  Two switches, both on every
+# product file: the SLP vectoriser off (it is what forms the packed operations from adjacent scalar ones), and the
+# target feature itself off for the device compilation, which also scalarises explicit float4 arithmetic (the host
+# pass prints "not a recognized feature ... ignoring", harmlessly).  Without packed f32 math both kernels are bit-stable
+# beside every neighbour tried, and the library is no slower (GEMM +-1 %, ViT step +-0.5 %, HTSAT -2 %).
+# debug_probe.hip keeps the feature: its probes emit those instructions on purpose.
+COMMON_FLAGS = ["-fno-slp-vectorize"]
+NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FILE_FLAGS: dict = {name: NO_PACKED_F32 for name in HIP_SOURCES if name != "debug_probe.hip"}
 
 
 def _newer(target: Path, deps) -> bool:
@@ -51,7 +61,7 @@ def build_hip(force: bool = False, verbose: bool = False, extra_flags=()) -> Pat
         objs.append(o)
         if force or _newer(o, [s] + list(CSRC.glob("*.h")) + [ROOT / "include" / "wise_hip.h"]):
             cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(s), "-o", str(o),
-                   *FILE_FLAGS.get(s.name, ()), *extra_flags]
+                   *COMMON_FLAGS, *FILE_FLAGS.get(s.name, ()), *extra_flags]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

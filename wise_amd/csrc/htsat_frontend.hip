@@ -1,6 +1,7 @@
 // MS-CLAP HTSAT audio front end: STFT power spectrum -> log-mel -> bn0, one kernel (htsat.hip calls it first).
 //
-// This file is compiled with -fno-slp-vectorize (wise_amd/build.py).  With the SLP vectoriser on, the butterflies
+// This file — like every product file since the same fault showed up in the search re-scoring kernel — is compiled
+// without packed f32 math (wise_amd/build.py).  With the SLP vectoriser on, the butterflies
 // become v_pk_{fma,mul,add}_f32 and the kernel, correct on its own, returns a few wrong frames whenever its waves
 // share a SIMD with waves of another stream's kernel that issues MFMA (the fused LayerNorm GEMM / fused MLP of a
 // second forward in flight, or a bare MFMA loop: tools/htsat_neighbours.py, DESIGN.md "Two HTSAT batches in flight").
