@@ -26,3 +26,32 @@ for beside in ("nothing", "MFMA", "global loads"):
         torch.cuda.synchronize()
     r = rep.tolist()
     print(f"beside {beside}: " + "; ".join(f"{n}: {r[i]}" for i, n in enumerate(names)), flush=True)
+
+# ---- the shape that failed in the product: rows of X dotted with a query, operands from global loads into packed fmas
+lib.wise_debug_pk_dot_probe.restype = ctypes.c_int
+lib.wise_debug_pk_dot_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_void_p]
+g = torch.Generator("cuda").manual_seed(5)
+N, d, blocks = 1_000_000, 512, 64
+X = torch.nn.functional.normalize(torch.randn(N, d, device="cuda", generator=g), dim=1)
+Qd = torch.nn.functional.normalize(torch.randn(blocks, d, device="cuda", generator=g), dim=1)
+rows = torch.randint(0, N, (blocks * 64,), device="cuda", generator=g, dtype=torch.int64)
+def dots():
+    out = torch.empty(blocks * 64, device="cuda")
+    lib.wise_debug_pk_dot_probe(X.data_ptr(), d, Qd.data_ptr(), rows.data_ptr(), blocks, out.data_ptr(), sts[0].cuda_stream)
+    return out
+torch.cuda.synchronize()
+ref = dots(); torch.cuda.synchronize()
+for beside in ("nothing", "MFMA"):
+    wrong_calls, worst = 0, 0.0
+    for rep in range(40):
+        if beside == "MFMA":
+            for _ in range(4): lib.wise_debug_neighbour(3, 2048, 1024, 64, src.data_ptr(), sink.data_ptr(), sts[1].cuda_stream)
+        got = dots()
+        if beside == "MFMA":
+            for _ in range(2): lib.wise_debug_neighbour(3, 2048, 1024, 64, src.data_ptr(), sink.data_ptr(), sts[1].cuda_stream)
+        torch.cuda.synchronize()
+        if not torch.equal(got, ref):
+            wrong_calls += 1
+            worst = max(worst, float((got - ref).abs().max()))
+    print(f"packed-fma dot products fed by global loads, beside {beside}: {wrong_calls} of 40 calls differ (max |diff| {worst:.3e})", flush=True)

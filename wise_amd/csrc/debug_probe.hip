@@ -223,7 +223,49 @@ __global__ __launch_bounds__(256, 2) void pk_probe_kernel(int iters, uint32_t* r
     }
     if (bad) atomicAdd(report + WHAT, bad);
 }
+
+// the shape of the kernel that failed in the product (candidate re-scoring): dot products of rows of X with a query,
+// four rows per wave, operands straight from global loads, accumulated with PACKED f32 fmas (vector types keep the
+// packing even with the SLP vectoriser off).  out[block][wave][4].
+__global__ __launch_bounds__(1024) void pk_dot_probe_kernel(const float* __restrict__ X, int d, const float* __restrict__ Q,
+                                                            const long long* __restrict__ rows, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d4 = d >> 2;
+    const float4* qv = reinterpret_cast<const float4*>(Q + (size_t)blockIdx.x * d);
+    long long r[4];
+    f32x2_t lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        r[u] = rows[(blockIdx.x * 16 + wave) * 4 + u];
+        lo[u] = f32x2_t{0.f, 0.f};
+        hi[u] = f32x2_t{0.f, 0.f};
+    }
+    for (int j = lane; j < d4; j += 64) {
+        const float4 b = qv[j];
+        float4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = reinterpret_cast<const float4*>(X + (size_t)r[u] * d)[j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            lo[u] = __builtin_elementwise_fma(f32x2_t{a[u].x, a[u].y}, f32x2_t{b.x, b.y}, lo[u]);
+            hi[u] = __builtin_elementwise_fma(f32x2_t{a[u].z, a[u].w}, f32x2_t{b.z, b.w}, hi[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float p = (lo[u][0] + lo[u][1]) + (hi[u][0] + hi[u][1]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) p += __shfl_xor(p, o, 64);
+        if (lane == 0) out[(blockIdx.x * 16 + wave) * 4 + u] = p;
+    }
+}
 }  // namespace
+
+extern "C" int wise_debug_pk_dot_probe(const float* X, int d, const float* Q, const long long* rows, int blocks, float* out,
+                                       void* stream) {
+    hipLaunchKernelGGL(pk_dot_probe_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, X, d, Q, rows, out);
+    return (int)hipGetLastError();
+}
 
 extern "C" int wise_debug_pk_probe(int what, int blocks, int lds_bytes, int iters, uint32_t* report, void* stream) {
     void (*k)(int, uint32_t*) = nullptr;
