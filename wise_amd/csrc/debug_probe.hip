@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void pk_probe_kernel(int iters, uint32_t* r
 // the shape of the kernel that failed in the product (candidate re-scoring): dot products of rows of X with a query,
 // four rows per wave, operands straight from global loads, accumulated with PACKED f32 fmas (vector types keep the
 // packing even with the SLP vectoriser off).  out[block][wave][4].
+template <int FORM>   // 0: pairs of one row's elements; 1: the same element of two rows, query element broadcast (op_sel)
 __global__ __launch_bounds__(1024) void pk_dot_probe_kernel(const float* __restrict__ X, int d, const float* __restrict__ Q,
                                                             const long long* __restrict__ rows, float* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -244,26 +245,99 @@ __global__ __launch_bounds__(1024) void pk_dot_probe_kernel(const float* __restr
         const float4 b = qv[j];
         float4 a[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = reinterpret_cast<const float4*>(X + (size_t)r[u] * d)[j];
+        for (int u = 0; u < 4; ++u)   // conditional loads, as in the product kernel (a negative row is "no candidate")
+            a[u] = r[u] >= 0 ? reinterpret_cast<const float4*>(X + (size_t)r[u] * d)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FORM == 0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            lo[u] = __builtin_elementwise_fma(f32x2_t{a[u].x, a[u].y}, f32x2_t{b.x, b.y}, lo[u]);
-            hi[u] = __builtin_elementwise_fma(f32x2_t{a[u].z, a[u].w}, f32x2_t{b.z, b.w}, hi[u]);
+            for (int u = 0; u < 4; ++u) {
+                lo[u] = __builtin_elementwise_fma(f32x2_t{a[u].x, a[u].y}, f32x2_t{b.x, b.y}, lo[u]);
+                hi[u] = __builtin_elementwise_fma(f32x2_t{a[u].z, a[u].w}, f32x2_t{b.z, b.w}, hi[u]);
+            }
+        } else {
+            // lo[0] = (p0, p1), lo[1] = (p2, p3): rows paired, one query element at a time
+            lo[0] = __builtin_elementwise_fma(f32x2_t{a[0].x, a[1].x}, f32x2_t{b.x, b.x}, lo[0]);
+            lo[1] = __builtin_elementwise_fma(f32x2_t{a[2].x, a[3].x}, f32x2_t{b.x, b.x}, lo[1]);
+            lo[0] = __builtin_elementwise_fma(f32x2_t{a[0].y, a[1].y}, f32x2_t{b.y, b.y}, lo[0]);
+            lo[1] = __builtin_elementwise_fma(f32x2_t{a[2].y, a[3].y}, f32x2_t{b.y, b.y}, lo[1]);
+            lo[0] = __builtin_elementwise_fma(f32x2_t{a[0].z, a[1].z}, f32x2_t{b.z, b.z}, lo[0]);
+            lo[1] = __builtin_elementwise_fma(f32x2_t{a[2].z, a[3].z}, f32x2_t{b.z, b.z}, lo[1]);
+            lo[0] = __builtin_elementwise_fma(f32x2_t{a[0].w, a[1].w}, f32x2_t{b.w, b.w}, lo[0]);
+            lo[1] = __builtin_elementwise_fma(f32x2_t{a[2].w, a[3].w}, f32x2_t{b.w, b.w}, lo[1]);
         }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        float p = (lo[u][0] + lo[u][1]) + (hi[u][0] + hi[u][1]);
+        float p = FORM == 0 ? (lo[u][0] + lo[u][1]) + (hi[u][0] + hi[u][1]) : lo[u >> 1][u & 1];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) p += __shfl_xor(p, o, 64);
         if (lane == 0) out[(blockIdx.x * 16 + wave) * 4 + u] = p;
     }
 }
+
+// the narrowed form: v_pk_fma_f32 with op_sel:[0,1,0] (both result halves read the HIGH half of src1), once with the
+// destination allocated over src1 (what the register allocator did in both failing kernels) and once with a
+// destination of its own; every result is checked against scalar fmas in the same lane.  report[form] counts wrong
+// halves.
+template <bool OVERLAP, int NOPS = 0>
+__global__ __launch_bounds__(256) void pk_overlap_probe_kernel(int iters, uint32_t* report) {
+    const int lane = threadIdx.x & 63;
+    uint32_t bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        f32x2_t a = {1.f + 0.001f * lane + it, 2.f - 0.003f * lane}, b = {0.5f + 0.01f * (it & 63), 1.25f + 0.002f * lane};
+        f32x2_t c = {3.f + lane, -1.f + 0.5f * it};
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float e0 = __builtin_fmaf(a[0], b[1], c[0]), e1 = __builtin_fmaf(a[1], b[1], c[1]);
+            f32x2_t d;
+            if (OVERLAP) {
+                d = b;
+                asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel:[0,1,0]" : "+v"(d) : "v"(a), "v"(c));
+            } else if (NOPS == 0) {
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+            } else if (NOPS == 1) {
+                asm volatile("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+            } else {
+                asm volatile("s_nop 3\n\tv_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+            }
+            const bool w0 = __float_as_uint(d[0]) != __float_as_uint(e0), w1 = __float_as_uint(d[1]) != __float_as_uint(e1);
+            bad += w0 + w1;
+            if (!OVERLAP && (w0 || w1)) {
+                // what did the wrong half compute?  the same product with src1's LOW half (op_sel dropped)?
+                const float alt0 = __builtin_fmaf(a[0], b[0], c[0]), alt1 = __builtin_fmaf(a[1], b[0], c[1]);
+                if (w0 && __float_as_uint(d[0]) == __float_as_uint(alt0)) atomicAdd(report + 2, 1u);
+                if (w1 && __float_as_uint(d[1]) == __float_as_uint(alt1)) atomicAdd(report + 3, 1u);
+                if (w0) atomicAdd(report + 4, 1u);
+                if (w1) atomicAdd(report + 5, 1u);
+                if (atomicAdd(report + 6, 1u) == 0) {
+                    report[8] = __float_as_uint(a[0]); report[9] = __float_as_uint(a[1]); report[10] = __float_as_uint(b[0]);
+                    report[11] = __float_as_uint(b[1]); report[12] = __float_as_uint(c[0]); report[13] = __float_as_uint(c[1]);
+                    report[14] = __float_as_uint(d[0]); report[15] = __float_as_uint(d[1]);
+                }
+            }
+            // next operands: keep magnitudes bounded
+            a = f32x2_t{d[1] * 0.5f + 1.f, d[0] * 0.25f - 1.f};
+            b = f32x2_t{b[1] * 0.75f + 0.1f, b[0] * 0.5f + 0.7f};
+            c = f32x2_t{c[1] * 0.5f, c[0] * 0.5f + 0.3f};
+        }
+    }
+    if (bad) atomicAdd(report + (OVERLAP ? 1 : NOPS == 0 ? 0 : 15 + NOPS), bad);
+}
 }  // namespace
 
+extern "C" int wise_debug_pk_overlap_probe(int blocks, int iters, uint32_t* report, void* stream) {
+    hipLaunchKernelGGL(pk_overlap_probe_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, report);
+    hipLaunchKernelGGL(pk_overlap_probe_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, report);
+    hipLaunchKernelGGL((pk_overlap_probe_kernel<false, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, report);
+    hipLaunchKernelGGL((pk_overlap_probe_kernel<false, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, report);
+    return (int)hipGetLastError();
+}
+
 extern "C" int wise_debug_pk_dot_probe(const float* X, int d, const float* Q, const long long* rows, int blocks, float* out,
-                                       void* stream) {
-    hipLaunchKernelGGL(pk_dot_probe_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, X, d, Q, rows, out);
+                                       void* stream, int form) {
+    if (form == 0)
+        hipLaunchKernelGGL(pk_dot_probe_kernel<0>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, X, d, Q, rows, out);
+    else
+        hipLaunchKernelGGL(pk_dot_probe_kernel<1>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, X, d, Q, rows, out);
     return (int)hipGetLastError();
 }
 
