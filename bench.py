@@ -222,9 +222,11 @@ def main():
     def vit_step_serial(i):
         out_holder["o"] = eng.forward(x)
 
+    def vit_step_one_stream(i):   # every launch on the caller's stream (wise_vit_forward_single)
+        out_holder["o"] = eng.forward(x, single_stream=True)
+
     if args.roofline_only:
-        lib.wise_debug_set_vit_streams(1)
-        vit_step = vit_step_serial
+        vit_step = vit_step_one_stream
     for i in range(args.warmup):
         vit_step(i)
     dt = timed_region(vit_step, args.steps, world)
@@ -243,11 +245,9 @@ def main():
     # region above overlaps two half-batches on two streams, which stretches every launch's wall time, so this
     # pass runs the forward on ONE stream: launch durations are then per-kernel and comparable with rocprofv3.
     n_gemm_per_fwd = 4 * (4 * spec.layers + 2)  # capacity (split launches, patch embed, projection)
-    lib.wise_debug_set_vit_streams(1)
     for i in range(2):
-        vit_step_serial(i)
-    prof = prof_pass(lib, vit_step_serial, args.steps, args.steps * n_gemm_per_fwd + 8)
-    lib.wise_debug_set_vit_streams(2)
+        vit_step_one_stream(i)
+    prof = prof_pass(lib, vit_step_one_stream, args.steps, args.steps * n_gemm_per_fwd + 8)
     g_ms, g_n, g_flop = prof[0]
     gemm_tflops = (g_flop / g_n) / (g_ms / g_n * 1e-3) / 1e12 if g_n else 0.0
     roofline = {

@@ -382,7 +382,7 @@ def test_searches_beside_matrix_kernels_of_another_stream():
     import ctypes
 
     from wise_amd import _lib
-    lib = _lib.lib()
+    lib = _lib.load_debug()   # the neighbour (a bare MFMA loop) lives in the debug twin; the searches are the product's
     lib.wise_debug_neighbour.restype = ctypes.c_int
     lib.wise_debug_neighbour.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3
     other = torch.cuda.Stream()

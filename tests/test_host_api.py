@@ -14,7 +14,11 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 # ---------------------------------------------------------------- C ABI
-def test_library_exports_every_declared_symbol():
+def test_library_exports_exactly_the_declared_symbols():
+    """libwise_hip.so exports what include/wise_hip.h declares — nothing less (every declaration resolves and has a
+    ctypes prototype) and nothing more (no wise_debug_* switches or C++ helpers leak out of the product library)."""
+    import subprocess
+
     from wise_amd import _lib
 
     lib = _lib.load()  # raises if the .so is missing or a symbol is absent
@@ -25,7 +29,25 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in wise_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype"
-    assert lib.wise_abi_version() == 1
+    assert set(_lib.SIGNATURES) == declared, set(_lib.SIGNATURES) ^ declared
+    nm = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True)
+    exported = {line.split()[-1] for line in nm.stdout.splitlines() if line.strip()}
+    assert exported == declared, f"exported but not declared: {sorted(exported - declared)}; missing: {sorted(declared - exported)}"
+    assert lib.wise_abi_version() == 2
+    # the flags of the correctness fix (no packed f32 VALU math) are the ones this very library was compiled with
+    flags = lib.wise_build_flags().decode()
+    assert "-fno-slp-vectorize" in flags and "-packed-fp32-ops" in flags, flags
+
+
+def test_debug_switches_live_only_in_the_debug_library():
+    from wise_amd import _lib, build
+
+    assert _lib.DEBUG_LIB_PATH.exists(), "python -m wise_amd.build builds libwise_hip_debug.so beside the product"
+    dbg = _lib.load_debug()
+    for name in ("wise_debug_neighbour", "wise_debug_set_gemm_variant", "wise_debug_pk_overlap_probe"):
+        assert hasattr(dbg, name)
+        assert not hasattr(_lib.load(), name)
+    assert "debug_probe.hip" not in build.HIP_SOURCES
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -114,6 +136,11 @@ def test_feature_extractor_base_and_factory_errors():
         FeatureExtractorFactory("mlfoundations/open_clip/ViT-Z-99/openai")
     with pytest.raises(ValueError, match="not available"):
         FeatureExtractorFactory("microsoft/clap/1999/Not-Applicable")
+    # msclap's other two model keys (microsoft_clap.py:20-31) are different architectures (Cnn14 + BERT; clapcap):
+    # refused at construction, never served by the 2023 kernels under their id
+    for version in ("2022", "clapcap"):
+        with pytest.raises(NotImplementedError, match="only the 2023 model"):
+            FeatureExtractorFactory(f"microsoft/clap/{version}/seeded-0")
 
 
 def test_openclip_preprocess_matches_reference_transform():
@@ -212,6 +239,15 @@ def test_webdataset_store_format_and_order(tmp_path):
     assert batches[0][0] == [0, 3, 6, 7, 8] and batches[0][1].shape == (5, 5)
     with pytest.raises(ValueError, match="failed to infer"):
         FeatureStoreFactory.load_store("video", tmp_path)
+    # the factory's other error paths (feature_store_factory.py:21,32-38): unknown type, mixed shard kinds, foreign extension
+    with pytest.raises(ValueError, match="unknown feature_store_type"):
+        FeatureStoreFactory.create_store("hdf5", "audio", tmp_path)
+    (tmp_path / "audio-000000.npz").write_bytes(b"")
+    with pytest.raises(ValueError, match="failed to infer"):
+        FeatureStoreFactory.load_store("audio", tmp_path)
+    (tmp_path / "image-000000.h5").write_bytes(b"")
+    with pytest.raises(ValueError, match="unknown store containing shard filenames with extension .h5"):
+        FeatureStoreFactory.load_store("image", tmp_path)
 
 
 # ---------------------------------------------------------------- SearchIndex surface + .faiss IO
@@ -270,35 +306,55 @@ def test_shard_range_partition():
         shard_range(10, 3, 3)
 
 
+def _gfx950_code_objects(shared_object: Path):
+    """The gfx950 code objects embedded in a hipcc-built shared object (one clang offload bundle per translation
+    unit, concatenated in .hip_fatbin)."""
+    import struct
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        fat = Path(td) / "fat.bin"
+        subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", str(shared_object)],
+                       check=True, capture_output=True)
+        blob = fat.read_bytes()
+    magic, pos, out = b"__CLANG_OFFLOAD_BUNDLE__", 0, []
+    while (i := blob.find(magic, pos)) >= 0:
+        (n,) = struct.unpack_from("<Q", blob, i + 24)
+        off = i + 32
+        for _ in range(n):
+            o, size, tlen = struct.unpack_from("<QQQ", blob, off)
+            off += 24
+            triple = blob[off:off + tlen].decode()
+            off += tlen
+            if "gfx950" in triple and size:
+                out.append(blob[i + o:i + o + size])
+        pos = i + 1
+    return out
+
+
 def test_no_packed_f32_math_in_the_product_kernels(tmp_path):
     """wise_amd/build.py compiles every product file without packed f32 VALU math (kernels using v_pk_{fma,mul,add}_f32
-    returned wrong values beside MFMA-issuing kernels of another stream: DESIGN.md).  Disassemble the device code of
-    each object and hold the build to that."""
-    import shutil
+    returned wrong values beside MFMA-issuing kernels of another stream: DESIGN.md).  Disassemble the device code
+    inside the libwise_hip.so that wise_amd._lib loads — not the intermediate objects — and hold it to that."""
     import subprocess
 
-    from wise_amd import build
+    from wise_amd import _lib
 
     llvm = Path("/opt/rocm/lib/llvm/bin")
-    if not (llvm / "llvm-objdump").exists() or shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists():
-        pytest.skip("ROCm LLVM tools not available")
-    build.build_hip()
-    checked = 0
-    for src in build.HIP_SOURCES:
-        if src == "debug_probe.hip":          # the probes emit those instructions on purpose
-            continue
-        obj = build.LIBDIR / "obj" / (Path(src).stem + ".o")
-        assert obj.exists(), obj
-        fat, co = tmp_path / "fat.bin", tmp_path / "dev.co"
-        r = subprocess.run([str(llvm / "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", str(obj)],
-                           capture_output=True, text=True)
-        if r.returncode != 0:                 # a file without kernels has no device code section
-            assert "not found" in r.stderr or "section" in r.stderr, r.stderr
-            continue
-        subprocess.run([str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
-        asm = subprocess.run([str(llvm / "llvm-objdump"), "-d", str(co)], check=True, capture_output=True, text=True).stdout
+    assert (llvm / "llvm-objdump").exists() and (llvm / "llvm-objcopy").exists(), "ROCm LLVM tools are part of the image"
+    _lib.load()
+    objs = _gfx950_code_objects(_lib.LIB_PATH)
+    assert len(objs) >= 8, f"{len(objs)} gfx950 code objects in {_lib.LIB_PATH}"
+    kernels = 0
+    for n, co in enumerate(objs):
+        f = tmp_path / f"dev{n}.co"
+        f.write_bytes(co)
+        asm = subprocess.run([str(llvm / "llvm-objdump"), "-d", str(f)], check=True, capture_output=True, text=True).stdout
         packed = [l for l in asm.splitlines() if "v_pk_fma_f32" in l or "v_pk_mul_f32" in l or "v_pk_add_f32" in l]
-        assert not packed, f"{src}: {len(packed)} packed f32 instructions, e.g. {packed[0].strip()}"
-        checked += 1
-    assert checked >= 8
+        assert not packed, f"code object {n}: {len(packed)} packed f32 instructions, e.g. {packed[0].strip()}"
+        kernels += asm.count("v_mfma_") > 0
+    assert kernels >= 4   # the disassembly really is the matrix-core kernels' code
+    # and the debug twin's probe object is the one place that has them on purpose
+    dbg = _gfx950_code_objects(_lib.DEBUG_LIB_PATH)
+    assert len(dbg) == len(objs) + 1

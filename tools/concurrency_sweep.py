@@ -5,6 +5,8 @@ import ctypes, sys
 from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import os
+os.environ.setdefault("WISE_AMD_DEBUG_LIB", "1")  # tuning switches live only in libwise_hip_debug.so
 from wise_amd import _lib
 from wise_amd.feature.htsat import HtsatEngine, random_htsat_state_dict
 from wise_amd.feature.vit import VitEngine, random_state_dict, spec_for

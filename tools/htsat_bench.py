@@ -10,6 +10,8 @@ from wise_amd.feature.htsat import HtsatEngine, random_htsat_state_dict  # noqa:
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 480000
+import os
+os.environ.setdefault("WISE_AMD_DEBUG_LIB", "1")  # tuning switches live only in libwise_hip_debug.so
 from wise_amd import _lib  # noqa: E402
 
 eng = HtsatEngine(random_htsat_state_dict(0), max_batch=B, max_samples=N)

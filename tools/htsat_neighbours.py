@@ -3,6 +3,8 @@ import sys
 from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import os
+os.environ.setdefault("WISE_AMD_DEBUG_LIB", "1")  # tuning switches live only in libwise_hip_debug.so
 from wise_amd import _lib
 from wise_amd.feature.htsat import HtsatEngine, random_htsat_state_dict
 B, N, Fc = 32, 480000, 1024

@@ -3,6 +3,8 @@ import sys, time
 from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import os
+os.environ.setdefault("WISE_AMD_DEBUG_LIB", "1")  # tuning switches live only in libwise_hip_debug.so
 from wise_amd import _lib
 from wise_amd.index.flat_ip import FlatIPIndex
 lib = _lib.lib()

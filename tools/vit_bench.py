@@ -8,6 +8,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import os
+os.environ.setdefault("WISE_AMD_DEBUG_LIB", "1")  # tuning switches live only in libwise_hip_debug.so
 from wise_amd import _lib  # noqa: E402
 from wise_amd.feature.vit import VitEngine, random_state_dict, spec_for  # noqa: E402
 

@@ -7,10 +7,12 @@ device is visible.  torch is used only to own device memory and streams.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 _LIB = None
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libwise_hip.so"
+DEBUG_LIB_PATH = LIB_PATH.with_name("libwise_hip_debug.so")
 
 WISE_OK = 0
 WISE_VIT_IN_F32 = 0
@@ -33,6 +35,7 @@ _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 SIGNATURES = {
     "wise_last_error": (C.c_char_p, []),
     "wise_abi_version": (_i, []),
+    "wise_build_flags": (C.c_char_p, []),
     "wise_device_ok": (_i, []),
     "wise_prof_begin": (_i, [_i]),
     "wise_prof_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
@@ -79,6 +82,10 @@ def load(path: Path | None = None):
     if _LIB is not None and path is None:
         return _LIB
     p = Path(path) if path else LIB_PATH
+    if path is None and os.environ.get("WISE_AMD_DEBUG_LIB") == "1":
+        # developer opt-in (tools/): bind the whole package to the debug twin so that its wise_debug_* switches act on
+        # the kernels the engines launch
+        p = DEBUG_LIB_PATH
     if not p.exists():
         raise RuntimeError(
             f"{p} is missing: build it with `python -m wise_amd.build` (hipcc --offload-arch=gfx950). "
@@ -95,6 +102,26 @@ def load(path: Path | None = None):
     if path is None:
         _LIB = lib
     return lib
+
+
+_DEBUG = None
+
+
+def load_debug():
+    """libwise_hip_debug.so: the same kernels built with their tuning / ablation switches live plus the hardware probes
+    (wise_debug_*).  For tools/ and the neighbour tests only — nothing under wise_amd/ calls this."""
+    global _DEBUG
+    if _DEBUG is None:
+        if not DEBUG_LIB_PATH.exists():
+            raise RuntimeError(f"{DEBUG_LIB_PATH} is missing: build it with `python -m wise_amd.build`")
+        import torch  # noqa: F401  (same reason as in load())
+        d = C.CDLL(str(DEBUG_LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(d, name)
+            fn.restype = res
+            fn.argtypes = args
+        _DEBUG = d
+    return _DEBUG
 
 
 def lib():

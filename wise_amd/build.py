@@ -1,11 +1,21 @@
-"""In-tree build of libwise_hip.so (hipcc, gfx950 only) and of the C oracle.
+"""In-tree build of libwise_hip.so (hipcc, gfx950 only), of its debug twin and of the C oracle.
 
 `python -m wise_amd.build` or `wise_amd.build.build_all()`.  The .so files are git-ignored but
 travel to the GPU box with the working tree, so nothing is compiled there unless a source is newer.
+
+Two libraries come out of the same sources:
+  lib/libwise_hip.so        the product: exports exactly the symbols include/wise_hip.h declares (a linker version
+                            script generated from the header), tuning / ablation switches compiled out.
+  lib/libwise_hip_debug.so  the same code built with -DWISE_DEBUG_KNOBS plus csrc/debug_probe.hip: the
+                            wise_debug_* entry points tools/ and the neighbour tests use.  Never loaded by wise_amd.
+An object is rebuilt when its source, a header, THIS FILE or its command line changed (the command line is kept
+beside the object): the flags below are a correctness fix, so a stale object built with other flags must not survive.
 """
 from __future__ import annotations
 
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -16,7 +26,11 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libwise_hip.so"
-HIP_SOURCES = ["common.hip", "ip_topk.hip", "ip_topk_mfma.hip", "gemm_bf16.hip", "vit.hip", "htsat.hip", "htsat_frontend.hip", "preprocess.hip", "text.hip", "debug_probe.hip"]
+LIB_DEBUG = LIBDIR / "libwise_hip_debug.so"
+HEADER = ROOT / "include" / "wise_hip.h"
+HIP_SOURCES = ["common.hip", "ip_topk.hip", "ip_topk_mfma.hip", "gemm_bf16.hip", "vit.hip", "htsat.hip",
+               "htsat_frontend.hip", "preprocess.hip", "text.hip"]
+DEBUG_ONLY_SOURCES = ["debug_probe.hip"]
 ARCH = "gfx950"
 # No packed f32 VALU math in the product kernels.  Kernels that use v_pk_{fma,mul,add}_f32 have twice been caught
 # returning wrong values — only while another stream's MFMA-issuing kernel shared the GPU, never alone: the HTSAT front
@@ -32,7 +46,12 @@ ARCH = "gfx950"
 # on purpose.
 COMMON_FLAGS = ["-fno-slp-vectorize"]
 NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-FILE_FLAGS: dict = {name: NO_PACKED_F32 for name in HIP_SOURCES if name != "debug_probe.hip"}
+FILE_FLAGS: dict = {name: NO_PACKED_F32 for name in HIP_SOURCES}
+
+
+def flags_string() -> str:
+    """What wise_build_flags() of the product library returns (include/wise_hip.h)."""
+    return " ".join(["-O3", f"--offload-arch={ARCH}", *COMMON_FLAGS, *NO_PACKED_F32])
 
 
 def _newer(target: Path, deps) -> bool:
@@ -49,36 +68,80 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: libwise_hip.so cannot be built")
 
 
-def build_hip(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
-    srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
-    deps = srcs + list(CSRC.glob("*.h")) + [ROOT / "include" / "wise_hip.h"]
-    if not force and not _newer(LIB, deps):
-        return LIB
-    LIBDIR.mkdir(parents=True, exist_ok=True)
-    objs = []
-    procs = []
-    objdir = LIBDIR / "obj"
-    objdir.mkdir(exist_ok=True)
+def declared_symbols() -> list:
+    """Every function include/wise_hip.h declares (the product library's whole export list)."""
+    names = set(re.findall(r"\b(wise_[a-z0-9_]+)\s*\(", HEADER.read_text()))
+    return sorted(names)
+
+
+def _compile(srcs, objdir: Path, defines, force: bool, verbose: bool, extra_flags=()):
+    """Compile each source to objdir; returns (objects, whether anything was rebuilt)."""
+    objdir.mkdir(parents=True, exist_ok=True)
+    headers = list(CSRC.glob("*.h")) + [HEADER]
+    objs, procs = [], []
     for s in srcs:
         o = objdir / (s.stem + ".o")
         objs.append(o)
-        if force or _newer(o, [s] + list(CSRC.glob("*.h")) + [ROOT / "include" / "wise_hip.h"]):
-            cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(s), "-o", str(o),
-                   *COMMON_FLAGS, *FILE_FLAGS.get(s.name, ()), *extra_flags]
+        cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+               *defines, "-c", str(s), "-o", str(o), *COMMON_FLAGS, *FILE_FLAGS.get(s.name, ()), *extra_flags]
+        stamp = o.with_suffix(".cmd")
+        cmdline = " ".join(cmd) + "\n# build.py " + hashlib.sha256(Path(__file__).read_bytes()).hexdigest()[:16] + "\n"
+        stale = force or _newer(o, [s] + headers) or not stamp.exists() or stamp.read_text() != cmdline
+        if stale:
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for s, p in procs:
+            procs.append((s, stamp, cmdline,
+                          subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, stamp, cmdline, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s.name}:\n{out}")
+        stamp.write_text(cmdline)
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+    return objs, bool(procs)
+
+
+def _link(objs, target: Path, version_script: Path | None):
+    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(target), *map(str, objs)]
+    if version_script is not None:
+        cmd.append(f"-Wl,--version-script={version_script}")
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+
+
+def _api_define():
+    return ['-DWISE_BUILD_FLAGS="' + flags_string() + '"']
+
+
+def build_hip(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
+    """The product library: exports == include/wise_hip.h, no debug switches."""
+    srcs = [CSRC / s for s in HIP_SOURCES]
+    LIBDIR.mkdir(parents=True, exist_ok=True)
+    objs, rebuilt = _compile(srcs, LIBDIR / "obj", _api_define(), force, verbose, extra_flags)
+    vs = LIBDIR / "obj" / "exports.map"
+    text = "{\n  global:\n" + "".join(f"    {n};\n" for n in declared_symbols()) + "  local: *;\n};\n"
+    if not vs.exists() or vs.read_text() != text:
+        vs.write_text(text)
+        rebuilt = True
+    if rebuilt or not LIB.exists():
+        _link(objs, LIB, vs)
     return LIB
+
+
+def build_debug(force: bool = False, verbose: bool = False) -> Path:
+    """The debug twin: the same kernels with their tuning / ablation switches live, plus the hardware probes."""
+    srcs = [CSRC / s for s in HIP_SOURCES + DEBUG_ONLY_SOURCES if (CSRC / s).exists()]
+    objs, rebuilt = _compile(srcs, LIBDIR / "obj_debug", _api_define() + ["-DWISE_DEBUG_KNOBS"], force, verbose)
+    vs = LIBDIR / "obj_debug" / "exports.map"
+    text = "{\n  global:\n    wise_*;\n  local: *;\n};\n"
+    if not vs.exists() or vs.read_text() != text:
+        vs.write_text(text)
+        rebuilt = True
+    if rebuilt or not LIB_DEBUG.exists():
+        _link(objs, LIB_DEBUG, vs)
+    return LIB_DEBUG
 
 
 def build_oracle(force: bool = False) -> Path | None:
@@ -100,10 +163,11 @@ def build_oracle(force: bool = False) -> Path | None:
 
 def build_all(force: bool = False, verbose: bool = False):
     lib = build_hip(force=force, verbose=verbose)
+    build_debug(force=force, verbose=verbose)
     orc = build_oracle(force=force)
     return lib, orc
 
 
 if __name__ == "__main__":
     lib, orc = build_all(force="--force" in sys.argv, verbose=True)
-    print("built", lib, orc)
+    print("built", lib, LIB_DEBUG, orc)

@@ -63,7 +63,11 @@ extern "C" int wise_prof_end(double* ms_sum, int64_t* launches, double* work_sum
 }
 
 extern "C" const char* wise_last_error(void) { return wise::g_err; }
-extern "C" int wise_abi_version(void) { return 1; }
+extern "C" int wise_abi_version(void) { return 2; }
+#ifndef WISE_BUILD_FLAGS
+#define WISE_BUILD_FLAGS "unknown (not built by wise_amd/build.py)"
+#endif
+extern "C" const char* wise_build_flags(void) { return WISE_BUILD_FLAGS; }
 extern "C" int wise_device_ok(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return 0;

@@ -21,12 +21,18 @@ namespace wise {
 enum : int { EPI_BF16 = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4, EPI_GELU_TANH = 5 };
 constexpr bool bf16_out(int mode) { return mode == EPI_BF16 || mode == EPI_QUICKGELU || mode == EPI_GELU || mode == EPI_GELU_TANH; }
 
+// Tuning / ablation switches.  They exist only in the debug build (libwise_hip_debug.so, -DWISE_DEBUG_KNOBS: tools/ and
+// wise_debug_set_gemm_variant); in the product library they are compile-time constants and the branches fold away.
+#ifdef WISE_DEBUG_KNOBS
 __device__ int g_group_m = 0;        // 0 = default; tuning knob (bits 16..23 of wise_debug_set_gemm_variant)
 __device__ int g_epi_lds = 1;        // bf16 epilogue through LDS (bit 30 of the debug knob turns it off)
 __device__ int g_dephase = 0;        // tuning knob (bits 24..27): initial s_sleep units for the second block per CU
 __device__ int g_store_nt = 1;       // non-temporal stores in the bf16 epilogue of the 256-row tiles: the C tile is read by a
                                      // later kernel, not by this one (ViT-L/14 +1.5 % end to end, ViT-B/32 unchanged)
 __device__ int g_skip_epilogue = 0;  // timing-only ablation (tools/gemm_bench.py), set via wise_debug_set_gemm_variant
+#else
+constexpr int g_group_m = 0, g_epi_lds = 1, g_dephase = 0, g_store_nt = 1, g_skip_epilogue = 0;
+#endif
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per buffer
@@ -751,12 +757,11 @@ static void launch_gemm_ln(const float* x, const float* lnw, const float* lnb, c
     constexpr size_t TBs = 128 * 64;
     const size_t wreg = (NF * TBs > (size_t)4 * 64 * 144) ? NF * TBs : (size_t)4 * 64 * 144;
     const size_t lds = NF * TBs + wreg;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), lds, st, x, lnw, lnb, Wt, bias, M, N, eps, out);
 }
 
@@ -765,12 +770,11 @@ static void launch_ring(const bf16_t* A, const bf16_t* Wt, const float* bias, in
                         hipStream_t st) {
     auto kern = gemm_ring_kernel<MODE, BKT, STAGES, MINB, ABL>;
     const size_t lds = (size_t)STAGES * 2 * 128 * BKT * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_set = true;
-    }
+    });
     const int grid = (M / BM) * ((N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, Wt, bias, M, N, K, out);
 }
@@ -780,12 +784,11 @@ static void launch_gemm(const bf16_t* A, const bf16_t* Wt, const float* bias, in
                         hipStream_t st) {
     auto kern = gemm_bf16_kernel<MODE, ABL>;
     const size_t lds = 4 * TILE_BYTES;  // 64 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_set = true;
-    }
+    });
     const int grid = (M / BM) * ((N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, Wt, bias, M, N, K, out);
 }
@@ -924,12 +927,11 @@ static void launch_big_pre(const bf16_t* A, const bf16_t* Wt, const float* bias,
     if constexpr (MODE == EPI_RESID) {
         auto kern = gemm_big_kernel<MODE, NT, 0, true>;
         const size_t lds = (size_t)2 * (256 + 64 * NT) * 128;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::once_flag attr_set;
+        std::call_once(attr_set, [&] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds);
-            attr_set = true;
-        }
+        });
         const int grid = (M / 256) * (N / (64 * NT));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
     }
@@ -940,12 +942,11 @@ static void launch_big(const bf16_t* A, const bf16_t* Wt, const float* bias, int
                        hipStream_t st) {
     auto kern = gemm_big_kernel<MODE, NT, ABL>;
     const size_t lds = (size_t)2 * (256 + 64 * NT) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_set = true;
-    }
+    });
     const int grid = (M / 256) * (N / (64 * NT));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
 }
@@ -1160,12 +1161,11 @@ static void launch_pp(const bf16_t* A, const bf16_t* Wt, const float* bias, int 
     constexpr int BMB = (WROWS == 64) ? 256 : (WROWS == 80) ? 320 : 2 * WROWS;
     constexpr int STAGES = (WROWS == 64) ? 5 : 4;
     const size_t lds = (size_t)STAGES * (BMB + BNB) * 32 * 2;  // 128 KiB / 120 KiB / 144 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_set = true;
-    }
+    });
     const int grid = (M / BMB) * (N / BNB);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
 }
@@ -1238,12 +1238,11 @@ int mlp96_fused(float* x, const float* lnw, const float* lnb, const bf16_t* W1, 
     WISE_CHECK_ARG(x && lnw && lnb && W1 && b1 && W2 && b2 && M > 0 && M % 128 == 0, "mlp96: bad argument (M=%d)", M);
     ProfScope prof(PROF_GEMM, 4.0 * (double)M * 96.0 * 384.0, st);
     const size_t lds = (size_t)9 * 128 * 64;  // 72 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp96_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(mlp96_kernel, dim3(M / 128), dim3(256), lds, st, x, lnw, lnb, W1, b1, W2, b2, eps);
     WISE_LAUNCH_CHECK("mlp96_kernel");
     return WISE_OK;
@@ -1349,6 +1348,7 @@ extern "C" int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float
 
 namespace wise { int g_ablate = 0; }  // timing-only ablations: bit 1 = skip LayerNorm launches, bit 2 = skip attention
 
+#ifdef WISE_DEBUG_KNOBS
 extern "C" int wise_debug_set_gemm_flags(int flags) {
     wise::g_tile320 = (flags & 1) ? 0 : 1;
     wise::g_ablate = flags & 6;
@@ -1371,3 +1371,4 @@ extern "C" int wise_debug_set_gemm_variant(int v) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_group_m), &gm, sizeof(int));
     return 0;
 }
+#endif  // WISE_DEBUG_KNOBS

@@ -589,11 +589,13 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
     return WISE_OK;
 }
 
+#ifdef WISE_DEBUG_KNOBS
 extern "C" int wise_debug_set_htsat(int flags) {
     wise::htsat::g_fuse_ln = 3 & ~flags;   // flags bit 0: no LayerNorm fusion at all, bit 1: no fused MLP
     wise::htsat::g_frontend_only = (flags >> 3) & 1;   // bit 3: front end only
     return 0;
 }
+#endif
 
 extern "C" int wise_htsat_tap(int what, const void* workspace_ptr, int batch, int samples, float* dst, int64_t count,
                               void* stream) {

@@ -760,6 +760,7 @@ static int dispatch_nq(const ScanPlan& p, const float* X, long long N, int d, co
 
 using namespace wise;
 
+#ifdef WISE_DEBUG_KNOBS
 extern "C" int wise_debug_set_scan(int rows, int blocks_per_cu) {
     g_scan_rows = rows & 0xFF;
     g_scan_blocks_per_cu = blocks_per_cu & 0xFF;
@@ -773,6 +774,7 @@ extern "C" int wise_debug_set_scan(int rows, int blocks_per_cu) {
     g_scan_sample = (rows >> 16) & 1 ? 0 : ((rows >> 17) & 0xFF ? (long long)((rows >> 17) & 0xFF) * 16384 : 32768);  // bit 16: no sample pass; bits 17-24: sample rows / 16384  // bit 11: f32 matrix-core scan instead of the split-bf16 candidates
     return 0;
 }
+#endif
 
 extern "C" size_t wise_ip_topk_workspace_bytes(int64_t N, int d, int nq, int k) {
     if (N < 0 || d < 4 || nq < 1 || k < 1 || k > 2048) return 0;

@@ -417,14 +417,13 @@ size_t mfma_scan_part_bytes(long long N, int k) { return (size_t)mfma_scan_lists
 int mfma_scan_launch(const float* X, long long N, int d, const float* qpad, int nq, int k, u64* part, bool split,
                      hipStream_t st) {
     const size_t lds = (size_t)32 * d * 4 + (size_t)WAVES * RING * CHUNK_BYTES + (size_t)WAVES * MFMA_KL * 32 * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_mfma_kernel<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_mfma_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     if (split && g_split_direct) {
         set_error("mfma_scan_launch: the register-queue scan is launched through split_scan_launch");
         return WISE_E_UNSUPPORTED;
@@ -619,12 +618,11 @@ bool split64_supported(int d) { return d % (4 * CW) == 0 && d <= 512; }   // who
 int split64_scan_launch(const float* X, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
                         const u64* tau0, hipStream_t st, const int* gate) {
     const size_t dl = (size_t)QB2 * d * 4 + (size_t)MFMA_KL * QB2 * 8 + QB2 * 4;
-    static bool dattr = false;
-    if (!dattr) {
+    static std::once_flag dattr;
+    std::call_once(dattr, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_split64_kernel<4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        dattr = true;
-    }
+    });
     hipLaunchKernelGGL(ip_scan_split64_kernel<4>, dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, X, N, d, qpad, nq, part,
                        row_offset, tau0, gate);
     WISE_LAUNCH_CHECK("ip_scan_split64_kernel");
@@ -788,14 +786,13 @@ bool shadow32_supported(int d) { return d % (4 * CW2) == 0 && d <= 1024; }
 int shadow64_scan_launch(const bf16_t* Xb, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
                          const u64* tau0, hipStream_t st, float* dump, int qb) {
     const size_t dl = (size_t)qb * d * 4 + (size_t)SHADOW_KL * qb * 8 + qb * 4;
-    static bool dattr = false;
-    if (!dattr) {
+    static std::once_flag dattr;
+    std::call_once(dattr, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 64>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 32>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        dattr = true;
-    }
+    });
     if (qb == 64)
         hipLaunchKernelGGL((ip_scan_shadow64_kernel<4, 64>), dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, Xb, N, d, qpad, nq,
                            part, row_offset, tau0, dump, g_mfma_abl);
@@ -811,14 +808,13 @@ int shadow64_scan_launch(const bf16_t* Xb, long long N, long long row_offset, in
 int split_scan_launch(const float* X, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
                       const u64* tau0, hipStream_t st) {
     const size_t dl = (size_t)32 * d * 4 + (size_t)WAVES * MFMA_KL * 32 * 8;
-    static bool dattr = false;
-    if (!dattr) {
+    static std::once_flag dattr;
+    std::call_once(dattr, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_split_direct_kernel<4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_split_direct_kernel<3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        dattr = true;
-    }
+    });
     if (g_split_direct == 3)
         hipLaunchKernelGGL(ip_scan_split_direct_kernel<3>, dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, X, N, d, qpad, nq,
                            part, row_offset, tau0, g_mfma_abl);

@@ -744,11 +744,13 @@ static size_t total_ws_for(const VitDims& d, int batch, int parts) {
 
 using namespace wise;
 
+#ifdef WISE_DEBUG_KNOBS
 extern "C" int wise_debug_set_vit_streams(int n) {
     g_vit_streams = n & 0xFF;
     if (n >> 8) g_attn_qt = n >> 8;  // bits 8..: attention query tiles per wave (2 or 4)
     return 0;
 }
+#endif
 
 extern "C" int wise_vit_layout(const wise_vit_config* cfg, int64_t* wb_elems, int64_t* pf_elems) {
     VitDims d;

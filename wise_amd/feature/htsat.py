@@ -146,6 +146,9 @@ class HtsatEngine:
         slot = self._slots[self._next_slot]
         self._next_slot ^= 1
         if slot["ws"] is None or slot["ws"].numel() < need:
+            # the slot's previous forward may still be running in the old workspace (allocated on the caller's stream,
+            # used on the slot's): wait for it before the allocator may reuse that block
+            slot["stream"].synchronize()
             slot["ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
         slot["stream"].wait_stream(torch.cuda.current_stream(self.device))
         out = torch.empty(B, OUT_DIM, dtype=torch.float32, device=self.device)

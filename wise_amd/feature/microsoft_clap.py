@@ -29,6 +29,12 @@ class MicrosoftClap(FeatureExtractor):
         assert len(id_tokens) == 4
         if id_tokens[2] not in CLAP_MODEL_NAMES:
             raise ValueError(f'Model version {id_tokens[2]} is not available. Available models are {CLAP_MODEL_NAMES}')
+        if id_tokens[2] != '2023':
+            # msclap builds a Cnn14 audio encoder + BERT for '2022' and HTSAT + GPT-2 (+ a caption decoder) for 'clapcap'
+            # (src/feature/microsoft_clap.py:20-31 accepts all three keys); only the 2023 pair exists here, and an
+            # embedding from the wrong architecture must never be returned under another model's id
+            raise NotImplementedError(f"MS-CLAP version {id_tokens[2]!r}: only the 2023 model (HTSAT audio encoder, GPT-2 "
+                                      f"caption encoder) is built as MI355X kernels")
         self.version = id_tokens[2]
         self.weights_tag = id_tokens[3]
         self.DEVICE = "cuda" if torch.cuda.is_available() else "cpu"
@@ -58,9 +64,6 @@ class MicrosoftClap(FeatureExtractor):
     @property
     def tokenizer(self):
         if self._tokenizer is None:
-            if self.version != '2023':
-                raise NotImplementedError(f"caption encoder of CLAP version {self.version} (BERT / clapcap) is not "
-                                          f"built; only the 2023 model's GPT-2 encoder is (SURVEY.md §8 a10)")
             from .gpt2_tokenizer import Gpt2Tokenizer
             self._tokenizer = Gpt2Tokenizer.default(77, allow_merge_less=seeded_tag(self.weights_tag) is not None)
         return self._tokenizer

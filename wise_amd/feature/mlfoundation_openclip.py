@@ -142,8 +142,8 @@ class MlfoundationOpenClip(FeatureExtractor):
         return st
 
     def _find_output_dim(self):
-        """Warm-up forward, as the reference does (mlfoundation_openclip.py:61-73); the text tower is
-        not part of this build, so only the image side is checked against the architecture table."""
+        """Warm-up forward, as the reference does (mlfoundation_openclip.py:61-73): one random image through the
+        tower; the text tower's embedding width is checked against the same dimension (:67-73)."""
         random_image = torch.rand((1, 3,) + self.input_image_size)
         feats = self.extract_image_features(self.preprocess_image(random_image))
         assert feats.shape[1] == self.output_dim

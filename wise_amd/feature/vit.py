@@ -194,7 +194,7 @@ class VitEngine:
         self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
         self._ws_batch = batch
 
-    def forward(self, images: torch.Tensor) -> torch.Tensor:
+    def _check_images(self, images: torch.Tensor):
         S = self.spec.image_size
         if images.dim() != 4 or tuple(images.shape[1:]) != (3, S, S):
             raise ValueError(f"expected [B,3,{S},{S}], got {tuple(images.shape)}")
@@ -204,12 +204,19 @@ class VitEngine:
             kind = _lib.WISE_VIT_IN_F32
         else:
             raise ValueError(f"images must be float32 or uint8, got {images.dtype}")
-        x = images.to(self.device).contiguous()
+        return images.to(self.device).contiguous(), kind
+
+    def forward(self, images: torch.Tensor, single_stream: bool = False) -> torch.Tensor:
+        """One batch -> [B, D] fp32 unit rows on the current torch stream.  By default the library overlaps two half
+        batches on two streams (wise_vit_forward); single_stream=True keeps every launch on the caller's stream
+        (wise_vit_forward_single: what a profiler or an event-bracketed measurement wants)."""
+        x, kind = self._check_images(images)
         B = x.shape[0]
         self.reserve(B)
         out = torch.empty(B, self.spec.embed_dim, dtype=torch.float32, device=self.device)
-        rc = self.lib.wise_vit_forward(C.byref(self.cfg), self.wb.data_ptr(), self.pf.data_ptr(), x.data_ptr(), kind, B,
-                                       out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr())
+        fn = self.lib.wise_vit_forward_single if single_stream else self.lib.wise_vit_forward
+        rc = fn(C.byref(self.cfg), self.wb.data_ptr(), self.pf.data_ptr(), x.data_ptr(), kind, B,
+                out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "wise_vit_forward")
         return out
 
@@ -222,16 +229,7 @@ class VitEngine:
         half batches of `forward`) and the other batch's kernels fill its LayerNorm / attention phases and tails.
         Use it where batches arrive in a stream (extract-features style loops) and a result is consumed one batch
         later; `forward` stays the call for a single batch."""
-        S = self.spec.image_size
-        if images.dim() != 4 or tuple(images.shape[1:]) != (3, S, S):
-            raise ValueError(f"expected [B,3,{S},{S}], got {tuple(images.shape)}")
-        if images.dtype == torch.uint8:
-            kind = _lib.WISE_VIT_IN_U8
-        elif images.dtype == torch.float32:
-            kind = _lib.WISE_VIT_IN_F32
-        else:
-            raise ValueError(f"images must be float32 or uint8, got {images.dtype}")
-        x = images.to(self.device).contiguous()
+        x, kind = self._check_images(images)
         B = x.shape[0]
         if not hasattr(self, "_slots"):
             self._slots, self._next_slot = [], 0
@@ -242,6 +240,9 @@ class VitEngine:
         slot = self._slots[self._next_slot]
         self._next_slot = (self._next_slot + 1) % nslots
         if slot["ws"] is None or slot["ws"].numel() < need:
+            # the old workspace may still be in use by this slot's previous forward, and it was allocated on another
+            # stream than the one that uses it: wait for that forward before the allocator may hand the block out again
+            slot["stream"].synchronize()
             slot["ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
         cur = torch.cuda.current_stream(self.device)
         slot["stream"].wait_stream(cur)              # the batch was produced on the caller's stream

@@ -1,5 +1,11 @@
-"""FeatureSearchIndex — drop-in for the reference's src/index/feature_search_index.py:13-114 with the
-flat inner-product index resident in HBM and searched by the HIP scan+top-k kernels.
+"""FeatureSearchIndex — the reference's plugin boundary for vector search (src/index/feature_search_index.py:13-114)
+over an index resident in HBM and searched by the HIP scan+top-k kernels.
+
+`__init__`, `get_index_filename`, `is_index_loaded` and `search` are restated VERBATIM from
+src/index/feature_search_index.py:14-31, :87-88 and :100-114 — they ARE the boundary, and their quirks are part of
+the contract a drop-in must keep (the prompt rules, the missing `f` prefix in the
+`query_type` error message, the 1-D return of the first query only).  `create_index` and `load_index` are new:
+they build / read the same `.faiss` files without faiss (wise_amd/index/faiss_io.py) into FlatIPIndex / IVFFlatIPIndex.
 
 Same constructor contract (asserts on 'features_dir'/'index_dir'), prompts, file naming
 (`{index_dir}/{media_type}-{index_type}.faiss`), skip-if-exists create, `load_index` that also
