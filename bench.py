@@ -98,57 +98,85 @@ def load_pmc_traffic(kernel_key):
 
 
 def cpu_baseline_vit(spec, sd, seconds):
-    """The oracle (CPU fp32 restatement of the reference path) at the reference's own batch of 8 frames
-    (extract-features.py:294), all host cores."""
+    """SURVEY 8(d) cfg-1 stand-in, image half: the reference's CPU extraction path on synthetic decoded frames —
+    uint8 [n,3,240,320] frames, 8 at a time exactly as extract-features.py:294,324-341 feeds them: per-frame PIL
+    transform (preprocess_image, mlfoundation_openclip.py:81-90) then the fp32 forward of the oracle, all host cores."""
     from oracle import vit_ref
+    from wise_amd.feature.mlfoundation_openclip import ClipImageTransform, to_pil_image
 
-    frames = torch.from_numpy(np.random.default_rng(1).integers(0, 256, size=(8, 3, 224, 224), dtype=np.uint8))
-    x = vit_ref.normalize_u8(frames)
-    threads = min(torch.get_num_threads(), 16)  # the GPU box's CPU share for one GPU
+    tr = ClipImageTransform(spec.image_size)
+    pool = torch.from_numpy(np.random.default_rng(0).integers(0, 256, size=(64, 3, 240, 320), dtype=np.uint8))
+    threads = min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU
     torch.set_num_threads(threads)
+
+    def chunk(c):
+        frames = pool[(8 * c) % 64:(8 * c) % 64 + 8]
+        x = torch.stack([tr(to_pil_image(f)) for f in frames])
+        return vit_ref.vit_forward(sd, x, patch=spec.patch, heads=spec.heads, act=spec.act)
+
     with torch.no_grad():
-        vit_ref.vit_forward(sd, x, patch=spec.patch, heads=spec.heads, act=spec.act)  # warm-up
-        n = 0
+        chunk(0)  # warm-up
+        n, t_pre = 0, 0.0
         t0 = time.perf_counter()
         while True:
-            vit_ref.vit_forward(sd, x, patch=spec.patch, heads=spec.heads, act=spec.act)
+            chunk(n // 8)
             n += 8
             dt = time.perf_counter() - t0
-            if dt >= seconds or n >= 4096:
+            if dt >= seconds or n >= 600:      # cfg-1: 600 frames = 30 videos x 10 s x 2 fps (docs/Tests.md:17-18)
                 break
     return {"value": round(n / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} frames in batches of 8 (the reference's chunk size), oracle/vit_ref.py fp32, {dt:.1f} s"}
+            "sample": f"{n} synthetic uint8 240x320 frames in chunks of 8 (cfg-1 shape, extract-features.py:294): per-frame "
+                      f"PIL transform + oracle/vit_ref.py fp32 forward, {threads} torch threads, {dt:.1f} s"}
 
 
-def cpu_baseline_search(d, k, seconds):
-    """The C oracle (sequential dot-product loop + heap, what faiss does for nq<20) on one core over a
-    1M-row sample; queries/s scaled to the 10M-row index."""
+def cpu_baseline_search(d, k, seconds, n_queries=20):
+    """SURVEY 8(d) cfg-1 stand-in, search half: what faiss's IndexFlatIP does on the host for one query — a BLAS
+    matrix-vector product over all rows on ALL host cores, then the k best (torch.mv + topk; the numpy restatement
+    oracle/ip_topk_ref.py is the same arithmetic) — over the largest sample host RAM allows, 20 queries as cfg-1 asks.
+    The one-core C heap loop (oracle/ip_topk_ref.c: faiss's small-nq code path without its SIMD) is timed beside it."""
+    import psutil
+
     from wise_amd.build import build_oracle
 
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    free = psutil.virtual_memory().available
+    n = 10_000_000 if free > 3 * 10_000_000 * d * 4 else (4_000_000 if free > 3 * 4_000_000 * d * 4 else 1_000_000)
+    g = torch.Generator().manual_seed(2)
+    X = torch.empty(n, d)
+    for s0 in range(0, n, 500_000):
+        blk = torch.randn(min(500_000, n - s0), d, generator=g)
+        X[s0:s0 + blk.shape[0]] = blk / blk.norm(dim=1, keepdim=True)
+    Q = torch.randn(64, d, generator=g)
+    Q /= Q.norm(dim=1, keepdim=True)
+    torch.topk(torch.mv(X, Q[0]), k)   # warm-up (page faults, BLAS threads)
+    nq, t0 = 0, time.perf_counter()
+    while True:
+        D, I = torch.topk(torch.mv(X, Q[nq % 64]), k)
+        nq += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or nq >= n_queries:
+            break
+    scale = 10_000_000 / n
+    per_query_10m = dt / nq * scale
+    out = {"value": round(1.0 / per_query_10m, 4), "unit": "queries/s", "cores": threads, "kind": "port",
+           "sample": f"{nq} queries, torch.mv + topk (BLAS, {threads} threads) over {n} x {d} fp32 unit rows"
+                     + ("" if n == 10_000_000 else f", time x{scale:g} for 10M rows") + f", {dt:.1f} s",
+           "effective_gbs": round(10_000_000 * d * 4 / per_query_10m / 1e9, 1)}
+    # one core, the sequential dot-product loop + heap (1M-row slice, x10)
     so = build_oracle()
     lib = C.CDLL(str(so))
     lib.wise_oracle_ip_topk.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                         C.c_int64, C.c_void_p, C.c_void_p]
     lib.wise_oracle_ip_topk.restype = None
-    n = 1_000_000
-    X = np.random.default_rng(2).standard_normal((n, d), dtype=np.float32)
-    X /= np.linalg.norm(X, axis=1, keepdims=True)
-    Q = np.random.default_rng(3).standard_normal((64, d), dtype=np.float32)
-    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
-    D = np.empty((1, k), np.float32)
-    I = np.empty((1, k), np.int64)
-    nq = 0
-    t0 = time.perf_counter()
-    while True:
-        lib.wise_oracle_ip_topk(X.ctypes.data, n, d, Q[nq % 64].ctypes.data, 1, k, None, 1, D.ctypes.data,
-                                I.ctypes.data)
-        nq += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or nq >= 64:
-            break
-    per_query_10m = dt / nq * 10.0
-    return {"value": round(1.0 / per_query_10m, 4), "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": f"{nq} queries over a 1M x {d} sample with oracle/ip_topk_ref.c, time x10 for 10M rows"}
+    Xn, Qn = X[:1_000_000].numpy(), Q.numpy()
+    Dn, In = np.empty((1, k), np.float32), np.empty((1, k), np.int64)
+    m, t0 = 0, time.perf_counter()
+    while m < 4 and time.perf_counter() - t0 < seconds / 3:
+        lib.wise_oracle_ip_topk(Xn.ctypes.data, 1_000_000, d, Qn[m].ctypes.data, 1, k, None, 1, Dn.ctypes.data, In.ctypes.data)
+        m += 1
+    out["one_core_c_loop_queries_per_s"] = round(m / (time.perf_counter() - t0) / 10.0, 4)
+    return out
 
 
 def cpu_baseline_preprocess(S, seconds=3.0):
@@ -359,25 +387,32 @@ def main():
         # the two kernels sum the d products in different orders: same ids, scores to the tested 2e-5
         assert torch.equal(I32[:1], I1) and bool((D32[:1] - D1).abs().max() <= 2e-5), \
             "batched and single-query scans disagree"
+        rows_per_rank = [n_loc]
+        if world > 1:
+            rows_per_rank = [None] * world
+            dist.all_gather_object(rows_per_rank, n_loc)
         result["search"] = {
             "metric": "queries/sec over 10M×512 index (flat IP, top-10, nq=1 per call as the reference issues them)",
             "value": round(qps, 2), "unit": "queries/s", "ms_per_step": round(sdt / s_steps * 1e3, 4),
             "steps": s_steps, "scaling": "strong", "dtype": "f32",
             "config": {"workload": f"IndexFlatIP search, N={N} rows x d={d} fp32 unit rows resident in HBM "
                                    f"({N * d * 4 / 1e9:.2f} GB) with a bf16 shadow copy ({N * d * 2 / 1e9:.2f} GB), k={k}, "
-                                   "nq=1; two-stage exact search: bf16 scan -> 64 candidates -> fp32 re-scoring + "
-                                   "certificate (fp32 scan when it fails)", "rows_per_gpu": n_loc,
-                       "parallelism": f"row-shard x{world} + RCCL all-gather of per-shard top-k"},
-            "roofline": {"kernel": "ip_scan_bf16_kernel<1,8> (stage 1 of the two-stage exact search)", "bound": "hbm",
+                                   "nq=1; two-stage exact search: sample -> threshold -> every row that could belong to "
+                                   "the top-k collected from the bf16 rows -> fp32 re-scoring (fp32 scan only if more "
+                                   "than 16384 rows qualify)", "rows_per_gpu": rows_per_rank,
+                       "parallelism": f"row-shard x{world} + ONE RCCL all-gather of the packed per-shard (score,id)[nq,k] lists",
+                       "allgather_payload_bytes_per_rank_nq1": int(getattr(index, "last_exchange_bytes", 0)) if world > 1
+                       else 0, "collectives_per_query": 1 if world > 1 else 0},
+            "roofline": {"kernel": "ip_collect_bf16_kernel<1,8> (the pass over the bf16 rows of the two-stage exact search)", "bound": "hbm",
                          "achieved": round(scan_gbs, 1),
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(scan_gbs / PEAK_HBM_GBS, 4),
                          "avg_launch_us": round(s_ms / max(s_n, 1) * 1e3, 2), "launches": int(s_n),
                          "bytes_per_launch": s_bytes / max(s_n, 1),
                          "note": "bytes the kernel has to move: the bf16 shadow rows, N*d*2 per query; the fp32 rows "
-                                 "(N*d*4, SURVEY 8(d)) are touched only for the 64 candidates and by the fallback scan",
+                                 "(N*d*4, SURVEY 8(d)) are touched only for the collected candidates and by the fallback scan",
                          "fp32_rows_equivalent_gbs": round(n_loc * d * 4 / (s_ms / max(s_n, 1) * 1e-3) / 1e9, 1),
-                         "traffic": load_pmc_traffic("ip_scan_bf16_kernel")},
-            "two_stage": {"certified": int(shadow_stats[0]), "fell_back_to_fp32_scan": int(shadow_stats[1]),
+                         "traffic": load_pmc_traffic("ip_collect_bf16_kernel")},
+            "two_stage": {"answered_from_the_shadow": int(shadow_stats[0]), "handed_to_fp32_scan": int(shadow_stats[1]),
                           "fp32_scan_only_queries_per_s": round(qps_f32, 2)},
             "batched_nq4_queries_per_s": round(4 * s_steps / sdt4, 2),
             "batched_nq32_queries_per_s": round(32 * s_steps / sdt32, 2),
@@ -400,6 +435,46 @@ def main():
                                       "note": "bf16 shadow rows (N*d*2 bytes) per call; whole call, per GPU",
                                       "traffic": load_pmc_traffic("ip_scan_shadow64_kernel")},
         }
+        # the regime the reference really indexes (2-fps frames of the same videos, extract-features.py:292-297,353): runs
+        # of 20 near-duplicate rows (cosine >= 0.999).  Same N, same kernels; queries are noisy copies of indexed rows
+        # (they have true neighbours) and random directions, alternating.  Rows are rewritten in place.
+        del index, local
+        torch.cuda.empty_cache()
+        per = 20
+        for s in range(0, n_loc, 1_000_000):
+            e = min(n_loc, s + 1_000_000)
+            items = (e - s + per - 1) // per
+            base = torch.randn(items, 1, d, generator=gen, device="cuda")
+            blk = (base / base.norm(dim=2, keepdim=True) + (0.03 / d ** 0.5) * torch.randn(items, per, d, generator=gen, device="cuda"))
+            X[s:e] = (blk / blk.norm(dim=2, keepdim=True)).reshape(-1, d)[:e - s]
+        local = FlatIPIndex(d).adopt(X, None, id_base=lo + 1)
+        index = ShardedFlatIPIndex(local)
+        gq = torch.Generator(device="cuda").manual_seed(9)          # the same queries on every rank
+        Qc = torch.randn(200, d, generator=gq, device="cuda")
+        Qc /= Qc.norm(dim=1, keepdim=True)
+        if rank == 0:
+            pick = torch.randint(0, n_loc, (100,), generator=gq, device="cuda")
+            Qc[0::2] = torch.nn.functional.normalize(X[pick] + 0.02 * Qc[0::2], dim=1)
+        if world > 1:
+            dist.broadcast(Qc, src=0)
+
+        def search_clustered(i):
+            res["DIc"] = index.search_device(Qc[i % 200:i % 200 + 1], k)
+
+        for i in range(3):
+            search_clustered(i)
+        cc0 = local.shadow_counts()
+        cdt = timed_region(search_clustered, s_steps, world)
+        cc1 = local.shadow_counts()
+        Dc, Ic = index.search_device(Qc[:1], k)
+        local.shadow = False
+        Dcf, Icf = index.search_device(Qc[:1], k)
+        assert torch.equal(Ic, Icf) and bool((Dc - Dcf).abs().max() <= 2e-6), "clustered rows: two-stage != f32 scan"
+        result["search"]["clustered"] = {
+            "queries_per_s": round(s_steps / cdt, 2), "ms_per_query": round(cdt / s_steps * 1e3, 4),
+            "answered_from_the_shadow": int(cc1[0] - cc0[0]), "handed_to_fp32_scan": int(cc1[1] - cc0[1]),
+            "workload": f"same N x d, rows in runs of {per} near-duplicates (cosine >= 0.999); queries alternate between "
+                        f"noisy copies of indexed rows and random directions; ids and scores equal the f32 scan's"}
         del X, local, index
         torch.cuda.empty_cache()
 
@@ -431,6 +506,28 @@ def main():
         adt = timed_region(clap_step, a_steps, world)
         assert abs(float(hold["o"].norm(dim=1).mean()) - 1.0) < 1e-3
         assert torch.equal(hold["p"].result(), hold["o"]), "HTSAT: in-flight and serial embeddings differ"
+        # roofline of the leg.  Two figures, because the forward is two kinds of work:
+        #  * the GEMM family (every wise_gemm_bf16 / gemm_ln / fused-MLP launch, HIP events on the launch stream) against
+        #    the bf16 MFMA peak;
+        #  * the whole forward against HBM: the bytes every kernel must move given the kernel boundaries as built
+        #    (fp32 residual stream, bf16 qkv / attention / hidden activations, inputs and outputs of each launch
+        #    counted once) — and, beside it, what a fully fused Swin block would move (x in, x out).
+        hprof = prof_pass(lib, clap_step_serial, a_steps, a_steps * 200 + 8)
+        hg_ms, hg_n, hg_flop = hprof[0]
+        T0, blocks = ab * 4096, 0.0
+        fused_ideal = 0.0
+        for depth, C_ in ((2, 96), (2, 192), (6, 384), (2, 768)):
+            T = T0 // (C_ // 96) ** 2
+            x32, a16 = T * C_ * 4, T * C_ * 2
+            ln_fused = C_ <= 192            # LayerNorm inside the GEMM's A-tile build (stages 1-2)
+            mlp_fused = C_ == 96            # the whole MLP in one kernel (stage 1)
+            attn_half = (x32 + 3 * a16 if ln_fused else x32 + a16 + a16 + 3 * a16) + (3 * a16 + a16) + (a16 + 2 * x32)
+            mlp_half = 2 * x32 if mlp_fused else ((x32 + 4 * a16 if ln_fused else x32 + a16 + a16 + 4 * a16) + 4 * a16 + 2 * x32)
+            blocks += depth * (attn_half + mlp_half)
+            fused_ideal += depth * 2 * x32
+        front = ab * 480000 * 4 + ab * 1024 * 64 * 4 * 2 + ab * 4096 * 96 * 4
+        hbm_bytes = blocks + front
+        step_s = adt_serial / a_steps
         extra["clap_htsat"] = {"value": round(world * ab * a_steps / adt, 1), "unit": "clips/s",
                                "ms_per_step": round(adt / a_steps * 1e3, 3), "steps": a_steps,
                                "batches_in_flight": 2,
@@ -438,7 +535,21 @@ def main():
                                "config": {"workload": "MS-CLAP 2023 HTSAT audio encoder + projection, 10-s clips "
                                                       "(480000 samples @48 kHz), bs=128 per GPU", "dtype": "bf16",
                                           "gflop_per_clip": 11.82},
-                               "tflops": round(world * ab * a_steps / adt * 11.82e9 / 1e12 / world, 2)}
+                               "tflops": round(world * ab * a_steps / adt * 11.82e9 / 1e12 / world, 2),
+                               "roofline": {
+                                   "kernel": "whole forward, one batch at a time (front end + 12 Swin blocks + head)",
+                                   "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
+                                   "achieved": round(hbm_bytes / step_s / 1e9, 1),
+                                   "frac": round(hbm_bytes / step_s / 1e9 / PEAK_HBM_GBS, 4),
+                                   "bytes_per_forward_at_kernel_boundaries": hbm_bytes,
+                                   "bytes_per_forward_if_each_block_were_one_kernel": fused_ideal + front,
+                                   "traffic": load_pmc_traffic("htsat_forward"),
+                                   "gemm_family": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_BF16_TFLOPS,
+                                                   "achieved": round(hg_flop / max(hg_ms, 1e-9) / 1e9, 2),
+                                                   "frac": round(hg_flop / max(hg_ms, 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                                   "launches_per_forward": int(hg_n // a_steps),
+                                                   "ms_per_forward": round(hg_ms / a_steps, 3),
+                                                   "share_of_forward": round(hg_ms / a_steps / (step_s * 1e3), 3)}}}
         del heng, wav
         torch.cuda.empty_cache()
         # cfg-4 (image half): ViT-L/14 at bs=256 per GPU

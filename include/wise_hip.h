@@ -67,29 +67,35 @@ int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, i
                      const int64_t* ids, int64_t id_base, float* outD, int64_t* outI,
                      void* workspace, size_t workspace_bytes, void* stream);
 
-/* The same search in two stages over a bf16 shadow copy of the rows — first of all for ONE query, the reference's call
- * shape (feature_search_index.py:113) —, exact by construction; described for one query: bf16
- * shadow copy of the rows, exact by construction:
- *   wise_ip_shadow_bf16   Xb [N,d] bf16 (round-to-nearest-even copy of X) and *max_norm = max_r |X[r,:]| (device float)
- *   wise_ip_topk_shadow_f32   (1) scan Xb (half the bytes of X) for the 64 best approximate scores, (2) recompute those
- *       64 from the fp32 rows, order them, write the first k, (3) certify: a row outside the 64 has approximate score
- *       <= t (the 64th candidate's, or the last key of a scan block's full list if larger), so exact score <= t + 2^-8 |q| max_norm (+ accumulation slack); if the k-th exact score is
- *       above that bound the result is the exact top-k, (4) otherwise the fp32 scan queued behind (it returns at once
- *       when the certificate held) recomputes the query.  All on the stream, no host round trip.
+/* The same search in two stages over a bf16 shadow copy of the rows (half the bytes of X per query), exact by
+ * construction; first of all for ONE query, the reference's call shape (feature_search_index.py:113):
+ *   wise_ip_shadow_bf16   Xb [N,d] bf16 (round-to-nearest-even copy of X) and two device floats norms[0] = max_r |X[r,:]|,
+ *       norms[1] = max_r |X[r,:] - Xb[r,:]| (the largest rounding residual: a score computed from Xb differs from the
+ *       exact one by at most eps = |q| norms[1] + f32 accumulation slack — Cauchy-Schwarz, no assumption on the data).
+ *   wise_ip_topk_shadow_f32, one query (N >= 2^18; smaller indexes are answered by wise_ip_topk_f32 itself):
+ *       (1) a sample of 64K rows (128 evenly spaced chunks) of Xb gives s_A, the k-th best approximate score seen;
+ *           the exact k-th best score of the index is then >= s_A - eps, and a row of the exact top-k scores
+ *           >= s_A - 2 eps approximately; (2) one pass over Xb collects EVERY row with approximate score >= s_A - 2 eps
+ *           (typically 1-3 thousand of 10M; up to 262144); (3) the collected scores themselves give a sharper bound
+ *           (their k-th largest slice maximum L: keep what reaches L - 2 eps, up to 16384 rows); (4) the scores of what
+ *           is left are recomputed from the fp32 rows and the k best are written.  Nothing is certified after the fact
+ *           and nothing depends on how the data is distributed (runs of near-duplicates — consecutive video frames —
+ *           only make the lists longer).  (5) If a list overflows, the fp32 scan queued behind answers instead (it
+ *           returns at once otherwise).
+ *       All on the stream, no host round trip.
  * Two or more queries (k <= 12, d = 256 or 512; three or more with k <= 16 for d = 768 or 1024, 32 at a time with the
- * fp32 VALU scan as the gated fallback) run the same scheme 64 queries at a time on the matrix cores: the bf16 rows
- * are MFMA operands as loaded, 48 candidates per query, per-query certificates, and the split-bf16 scan of the fp32 rows
- * (wise_ip_topk_f32's batched path) queued behind as the gated fallback of the pass.  Otherwise: one query at a time.
+ * fp32 VALU scan as the gated fallback) run 64 queries at a time on the matrix cores: the bf16 rows are MFMA operands as
+ * loaded, the 48 best candidates per query are re-scored in fp32, and a per-query certificate (k-th exact score above
+ * the 48th approximate score + eps) decides whether the split-bf16 scan of the fp32 rows (wise_ip_topk_f32's batched
+ * path), queued behind and gated, redoes the pass.  Otherwise: one query at a time.
+ * counters (device, two int32, may be NULL): [0] += queries answered from the shadow, [1] += queries handed to the fp32
+ * scan.  They belong to the caller (one pair per index); the library keeps no process-wide state for this.
  * Same outputs, ties and padding as wise_ip_topk_f32.  Limits: d % 8 == 0, 8 <= d <= 1024, k <= 16, N >= 1, nq <= 1024. */
-int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* Xb, float* max_norm, void* stream);
+int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* Xb, float* norms /*[2]*/, void* stream);
 size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, int k);
-int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* max_norm, int64_t N, int d, const float* Q,
+int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* norms /*[2]*/, int64_t N, int d, const float* Q,
                             int nq, int k, const int64_t* ids, int64_t id_base, float* outD, int64_t* outI,
-                            void* workspace, size_t workspace_bytes, void* stream);
-/* Process-wide counters of two-stage searches: out[0] certified, out[1] recomputed by the fp32 scan, since the previous
- * call (which resets them).  Synchronises the device.  A caller whose data defeats the certificate most of the time
- * should call wise_ip_topk_f32 instead (FlatIPIndex does that by itself). */
-int wise_ip_shadow_stats(int* certified_and_fallback);
+                            int32_t* counters, void* workspace, size_t workspace_bytes, void* stream);
 
 /* IndexIVFFlat search, second stage (the first stage — the `nprobe` nearest centroids of each query — is
  * wise_ip_topk_f32 over the centroid table): scan the probed inverted lists and keep the k best.

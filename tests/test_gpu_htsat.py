@@ -72,6 +72,30 @@ def test_golden_10s_clip_and_batch_independence(engine, waves, golden_dir):
     assert torch.equal(c[:2], a) and torch.equal(c[2], a[0])
 
 
+def test_batch128_of_10s_clips(waves, golden_dir):
+    """BASELINE cfg-5 at its own size: 128 clips x 480000 samples (10 s @48 kHz; the reference feeds
+    microsoft_clap.py:45-51 one 4-s segment at a time).  Clip 0 is the golden 10-s clip and must match the oracle's
+    vector; every row unit-norm; a clip's embedding is the one it gets alone (batch independence, bit for bit); the
+    pipelined form returns the same bits."""
+    _, w10 = waves
+    g = np.load(golden_dir / "htsat.npz")
+    B, N = 128, 480000
+    eng = HtsatEngine(random_htsat_state_dict(0), max_batch=B, max_samples=N)
+    w = 0.1 * torch.randn(B, N, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+    w[0] = w10[0].cuda()
+    out = eng.forward(w)
+    assert out.shape == (B, 1024) and out.dtype == torch.float32
+    assert torch.allclose(out.norm(dim=1).cpu(), torch.ones(B), atol=1e-5)
+    assert cosine(out[:1].cpu(), torch.from_numpy(g["out10"])) >= 1 - 1e-3
+    for b in (0, 1, 77, 127):
+        assert torch.equal(eng.forward(w[b:b + 1]), out[b:b + 1])
+    assert torch.equal(eng.forward(w[40:103]), out[40:103])           # a ragged sub-batch
+    assert torch.equal(eng.forward_pipelined(w).result(), out)
+    # the oracle itself on one more clip of the batch (a few seconds of CPU)
+    ref = htsat_ref.htsat_forward(random_htsat_state_dict(0), w[127:128].cpu())
+    assert cosine(out[127:128].cpu(), ref) >= 1 - 1e-3
+
+
 def test_microsoft_clap_plugin_surface(waves, golden_dir):
     """Through the reference's plugin API (microsoft_clap.py:33-51): preprocess_audio -> extract_audio_features."""
     w4, _ = waves

@@ -177,6 +177,27 @@ def test_vit_b32_batch256_consistency(golden_dir):
     assert torch.equal(out_r, out[:37])
 
 
+def test_vit_l14_batch256_consistency(golden_dir):
+    """BASELINE cfg-4, image half: ViT-L/14 at bs=256 (the reference's own shape test: [8,768] from ViT-L-14,
+    src/feature/test_feature_extractor.py:33-34).  Frames 0..1 are the golden frames; every row unit-norm, golden rows
+    match the oracle's vectors, results independent of the batch a frame sits in, pipelined == one at a time."""
+    spec, g, frames = load_golden(golden_dir, "vit_l14.npz")
+    sd = random_state_dict(spec, int(g["weight_seed"]))
+    eng = VitEngine(spec, sd, max_batch=256)
+    n_gold = frames.shape[0]
+    rest = torch.from_numpy(np.random.default_rng(98).integers(0, 256, size=(256 - n_gold, 3, 224, 224), dtype=np.uint8))
+    batch = torch.cat([frames, rest], dim=0)
+    out = eng.forward(batch).cpu()
+    assert out.shape == (256, 768) and out.dtype == torch.float32
+    assert torch.allclose(out.norm(dim=1), torch.ones(256), atol=1e-5)
+    assert cosine(out[:n_gold], torch.from_numpy(g["out"])) >= 1 - COS_TOL
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(eng.forward(batch[perm]).cpu(), out[perm])
+    assert torch.equal(eng.forward(batch, single_stream=True).cpu(), out)
+    assert torch.equal(eng.forward_pipelined(batch).result().cpu(), out)
+    assert torch.equal(eng.forward(batch[:19]).cpu(), out[:19])
+
+
 @pytest.mark.parametrize("M,N,K,mode", [(256, 288, 96, 0), (1024, 384, 96, 2), (128, 576, 192, 0), (256, 768, 192, 2),
                                         (128, 96, 96, 0), (384, 200, 96, 1), (128, 1024, 192, 5)])
 def test_gemm_with_fused_layernorm(M, N, K, mode):

@@ -43,8 +43,7 @@ SIGNATURES = {
     "wise_ip_topk_f32": (_i, [_vp, _i64, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "wise_ip_shadow_bf16": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     "wise_ip_topk_shadow_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
-    "wise_ip_shadow_stats": (_i, [_vp]),
-    "wise_ip_topk_shadow_f32": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "wise_ip_topk_shadow_f32": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "wise_ivf_scan_workspace_bytes": (_sz, [_i, _i, _i]),
     "wise_ivf_scan_f32": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "wise_select_topk_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),

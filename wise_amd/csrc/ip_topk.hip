@@ -427,33 +427,53 @@ constexpr int SHADOW_C = 64;   // candidates re-scored per query
 constexpr int SHADOW_L = 16;   // candidates a scan block keeps (its last key bounds what it dropped)
 
 __global__ __launch_bounds__(256) void shadow_bf16_kernel(const float* __restrict__ X, long long N, int d,
-                                                          bf16_t* __restrict__ Xb, float* __restrict__ max_norm) {
-    // a wave per row, waves stride over the rows: bf16 (RNE) copy and the largest row norm (non-negative floats order
-    // like their bit patterns; one atomic per wave at the end)
+                                                          bf16_t* __restrict__ Xb, float* __restrict__ norms) {
+    // a wave per row, waves stride over the rows: bf16 (RNE) copy, the largest row norm -> norms[0] and the largest
+    // norm of a row's rounding residual |x - bf16(x)| -> norms[1] (non-negative floats order like their bit patterns; one
+    // atomic pair per wave at the end).  The residual norm is what bounds a score's error: |q.x - q.bf16(x)| <= |q| |x - bf16(x)|;
+    // for rows with random mantissas it is ~0.4 x the worst case 2^-8 |x|.
     const int lane = threadIdx.x & 63;
     const long long w0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
-    float best = 0.f;
+    float best = 0.f, best_err = 0.f;
     for (long long row = w0; row < N; row += nw) {
         const float4* xr = reinterpret_cast<const float4*>(X + row * d);
         uint2* br = reinterpret_cast<uint2*>(Xb + row * d);
-        float ss = 0.f;
+        float ss = 0.f, ee = 0.f;
         for (int c = lane; c < (d >> 2); c += 64) {
             const float4 v = xr[c];
             ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-            br[c] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+            const uint2 pk = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+            br[c] = pk;
+            const float e0 = v.x - __uint_as_float(pk.x << 16), e1 = v.y - __uint_as_float(pk.x & 0xFFFF0000u);
+            const float e2 = v.z - __uint_as_float(pk.y << 16), e3 = v.w - __uint_as_float(pk.y & 0xFFFF0000u);
+            ee += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        for (int o = 32; o >= 1; o >>= 1) { ss += __shfl_xor(ss, o, 64); ee += __shfl_xor(ee, o, 64); }
         best = ss > best ? ss : best;
+        best_err = ee > best_err ? ee : best_err;
     }
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(max_norm), __float_as_uint(sqrtf(best)));
+    if (lane == 0) {
+        atomicMax(reinterpret_cast<unsigned*>(norms), __float_as_uint(sqrtf(best)));
+        atomicMax(reinterpret_cast<unsigned*>(norms) + 1, __float_as_uint(sqrtf(best_err)));
+    }
+}
+
+// the score error two searches of the same query may differ by: rounding residual of the shadow rows (Cauchy-Schwarz
+// with the largest residual norm) + f32 accumulation error of both dot products (d 2^-23 |q| max|x|)
+__device__ __forceinline__ float shadow_eps(const float* __restrict__ norms, int d, float qq) {
+    return (norms[1] + (float)d * 1.1920929e-7f * norms[0]) * 1.0001f * sqrtf(qq);
 }
 
 // NV8 = 16-byte chunks (8 bf16) per lane per row, R rows per group, one query
+// chunk_shift >= 0: the scan visits a SAMPLE of the rows — logical group g stands for physical group
+// (g >> chunk_shift) * chunk_stride + (g & ((1 << chunk_shift) - 1)): evenly spaced chunks of 2^chunk_shift groups; N
+// is then the number of sampled rows and row numbers in the keys are physical
 template <int NV8, int NQ, int R>
 __global__ __launch_bounds__(256) void ip_scan_bf16_kernel(const uint4* __restrict__ Xb, long long N, int d8,
                                                            const float* __restrict__ Q /*[NQ][d]*/, int kl, int cap,
-                                                           u64* __restrict__ part /*[grid][NQ][kl]*/) {
+                                                           u64* __restrict__ part /*[grid][NQ][kl]*/,
+                                                           int chunk_shift = -1, long long chunk_stride = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -483,13 +503,15 @@ __global__ __launch_bounds__(256) void ip_scan_bf16_kernel(const uint4* __restri
     const bool owner = (lane & ((64 >> LOGR) - 1)) == 0;
 
     for (long long g = gw; g < ngroups; g += nw) {
-        const long long row0 = g * R;
+        // (a sample never has a ragged last group: the host samples whole chunks)
+        const long long row0 = (chunk_shift >= 0 ? (g >> chunk_shift) * chunk_stride + (g & ((1ll << chunk_shift) - 1)) : g) * R;
+        const long long row_end = chunk_shift >= 0 ? row0 + R : N;
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         u32x4_t x[R][NV8];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             long long row = row0 + r;
-            if (row >= N) row = N - 1;
+            if (row >= row_end) row = row_end - 1;
 #pragma unroll
             for (int v = 0; v < NV8; ++v) {
                 const int c = v * 64 + lane;
@@ -532,7 +554,7 @@ __global__ __launch_bounds__(256) void ip_scan_bf16_kernel(const uint4* __restri
             for (int m = (32 >> LOGR); m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
             const long long row = row0 + myr;
             const u64 key = make_key(s, (unsigned)row);
-            const bool pass = owner && (row < N) && (key > wl[q].tau);
+            const bool pass = owner && (row < row_end) && (key > wl[q].tau);
             wl[q].offer(pass, key, lane, R);
         }
     }
@@ -558,18 +580,296 @@ __global__ __launch_bounds__(256) void ip_scan_bf16_kernel(const uint4* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One query over the bf16 shadow, THRESHOLD form (the reference's call shape: nq = 1, k <= 16).
+// The candidate set is not "the best C rows" (which says nothing when more than C rows sit within the bf16 error of the
+// k-th score: frames of one video) but EVERY row whose approximate score could still belong to a top-k row:
+//   sample   ip_scan_bf16_kernel over evenly spaced chunks (~64K rows) -> s_A, the k-th best approximate score there.
+//            k rows have exact score >= s_A - eps, so the exact k-th best score S* of the index is >= s_A - eps, and a
+//            row of the exact top-k has approximate score >= S* - eps >= s_A - 2 eps =: thr.
+//   collect  (this kernel) streams all of Xb once and appends (approximate score, row) of every row with score >= thr
+//            to one global list (one atomicAdd per wave and hit; a hit is one row in several thousand).
+//   rescore  exact f32 dot products of the collected rows; select: the k best of those, written out.
+//   refine   the collected list itself gives a far better bound than the sample did: L = the k-th largest of 1024 slice
+//            maxima of the collected approximate scores (k different rows reach it), so S* >= L - eps and only rows with
+//            approximate score >= L - 2 eps go on — on iid rows ~1500 collected shrink to a few dozen, on clustered rows
+//            (where whole runs pass the sample's threshold) tens of thousands shrink to the runs that matter.
+//   rescore  exact f32 dot products of what is left; select: the k best of those, written out.
+// Exact by construction whatever the data looks like — clustered, near-duplicate, all-equal — as long as the lists hold
+// the candidates (COLLECT_CAP collected, RESCORE_CAP after refinement); otherwise the gate is raised and the f32 scan
+// queued behind answers.  eps: shadow_eps().  thr is recomputed by every wave from the sample's sorted scores (one L2 read).
+// ------------------------------------------------------------------------------------------------
+constexpr int COLLECT_CAP = 262144;         // rows the collect pass may hand on (2 MiB of keys)
+constexpr int RESCORE_CAP = 16384;          // rows re-scored = 16 keys per thread of the 1024-thread select kernel
+constexpr int SAMPLE_CHUNK_SHIFT = 6;       // a sample chunk = 64 groups of 8 rows = 512 rows (512 KiB at d = 512)
+constexpr int SAMPLE_CHUNKS = 128;          // 65536 sampled rows
+constexpr long long COLLECT_MIN_ROWS = 1ll << 18;
+constexpr int SAMPLE_GRID = 256;            // blocks of the sample scan (1024 waves x 8 groups)   // below this the f32 scan answers directly (a sample would be a quarter of it)
+
+template <int NV8, int R>
+__global__ __launch_bounds__(256) void ip_collect_bf16_kernel(const uint4* __restrict__ Xb, long long N, int d8,
+                                                              const float* __restrict__ Q,
+                                                              const float* __restrict__ sample_scores /*descending*/,
+                                                              int k, const float* __restrict__ norms,
+                                                              int* __restrict__ counter, u64* __restrict__ cand, int cap) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float qv[NV8][8];
+    float qq = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV8; ++v) {
+        const int c = v * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            qv[v][e] = (c < d8) ? Q[c * 8 + e] : 0.f;
+            qq = fmaf(qv[v][e], qv[v][e], qq);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    const float thr = sample_scores[k - 1] - 2.f * shadow_eps(norms, d8 * 8, qq);
+
+    const long long ngroups = (N + R - 1) / R;
+    const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+    int myr = 0;
+    {
+        int bit = 5;
+#pragma unroll
+        for (int h = R / 2; h >= 1; h >>= 1, --bit) myr += ((lane >> bit) & 1) * h;
+    }
+    constexpr int LOGR = (R == 8) ? 3 : (R == 4) ? 2 : (R == 2) ? 1 : 0;
+    const bool owner = (lane & ((64 >> LOGR) - 1)) == 0;
+    for (long long g = gw; g < ngroups; g += nw) {
+        const long long row0 = g * R;
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t x[R][NV8];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            long long row = row0 + r;
+            if (row >= N) row = N - 1;
+#pragma unroll
+            for (int v = 0; v < NV8; ++v) {
+                const int c = v * 64 + lane;
+                if (NV8 * 64 == d8 || c < d8)
+                    x[r][v] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(Xb) + row * d8 + c);
+                else
+                    x[r][v] = u32x4_t{0u, 0u, 0u, 0u};
+            }
+        }
+        float a[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV8; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned u = x[r][v][e];
+                    s = fmaf(__uint_as_float(u << 16), qv[v][2 * e], s);
+                    s = fmaf(__uint_as_float(u & 0xFFFF0000u), qv[v][2 * e + 1], s);
+                }
+            a[r] = s;
+        }
+        int bit = 5;
+#pragma unroll
+        for (int h = R / 2; h >= 1; h >>= 1, --bit) {
+            const int m = 1 << bit;
+            const bool up = (lane >> bit) & 1;
+#pragma unroll
+            for (int i = 0; i < h; ++i) {
+                float send = up ? a[i] : a[i + h];
+                float keep = up ? a[i + h] : a[i];
+                a[i] = keep + __shfl_xor(send, m, 64);
+            }
+        }
+        float sc = a[0];
+#pragma unroll
+        for (int m = (32 >> LOGR); m >= 1; m >>= 1) sc += __shfl_xor(sc, m, 64);
+        const long long row = row0 + myr;
+        const bool pass = owner && (row < N) && (sc >= thr);
+        const u64 mask = __ballot(pass);
+        if (mask != 0) {
+            const int first = __ffsll((long long)mask) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd(counter, __popcll(mask));
+            base = __shfl(base, first, 64);
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pass && pos < cap) cand[pos] = make_key(sc, (unsigned)row);
+        }
+    }
+}
+
+// Refinement of the collected list (one block): L = k-th largest of the 1024 threads' slice maxima, keep what reaches
+// L - 2 eps, compacted into cand2 (order irrelevant: the final selection orders by exact score and row).
+// ctl: [0] collected (written by the collect pass), [1] gate, [2] kept (written here).
+__global__ __launch_bounds__(1024) void collect_refine_kernel(int* __restrict__ ctl, const u64* __restrict__ cand, int k,
+                                                              const float* __restrict__ Q, int d,
+                                                              const float* __restrict__ norms, u64* __restrict__ cand2,
+                                                              int* __restrict__ stats) {
+    __shared__ u64 wmax[16];
+    __shared__ float wsum[16];
+    __shared__ int kept;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = ctl[0];
+    if (n > COLLECT_CAP) {
+        if (tid == 0) { atomicOr(ctl + 1, 1); if (stats) atomicAdd(stats + 1, 1); }
+        return;
+    }
+    if (tid == 0) kept = 0;
+    u64 mine = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const u64 key = cand[i];
+        mine = key > mine ? key : mine;
+    }
+    float qq = 0.f;
+    for (int j = tid; j < d; j += 1024) qq = fmaf(Q[j], Q[j], qq);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    if (lane == 0) wsum[wave] = qq;
+    u64 L = 0;
+    for (int r = 0; r < k; ++r) {
+        u64 m = mine;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const u64 other = __shfl_xor(m, o, 64);
+            m = other > m ? other : m;
+        }
+        if (lane == 0) wmax[wave] = m;
+        __syncthreads();
+        u64 g = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) g = wmax[w] > g ? wmax[w] : g;
+        L = g;
+        if (mine == g) mine = 0;
+        __syncthreads();
+    }
+    qq = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) qq += wsum[w];
+    // fewer than k non-empty slices (n < k cannot happen: the sampled rows themselves are collected): keep everything
+    const float t2 = L != 0 ? f32_unorder((unsigned)(L >> 32)) - 2.f * shadow_eps(norms, d, qq) : -3.4028234663852886e38f;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const u64 key = i < n ? cand[i] : 0;
+        const bool pass = key != 0 && f32_unorder((unsigned)(key >> 32)) >= t2;
+        const u64 mask = __ballot(pass);
+        if (mask != 0) {
+            const int first = __ffsll((long long)mask) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd(&kept, __popcll(mask));
+            base = __shfl(base, first, 64);
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pass && pos < RESCORE_CAP) cand2[pos] = key;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ctl[2] = kept;
+        if (kept > RESCORE_CAP) { atomicOr(ctl + 1, 1); if (stats) atomicAdd(stats + 1, 1); }
+    }
+}
+
+// exact f32 scores of the kept rows: a wave per candidate (two in flight), grid-stride; ekeys[i] = (exact score, row)
+__global__ __launch_bounds__(256) void collect_rescore_kernel(const float* __restrict__ X, int d, const float* __restrict__ Q,
+                                                              const int* __restrict__ ctl,
+                                                              const u64* __restrict__ cand, u64* __restrict__ ekeys) {
+    if (ctl[1] != 0) return;                    // a list overflowed: the f32 scan answers
+    const int n = ctl[2];
+    const int lane = threadIdx.x & 63;
+    const int d4 = d >> 2;
+    const float4* qv = reinterpret_cast<const float4*>(Q);
+    const int w0 = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    for (int i0 = w0 * 2; i0 < n; i0 += nw * 2) {
+        long long rows[2];
+        float p[2] = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            rows[u] = i0 + u < n ? (long long)(0xFFFFFFFFu - (unsigned)(cand[i0 + u] & 0xFFFFFFFFull)) : -1;
+        for (int j = lane; j < d4; j += 64) {
+            const float4 b = qv[j];
+            float4 a[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                a[u] = rows[u] >= 0 ? reinterpret_cast<const float4*>(X + (size_t)rows[u] * d)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                p[u] = fmaf(a[u].x, b.x, p[u]); p[u] = fmaf(a[u].y, b.y, p[u]);
+                p[u] = fmaf(a[u].z, b.z, p[u]); p[u] = fmaf(a[u].w, b.w, p[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) p[u] += __shfl_xor(p[u], o, 64);
+            if (lane == 0 && rows[u] >= 0) ekeys[i0 + u] = make_key(p[u], (unsigned)rows[u]);
+        }
+    }
+}
+
+// the k best of the n <= RESCORE_CAP exact keys (16 per thread in registers, k rounds of a block-wide maximum), written
+// as (score, id); counters: [0] += 1 when answered here ([1] was raised by the refinement when a list overflowed)
+__global__ __launch_bounds__(1024) void collect_select_kernel(const int* __restrict__ ctl,
+                                                              const u64* __restrict__ ekeys, int k,
+                                                              const long long* __restrict__ ids, long long id_base,
+                                                              float* __restrict__ outD, long long* __restrict__ outI,
+                                                              int* __restrict__ stats) {
+    __shared__ u64 wmax[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (ctl[1] != 0) return;
+    const int n = ctl[2];
+    constexpr int PER = RESCORE_CAP / 1024;
+    u64 mine[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int idx = j * 1024 + tid;
+        mine[j] = idx < n ? ekeys[idx] : 0;
+    }
+    for (int r = 0; r < k; ++r) {
+        u64 m = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) m = mine[j] > m ? mine[j] : m;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const u64 other = __shfl_xor(m, o, 64);
+            m = other > m ? other : m;
+        }
+        if (lane == 0) wmax[wave] = m;
+        __syncthreads();
+        u64 g = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) g = wmax[w] > g ? wmax[w] : g;
+        if (tid == 0) {
+            if (g != 0) {
+                const long long row = (long long)(0xFFFFFFFFu - (unsigned)(g & 0xFFFFFFFFull));
+                outD[r] = f32_unorder((unsigned)(g >> 32));
+                outI[r] = ids ? ids[row] : id_base + row;
+            } else {
+                outD[r] = -3.4028234663852886e38f;
+                outI[r] = -1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) mine[j] = (mine[j] == g) ? 0 : mine[j];   // keys are unique (the row is part of them)
+        __syncthreads();
+    }
+    if (tid == 0 && stats) atomicAdd(stats, 1);
+}
+
 // exact scores of a query's C <= 64 candidates (16 waves, up to four candidates each, all their loads in flight at once),
 // then wave 0 orders them, writes the first k, and evaluates the certificate; block q = query q of the pass.
-// *gate is raised (never cleared here) when a query cannot be certified.
+// *gate is raised (never cleared here) when a query cannot be certified.  (The batched two-stage search.)
+// Certificate: every block's list is as long as the candidate set kept (C), so the C-th best candidate's approximate
+// score t bounds every row that was dropped anywhere; a dropped row's exact score is <= t + eps (shadow_eps); if the
+// k-th exact score is above that the answer is the exact top-k.  all_rows: the index has no more than C rows, nothing
+// was dropped.
 __global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __restrict__ X, int d, const float* __restrict__ Q,
                                                                const float* __restrict__ cand_scores,
                                                                const long long* __restrict__ cand_rows, int C, int k,
                                                                const long long* __restrict__ ids, long long id_base,
-                                                               const float* __restrict__ max_norm,
+                                                               const float* __restrict__ norms,
                                                                float* __restrict__ outD, long long* __restrict__ outI,
                                                                int* __restrict__ gate, int* __restrict__ stats,
-                                                               const u64* __restrict__ block_lists = nullptr,
-                                                               int nblocks = 0, int per_block = 0, int nq_lists = 1) {
+                                                               int all_rows) {
     __shared__ float exact[64];
     const int q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -635,32 +935,14 @@ __global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __re
         outI[lane] = -1;
     }
     // certificate: the k-th exact score (held by the lane of rank k-1) against the bound on everything not kept
-    float t = cand_scores[C - 1];                                    // lowest approximate score the merge kept
-    if (block_lists) {
-        // scan blocks kept only their `per_block` best: a row a block dropped scores at most that block's last key
-        u64 worst = 0;
-        for (int b = lane; b < nblocks; b += 64) {
-            const u64 kb = block_lists[((size_t)b * nq_lists + q) * per_block + per_block - 1];
-            worst = kb > worst ? kb : worst;
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const u64 other = __shfl_xor(worst, o, 64);
-            worst = other > worst ? other : worst;
-        }
-        if (worst != 0) {
-            const float tb = f32_unorder((unsigned)(worst >> 32));
-            t = tb > t ? tb : t;
-        }
-    }
-    // 2^-8: bf16 round-to-nearest of every x_c; d * 2^-23: worst-case f32 accumulation error of the two dot products
-    const float eps = (0.00390625f + (float)d * 1.1920929e-7f) * 1.0001f * sqrtf(qq) * max_norm[0];
+    const float t = cand_scores[C - 1];                              // lowest approximate score the merge kept
+    const float eps = shadow_eps(norms, d, qq);
     const bool holder = my_key != 0 && rank == k - 1;
     const bool ok_lane = holder && (my_score > t + eps);
-    const bool certified = valid < C || (valid >= k && __ballot(ok_lane) != 0);
+    const bool certified = all_rows != 0 || (valid >= k && __ballot(ok_lane) != 0);
     if (lane == 0) {
         if (!certified) atomicOr(gate, 1);
-        atomicAdd(stats + (certified ? 0 : 1), 1);
+        if (stats) atomicAdd(stats + (certified ? 0 : 1), 1);
     }
 }
 
@@ -986,7 +1268,6 @@ extern "C" int wise_ivf_scan_f32(const float* X, int64_t N, int d, const int64_t
 
 // ---- two-stage exact search over a bf16 shadow (see the kernels above)
 namespace wise {
-__device__ int g_shadow_stats[2];   // certified, fell back (debug / tests)
 static int shadow_grid(long long N) {
     long long need = ((N + 7) / 8 + 3) / 4;
     if (need < 4) need = 4;
@@ -998,11 +1279,12 @@ static int shadow_grid(long long N) {
 static bool shadow_supported(int d, int k) { return d % 8 == 0 && d >= 8 && d <= 1024 && k >= 1 && k <= 16; }
 }  // namespace wise
 
-extern "C" int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* Xb, float* max_norm, void* stream) {
+extern "C" int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* Xb, float* norms, void* stream) {
+    float* max_norm = norms;
     WISE_CHECK_ARG(d >= 8 && d % 8 == 0 && N >= 0 && (X && Xb || N == 0) && max_norm, "ip_shadow_bf16: bad argument");
     WISE_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Xb & 15) == 0, "ip_shadow_bf16: X and Xb must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(max_norm, 0, sizeof(float), st);
+    hipError_t e = hipMemsetAsync(max_norm, 0, 2 * sizeof(float), st);
     if (e != hipSuccess) { set_error("ip_shadow_bf16: %s", hipGetErrorString(e)); return (int)e; }
     if (N > 0) {
         const long long want = (N + 3) / 4;
@@ -1020,15 +1302,18 @@ extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, 
         const ScanPlan pm = plan_scan(N, d, m, k);
         if (pm.grid > p.grid) p.grid = pm.grid;
     }
-    // few queries: candidate lists of the bf16 scan | candidates | gate | lists of the gated f32 scan
-    size_t one = align_up((size_t)shadow_grid(N) * 4 * SHADOW_L * sizeof(u64), 256) + align_up((size_t)4 * SHADOW_C * 12, 256) +
-                 256 + align_up((size_t)p.grid * 4 * k * sizeof(u64), 256);
+    // one query: sample block lists | sample's best SHADOW_L | control words | collected keys | kept keys | exact keys | lists of the gated f32 scan
+    size_t one = align_up((size_t)SAMPLE_GRID * SHADOW_L * sizeof(u64), 256) + align_up((size_t)SHADOW_L * 12, 256) + 256 +
+                 align_up((size_t)COLLECT_CAP * sizeof(u64), 256) + 2 * align_up((size_t)RESCORE_CAP * sizeof(u64), 256) +
+                 align_up((size_t)p.grid * 4 * k * sizeof(u64), 256);
     // batches: lists of both passes of either scan | 64 padded queries | candidates | thresholds | gate
     size_t many = align_up((size_t)3 * split64_lists(N) * MFMA_QB2 * SHADOW_KL * sizeof(u64), 256) +
                   align_up((size_t)MFMA_QB2 * d * sizeof(float), 256) + align_up((size_t)MFMA_QB2 * SHADOW_KL * 12, 256) +
                   512 + 256 + align_up((size_t)MFMA_QB2 * 2 * g_scan_sample * sizeof(float), 256) +
                   align_up((size_t)MFMA_QB2 * SHADOW_KL * sizeof(long long), 256);
-    return one > many ? one : many;
+    const size_t small = N < COLLECT_MIN_ROWS ? wise_ip_topk_workspace_bytes(N, d, nq, k) : 0;   // answered by the f32 scan
+    size_t best = one > many ? one : many;
+    return best > small ? best : small;
 }
 
 namespace wise {
@@ -1066,74 +1351,85 @@ __global__ __launch_bounds__(1024) void segmax_threshold_kernel(const float* __r
     }
 }
 
-static int* shadow_stats_ptr() {
-    static int* stats = nullptr;
-    if (!stats) (void)hipGetSymbolAddress(reinterpret_cast<void**>(&stats), HIP_SYMBOL(wise::g_shadow_stats));
-    return stats;
-}
-
-// 1, 2 or 4 queries in one pass over the bf16 rows (VALU scan, the queries in registers): per-block lists of SHADOW_L
-// candidates per query -> the 64 best per query -> exact scores + certificates -> the f32 scan of the same queries,
-// gated on "some certificate failed"
-template <int NQ>
-static int shadow_search_few(const float* X, const bf16_t* Xb, const float* max_norm, long long N, int d, const float* q,
-                             int k, const long long* ids, long long id_base, float* outD, long long* outI,
+// One query (threshold form, see ip_collect_bf16_kernel): sample scan -> its SHADOW_L best -> collect every row that
+// could belong to the top-k -> exact scores -> the k best; the f32 scan queued behind runs only if the list overflowed.
+static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norms, long long N, int d, const float* q,
+                             int k, const long long* ids, long long id_base, float* outD, long long* outI, int* stats,
                              unsigned char* wsb, hipStream_t st) {
-    const int sgrid = shadow_grid(N);
     u64* spart = reinterpret_cast<u64*>(wsb);
-    size_t off = align_up((size_t)sgrid * 4 * SHADOW_L * sizeof(u64), 256);
-    long long* cand_rows = reinterpret_cast<long long*>(wsb + off);
-    float* cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)4 * SHADOW_C * 8);
-    off += align_up((size_t)4 * SHADOW_C * 12, 256);
-    int* gate = reinterpret_cast<int*>(wsb + off);
+    size_t off = align_up((size_t)SAMPLE_GRID * SHADOW_L * sizeof(u64), 256);
+    long long* samp_rows = reinterpret_cast<long long*>(wsb + off);
+    float* samp_scores = reinterpret_cast<float*>(wsb + off + (size_t)SHADOW_L * 8);
+    off += align_up((size_t)SHADOW_L * 12, 256);
+    int* counter = reinterpret_cast<int*>(wsb + off);     // ctl: [0] collected, [1] gate, [2] kept
+    int* gate = counter + 1;
     off += 256;
+    u64* cand = reinterpret_cast<u64*>(wsb + off);
+    off += align_up((size_t)COLLECT_CAP * sizeof(u64), 256);
+    u64* cand2 = reinterpret_cast<u64*>(wsb + off);
+    off += align_up((size_t)RESCORE_CAP * sizeof(u64), 256);
+    u64* ekeys = reinterpret_cast<u64*>(wsb + off);
+    off += align_up((size_t)RESCORE_CAP * sizeof(u64), 256);
     u64* epart = reinterpret_cast<u64*>(wsb + off);
-    const int scap = list_cap(SHADOW_L), mcap = list_cap(SHADOW_C);
-    hipError_t e = hipMemsetAsync(gate, 0, sizeof(int), st);
+    const int d8 = d / 8, nv8 = (d8 + 63) / 64;
+    if (nv8 > 2) { set_error("ip_topk_shadow: no kernel for d=%d", d); return WISE_E_INVALID; }
+    const uint4* xb = reinterpret_cast<const uint4*>(Xb);
+    hipError_t e = hipMemsetAsync(counter, 0, 4 * sizeof(int), st);
     if (e != hipSuccess) { set_error("ip_topk_shadow: %s", hipGetErrorString(e)); return (int)e; }
+    // ---- sample: SAMPLE_CHUNKS evenly spaced chunks of 2^SAMPLE_CHUNK_SHIFT groups of 8 rows
+    {
+        const long long groups = N / 8;                  // whole groups only: a sampled group is never ragged
+        const long long chunk_groups = 1ll << SAMPLE_CHUNK_SHIFT;
+        const long long stride = (groups - chunk_groups) / (SAMPLE_CHUNKS - 1);      // last chunk ends inside the index
+        const long long nsample = (long long)SAMPLE_CHUNKS * chunk_groups * 8;
+        const int scap = list_cap(SHADOW_L);
+        const size_t lds = (size_t)4 * scap * 8;
+        if (nv8 == 1)
+            hipLaunchKernelGGL((ip_scan_bf16_kernel<1, 1, 8>), dim3(SAMPLE_GRID), dim3(256), lds, st, xb, nsample, d8, q, SHADOW_L,
+                               scap, spart, SAMPLE_CHUNK_SHIFT, stride);
+        else
+            hipLaunchKernelGGL((ip_scan_bf16_kernel<2, 1, 8>), dim3(SAMPLE_GRID), dim3(256), lds, st, xb, nsample, d8, q, SHADOW_L,
+                               scap, spart, SAMPLE_CHUNK_SHIFT, stride);
+        WISE_LAUNCH_CHECK("ip_scan_bf16_kernel (sample)");
+        int mw = 8192 / scap;
+        if (mw > 16) mw = 16;
+        hipLaunchKernelGGL(merge_keys_kernel, dim3(1), dim3(mw * 64), (size_t)mw * scap * 8, st, spart, SAMPLE_GRID, 1, SHADOW_L,
+                           scap, (const long long*)nullptr, 0ll, samp_scores, samp_rows, 0);
+        WISE_LAUNCH_CHECK("merge_keys_kernel (sample)");
+    }
+    // ---- collect over all rows
     {
         ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
-        const int d8 = d / 8;
-        const size_t lds = (size_t)4 * NQ * scap * 8;
-        const uint4* xb = reinterpret_cast<const uint4*>(Xb);
-        switch ((d8 + 63) / 64) {
-            case 1: hipLaunchKernelGGL((ip_scan_bf16_kernel<1, NQ, 8>), dim3(sgrid), dim3(256), lds, st, xb, N, d8, q,
-                                       SHADOW_L, scap, spart); break;
-            case 2:
-                if constexpr (NQ <= 2) {
-                    hipLaunchKernelGGL((ip_scan_bf16_kernel<2, NQ, 8>), dim3(sgrid), dim3(256), lds, st, xb, N, d8, q,
-                                       SHADOW_L, scap, spart);
-                    break;
-                }
-                set_error("ip_topk_shadow: no %d-query kernel for d=%d", NQ, d); return WISE_E_INVALID;
-            default: set_error("ip_topk_shadow: no kernel for d=%d", d); return WISE_E_INVALID;
-        }
-        WISE_LAUNCH_CHECK("ip_scan_bf16_kernel");
+        const int grid = shadow_grid(N);
+        if (nv8 == 1)
+            hipLaunchKernelGGL((ip_collect_bf16_kernel<1, 8>), dim3(grid), dim3(256), 0, st, xb, N, d8, q, samp_scores, k, norms,
+                               counter, cand, COLLECT_CAP);
+        else
+            hipLaunchKernelGGL((ip_collect_bf16_kernel<2, 8>), dim3(grid), dim3(256), 0, st, xb, N, d8, q, samp_scores, k, norms,
+                               counter, cand, COLLECT_CAP);
+        WISE_LAUNCH_CHECK("ip_collect_bf16_kernel");
     }
-    int mw = 8192 / mcap;
-    if (mw > 16) mw = 16;
-    // lists of SHADOW_L keys in, the SHADOW_C best out
-    hipLaunchKernelGGL(merge_keys_kernel, dim3(NQ), dim3(mw * 64), (size_t)mw * mcap * 8, st, spart, sgrid, NQ, SHADOW_C, mcap,
-                       (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0, (const int*)nullptr, SHADOW_L);
-    WISE_LAUNCH_CHECK("merge_keys_kernel");
-    hipLaunchKernelGGL(rescore_certify_kernel, dim3(NQ), dim3(1024), 0, st, X, d, q, cand_scores, cand_rows, SHADOW_C, k, ids,
-                       id_base, max_norm, outD, outI, gate, shadow_stats_ptr(), spart, sgrid, SHADOW_L, NQ);
-    WISE_LAUNCH_CHECK("rescore_certify_kernel");
-    // the f32 scan of the same queries, which returns at once unless a certificate failed
-    ScanPlan p = plan_scan(N, d, NQ, k);
-    if (p.nq_per_pass != NQ) { set_error("ip_topk_shadow: f32 plan serves %d queries per pass, not %d", p.nq_per_pass, NQ); return WISE_E_INVALID; }
+    hipLaunchKernelGGL(collect_refine_kernel, dim3(1), dim3(1024), 0, st, counter, cand, k, q, d, norms, cand2, stats);
+    WISE_LAUNCH_CHECK("collect_refine_kernel");
+    hipLaunchKernelGGL(collect_rescore_kernel, dim3(64), dim3(256), 0, st, X, d, q, counter, cand2, ekeys);
+    WISE_LAUNCH_CHECK("collect_rescore_kernel");
+    hipLaunchKernelGGL(collect_select_kernel, dim3(1), dim3(1024), 0, st, counter, ekeys, k, ids, id_base, outD, outI, stats);
+    WISE_LAUNCH_CHECK("collect_select_kernel");
+    // ---- the f32 scan of the same query, which returns at once unless the list overflowed
+    ScanPlan p = plan_scan(N, d, 1, k);
+    if (p.nq_per_pass != 1) { set_error("ip_topk_shadow: f32 plan serves %d queries per pass", p.nq_per_pass); return WISE_E_INVALID; }
     const int nv = (d / 4 + 63) / 64;
     bool launched = false;
-    if constexpr (NQ * 1 <= 8) if (nv == 1) { launch_scan<1, NQ>(p, X, N, d, q, k, epart, st, gate); launched = true; }
-    if constexpr (NQ * 2 <= 8) if (nv == 2) { launch_scan<2, NQ>(p, X, N, d, q, k, epart, st, gate); launched = true; }
-    if constexpr (NQ * 3 <= 8) if (nv == 3) { launch_scan<3, NQ>(p, X, N, d, q, k, epart, st, gate); launched = true; }
-    if constexpr (NQ * 4 <= 8) if (nv == 4) { launch_scan<4, NQ>(p, X, N, d, q, k, epart, st, gate); launched = true; }
-    if (!launched) { set_error("ip_topk_shadow: no f32 kernel for d=%d with %d queries", d, NQ); return WISE_E_INVALID; }
+    if (nv == 1) { launch_scan<1, 1>(p, X, N, d, q, k, epart, st, gate); launched = true; }
+    if (nv == 2) { launch_scan<2, 1>(p, X, N, d, q, k, epart, st, gate); launched = true; }
+    if (nv == 3) { launch_scan<3, 1>(p, X, N, d, q, k, epart, st, gate); launched = true; }
+    if (nv == 4) { launch_scan<4, 1>(p, X, N, d, q, k, epart, st, gate); launched = true; }
+    if (!launched) { set_error("ip_topk_shadow: no f32 kernel for d=%d", d); return WISE_E_INVALID; }
     WISE_LAUNCH_CHECK("ip_scan_kernel (gated)");
     int emw = 8192 / p.cap;
     if (emw < 1) emw = 1;
     if (emw > 16) emw = 16;
-    hipLaunchKernelGGL(merge_keys_kernel, dim3(NQ), dim3(emw * 64), (size_t)emw * p.cap * 8, st, epart, p.grid, NQ, k, p.cap,
+    hipLaunchKernelGGL(merge_keys_kernel, dim3(1), dim3(emw * 64), (size_t)emw * p.cap * 8, st, epart, p.grid, 1, k, p.cap,
                        ids, id_base, outD, outI, 0, gate);
     WISE_LAUNCH_CHECK("merge_keys_kernel (gated)");
     return WISE_OK;
@@ -1143,7 +1439,7 @@ static int shadow_search_few(const float* X, const bf16_t* Xb, const float* max_
 // certificates -> if any failed, the split-bf16 scan of the f32 rows (candidates exact to 2^-16) and its re-scoring, gated
 static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max_norm, long long N, int d, const float* Q,
                               int nqa, int k, const long long* ids, long long id_base, float* outD, long long* outI,
-                              unsigned char* wsb, hipStream_t st, int QB /*64, or 32 for 512 < d <= 1024*/) {
+                              int* stats, unsigned char* wsb, hipStream_t st, int QB /*64, or 32 for 512 < d <= 1024*/) {
     u64* mpart = reinterpret_cast<u64*>(wsb);
     size_t off = align_up((size_t)3 * split64_lists(N) * MFMA_QB2 * SHADOW_KL * sizeof(u64), 256);
     float* mq = reinterpret_cast<float*>(wsb + off);
@@ -1206,7 +1502,7 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max
                            (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
         WISE_LAUNCH_CHECK("merge_keys_kernel");
         hipLaunchKernelGGL(rescore_certify_kernel, dim3(nqa), dim3(1024), 0, st, X, d, mq, cand_scores, cand_rows, kl, k, ids,
-                           id_base, max_norm, outD, outI, gate, shadow_stats_ptr());
+                           id_base, max_norm, outD, outI, gate, stats, N <= (long long)kl ? 1 : 0);
         WISE_LAUNCH_CHECK("rescore_certify_kernel");
     }
     // ---- gated fallback over the f32 rows: every launch returns at once while *gate == 0
@@ -1264,13 +1560,14 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max
 }
 }  // namespace wise
 
-extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* max_norm, int64_t N, int d,
+extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* norms, int64_t N, int d,
                                        const float* Q, int nq, int k, const int64_t* ids, int64_t id_base, float* outD,
-                                       int64_t* outI, void* workspace, size_t workspace_bytes, void* stream) {
+                                       int64_t* outI, int32_t* counters, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
     WISE_CHECK_ARG(shadow_supported(d, k), "ip_topk_shadow: d=%d must be a multiple of 8 in [8,1024], k=%d in [1,16]", d, k);
     WISE_CHECK_ARG(N > 0 && N < 0xFFFFFFFFll, "ip_topk_shadow: N=%lld out of range", (long long)N);
     WISE_CHECK_ARG(nq >= 1 && nq <= 1024, "ip_topk_shadow: nq=%d out of [1,1024]", nq);
-    WISE_CHECK_ARG(X && Xb && max_norm && Q && outD && outI, "ip_topk_shadow: null pointer");
+    WISE_CHECK_ARG(X && Xb && norms && Q && outD && outI, "ip_topk_shadow: null pointer");
     WISE_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Xb & 15) == 0 && ((uintptr_t)Q & 15) == 0,
                    "ip_topk_shadow: X, Xb and Q must be 16-byte aligned");
     const size_t need = wise_ip_topk_shadow_workspace_bytes(N, d, nq, k);
@@ -1295,30 +1592,24 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
         const int qb = batched ? MFMA_QB2 : MFMA_QB;
         for (int q0 = 0; q0 < nq; q0 += qb) {
             const int nqa = nq - q0 < qb ? nq - q0 : qb;
-            int rc = shadow_search_pass(X, Xb, max_norm, N, d, Q + (size_t)q0 * d, nqa, k, lids, (long long)id_base,
-                                        outD + (size_t)q0 * k, lI + (size_t)q0 * k, wsb, st, qb);
+            int rc = shadow_search_pass(X, Xb, norms, N, d, Q + (size_t)q0 * d, nqa, k, lids, (long long)id_base,
+                                        outD + (size_t)q0 * k, lI + (size_t)q0 * k, counters, wsb, st, qb);
             if (rc) return rc;
         }
         return WISE_OK;
     }
-    // otherwise one query per pass of the VALU scan (shadow_search_few<2> / <4> exist and are exact, but their
-    // cross-lane reductions make them no faster than separate passes)
+    // otherwise one query at a time in the threshold form; an index too small for a sample (a few hundred MB at most)
+    // is answered by the f32 scan directly
+    if (N < COLLECT_MIN_ROWS) {
+        const size_t fneed = wise_ip_topk_workspace_bytes(N, d, nq, k);
+        if (fneed == 0 || fneed > workspace_bytes) { set_error("ip_topk_shadow: workspace %zu < %zu bytes", workspace_bytes, fneed); return WISE_E_WORKSPACE; }
+        return wise_ip_topk_f32(X, N, d, Q, nq, k, ids, id_base, outD, outI, workspace, workspace_bytes, stream);
+    }
     for (int q = 0; q < nq; ++q) {
-        int rc = shadow_search_few<1>(X, Xb, max_norm, N, d, Q + (size_t)q * d, k, lids, (long long)id_base,
-                                      outD + (size_t)q * k, lI + (size_t)q * k, wsb, st);
+        int rc = shadow_search_one(X, Xb, norms, N, d, Q + (size_t)q * d, k, lids, (long long)id_base,
+                                   outD + (size_t)q * k, lI + (size_t)q * k, counters, wsb, st);
         if (rc) return rc;
     }
-    return WISE_OK;
-}
-
-// how many two-stage searches of this process were certified / fell back since the last call (counters reset); a
-// caller whose data defeats the certificate most of the time should search the f32 rows directly
-extern "C" int wise_ip_shadow_stats(int* certified_and_fallback /*[2], host*/) {
-    int* stats = shadow_stats_ptr();
-    hipError_t e = stats ? hipSuccess : hipErrorNotFound;
-    if (e == hipSuccess) e = hipMemcpy(certified_and_fallback, stats, 2 * sizeof(int), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemset(stats, 0, 2 * sizeof(int));
-    if (e != hipSuccess) { set_error("shadow_stats: %s", hipGetErrorString(e)); return (int)e; }
     return WISE_OK;
 }
 

@@ -14,10 +14,19 @@ batch while the host writes the previous one.  Store order is unchanged: results
 
 `create_vector(modality, media_id, timestamp, end_timestamp) -> int` stands where VectorRepo.create
 stands (extract-features.py:348-357,364-372); SQLite itself is outside this build.
+
+Several GPUs (one process per GPU): extraction shards by FILES, the way the reference's DataLoader
+shards them over its decode workers — `islice(files, worker_id, None, n_workers)` (src/dataloader/dataset.py:334) —
+with no collective on the data path: `rank_files` gives a rank its files, `RankVectorIds` hands out vector ids that
+are unique across ranks without talking to anyone (the n-th vector of rank r gets id n * world + r + 1), and
+`open_rank_stores` opens each modality's store for writing in the rank's own shard range
+(`{media_type}-{rank * RANK_SHARD_STRIDE + n:06d}.tar`), so all ranks write one store directory and a reader
+(FeatureStoreFactory.load_store, create_index) sees one store.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Optional, Tuple
+import itertools
+from typing import Callable, Dict, Iterable, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -117,3 +126,47 @@ class BatchedExtractionDriver:
         self.flush()
         for store in self.stores.values():
             store.close()
+
+
+# ---- one process per GPU: file-level sharding, no collective on the data path ---------------------------------------
+RANK_SHARD_STRIDE = 100_000      # shard numbers of rank r: r * RANK_SHARD_STRIDE ... (a rank would need 2e8 vectors to run out)
+
+
+def rank_files(files: Iterable, rank: int, world: int) -> List:
+    """The files rank `rank` of `world` extracts: every world-th file starting at `rank`, exactly how the reference
+    deals files to DataLoader workers (src/dataloader/dataset.py:322-336)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    return list(itertools.islice(files, rank, None, world))
+
+
+class RankVectorIds:
+    """`create_vector` for one rank: ids n * world + rank + 1 (n = 0, 1, ... in this rank's creation order) — unique
+    over all ranks, positive like SQLite's autoincrement (src/db/tables/__init__.py:35-38), no communication.  The rows
+    (id, modality, media id, timestamps) are kept for whoever imports them into the `vectors` table afterwards."""
+
+    def __init__(self, rank: int, world: int):
+        if not (0 <= rank < world):
+            raise ValueError(f"rank {rank} outside world {world}")
+        self.rank, self.world, self.rows = rank, world, []
+
+    def __call__(self, modality, media_id, timestamp, end_timestamp) -> int:
+        vid = len(self.rows) * self.world + self.rank + 1
+        self.rows.append((vid, modality, media_id, timestamp, end_timestamp))
+        return vid
+
+
+def open_rank_stores(store_type, features_dirs: Dict[str, object], rank: int, world: int, shard_maxcount: int = 2048,
+                     shard_maxsize: int = 20 * 1024 * 1024) -> Dict[str, object]:
+    """One writable store per modality for this rank, in the rank's own shard range of the shared directory
+    (defaults: the reference's roll-over limits, extract-features.py:158,166)."""
+    from .feature.store.feature_store_factory import FeatureStoreFactory
+
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    stores = {}
+    for media_type, d in features_dirs.items():
+        st = FeatureStoreFactory.create_store(store_type, media_type, str(d))
+        st.enable_write(shard_maxcount, shard_maxsize, first_shard=rank * RANK_SHARD_STRIDE)
+        stores[media_type] = st
+    return stores

@@ -18,11 +18,14 @@ class NumpySaveStore(FeatureStore):
         self.store_name = store_name
         self.store_data_dir = Path(store_data_dir)
 
-    def enable_write(self, shard_maxcount, shard_maxsize, verbose=0):
+    def enable_write(self, shard_maxcount, shard_maxsize, verbose=0, first_shard=0):
+        """first_shard (not in the reference; default = its behaviour): number of the first shard file this writer
+        creates, so that several processes can write disjoint shard ranges of one store."""
         self.shard_maxcount = shard_maxcount
         self.shard_maxsize = shard_maxsize
         self.verbose = verbose
         self.current_shard_index = -1
+        self.first_shard_index = int(first_shard)
 
     def enable_read(self, shard_shuffle=False, shuffle_values=False, shuffle_bufsize=10000):
         self.shard_shuffle = shard_shuffle
@@ -54,7 +57,7 @@ class NumpySaveStore(FeatureStore):
             self.shard_features = np.ndarray((self.shard_maxcount, self.feature_dim), dtype=np.float32)
             self.shard_feature_id = np.ndarray((self.shard_maxcount), dtype=np.int32)
             self.shard_feature_index = 0
-            self.current_shard_index = 0
+            self.current_shard_index = getattr(self, 'first_shard_index', 0)
         if self.feature_dim != features.shape[1]:
             raise ValueError(f'feature dimension cannot change and must be {self.feature_dim}')
         if features.shape[0] != 1:

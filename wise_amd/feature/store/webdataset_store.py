@@ -32,11 +32,13 @@ class WebdatasetStore(FeatureStore):
         self._tar = None
 
     # ---- write ----
-    def enable_write(self, shard_maxcount, shard_maxsize, verbose=0):
+    def enable_write(self, shard_maxcount, shard_maxsize, verbose=0, first_shard=0):
+        """first_shard (not in the reference, default = its behaviour): number of the first tar this writer creates —
+        one process per GPU writes its own shard range of the same store (wise_amd/extract.py:open_rank_stores)."""
         self.shard_maxcount = shard_maxcount
         self.shard_maxsize = shard_maxsize
         self.verbose = verbose
-        self._shard = 0
+        self._shard = int(first_shard)
         self._count = 0
         self._size = 0
         self._tar = None

@@ -107,6 +107,7 @@ class FeatureSearchIndex(SearchIndex):
         else:
             X, ids = faiss_io.read_idmap_flat_ip(index_fn)
             index = FlatIPIndex(X.shape[1])
+            index.reserve(X.shape[0])                # one [N,d] device tensor, filled slice by slice
             for s in range(0, X.shape[0], 1 << 20):  # stream the memory-mapped rows into HBM
                 index.add_with_ids(np.ascontiguousarray(X[s:s + (1 << 20)]), ids[s:s + (1 << 20)])
         self.index = index

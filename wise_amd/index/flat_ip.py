@@ -30,8 +30,12 @@ class FlatIPIndex:
             shadow = os.environ.get("WISE_FLAT_SHADOW", "1") != "0"
         self.shadow = bool(shadow) and d % 8 == 0 and d <= 1024
         self._Xb: Optional[torch.Tensor] = None      # [N,d] bf16 bits (int16) on device
-        self._max_norm: Optional[torch.Tensor] = None
+        self._norms: Optional[torch.Tensor] = None   # device [2]: largest row norm, largest bf16 rounding-residual norm
         self._sws: Optional[torch.Tensor] = None
+        # two-stage search counters of THIS index: device [2] int32 the kernels add to (answered from the shadow, handed
+        # to the fp32 scan); read back without ever blocking the search path (pinned snapshot + event)
+        self._counters: Optional[torch.Tensor] = None
+        self._snap = self._snap_event = None
         self._shadow_calls = 0
         self.shadow_certified = self.shadow_fallback = 0
         self._chunks: List[torch.Tensor] = []
@@ -48,6 +52,16 @@ class FlatIPIndex:
     def ntotal(self) -> int:
         return self._n
 
+    def reserve(self, n: int) -> None:
+        """Room for n rows in HBM up front: later add_with_ids calls copy into their slice of ONE [n,d] tensor instead of
+        queueing chunks that a final torch.cat would have to duplicate (an index larger than ~40 % of HBM could not be
+        loaded through chunks; load_index knows the row count from the file header)."""
+        if self._n or self._chunks:
+            raise ValueError("reserve: the index already holds rows")
+        self._rX = torch.empty(int(n), self.d, dtype=torch.float32, device=self.device)
+        self._rids = torch.empty(int(n), dtype=torch.int64, device=self.device)
+        self._rfill = 0
+
     def add_with_ids(self, x, ids) -> None:
         """x [n,d] float32, ids [n] int64 (feature_search_index.py:81)."""
         if not torch.is_tensor(x):
@@ -60,6 +74,18 @@ class FlatIPIndex:
             raise ValueError(f"add_with_ids: expected [n,{self.d}], got {tuple(x.shape)}")
         if ids.shape != (x.shape[0],):
             raise ValueError("add_with_ids: ids must have one entry per row")
+        rX = getattr(self, "_rX", None)
+        if rX is not None and self._rfill + x.shape[0] <= rX.shape[0]:
+            a, b = self._rfill, self._rfill + x.shape[0]
+            rX[a:b].copy_(x)                       # host -> its slice of the reserved tensor, no intermediate
+            self._rids[a:b].copy_(ids)
+            self._rfill = b
+            self._X, self._ids = rX[:b], self._rids[:b]
+            self._Xb = None
+            self._n = b
+            return
+        if rX is not None:                          # more rows than reserved: fall back to chunks from here on
+            self._rX = None
         self._chunks.append(x.to(self.device, torch.float32))
         self._id_chunks.append(ids.to(self.device, torch.int64))
         self._n += x.shape[0]
@@ -86,6 +112,7 @@ class FlatIPIndex:
             self._ids = torch.cat(idp, dim=0).contiguous()
             self._chunks, self._id_chunks = [], []
             self._Xb = None
+            self._rX = None
         if self._X is None:
             self._X = torch.empty(0, self.d, dtype=torch.float32, device=self.device)
             self._ids = torch.empty(0, dtype=torch.int64, device=self.device)
@@ -114,13 +141,13 @@ class FlatIPIndex:
             need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k)
             if self._sws is None or self._sws.numel() < need:
                 self._sws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            rc = lib.wise_ip_topk_shadow_f32(self._X.data_ptr(), self._Xb.data_ptr(), self._max_norm.data_ptr(), self._n,
+            rc = lib.wise_ip_topk_shadow_f32(self._X.data_ptr(), self._Xb.data_ptr(), self._norms.data_ptr(), self._n,
                                              self.d, q.data_ptr(), nq, k, _lib.ptr(self._ids), self.id_base, D.data_ptr(),
-                                             I.data_ptr(), self._sws.data_ptr(), self._sws.numel(), _lib.stream_ptr())
+                                             I.data_ptr(), self._counters.data_ptr(), self._sws.data_ptr(),
+                                             self._sws.numel(), _lib.stream_ptr())
             _lib.check(rc, "wise_ip_topk_shadow_f32")
             self._shadow_calls += 1
-            if self._shadow_calls % 64 == 0:
-                self._review_shadow(lib)
+            self._review_shadow()
             return D, I
         need = lib.wise_ip_topk_workspace_bytes(self._n, self.d, nq, k)
         if need == 0:
@@ -143,28 +170,42 @@ class FlatIPIndex:
             self.shadow = False
             return False
         self._Xb = torch.empty(self._n, self.d, dtype=torch.int16, device=self.device)
-        self._max_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
-        rc = lib.wise_ip_shadow_bf16(self._X.data_ptr(), self._n, self.d, self._Xb.data_ptr(), self._max_norm.data_ptr(),
+        self._norms = torch.zeros(2, dtype=torch.float32, device=self.device)
+        if self._counters is None:
+            self._counters = torch.zeros(2, dtype=torch.int32, device=self.device)
+        rc = lib.wise_ip_shadow_bf16(self._X.data_ptr(), self._n, self.d, self._Xb.data_ptr(), self._norms.data_ptr(),
                                      _lib.stream_ptr())
         _lib.check(rc, "wise_ip_shadow_bf16")
         return True
 
-    def _review_shadow(self, lib) -> None:
-        """Every 64 two-stage searches: if the fp32 scan had to redo most of them (data whose neighbours sit closer
-        together than the bf16 error bound), stop paying for the first stage."""
-        import ctypes
-        st = (ctypes.c_int * 2)()
-        _lib.check(lib.wise_ip_shadow_stats(st), "wise_ip_shadow_stats")
-        self.shadow_certified += st[0]
-        self.shadow_fallback += st[1]
-        if st[1] > st[0]:
-            self.shadow = False
-            self._Xb = self._sws = None
+    def _review_shadow(self) -> None:
+        """Never blocks: every 64 two-stage searches a snapshot of this index's counters is copied to pinned memory
+        behind an event; a later call that finds the event complete reads it.  If the fp32 scan had to answer most
+        queries of a snapshot (more rows within the bf16 error of the k-th score than the candidate list holds), stop
+        paying for the first stage."""
+        if self._snap_event is not None and self._snap_event.query():
+            done, handed = int(self._snap[0]), int(self._snap[1])
+            self._snap_event = None
+            d_done, d_handed = done - self.shadow_certified, handed - self.shadow_fallback
+            self.shadow_certified, self.shadow_fallback = done, handed
+            if d_handed > d_done:
+                self.shadow = False
+                self._Xb = self._sws = None
+                return
+        if self._snap_event is None and self._shadow_calls % 64 == 0 and self._counters is not None:
+            if self._snap is None:
+                self._snap = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._snap.copy_(self._counters, non_blocking=True)
+            self._snap_event = torch.cuda.Event()
+            self._snap_event.record()
 
     def shadow_counts(self):
-        """(certified, recomputed by the fp32 scan) over this process's two-stage searches seen by this index so far."""
-        self._review_shadow(_lib.lib())
-        return self.shadow_certified, self.shadow_fallback
+        """(answered from the shadow, recomputed by the fp32 scan) over the two-stage searches of THIS index so far.
+        Synchronises (a diagnostic, not part of the search path)."""
+        if self._counters is None:
+            return 0, 0
+        c = self._counters.cpu()
+        return int(c[0]), int(c[1])
 
     def search(self, x, k: int):
         """faiss signature: x np.ndarray [nq,d] float32 -> (D, I) numpy (feature_search_index.py:113)."""
