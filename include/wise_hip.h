@@ -111,9 +111,14 @@ int wise_ivf_scan_f32(const float* X, int64_t N, int d, const int64_t* list_off,
                       const float* Q, int nq, const int64_t* probes, int nprobe, int k, float* outD, int64_t* outI,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Dense scores [nq, N] = Q x X^T in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain per
+ * score).  The coarse stage of IndexIVFFlat when nprobe is a sizeable part of nlist — the reference's nprobe = 1024
+ * (config.py:19, api/routes.py:899-902) over 10 round(sqrt(N)) cells: all centroid scores, then wise_select_topk_f32.
+ * X [N,d], Q [nq,d] fp32, 16-byte aligned, d % 4 == 0. */
+int wise_ip_scores_f32(const float* X, int64_t N, int d, const float* Q, int nq, float* scores, void* stream);
 /* Indices of the k largest entries of each row of scores [rows, n] fp32 (ties: lower index), written in ascending
- * index order, -1 padding when n < k.  The coarse stage of IndexIVFFlat for large nprobe: scores = Q x centroids^T
- * (a plain library GEMM on the caller's side), then this selection.  NaN scores are not supported. */
+ * index order, -1 padding when n < k.  The second half of the coarse stage (scores from wise_ip_scores_f32).  NaN
+ * scores are not supported. */
 int wise_select_topk_f32(const float* scores, int rows, int n, int k, int64_t* out, void* stream);
 
 /* Merge `parts` partial top-k lists (e.g. one per GPU after the RCCL all-gather) into one.

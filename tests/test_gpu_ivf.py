@@ -163,3 +163,53 @@ def test_select_topk_kernel(rows, n, k):
         if not (S[r] == 0).any():
             assert set(got[r, :kk]) == set(order)
         assert (got[r, kk:] == -1).all()
+
+
+@pytest.mark.parametrize("N,d,nq", [(31620, 512, 1), (31620, 512, 256), (1000, 768, 40), (129, 64, 33), (5, 4, 1), (300, 100, 7)])
+def test_dense_scores_kernel(N, d, nq):
+    """wise_ip_scores_f32 (the coarse stage at the reference's nprobe = 1024, config.py:19): exact-f32 scores on the
+    matrix cores.  One-hot queries must return the rows' elements bit for bit (and catch a transposed tile);
+    general queries agree with a float64 product to f32 accumulation accuracy."""
+    from wise_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(N + d + nq)
+    X = rng.standard_normal((N, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    cols = rng.integers(0, d, size=nq)
+    hot = min(nq, 5)
+    Q[:hot] = 0
+    Q[np.arange(hot), cols[:hot]] = 1.0
+    Xd, Qd = torch.from_numpy(X).cuda(), torch.from_numpy(Q).cuda()
+    S = torch.full((nq, N), float("nan"), device="cuda")
+    _lib.check(lib.wise_ip_scores_f32(Xd.data_ptr(), N, d, Qd.data_ptr(), nq, S.data_ptr(), _lib.stream_ptr()), "scores")
+    got = S.cpu().numpy()
+    assert np.isfinite(got).all()
+    for i in range(hot):
+        assert np.array_equal(got[i], X[:, cols[i]])
+    ref = Q.astype(np.float64) @ X.astype(np.float64).T
+    bound = 2e-7 * (np.abs(Q).astype(np.float64) @ np.abs(X).astype(np.float64).T) + 1e-12
+    assert (np.abs(got - ref) <= bound).all()
+
+
+def test_coarse_stage_at_the_reference_nprobe_uses_no_library_gemm():
+    """nprobe = 1024 (config.py:19): probes = the 1024 best centroids by exact-f32 score; against numpy on the same
+    centroids, and nothing but this library's kernels on the path (the index never calls torch.matmul for it)."""
+    import inspect
+
+    from wise_amd.index import ivf_flat
+    src = inspect.getsource(ivf_flat.IVFFlatIPIndex.probes_device)
+    assert "@" not in src.split('"""')[2] and "matmul" not in src
+    nlist, d, nq = 4000, 128, 6
+    cent = unit_rows(nlist, d, 5)
+    idx = IVFFlatIPIndex(d, nlist)
+    idx.set_centroids(cent)
+    Q = torch.from_numpy(unit_rows(nq, d, 6)).cuda()
+    probes = idx.probes_device(Q, 1024).cpu().numpy()
+    S = (Q.cpu().numpy().astype(np.float64) @ cent.astype(np.float64).T)
+    for q in range(nq):
+        want = set(np.argsort(-S[q])[:1024])
+        got = set(probes[q])
+        edge = np.sort(S[q])[-1024]
+        # only centroids within f32 rounding of the 1024th score may differ
+        assert all(abs(S[q, c] - edge) < 1e-6 for c in want ^ got)
+        assert len(got) == 1024

@@ -46,6 +46,7 @@ SIGNATURES = {
     "wise_ip_topk_shadow_f32": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "wise_ivf_scan_workspace_bytes": (_sz, [_i, _i, _i]),
     "wise_ivf_scan_f32": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "wise_ip_scores_f32": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp]),
     "wise_select_topk_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "wise_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "wise_reconstruct_batch": (_i, [_vp, _i64, _i, _vp, _i64, _vp, _i, _vp, _vp]),

@@ -1613,6 +1613,74 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
     return WISE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dense scores S[nq, N] = Q . X^T in exact f32 on the matrix cores (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain,
+// bit-identical to a scalar loop) — the coarse stage of IndexIVFFlat when nprobe is a sizeable part of nlist (the
+// reference's nprobe = 1024 of 31,620 cells, config.py:19 / api/routes.py:899-902): a threshold list stops filtering
+// there, so all scores are written and select_topk_kernel picks the nprobe best.
+// Block = 4 waves = 128 rows of X x 32 queries; a wave owns a 32 x 32 tile (16 accumulator registers).  X and Q tiles
+// go through LDS in 64-column chunks (row stride 65 floats: the MFMA operand read — 32 lanes, 32 different rows, one
+// column — is conflict-free).  ~2 x 988 x 8 x 256 MFMAs for 31,620 x 512 x 256 queries: tens of microseconds.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ip_scores_f32_kernel(const float* __restrict__ X, long long N, int d,
+                                                            const float* __restrict__ Q, int nq,
+                                                            float* __restrict__ S /*[nq][N]*/) {
+    constexpr int KC = 64, LD = KC + 1;
+    __shared__ float xs[128 * LD];
+    __shared__ float qs[32 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long n0 = (long long)blockIdx.x * 128;
+    const int q0 = blockIdx.y * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int c0 = 0; c0 < d; c0 += KC) {
+        // stage: 128 x 64 floats of X (8 float4 per thread) and 32 x 64 of Q (2 per thread); zero past the edges
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int idx = t * 256 + tid, r = idx >> 4, c4 = (idx & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + r < N && c0 + c4 < d) v = *reinterpret_cast<const float4*>(X + (size_t)(n0 + r) * d + c0 + c4);
+            float* dst = xs + r * LD + c4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int idx = t * 256 + tid, r = idx >> 4, c4 = (idx & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q0 + r < nq && c0 + c4 < d) v = *reinterpret_cast<const float4*>(Q + (size_t)(q0 + r) * d + c0 + c4);
+            float* dst = qs + r * LD + c4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        __syncthreads();
+        const float* xa = xs + (wave * 32 + (lane & 31)) * LD + (lane >> 5);
+        const float* qb = qs + (lane & 31) * LD + (lane >> 5);
+#pragma unroll 8
+        for (int kk = 0; kk < KC; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[kk], qb[kk], acc, 0, 0, 0);   // D[row of X][query]
+        __syncthreads();
+    }
+    // acc[reg]: X row (reg&3) + 8*(reg>>2) + 4*(lane>>5) of the wave's 32, query lane&31
+    const int q = q0 + (lane & 31);
+    if (q < nq) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const long long n = n0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (n < N) S[(size_t)q * N + n] = acc[reg];
+        }
+    }
+}
+
+extern "C" int wise_ip_scores_f32(const float* X, int64_t N, int d, const float* Q, int nq, float* scores, void* stream) {
+    WISE_CHECK_ARG(X && Q && scores && N >= 1 && nq >= 1 && nq <= 65535 * 32 && d >= 4 && d % 4 == 0,
+                   "ip_scores: bad argument (N=%lld d=%d nq=%d)", (long long)N, d, nq);
+    WISE_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Q & 15) == 0, "ip_scores: X and Q must be 16-byte aligned");
+    hipLaunchKernelGGL(ip_scores_f32_kernel, dim3((unsigned)((N + 127) / 128), (unsigned)((nq + 31) / 32)), dim3(256), 0,
+                       (hipStream_t)stream, X, (long long)N, d, Q, nq, scores);
+    WISE_LAUNCH_CHECK("ip_scores_f32_kernel");
+    return WISE_OK;
+}
+
 extern "C" int wise_select_topk_f32(const float* scores, int rows, int n, int k, int64_t* out, void* stream) {
     WISE_CHECK_ARG(scores && out && rows >= 1 && n >= 1 && k >= 1, "select_topk: bad argument");
     hipLaunchKernelGGL(select_topk_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, scores, n, k,

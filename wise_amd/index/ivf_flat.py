@@ -8,7 +8,8 @@ api/routes.py:899-909 then sets `parallel_mode`, `nprobe` and calls `make_direct
                       does for an inner-product IVF), run on the GPU as dense products; deterministic (seeded
                       sample for the initial centroids, empty cells re-seeded from the fullest cell)
   add_with_ids(x,ids) rows are assigned to the centroid of largest inner product and kept grouped by list
-  search(q, k)        stage 1: `nprobe` best centroids per query = wise_ip_topk_f32 over the centroid table;
+  search(q, k)        stage 1: `nprobe` best centroids per query = wise_ip_topk_f32 over the centroid table (nprobe
+                      <= 64) or wise_ip_scores_f32 + wise_select_topk_f32 (the reference's nprobe = 1024);
                       stage 2: wise_ivf_scan_f32 over the probed lists (the flat scan kernel run per list segment)
 An approximate index cannot be pinned value-for-value against faiss (its k-means starts from faiss's own random
 permutation); what IS exact and tested: given the same centroids and lists, the result equals the brute-force top-k
@@ -163,13 +164,17 @@ class IVFFlatIPIndex:
     def probes_device(self, q: torch.Tensor, nprobe: int) -> torch.Tensor:
         """[nq, nprobe] int64 list numbers: the nprobe centroids of largest inner product (-1 padding when
         nprobe > nlist).  Few probes: the flat top-k kernel over the centroid table.  Many probes (threshold lists
-        stop filtering when k is a sizeable fraction of nlist): scores by a library GEMM, then the radix-select
-        kernel; the probes then come in list order, which the list scan does not care about."""
+        stop filtering when k is a sizeable fraction of nlist): all centroid scores in exact fp32 on the matrix
+        cores (wise_ip_scores_f32), then the radix-select kernel; the probes then come in list order, which the
+        list scan does not care about."""
         if nprobe <= 64:
             _, I = self._quantizer.search_device(q, nprobe)
             return I
         lib = _lib.lib()
-        scores = (q @ self.centroids.t()).contiguous()
+        scores = torch.empty(q.shape[0], self.nlist, dtype=torch.float32, device=self.device)
+        rc = lib.wise_ip_scores_f32(self.centroids.data_ptr(), self.nlist, self.d, q.data_ptr(), q.shape[0],
+                                    scores.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "wise_ip_scores_f32")
         out = torch.empty(q.shape[0], nprobe, dtype=torch.int64, device=self.device)
         rc = lib.wise_select_topk_f32(scores.data_ptr(), q.shape[0], self.nlist, nprobe, out.data_ptr(),
                                       _lib.stream_ptr())
