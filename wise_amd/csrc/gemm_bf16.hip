@@ -30,8 +30,15 @@ __device__ int g_dephase = 0;        // tuning knob (bits 24..27): initial s_sle
 __device__ int g_store_nt = 1;       // non-temporal stores in the bf16 epilogue of the 256-row tiles: the C tile is read by a
                                      // later kernel, not by this one (ViT-L/14 +1.5 % end to end, ViT-B/32 unchanged)
 __device__ int g_skip_epilogue = 0;  // timing-only ablation (tools/gemm_bench.py), set via wise_debug_set_gemm_variant
+__device__ unsigned long long* g_stamp_buf = nullptr;   // in-kernel s_memtime stamps of one block (tools/gemm_stamps.py)
+__device__ int g_stamp_block = 0;
+#define WISE_STAMP(slot)                                                                              \
+    do {                                                                                              \
+        if (stamp_on) sbuf[(size_t)(kt) * 8 + (slot)] = __builtin_amdgcn_s_memtime();                 \
+    } while (0)
 #else
 constexpr int g_group_m = 0, g_epi_lds = 1, g_dephase = 0, g_store_nt = 1, g_skip_epilogue = 0;
+#define WISE_STAMP(slot) do {} while (0)
 #endif
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -1039,7 +1046,7 @@ __device__ __forceinline__ void epilogue_big_lds(f32x4 (&acc)[MI][4], const floa
 // (waves 2x4, 4 stages of 36 KiB) for shapes that fill the chip in whole rounds only with 320-row tiles
 // (M = 6400, N = 3072: 240 tiles).  A 320-row A tile is 20 KiB per stage = 2.5 rounds of the 8 waves, so waves
 // 0-3 (the early group) issue one LDS-DMA more per K-tile than waves 4-7: the counted vmcnt differs per group.
-template <int MODE, int WROWS>
+template <int MODE, int WROWS, int STG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                          const float* __restrict__ bias, int M, int N, int K,
                                                          void* __restrict__ out) {
@@ -1047,7 +1054,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
     constexpr int BKT = 32, NT = 4, MI = WROWS / 16;
     constexpr int BMB = (WROWS == 64) ? 256 : (WROWS == 80) ? 320 : 2 * WROWS;   // 80: 320 x 128, four wave rows
     constexpr int WM_WAVES = BMB / WROWS, WN_WAVES = 8 / WM_WAVES, BNB = WN_WAVES * 64;
-    constexpr int STAGES = (WROWS == 64) ? 5 : 4;
+    constexpr int STAGES = STG ? STG : ((WROWS == 64) ? 5 : 4);
     constexpr int TA = BMB * BKT * 2, TBt = BNB * BKT * 2, SB = TA + TBt;
     // LDS-DMA instructions per thread per K-tile: waves 0-3 take the partial last round of a 320-row A tile
     constexpr int GPS_E = (TA / 1024 + 7) / 8 + TBt / 8192, GPS_L = TA / 8192 + TBt / 8192;
@@ -1083,11 +1090,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
         __builtin_amdgcn_s_barrier();
     }
     int cur = 0;
+#ifdef WISE_DEBUG_KNOBS
+    // stamps: lane 0 of waves 0 (early group) and 4 (late group) of block g_stamp_block; 8 slots per K-tile
+    const bool stamp_on = g_stamp_buf != nullptr && (int)blockIdx.x == g_stamp_block && lane == 0 && (wave & 3) == 0;
+    unsigned long long* sbuf = g_stamp_buf + (size_t)(wave >> 2) * 4096;
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         // ---- L part
+        WISE_STAMP(0);
         if (kt + STAGES - 2 < nk) wait_inflight(); else wait_vmcnt<0>();   // my share of tile kt has landed
+        WISE_STAMP(1);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        WISE_STAMP(2);
         if (kt + STAGES - 1 < nk) {
             int ns = cur + STAGES - 1;
             if (ns >= STAGES) ns -= STAGES;
@@ -1103,12 +1118,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[i] = lds_frag_ring<BKT>(At, wm * WROWS + i * 16 + (lane & 15), chunk);
         // my share of tile kt+1 has landed before the barrier after which the other group may read it
+        WISE_STAMP(3);
         if (kt + STAGES - 1 < nk) wait_inflight(); else wait_vmcnt<0>();
+        WISE_STAMP(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        WISE_STAMP(5);
         __builtin_amdgcn_s_barrier();
         // ---- M part: registers only
         __builtin_amdgcn_sched_barrier(0);
+        WISE_STAMP(6);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -1117,6 +1136,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        WISE_STAMP(7);
         cur = (cur + 1 == STAGES) ? 0 : cur + 1;
     }
     if (!late) __builtin_amdgcn_s_barrier();
@@ -1153,13 +1173,155 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
     }
 }
 
-template <int MODE, int WROWS>
+#ifdef WISE_DEBUG_KNOBS
+// ------------------------------------------------------------------------------------------------
+// Ping-pong kernel, second form: the fragment reads ride inside the MFMA cluster.  (MEASURED SLOWER — round 2, kept in
+// the debug library only as variant 50: 881 -> 795 TFLOP/s on 12800x2304x768, 1254 -> 1122 on 8192^3.  The reads
+// lengthen the cluster by more than they take off the part between clusters: on this chip work moved between the two
+// waves of a SIMD does not net, as MI355X_MICROARCH.md says for balanced pairings — and it does not for this one.)
+// In-kernel stamps of gemm_pp_kernel (tools/gemm_stamps.py) showed why its main loop stops at ~1100 TFLOP/s: per K-tile
+// a wave spends ~650 cycles in its 32-MFMA cluster but ~1100 in the part around it (two counted vmcnt waits, LDS-DMA
+// issue, 12 ds_read_b128 and the wait for them), so the partner wave's cluster cannot cover it and the matrix pipe
+// idles ~45 % of the time.  Here the reads of tile kt+1 are issued BETWEEN the MFMAs of tile kt: a row fragment is
+// reloaded right after its last use (same registers), the four column fragments go to a second register set first, so
+// nothing waits for LDS outside the cluster any more — an MFMA gap takes two ds_read_b128 for ~3 cycles
+// (MI355X_MICROARCH.md, LDS) — and the part between the clusters shrinks to: counted vmcnt, barrier, LDS-DMA issue.
+// Synchronisation (late group one barrier behind, as before; two barriers Ba, Bb per K-tile and wave):
+//   RAW  tile kt+1 is read during M(kt), i.e. after Bb(kt) by the early group and one barrier later by the late one:
+//        every wave waits for its own share of tile kt+1 before Ba(kt) and before Bb(kt);
+//   WAR  L(kt) refills the slot of tile kt-1 with tile kt+3; tile kt-1 was read during M(kt-2), and every wave retires
+//        its LDS reads (lgkmcnt(0), cheap: they were issued a whole part earlier) before Bb, so all reads of tile kt-1
+//        are complete before the barrier that precedes any refill of its slot.
+// 256x256 tile (WROWS = 128), 4-stage ring of 32-deep K-tiles, 8 waves as 2 x 4.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+                                                          const float* __restrict__ bias, int M, int N, int K,
+                                                          void* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BKT = 32, NT = 4, MI = 8, WROWS = 128, BMB = 256, BNB = 256, STAGES = 4;
+    constexpr int TA = BMB * BKT * 2, TBt = BNB * BKT * 2, SB = TA + TBt;
+    constexpr int GPS = TA / 8192 + TBt / 8192;        // LDS-DMA instructions per thread per K-tile (4)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool late = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+
+    int tm, tn;
+    tile_coords(M / BMB, N / BNB, g_group_m ? g_group_m : 4, &tm, &tn);
+    const int m0 = tm * BMB, n0 = tn * BNB;
+
+    f32x4 acc[MI][NT];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BKT;
+    // wait until my share of tile t has landed, given that my LDS-DMAs were issued in tile order up to tile `issued`
+    auto wait_tile = [&](int t, int issued) {
+        const int younger = issued - t;              // tiles issued after t that may stay in flight
+        if (younger >= 2) wait_vmcnt<2 * GPS>();
+        else if (younger == 1) wait_vmcnt<GPS>();
+        else wait_vmcnt<0>();
+    };
+    auto stage = [&](int t) {
+        const int slot = t % STAGES;
+        stage_rows8_ring<BMB, BKT>(A, K, m0, t * BKT, smem + slot * SB, wave, lane);
+        stage_rows8_ring<BNB, BKT>(Wt, K, n0, t * BKT, smem + slot * SB + TA, wave, lane);
+    };
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nk) stage(t);
+    int issued = (nk < STAGES - 1 ? nk : STAGES - 1) - 1;    // newest tile whose DMAs this wave has issued
+    // tile 0 -> registers (both groups at the same barrier; the late group then falls one barrier behind)
+    wait_tile(0, issued);
+    __builtin_amdgcn_s_barrier();
+    const int chunk = lane >> 4;
+    bf16x8 wf[NT], wfn[NT], af[MI];
+    {
+        const unsigned char* At = smem;
+        const unsigned char* Bt = At + TA;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = lds_frag_ring<BKT>(Bt, wn * 64 + j * 16 + (lane & 15), chunk);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = lds_frag_ring<BKT>(At, wm * WROWS + i * 16 + (lane & 15), chunk);
+    }
+    if (late) {
+        wait_tile(1 < nk ? 1 : 0, issued);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        // ---- L part: barrier, then refill the slot of tile kt-1
+        if (more) wait_tile(kt + 1, issued);
+        __builtin_amdgcn_s_barrier();                                   // Ba(kt)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + STAGES - 1 < nk) { stage(kt + STAGES - 1); issued = kt + STAGES - 1; }   // slot of tile kt-1 (kt = 0: unused so far)
+        if (more) wait_tile(kt + 1, issued);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // my reads of tile kt (and older) are complete
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                                   // Bb(kt)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- M part: 32 MFMAs on tile kt, the 12 fragment reads of tile kt+1 between them
+        const unsigned char* At = smem + ((kt + 1) % STAGES) * SB;
+        const unsigned char* Bt = At + TA;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            if (more) {
+                af[i] = lds_frag_ring<BKT>(At, wm * WROWS + i * 16 + (lane & 15), chunk);
+                // the column fragments of the next tile behind the first MFMAs (the compiler guards the first MFMA of
+                // the cluster with lgkmcnt(0): nothing new may be outstanding there)
+                if (i < NT) wfn[i] = lds_frag_ring<BKT>(Bt, wn * 64 + i * 16 + (lane & 15), chunk);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j] = wfn[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+    constexpr bool BF16OUT = bf16_out(MODE);
+    if (BF16OUT) {
+        __syncthreads();  // both groups are past their last fragment read: the ring is dead
+        epilogue_big_lds<MODE, MI>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
+    } else {
+        __syncthreads();
+        epilogue_f32_lds_wave<MODE, MI, NT>(acc, bias, reinterpret_cast<float*>(out), N, m0 + wm * WROWS, n0 + wn * 64,
+                                            lane, smem + wave * 16384);
+    }
+}
+
+template <int MODE>
+static void launch_pp2(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
+                       hipStream_t st) {
+    auto kern = gemm_pp2_kernel<MODE>;
+    const size_t lds = (size_t)4 * (256 + 256) * 32 * 2;  // 128 KiB
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    });
+    const int grid = (M / 256) * (N / 256);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
+}
+
+#endif  // WISE_DEBUG_KNOBS
+
+template <int MODE, int WROWS, int STG = 0>
 static void launch_pp(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
                       hipStream_t st) {
-    auto kern = gemm_pp_kernel<MODE, WROWS>;
+    auto kern = gemm_pp_kernel<MODE, WROWS, STG>;
     constexpr int BNB = (WROWS == 64 || WROWS == 80) ? 128 : 256;
     constexpr int BMB = (WROWS == 64) ? 256 : (WROWS == 80) ? 320 : 2 * WROWS;
-    constexpr int STAGES = (WROWS == 64) ? 5 : 4;
+    constexpr int STAGES = STG ? STG : ((WROWS == 64) ? 5 : 4);
     const size_t lds = (size_t)STAGES * (BMB + BNB) * 32 * 2;  // 128 KiB / 120 KiB / 144 KiB
     static std::once_flag attr_set;
     std::call_once(attr_set, [&] {
@@ -1190,6 +1352,16 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 40: if (M % 256 == 0 && N % 256 == 0) { launch_pp<MODE, 128>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+#ifdef WISE_DEBUG_KNOBS
+        case 45: if (M % 256 == 0 && N % 256 == 0) { launch_pp<MODE, 128, 5>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 46: if (M % 256 == 0 && N % 128 == 0) { launch_pp<MODE, 64, 3>(A, Wt, bias, M, N, K, out, st); break; }   // 72 KiB: two blocks per CU
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+#endif
+#ifdef WISE_DEBUG_KNOBS
+        case 50: if (M % 256 == 0 && N % 256 == 0 && K >= 96) { launch_pp2<MODE>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+#endif
         case 44: if (M % 320 == 0 && N % 128 == 0) { launch_pp<MODE, 80>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 41: if (M % 256 == 0 && N % 128 == 0) { launch_pp<MODE, 64>(A, Wt, bias, M, N, K, out, st); break; }
@@ -1204,7 +1376,7 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
 
 static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode,
                        void* out, hipStream_t st) {
-    if (K % 64 != 0 && v != 40 && v != 42) v = 1;
+    if (K % 64 != 0 && v != 40 && v != 42 && v != 45 && v != 46 && v != 50) v = 1;
     else if (N % BN != 0 && v != 1) v = 0;  // N edge is handled by the 128x128 kernels only
     switch (mode) {
         case EPI_BF16: launch_variant<EPI_BF16>(v, A, Wt, bias, M, N, K, out, st); break;
@@ -1349,6 +1521,11 @@ extern "C" int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float
 namespace wise { int g_ablate = 0; }  // timing-only ablations: bit 1 = skip LayerNorm launches, bit 2 = skip attention
 
 #ifdef WISE_DEBUG_KNOBS
+extern "C" int wise_debug_set_gemm_stamps(unsigned long long* buf /*device, 8192 entries, or null*/, int block) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_stamp_buf), &buf, sizeof(buf));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_stamp_block), &block, sizeof(int));
+    return 0;
+}
 extern "C" int wise_debug_set_gemm_flags(int flags) {
     wise::g_tile320 = (flags & 1) ? 0 : 1;
     wise::g_ablate = flags & 6;
