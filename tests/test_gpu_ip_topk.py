@@ -344,10 +344,11 @@ def test_small_index_with_near_ties_in_one_block():
     assert np.array_equal(I, Ir) and np.allclose(D, Dr, atol=2e-6)
 
 
-def test_batched_two_stage_search_certifies_or_falls_back():
-    """A batch of 40 queries on an index with a bf16 shadow: ordinary queries are certified from the bf16 pass; one query
-    with 80 near-duplicate neighbours cannot be, and the pass is redone from the f32 rows.  Either way: the oracle's."""
-    N, d, k = 60000, 512, 10
+def test_batched_two_stage_search_on_ordinary_and_on_overflowing_queries():
+    """A batch of 40 queries on an index with a bf16 shadow (threshold form on the matrix cores): ordinary queries are
+    answered from the bf16 pass; one query with 70,000 rows inside the bf16 error band of its best scores overflows its
+    list, and the pass is redone from the f32 rows.  Either way: the oracle's."""
+    N, d, k = 300000, 512, 10
     X = unit_rows(N, d, 71)
     Q = unit_rows(40, d, 72)
     ids = np.arange(N, dtype=np.int64) + 5
@@ -358,21 +359,45 @@ def test_batched_two_stage_search_certifies_or_falls_back():
     assert counts_since(idx, before) == (40, 0)
     check_against_oracle(X, Q, k, ids, D, I)
     rng = np.random.default_rng(73)
-    for c in rng.choice(N, size=80, replace=False):
-        v = Q[7] + 1e-3 * rng.standard_normal(d).astype(np.float32)
-        X[c] = v / np.linalg.norm(v)
+    for n, c in enumerate(rng.choice(N, size=70000, replace=False)):
+        v = rng.standard_normal(d).astype(np.float32)
+        v -= (v @ Q[7]) * Q[7]
+        v /= np.linalg.norm(v)
+        sc = 1.0 - 4e-5 * n if n < 12 else rng.uniform(0.9975, 0.9990)
+        X[c] = sc * Q[7] + np.sqrt(1 - sc * sc) * v
     idx2 = FlatIPIndex(d, shadow=True)
     idx2.add_with_ids(X, ids)
     D2, I2 = idx2.search(Q, k)
-    certified, fallback = idx2.shadow_counts()
-    assert fallback >= 1 and certified + fallback == 40
+    answered, handed = idx2.shadow_counts()
+    assert handed >= 1 and answered + handed == 40
     assert counts_since(idx, before) == (40, 0)               # the first index's counters did not move
     check_against_oracle(X, Q, k, ids, D2, I2)
 
 
+def test_batched_search_on_clustered_rows_needs_no_fallback():
+    """Runs of 20 near-duplicates (cosine >= 0.999): the batched threshold form answers every query from the shadow and
+    returns what the f32 path returns."""
+    d, k = 512, 10
+    X = clustered_rows(20000, 20, d, 47)
+    N = X.shape[0]
+    ids = np.arange(N, dtype=np.int64) + 1
+    Q = unit_rows(70, d, 48)
+    Q[::2] = X[np.random.default_rng(49).integers(0, N, 35)] + 0.02 * Q[::2]
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    idx = FlatIPIndex(d, shadow=True)
+    idx.add_with_ids(X, ids)
+    ref = FlatIPIndex(d, shadow=False)
+    ref.add_with_ids(X, ids)
+    D, I = idx.search(Q, k)
+    assert idx.shadow_counts() == (70, 0)
+    Dr, Ir = ref.search(Q, k)
+    check_against_oracle(X, Q, k, ids, D, I)
+    assert np.allclose(D, Dr, atol=2e-6)
+    assert (I == Ir).mean() > 0.99            # ids may swap only between scores equal to f32 rounding
+
+
 def test_batched_two_stage_search_with_threshold_passes():
-    """Large enough (N >= 16 x 32768) for the threshold pass of the batched bf16 scan: scores of the first 64K rows dumped,
-    the 48th best per query picked by radix select, the rest scanned under it."""
+    """d = 256 rows, 70 queries (one full pass of 64 and one of 6)."""
     N, d, k = 600000, 256, 10
     X = unit_rows(N, d, 81)
     Q = unit_rows(70, d, 82)
@@ -459,7 +484,7 @@ def test_cfg4_shard_6p25m_x_768():
 
 
 @pytest.mark.parametrize("N,d,nq,k", [(50000, 512, 4, 10), (33333, 512, 7, 16), (20000, 768, 3, 5), (70, 256, 6, 10),
-                                      (40000, 1024, 2, 10)])
+                                      (40000, 1024, 2, 10), (300000, 512, 4, 10), (270000, 768, 3, 5), (280000, 256, 2, 16)])
 def test_few_queries_through_the_two_stage_search(N, d, nq, k):
     """2-7 queries: one 64-query matrix-core pass over the bf16 rows where those kernels apply (k <= 12, d = 256 / 512),
     else one query at a time (2-3 queries) or the f32 batch kernels; each certified or recomputed from the f32 rows."""
@@ -470,10 +495,10 @@ def test_few_queries_through_the_two_stage_search(N, d, nq, k):
     idx.add_with_ids(X, ids)
     D, I = idx.search(Q, k)
     certified, fallback = idx.shadow_counts()
-    # 64-query passes (k <= 12, d = 256 / 512) or 32-query passes (3+ queries, d = 768 / 1024) count; one query at a time
-    # (2-3 queries outside those shapes) is, at these sizes (< 2^18 rows), the fp32 scan itself
-    batched = (k <= 12 and d in (256, 512)) or (nq >= 3 and d in (768, 1024))
-    assert certified + fallback == (nq if batched else 0)
+    # indexes below 2^18 rows never enter the two-stage path (the f32 scans answer); above: 64-query passes (k <= 12,
+    # d = 256 / 512), 32-query passes (3+ queries, d = 768 / 1024), or one query at a time (2-3 queries)
+    two_stage = N >= THRESHOLD_FORM_MIN_ROWS and ((k <= 12 and d in (256, 512)) or (nq >= 3 and d in (768, 1024)) or nq <= 3)
+    assert (certified, fallback) == ((nq, 0) if two_stage else (0, 0))
     check_against_oracle(X, Q, k, ids, D, I)
     ref = FlatIPIndex(d, shadow=False)
     ref.add_with_ids(X, ids)
@@ -481,7 +506,7 @@ def test_few_queries_through_the_two_stage_search(N, d, nq, k):
     assert np.array_equal(I, Ir) and np.allclose(D, Dr, atol=2e-6)
 
 
-@pytest.mark.parametrize("N,d,nq,k", [(40000, 768, 40, 10), (30000, 1024, 5, 16), (600000, 768, 33, 10)])
+@pytest.mark.parametrize("N,d,nq,k", [(280000, 768, 40, 10), (30000, 1024, 5, 16), (600000, 768, 33, 10), (300000, 1024, 5, 16)])
 def test_batched_two_stage_search_for_wide_rows(N, d, nq, k):
     """512 < d <= 1024 (768 is the ViT-L/14 dimension): 32 queries per pass over the bf16 rows on the matrix cores, the
     f32 VALU scan as the gated fallback."""
@@ -492,18 +517,21 @@ def test_batched_two_stage_search_for_wide_rows(N, d, nq, k):
     idx.add_with_ids(X, ids)
     D, I = idx.search(Q, k)
     certified, fallback = idx.shadow_counts()
-    assert certified + fallback == nq
+    assert certified + fallback == (nq if N >= THRESHOLD_FORM_MIN_ROWS else 0)
     check_against_oracle(X, Q, k, ids, D, I)
 
 
 def test_wide_row_batch_falls_back_to_the_f32_scan():
-    N, d, k = 30000, 768, 10
+    N, d, k = 270000, 768, 10
     X = unit_rows(N, d, 91)
     Q = unit_rows(12, d, 92)
     rng = np.random.default_rng(93)
-    for c in rng.choice(N, size=80, replace=False):
-        v = Q[5] + 1e-3 * rng.standard_normal(d).astype(np.float32)
-        X[c] = v / np.linalg.norm(v)
+    for n, c in enumerate(rng.choice(N, size=70000, replace=False)):
+        v = rng.standard_normal(d).astype(np.float32)
+        v -= (v @ Q[5]) * Q[5]
+        v /= np.linalg.norm(v)
+        sc = 1.0 - 4e-5 * n if n < 12 else rng.uniform(0.9975, 0.9990)
+        X[c] = sc * Q[5] + np.sqrt(1 - sc * sc) * v
     ids = np.arange(N, dtype=np.int64) + 1
     idx = FlatIPIndex(d, shadow=True)
     idx.add_with_ids(X, ids)

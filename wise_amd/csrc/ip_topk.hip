@@ -412,19 +412,10 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// Two-stage exact search over a bf16 shadow of the index (nq = 1, k <= 16), wise_ip_topk_shadow_f32:
-//   1. ip_scan_bf16_kernel streams Xb [N,d] bf16 (half the bytes of X) against the f32 query and keeps the
-//      SHADOW_C = 64 best approximate scores per wave (same selection machinery as ip_scan_kernel);
-//   2. merge_keys_kernel folds them into the 64 best candidates of the query;
-//   3. rescore_certify_kernel recomputes the candidates' scores from the f32 rows, orders them, writes the first k,
-//      and checks a certificate: every row outside the candidate set has approximate score <= t (the 64th
-//      candidate's), hence exact score <= t + eps with eps = (2^-8 + d 2^-23) |q| max|x| (bf16 rounding of x and the
-//      f32 accumulation error of both dot products, Cauchy-Schwarz); if the k-th exact score is above t + eps the answer is the exact top-k;
-//   4. otherwise *gate = 1 and the f32 scan + merge queued behind (which return at once when *gate == 0) recompute
-//      the query exactly.  No host round trip either way.
+// Two-stage exact search over a bf16 shadow of the index, wise_ip_topk_shadow_f32 (the threshold form is described at
+// ip_collect_bf16_kernel below; the batched form runs the same steps with the bf16 rows on the matrix cores,
+// ip_topk_mfma.hip).
 // ------------------------------------------------------------------------------------------------
-constexpr int SHADOW_C = 64;   // candidates re-scored per query
-constexpr int SHADOW_L = 16;   // candidates a scan block keeps (its last key bounds what it dropped)
 
 __global__ __launch_bounds__(256) void shadow_bf16_kernel(const float* __restrict__ X, long long N, int d,
                                                           bf16_t* __restrict__ Xb, float* __restrict__ norms) {
@@ -465,188 +456,42 @@ __device__ __forceinline__ float shadow_eps(const float* __restrict__ norms, int
     return (norms[1] + (float)d * 1.1920929e-7f * norms[0]) * 1.0001f * sqrtf(qq);
 }
 
-// NV8 = 16-byte chunks (8 bf16) per lane per row, R rows per group, one query
-// chunk_shift >= 0: the scan visits a SAMPLE of the rows — logical group g stands for physical group
-// (g >> chunk_shift) * chunk_stride + (g & ((1 << chunk_shift) - 1)): evenly spaced chunks of 2^chunk_shift groups; N
-// is then the number of sampled rows and row numbers in the keys are physical
-template <int NV8, int NQ, int R>
-__global__ __launch_bounds__(256) void ip_scan_bf16_kernel(const uint4* __restrict__ Xb, long long N, int d8,
-                                                           const float* __restrict__ Q /*[NQ][d]*/, int kl, int cap,
-                                                           u64* __restrict__ part /*[grid][NQ][kl]*/,
-                                                           int chunk_shift = -1, long long chunk_stride = 0) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    u64* lds = reinterpret_cast<u64*>(smem);   // wave w, query q -> lds + (w*NQ + q)*cap
-    float qv[NQ][NV8][8];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
+// One group of R rows of the bf16 shadow against the query held in registers: every lane ends up with the score of row
+// `row0 + myr` (valid in the lanes with `owner`): 16-byte non-temporal loads, bf16 -> f32 by shift / mask, f32 fma chains,
+// butterfly transpose-reduce over the lanes.  NV8 = 16-byte chunks (8 bf16) per lane and row.
+template <int NV8, int R>
+struct ShadowGroup {
+    static constexpr int LOGR = (R == 8) ? 3 : (R == 4) ? 2 : (R == 2) ? 1 : 0;
+    float qv[NV8][8];
+    int myr;
+    bool owner;
+    __device__ float load_query(const float* __restrict__ Q, int d8, int lane) {   // returns |q|^2
+        float qq = 0.f;
 #pragma unroll
         for (int v = 0; v < NV8; ++v) {
             const int c = v * 64 + lane;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) qv[q][v][e] = (c < d8) ? Q[(size_t)q * d8 * 8 + c * 8 + e] : 0.f;
+            for (int e = 0; e < 8; ++e) {
+                qv[v][e] = (c < d8) ? Q[c * 8 + e] : 0.f;
+                qq = fmaf(qv[v][e], qv[v][e], qq);
+            }
         }
-    WaveList wl[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) wl[q].init(lds + (size_t)(wave * NQ + q) * cap, cap, kl, lane);
-
-    const long long ngroups = (N + R - 1) / R;
-    const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
-    int myr = 0;
-    {
+        for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
+        myr = 0;
         int bit = 5;
 #pragma unroll
         for (int h = R / 2; h >= 1; h >>= 1, --bit) myr += ((lane >> bit) & 1) * h;
+        owner = (lane & ((64 >> LOGR) - 1)) == 0;
+        return qq;
     }
-    constexpr int LOGR = (R == 8) ? 3 : (R == 4) ? 2 : (R == 2) ? 1 : 0;
-    const bool owner = (lane & ((64 >> LOGR) - 1)) == 0;
-
-    for (long long g = gw; g < ngroups; g += nw) {
-        // (a sample never has a ragged last group: the host samples whole chunks)
-        const long long row0 = (chunk_shift >= 0 ? (g >> chunk_shift) * chunk_stride + (g & ((1ll << chunk_shift) - 1)) : g) * R;
-        const long long row_end = chunk_shift >= 0 ? row0 + R : N;
+    __device__ float score(const uint4* __restrict__ Xb, long long row0, long long row_end, int d8, int lane) const {
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         u32x4_t x[R][NV8];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             long long row = row0 + r;
             if (row >= row_end) row = row_end - 1;
-#pragma unroll
-            for (int v = 0; v < NV8; ++v) {
-                const int c = v * 64 + lane;
-                if (NV8 * 64 == d8 || c < d8)
-                    x[r][v] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(Xb) + row * d8 + c);
-                else
-                    x[r][v] = u32x4_t{0u, 0u, 0u, 0u};
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            float a[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float s = 0.f;
-#pragma unroll
-                for (int v = 0; v < NV8; ++v)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned u = x[r][v][e];
-                        s = fmaf(__uint_as_float(u << 16), qv[q][v][2 * e], s);
-                        s = fmaf(__uint_as_float(u & 0xFFFF0000u), qv[q][v][2 * e + 1], s);
-                    }
-                a[r] = s;
-            }
-            int bit = 5;
-#pragma unroll
-            for (int h = R / 2; h >= 1; h >>= 1, --bit) {
-                const int m = 1 << bit;
-                const bool up = (lane >> bit) & 1;
-#pragma unroll
-                for (int i = 0; i < h; ++i) {
-                    float send = up ? a[i] : a[i + h];
-                    float keep = up ? a[i + h] : a[i];
-                    a[i] = keep + __shfl_xor(send, m, 64);
-                }
-            }
-            float s = a[0];
-#pragma unroll
-            for (int m = (32 >> LOGR); m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-            const long long row = row0 + myr;
-            const u64 key = make_key(s, (unsigned)row);
-            const bool pass = owner && (row < row_end) && (key > wl[q].tau);
-            wl[q].offer(pass, key, lane, R);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) wl[q].compact(lane);
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            for (int w = 1; w < 4; ++w) {
-                const u64* other = lds + (size_t)(w * NQ + q) * cap;
-                for (int i0 = 0; i0 < kl; i0 += 64) {
-                    const int i = i0 + lane;
-                    const u64 key = (i < kl) ? other[i] : 0;
-                    const bool pass = (key != 0) && (key > wl[q].tau);
-                    wl[q].offer(pass, key, lane, 64);
-                }
-            }
-            wl[q].compact(lane);
-            u64* dst = part + ((size_t)blockIdx.x * NQ + q) * kl;
-            for (int i = lane; i < kl; i += 64) dst[i] = wl[q].buf[i];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// One query over the bf16 shadow, THRESHOLD form (the reference's call shape: nq = 1, k <= 16).
-// The candidate set is not "the best C rows" (which says nothing when more than C rows sit within the bf16 error of the
-// k-th score: frames of one video) but EVERY row whose approximate score could still belong to a top-k row:
-//   sample   ip_scan_bf16_kernel over evenly spaced chunks (~64K rows) -> s_A, the k-th best approximate score there.
-//            k rows have exact score >= s_A - eps, so the exact k-th best score S* of the index is >= s_A - eps, and a
-//            row of the exact top-k has approximate score >= S* - eps >= s_A - 2 eps =: thr.
-//   collect  (this kernel) streams all of Xb once and appends (approximate score, row) of every row with score >= thr
-//            to one global list (one atomicAdd per wave and hit; a hit is one row in several thousand).
-//   rescore  exact f32 dot products of the collected rows; select: the k best of those, written out.
-//   refine   the collected list itself gives a far better bound than the sample did: L = the k-th largest of 1024 slice
-//            maxima of the collected approximate scores (k different rows reach it), so S* >= L - eps and only rows with
-//            approximate score >= L - 2 eps go on — on iid rows ~1500 collected shrink to a few dozen, on clustered rows
-//            (where whole runs pass the sample's threshold) tens of thousands shrink to the runs that matter.
-//   rescore  exact f32 dot products of what is left; select: the k best of those, written out.
-// Exact by construction whatever the data looks like — clustered, near-duplicate, all-equal — as long as the lists hold
-// the candidates (COLLECT_CAP collected, RESCORE_CAP after refinement); otherwise the gate is raised and the f32 scan
-// queued behind answers.  eps: shadow_eps().  thr is recomputed by every wave from the sample's sorted scores (one L2 read).
-// ------------------------------------------------------------------------------------------------
-constexpr int COLLECT_CAP = 262144;         // rows the collect pass may hand on (2 MiB of keys)
-constexpr int RESCORE_CAP = 16384;          // rows re-scored = 16 keys per thread of the 1024-thread select kernel
-constexpr int SAMPLE_CHUNK_SHIFT = 6;       // a sample chunk = 64 groups of 8 rows = 512 rows (512 KiB at d = 512)
-constexpr int SAMPLE_CHUNKS = 128;          // 65536 sampled rows
-constexpr long long COLLECT_MIN_ROWS = 1ll << 18;
-constexpr int SAMPLE_GRID = 256;            // blocks of the sample scan (1024 waves x 8 groups)   // below this the f32 scan answers directly (a sample would be a quarter of it)
-
-template <int NV8, int R>
-__global__ __launch_bounds__(256) void ip_collect_bf16_kernel(const uint4* __restrict__ Xb, long long N, int d8,
-                                                              const float* __restrict__ Q,
-                                                              const float* __restrict__ sample_scores /*descending*/,
-                                                              int k, const float* __restrict__ norms,
-                                                              int* __restrict__ counter, u64* __restrict__ cand, int cap) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    float qv[NV8][8];
-    float qq = 0.f;
-#pragma unroll
-    for (int v = 0; v < NV8; ++v) {
-        const int c = v * 64 + lane;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            qv[v][e] = (c < d8) ? Q[c * 8 + e] : 0.f;
-            qq = fmaf(qv[v][e], qv[v][e], qq);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
-    const float thr = sample_scores[k - 1] - 2.f * shadow_eps(norms, d8 * 8, qq);
-
-    const long long ngroups = (N + R - 1) / R;
-    const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
-    int myr = 0;
-    {
-        int bit = 5;
-#pragma unroll
-        for (int h = R / 2; h >= 1; h >>= 1, --bit) myr += ((lane >> bit) & 1) * h;
-    }
-    constexpr int LOGR = (R == 8) ? 3 : (R == 4) ? 2 : (R == 2) ? 1 : 0;
-    const bool owner = (lane & ((64 >> LOGR) - 1)) == 0;
-    for (long long g = gw; g < ngroups; g += nw) {
-        const long long row0 = g * R;
-        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-        u32x4_t x[R][NV8];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            long long row = row0 + r;
-            if (row >= N) row = N - 1;
 #pragma unroll
             for (int v = 0; v < NV8; ++v) {
                 const int c = v * 64 + lane;
@@ -685,8 +530,123 @@ __global__ __launch_bounds__(256) void ip_collect_bf16_kernel(const uint4* __res
         float sc = a[0];
 #pragma unroll
         for (int m = (32 >> LOGR); m >= 1; m >>= 1) sc += __shfl_xor(sc, m, 64);
-        const long long row = row0 + myr;
-        const bool pass = owner && (row < N) && (sc >= thr);
+        return sc;
+    }
+};
+
+// The SAMPLE pass of the single-query search: evenly spaced chunks of 2^chunk_shift groups of R rows (chunk_stride groups
+// apart); every wave scores its share of the sampled groups and writes the best score it saw (wave_best[global wave]).
+// The k-th largest of those per-wave maxima is reached by k different sampled rows (sample_threshold_kernel).
+template <int NV8, int R>
+__global__ __launch_bounds__(256) void ip_sample_bf16_kernel(const uint4* __restrict__ Xb, long long n_groups, int d8,
+                                                             const float* __restrict__ Q, int chunk_shift,
+                                                             long long chunk_stride, float* __restrict__ wave_best) {
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    ShadowGroup<NV8, R> grp;
+    grp.load_query(Q, d8, lane);
+    float best = -3.4028234663852886e38f;
+    for (long long g = gw; g < n_groups; g += nw) {
+        const long long row0 = ((g >> chunk_shift) * chunk_stride + (g & ((1ll << chunk_shift) - 1))) * R;
+        const float sc = grp.score(Xb, row0, row0 + R, d8, lane);     // whole groups only: no ragged edge in a sample
+        best = (grp.owner && sc > best) ? sc : best;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+    if (lane == 0) wave_best[gw] = best;
+}
+
+// thr = (k-th largest of the n per-wave sample maxima) - 2 eps(q): one block; k rounds of a block-wide maximum
+__global__ __launch_bounds__(1024) void sample_threshold_kernel1(const float* __restrict__ wave_best, int n, int k,
+                                                                 const float* __restrict__ Q, int d,
+                                                                 const float* __restrict__ norms, float* __restrict__ thr) {
+    __shared__ float wmax[16];
+    __shared__ float wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // keys (score, slot) so that equal scores in different slots stay different rows
+    u64 mine[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = j * 1024 + tid;
+        if (idx < n) mine[j] = make_key(wave_best[idx], (unsigned)idx);
+    }
+    float qq = 0.f;
+    for (int j = tid; j < d; j += 1024) qq = fmaf(Q[j], Q[j], qq);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    if (lane == 0) wsum[wave] = qq;
+    __shared__ u64 wk[16];
+    u64 L = 0;
+    for (int r = 0; r < k; ++r) {
+        u64 m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = mine[j] > m ? mine[j] : m;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const u64 other = __shfl_xor(m, o, 64);
+            m = other > m ? other : m;
+        }
+        if (lane == 0) wk[wave] = m;
+        __syncthreads();
+        u64 g = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) g = wk[w] > g ? wk[w] : g;
+        L = g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mine[j] = (mine[j] == g) ? 0 : mine[j];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        qq = 0.f;
+        for (int w = 0; w < 16; ++w) qq += wsum[w];
+        thr[0] = L != 0 ? f32_unorder((unsigned)(L >> 32)) - 2.f * shadow_eps(norms, d, qq) : -3.4028234663852886e38f;
+    }
+    (void)wmax;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One query over the bf16 shadow, THRESHOLD form (the reference's call shape: nq = 1, k <= 16).
+// The candidate set is not "the best C rows" (which says nothing when more than C rows sit within the bf16 error of the
+// k-th score: frames of one video) but EVERY row whose approximate score could still belong to a top-k row:
+//   sample   ip_sample_bf16_kernel over evenly spaced chunks (~64K rows) -> s_A, a score that k sampled rows reach
+//            (the k-th largest per-wave maximum).
+//            k rows have exact score >= s_A - eps, so the exact k-th best score S* of the index is >= s_A - eps, and a
+//            row of the exact top-k has approximate score >= S* - eps >= s_A - 2 eps =: thr.
+//   collect  (this kernel) streams all of Xb once and appends (approximate score, row) of every row with score >= thr
+//            to one global list (one atomicAdd per wave and hit; a hit is one row in several thousand).
+//   rescore  exact f32 dot products of the collected rows; select: the k best of those, written out.
+//   refine   the collected list itself gives a far better bound than the sample did: L = the k-th largest of 1024 slice
+//            maxima of the collected approximate scores (k different rows reach it), so S* >= L - eps and only rows with
+//            approximate score >= L - 2 eps go on — on iid rows ~1500 collected shrink to a few dozen, on clustered rows
+//            (where whole runs pass the sample's threshold) tens of thousands shrink to the runs that matter.
+//   rescore  exact f32 dot products of what is left; select: the k best of those, written out.
+// Exact by construction whatever the data looks like — clustered, near-duplicate, all-equal — as long as the lists hold
+// the candidates (COLLECT_CAP collected, RESCORE_CAP after refinement); otherwise the gate is raised and the f32 scan
+// queued behind answers.  eps: shadow_eps().
+// ------------------------------------------------------------------------------------------------
+constexpr int COLLECT_CAP = 262144;         // rows the collect pass may hand on (2 MiB of keys)
+constexpr int RESCORE_CAP = 16384;          // rows re-scored = 16 keys per thread of the 1024-thread select kernel
+constexpr int SAMPLE_CHUNK_SHIFT = 6;       // a sample chunk = 64 groups of 8 rows = 512 rows (512 KiB at d = 512)
+constexpr int SAMPLE_CHUNKS = 128;          // 65536 sampled rows
+constexpr long long COLLECT_MIN_ROWS = 1ll << 18;
+constexpr int SAMPLE_GRID = 512;            // blocks of the sample scan: 2048 waves x 4 groups, one maximum each   // below this the f32 scan answers directly (a sample would be a quarter of it)
+
+template <int NV8, int R>
+__global__ __launch_bounds__(256) void ip_collect_bf16_kernel(const uint4* __restrict__ Xb, long long N, int d8,
+                                                              const float* __restrict__ Q, const float* __restrict__ thr_p,
+                                                              int* __restrict__ counter, u64* __restrict__ cand, int cap) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    ShadowGroup<NV8, R> grp;
+    grp.load_query(Q, d8, lane);
+    const float thr = thr_p[0];
+    const long long ngroups = (N + R - 1) / R;
+    const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+    for (long long g = gw; g < ngroups; g += nw) {
+        const long long row0 = g * R;
+        const float sc = grp.score(Xb, row0, N, d8, lane);
+        const long long row = row0 + grp.myr;
+        const bool pass = grp.owner && (row < N) && (sc >= thr);
         const u64 mask = __ballot(pass);
         if (mask != 0) {
             const int first = __ffsll((long long)mask) - 1;
@@ -702,17 +662,25 @@ __global__ __launch_bounds__(256) void ip_collect_bf16_kernel(const uint4* __res
 // Refinement of the collected list (one block): L = k-th largest of the 1024 threads' slice maxima, keep what reaches
 // L - 2 eps, compacted into cand2 (order irrelevant: the final selection orders by exact score and row).
 // ctl: [0] collected (written by the collect pass), [1] gate, [2] kept (written here).
-__global__ __launch_bounds__(1024) void collect_refine_kernel(int* __restrict__ ctl, const u64* __restrict__ cand, int k,
-                                                              const float* __restrict__ Q, int d,
+// One query per blockIdx.y (the batched search runs a whole pass of queries through the same three kernels): query q
+// uses ctl + 4 q, cand + q cap, cand2 / ekeys + q RESCORE_CAP, Q + q d.  pass_gate (optional): raised when ANY query of
+// the launch overflows, for fallbacks that redo the whole pass.
+__global__ __launch_bounds__(1024) void collect_refine_kernel(int* __restrict__ ctl, const u64* __restrict__ cand, int cap,
+                                                              int k, const float* __restrict__ Q, int d,
                                                               const float* __restrict__ norms, u64* __restrict__ cand2,
-                                                              int* __restrict__ stats) {
+                                                              int* __restrict__ stats, int* __restrict__ pass_gate,
+                                                              float extra_rel /*score error beyond shadow_eps, x |q| max|x|*/) {
     __shared__ u64 wmax[16];
     __shared__ float wsum[16];
     __shared__ int kept;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ctl += 4 * blockIdx.y;
+    cand += (size_t)blockIdx.y * cap;
+    cand2 += (size_t)blockIdx.y * RESCORE_CAP;
+    Q += (size_t)blockIdx.y * d;
     const int n = ctl[0];
-    if (n > COLLECT_CAP) {
-        if (tid == 0) { atomicOr(ctl + 1, 1); if (stats) atomicAdd(stats + 1, 1); }
+    if (n > cap) {
+        if (tid == 0) { atomicOr(ctl + 1, 1); if (pass_gate) atomicOr(pass_gate, 1); if (stats) atomicAdd(stats + 1, 1); }
         return;
     }
     if (tid == 0) kept = 0;
@@ -747,7 +715,8 @@ __global__ __launch_bounds__(1024) void collect_refine_kernel(int* __restrict__ 
 #pragma unroll
     for (int w = 0; w < 16; ++w) qq += wsum[w];
     // fewer than k non-empty slices (n < k cannot happen: the sampled rows themselves are collected): keep everything
-    const float t2 = L != 0 ? f32_unorder((unsigned)(L >> 32)) - 2.f * shadow_eps(norms, d, qq) : -3.4028234663852886e38f;
+    const float eps = shadow_eps(norms, d, qq) + extra_rel * sqrtf(qq) * norms[0];
+    const float t2 = L != 0 ? f32_unorder((unsigned)(L >> 32)) - 2.f * eps : -3.4028234663852886e38f;
     for (int i0 = 0; i0 < n; i0 += 1024) {
         const int i = i0 + tid;
         const u64 key = i < n ? cand[i] : 0;
@@ -765,7 +734,7 @@ __global__ __launch_bounds__(1024) void collect_refine_kernel(int* __restrict__ 
     __syncthreads();
     if (tid == 0) {
         ctl[2] = kept;
-        if (kept > RESCORE_CAP) { atomicOr(ctl + 1, 1); if (stats) atomicAdd(stats + 1, 1); }
+        if (kept > RESCORE_CAP) { atomicOr(ctl + 1, 1); if (pass_gate) atomicOr(pass_gate, 1); if (stats) atomicAdd(stats + 1, 1); }
     }
 }
 
@@ -773,6 +742,10 @@ __global__ __launch_bounds__(1024) void collect_refine_kernel(int* __restrict__ 
 __global__ __launch_bounds__(256) void collect_rescore_kernel(const float* __restrict__ X, int d, const float* __restrict__ Q,
                                                               const int* __restrict__ ctl,
                                                               const u64* __restrict__ cand, u64* __restrict__ ekeys) {
+    ctl += 4 * blockIdx.y;
+    cand += (size_t)blockIdx.y * RESCORE_CAP;
+    ekeys += (size_t)blockIdx.y * RESCORE_CAP;
+    Q += (size_t)blockIdx.y * d;
     if (ctl[1] != 0) return;                    // a list overflowed: the f32 scan answers
     const int n = ctl[2];
     const int lane = threadIdx.x & 63;
@@ -815,8 +788,35 @@ __global__ __launch_bounds__(1024) void collect_select_kernel(const int* __restr
                                                               int* __restrict__ stats) {
     __shared__ u64 wmax[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ctl += 4 * blockIdx.y;
+    ekeys += (size_t)blockIdx.y * RESCORE_CAP;
+    outD += (size_t)blockIdx.y * k;
+    outI += (size_t)blockIdx.y * k;
     if (ctl[1] != 0) return;
     const int n = ctl[2];
+    if (n <= 1024) {
+        // the usual case (a few dozen rows survive the refinement): rank by counting — every thread holds one key and
+        // counts the keys above it (LDS broadcast reads); rank r < k writes output r.  One barrier.
+        __shared__ u64 keys[1024];
+        const u64 mykey = tid < n ? ekeys[tid] : 0;
+        keys[tid] = mykey;
+        __syncthreads();
+        if (tid < n) {
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += keys[j] > mykey;
+            if (rank < k) {
+                const long long row = (long long)(0xFFFFFFFFu - (unsigned)(mykey & 0xFFFFFFFFull));
+                outD[rank] = f32_unorder((unsigned)(mykey >> 32));
+                outI[rank] = ids ? ids[row] : id_base + row;
+            }
+        }
+        if (tid >= n && tid < k) {        // fewer rows than k: padding
+            outD[tid] = -3.4028234663852886e38f;
+            outI[tid] = -1;
+        }
+        if (tid == 0 && stats) atomicAdd(stats, 1);
+        return;
+    }
     constexpr int PER = RESCORE_CAP / 1024;
     u64 mine[PER];
 #pragma unroll
@@ -853,97 +853,6 @@ __global__ __launch_bounds__(1024) void collect_select_kernel(const int* __restr
         __syncthreads();
     }
     if (tid == 0 && stats) atomicAdd(stats, 1);
-}
-
-// exact scores of a query's C <= 64 candidates (16 waves, up to four candidates each, all their loads in flight at once),
-// then wave 0 orders them, writes the first k, and evaluates the certificate; block q = query q of the pass.
-// *gate is raised (never cleared here) when a query cannot be certified.  (The batched two-stage search.)
-// Certificate: every block's list is as long as the candidate set kept (C), so the C-th best candidate's approximate
-// score t bounds every row that was dropped anywhere; a dropped row's exact score is <= t + eps (shadow_eps); if the
-// k-th exact score is above that the answer is the exact top-k.  all_rows: the index has no more than C rows, nothing
-// was dropped.
-__global__ __launch_bounds__(1024) void rescore_certify_kernel(const float* __restrict__ X, int d, const float* __restrict__ Q,
-                                                               const float* __restrict__ cand_scores,
-                                                               const long long* __restrict__ cand_rows, int C, int k,
-                                                               const long long* __restrict__ ids, long long id_base,
-                                                               const float* __restrict__ norms,
-                                                               float* __restrict__ outD, long long* __restrict__ outI,
-                                                               int* __restrict__ gate, int* __restrict__ stats,
-                                                               int all_rows) {
-    __shared__ float exact[64];
-    const int q = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int d4 = d >> 2;
-    const float4* qv = reinterpret_cast<const float4*>(Q + (size_t)q * d);
-    cand_scores += (size_t)q * C;
-    cand_rows += (size_t)q * C;
-    outD += (size_t)q * k;
-    outI += (size_t)q * k;
-    {
-        constexpr int PER = 4;
-        long long rows[PER];
-        float p[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int c = wave * PER + u;
-            rows[u] = c < C ? cand_rows[c] : -1;
-            p[u] = 0.f;
-        }
-        for (int j = lane; j < d4; j += 64) {
-            const float4 b = qv[j];
-            float4 a[PER];
-#pragma unroll
-            for (int u = 0; u < PER; ++u)
-                a[u] = rows[u] >= 0 ? reinterpret_cast<const float4*>(X + (size_t)rows[u] * d)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                p[u] = fmaf(a[u].x, b.x, p[u]); p[u] = fmaf(a[u].y, b.y, p[u]);
-                p[u] = fmaf(a[u].z, b.z, p[u]); p[u] = fmaf(a[u].w, b.w, p[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) p[u] += __shfl_xor(p[u], o, 64);
-            if (lane == 0) exact[wave * PER + u] = p[u];
-        }
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    const long long my_row = lane < C ? cand_rows[lane] : -1;
-    const float my_score = exact[lane];
-    float qq = 0.f;
-    for (int j = lane; j < d4; j += 64) {
-        const float4 b = qv[j];
-        qq += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
-    const u64 my_key = my_row >= 0 ? make_key(my_score, (unsigned)my_row) : 0;
-    int rank = 0, valid = 0;
-    for (int c = 0; c < 64; ++c) {
-        const u64 other = __shfl(my_key, c, 64);
-        rank += other > my_key;
-        valid += other != 0;
-    }
-    if (my_key != 0 && rank < k) {
-        outD[rank] = my_score;
-        outI[rank] = ids ? ids[my_row] : id_base + my_row;
-    }
-    if (lane < k && lane >= valid) {
-        outD[lane] = -3.4028234663852886e38f;
-        outI[lane] = -1;
-    }
-    // certificate: the k-th exact score (held by the lane of rank k-1) against the bound on everything not kept
-    const float t = cand_scores[C - 1];                              // lowest approximate score the merge kept
-    const float eps = shadow_eps(norms, d, qq);
-    const bool holder = my_key != 0 && rank == k - 1;
-    const bool ok_lane = holder && (my_score > t + eps);
-    const bool certified = all_rows != 0 || (valid >= k && __ballot(ok_lane) != 0);
-    if (lane == 0) {
-        if (!certified) atomicOr(gate, 1);
-        if (stats) atomicAdd(stats + (certified ? 0 : 1), 1);
-    }
 }
 
 static int next_pow2(int v) {
@@ -1271,7 +1180,7 @@ namespace wise {
 static int shadow_grid(long long N) {
     long long need = ((N + 7) / 8 + 3) / 4;
     if (need < 4) need = 4;
-    need = (need + 3) / 4 * 4;   // a multiple of 4: four block lists of SHADOW_L keys read as one list of SHADOW_C
+    need = (need + 3) / 4 * 4;
     // two blocks per CU: as fast as four (1.65 vs 1.69 ms at 10M x 512) and half the lists to merge
     const long long cap = g_scan_blocks_per_cu > 0 ? 256ll * g_scan_blocks_per_cu : 512;
     return need < cap ? (int)need : (int)cap;
@@ -1295,6 +1204,7 @@ extern "C" int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* X
     return WISE_OK;
 }
 
+namespace wise { struct PassWsSize { size_t total; }; static size_t pass_workspace_bytes(long long N, int d, int k); }
 extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, int k) {
     if (N < 0 || nq < 1 || !shadow_supported(d, k)) return 0;
     ScanPlan p = plan_scan(N, d, 1, k);
@@ -1302,29 +1212,28 @@ extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, 
         const ScanPlan pm = plan_scan(N, d, m, k);
         if (pm.grid > p.grid) p.grid = pm.grid;
     }
-    // one query: sample block lists | sample's best SHADOW_L | control words | collected keys | kept keys | exact keys | lists of the gated f32 scan
-    size_t one = align_up((size_t)SAMPLE_GRID * SHADOW_L * sizeof(u64), 256) + align_up((size_t)SHADOW_L * 12, 256) + 256 +
+    // one query: per-wave sample maxima | threshold | control words | collected keys | kept keys | exact keys | lists of the gated f32 scan
+    size_t one = align_up((size_t)SAMPLE_GRID * 4 * sizeof(float), 256) + 256 + 256 +
                  align_up((size_t)COLLECT_CAP * sizeof(u64), 256) + 2 * align_up((size_t)RESCORE_CAP * sizeof(u64), 256) +
                  align_up((size_t)p.grid * 4 * k * sizeof(u64), 256);
-    // batches: lists of both passes of either scan | 64 padded queries | candidates | thresholds | gate
-    size_t many = align_up((size_t)3 * split64_lists(N) * MFMA_QB2 * SHADOW_KL * sizeof(u64), 256) +
-                  align_up((size_t)MFMA_QB2 * d * sizeof(float), 256) + align_up((size_t)MFMA_QB2 * SHADOW_KL * 12, 256) +
-                  512 + 256 + align_up((size_t)MFMA_QB2 * 2 * g_scan_sample * sizeof(float), 256) +
-                  align_up((size_t)MFMA_QB2 * SHADOW_KL * sizeof(long long), 256);
+    // batches: see pass_workspace()
+    const size_t many = pass_workspace_bytes(N, d, k);
     const size_t small = N < COLLECT_MIN_ROWS ? wise_ip_topk_workspace_bytes(N, d, nq, k) : 0;   // answered by the f32 scan
     size_t best = one > many ? one : many;
     return best > small ? best : small;
 }
 
 namespace wise {
-// Threshold of query q from its n dumped sample scores: thread t takes the maximum of elements t, t + 1024, ... (1024
-// disjoint segments, each maximum a different row), the block sorts the 1024 maxima, and tau0[q] is the smallest key a
-// score equal to the kl-th largest maximum can have.  At least kl rows reach that score, so nothing below it can be
-// among the best kl of the whole index; with n = 64K it is within a hair of the exact kl-th best of the sample (the top
-// scores rarely share a segment) at a tenth of the cost of selecting it (radix select: 176 us, this: ~15 us).
-__global__ __launch_bounds__(1024) void segmax_threshold_kernel(const float* __restrict__ scores, long long n, int kl,
-                                                                u64* __restrict__ tau0) {
+// Threshold of query q from its n dumped SAMPLE scores: thread t takes the maximum of elements t, t + 1024, ... (1024
+// disjoint segments, each maximum a different row), the block sorts the 1024 maxima, L = the k-th largest: k sampled rows
+// reach it, so the exact k-th best score of the index is >= L - eps and a row of the exact top-k scores >= L - 2 eps
+// approximately.  thr[q] = L - 2 eps(q).  (A segment maximum costs a tenth of an exact selection: ~15 us against 176.)
+__global__ __launch_bounds__(1024) void batch_threshold_kernel(const float* __restrict__ scores, long long n, int k,
+                                                               const float* __restrict__ Q, int d,
+                                                               const float* __restrict__ norms, float extra_rel,
+                                                               float* __restrict__ thr) {
     __shared__ float mx[1024];
+    __shared__ float wsum[16];
     const int q = blockIdx.x, t = threadIdx.x;
     const float* sq = scores + (size_t)q * n;
     float m = -3.4028234663852886e38f;
@@ -1333,6 +1242,11 @@ __global__ __launch_bounds__(1024) void segmax_threshold_kernel(const float* __r
         m = v > m ? v : m;
     }
     mx[t] = m;
+    float qq = 0.f;
+    for (int j = t; j < d; j += 1024) qq = fmaf(Q[(size_t)q * d + j], Q[(size_t)q * d + j], qq);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    if ((t & 63) == 0) wsum[t >> 6] = qq;
     __syncthreads();
     for (int size = 2; size <= 1024; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -1346,21 +1260,22 @@ __global__ __launch_bounds__(1024) void segmax_threshold_kernel(const float* __r
             __syncthreads();
         }
     if (t == 0) {
-        const float lo = mx[kl - 1];   // n >= 1024 * 1 here (host check), so every segment holds a row
-        tau0[q] = ((u64)f32_order(lo) << 32);
+        qq = 0.f;
+        for (int w = 0; w < 16; ++w) qq += wsum[w];
+        const float eps = shadow_eps(norms, d, qq) + extra_rel * sqrtf(qq) * norms[0];
+        thr[q] = mx[k - 1] - 2.f * eps;     // n >= 1024 sampled rows (host check): every segment holds a row
     }
 }
 
-// One query (threshold form, see ip_collect_bf16_kernel): sample scan -> its SHADOW_L best -> collect every row that
+// One query (threshold form, see ip_collect_bf16_kernel): sample scan -> threshold -> collect every row that
 // could belong to the top-k -> exact scores -> the k best; the f32 scan queued behind runs only if the list overflowed.
 static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norms, long long N, int d, const float* q,
                              int k, const long long* ids, long long id_base, float* outD, long long* outI, int* stats,
                              unsigned char* wsb, hipStream_t st) {
-    u64* spart = reinterpret_cast<u64*>(wsb);
-    size_t off = align_up((size_t)SAMPLE_GRID * SHADOW_L * sizeof(u64), 256);
-    long long* samp_rows = reinterpret_cast<long long*>(wsb + off);
-    float* samp_scores = reinterpret_cast<float*>(wsb + off + (size_t)SHADOW_L * 8);
-    off += align_up((size_t)SHADOW_L * 12, 256);
+    float* wave_best = reinterpret_cast<float*>(wsb);
+    size_t off = align_up((size_t)SAMPLE_GRID * 4 * sizeof(float), 256);
+    float* thr = reinterpret_cast<float*>(wsb + off);
+    off += 256;
     int* counter = reinterpret_cast<int*>(wsb + off);     // ctl: [0] collected, [1] gate, [2] kept
     int* gate = counter + 1;
     off += 256;
@@ -1381,35 +1296,31 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norm
         const long long groups = N / 8;                  // whole groups only: a sampled group is never ragged
         const long long chunk_groups = 1ll << SAMPLE_CHUNK_SHIFT;
         const long long stride = (groups - chunk_groups) / (SAMPLE_CHUNKS - 1);      // last chunk ends inside the index
-        const long long nsample = (long long)SAMPLE_CHUNKS * chunk_groups * 8;
-        const int scap = list_cap(SHADOW_L);
-        const size_t lds = (size_t)4 * scap * 8;
+        const long long sgroups = (long long)SAMPLE_CHUNKS * chunk_groups;
         if (nv8 == 1)
-            hipLaunchKernelGGL((ip_scan_bf16_kernel<1, 1, 8>), dim3(SAMPLE_GRID), dim3(256), lds, st, xb, nsample, d8, q, SHADOW_L,
-                               scap, spart, SAMPLE_CHUNK_SHIFT, stride);
+            hipLaunchKernelGGL((ip_sample_bf16_kernel<1, 8>), dim3(SAMPLE_GRID), dim3(256), 0, st, xb, sgroups, d8, q,
+                               SAMPLE_CHUNK_SHIFT, stride, wave_best);
         else
-            hipLaunchKernelGGL((ip_scan_bf16_kernel<2, 1, 8>), dim3(SAMPLE_GRID), dim3(256), lds, st, xb, nsample, d8, q, SHADOW_L,
-                               scap, spart, SAMPLE_CHUNK_SHIFT, stride);
-        WISE_LAUNCH_CHECK("ip_scan_bf16_kernel (sample)");
-        int mw = 8192 / scap;
-        if (mw > 16) mw = 16;
-        hipLaunchKernelGGL(merge_keys_kernel, dim3(1), dim3(mw * 64), (size_t)mw * scap * 8, st, spart, SAMPLE_GRID, 1, SHADOW_L,
-                           scap, (const long long*)nullptr, 0ll, samp_scores, samp_rows, 0);
-        WISE_LAUNCH_CHECK("merge_keys_kernel (sample)");
+            hipLaunchKernelGGL((ip_sample_bf16_kernel<2, 8>), dim3(SAMPLE_GRID), dim3(256), 0, st, xb, sgroups, d8, q,
+                               SAMPLE_CHUNK_SHIFT, stride, wave_best);
+        WISE_LAUNCH_CHECK("ip_sample_bf16_kernel");
+        hipLaunchKernelGGL(sample_threshold_kernel1, dim3(1), dim3(1024), 0, st, wave_best, SAMPLE_GRID * 4, k, q, d, norms, thr);
+        WISE_LAUNCH_CHECK("sample_threshold_kernel1");
     }
     // ---- collect over all rows
     {
         ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
         const int grid = shadow_grid(N);
         if (nv8 == 1)
-            hipLaunchKernelGGL((ip_collect_bf16_kernel<1, 8>), dim3(grid), dim3(256), 0, st, xb, N, d8, q, samp_scores, k, norms,
-                               counter, cand, COLLECT_CAP);
+            hipLaunchKernelGGL((ip_collect_bf16_kernel<1, 8>), dim3(grid), dim3(256), 0, st, xb, N, d8, q, thr, counter, cand,
+                               COLLECT_CAP);
         else
-            hipLaunchKernelGGL((ip_collect_bf16_kernel<2, 8>), dim3(grid), dim3(256), 0, st, xb, N, d8, q, samp_scores, k, norms,
-                               counter, cand, COLLECT_CAP);
+            hipLaunchKernelGGL((ip_collect_bf16_kernel<2, 8>), dim3(grid), dim3(256), 0, st, xb, N, d8, q, thr, counter, cand,
+                               COLLECT_CAP);
         WISE_LAUNCH_CHECK("ip_collect_bf16_kernel");
     }
-    hipLaunchKernelGGL(collect_refine_kernel, dim3(1), dim3(1024), 0, st, counter, cand, k, q, d, norms, cand2, stats);
+    hipLaunchKernelGGL(collect_refine_kernel, dim3(1), dim3(1024), 0, st, counter, cand, COLLECT_CAP, k, q, d, norms, cand2,
+                       stats, (int*)nullptr, 0.f);
     WISE_LAUNCH_CHECK("collect_refine_kernel");
     hipLaunchKernelGGL(collect_rescore_kernel, dim3(64), dim3(256), 0, st, X, d, q, counter, cand2, ekeys);
     WISE_LAUNCH_CHECK("collect_rescore_kernel");
@@ -1435,75 +1346,85 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norm
     return WISE_OK;
 }
 
-// up to 64 queries: bf16 MFMA scan (sample pass + main pass) -> SHADOW_KL candidates per query -> exact scores +
-// certificates -> if any failed, the split-bf16 scan of the f32 rows (candidates exact to 2^-16) and its re-scoring, gated
-static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* max_norm, long long N, int d, const float* Q,
+constexpr int BATCH_CAP = 65536;            // rows per query the batched collect pass may hand on
+constexpr float BATCH_EXTRA_REL = 1.0e-5f;  // the two-piece bf16 query of the MFMA scan leaves <= 2^-17 |q| of each score unaccounted
+constexpr int BATCH_SAMPLE_SHIFT = 4;       // a sample chunk = 16 groups of 32 rows = 512 rows
+
+struct PassWs {
+    u64* mpart; float* mq; long long* cand_rows; float* cand_scores; u64* tau0; int* ctl; int* gate; float* thr;
+    float* dump; u64* cand; u64* cand2; u64* ekeys; size_t total;
+};
+static PassWs pass_workspace(unsigned char* wsb, long long N, int d, int k) {
+    PassWs w;
+    size_t off = 0;
+    const ScanPlan p2 = plan_scan(N, d, 2, k);
+    size_t lists = (size_t)2 * split64_lists(N) * MFMA_QB2 * MFMA_KL * sizeof(u64);
+    const size_t valu = (size_t)p2.grid * 4 * k * sizeof(u64);
+    if (valu > lists) lists = valu;
+    w.mpart = reinterpret_cast<u64*>(wsb + off); off += align_up(lists, 256);
+    w.mq = reinterpret_cast<float*>(wsb + off); off += align_up((size_t)MFMA_QB2 * d * sizeof(float), 256);
+    w.cand_rows = reinterpret_cast<long long*>(wsb + off);
+    w.cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)MFMA_QB2 * MFMA_KL * 8);
+    off += align_up((size_t)MFMA_QB2 * MFMA_KL * 12, 256);
+    w.tau0 = reinterpret_cast<u64*>(wsb + off); off += 512;
+    w.ctl = reinterpret_cast<int*>(wsb + off); off += MFMA_QB2 * 4 * sizeof(int);
+    w.gate = reinterpret_cast<int*>(wsb + off); off += 256;
+    w.thr = reinterpret_cast<float*>(wsb + off); off += 256;
+    w.dump = reinterpret_cast<float*>(wsb + off); off += align_up((size_t)MFMA_QB2 * SAMPLE_CHUNKS * 512 * sizeof(float), 256);
+    w.cand = reinterpret_cast<u64*>(wsb + off); off += align_up((size_t)MFMA_QB2 * BATCH_CAP * sizeof(u64), 256);
+    w.cand2 = reinterpret_cast<u64*>(wsb + off); off += align_up((size_t)MFMA_QB2 * RESCORE_CAP * sizeof(u64), 256);
+    w.ekeys = reinterpret_cast<u64*>(wsb + off); off += align_up((size_t)MFMA_QB2 * RESCORE_CAP * sizeof(u64), 256);
+    w.total = off;
+    return w;
+}
+
+static size_t pass_workspace_bytes(long long N, int d, int k) { return pass_workspace(nullptr, N, d, k).total; }
+
+// up to 64 queries (32 for 512 < d <= 1024) in the threshold form, the bf16 rows on the matrix cores: sample pass ->
+// per-query thresholds -> one pass over all bf16 rows collecting every (query, row) that could matter -> per query:
+// refine, exact scores, the k best.  If any query's list overflows the pass gate is raised and the scan of the f32 rows
+// queued behind (split-bf16 candidates + exact re-scoring, or the f32 VALU scan for d > 512) redoes the pass.
+static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* norms, long long N, int d, const float* Q,
                               int nqa, int k, const long long* ids, long long id_base, float* outD, long long* outI,
                               int* stats, unsigned char* wsb, hipStream_t st, int QB /*64, or 32 for 512 < d <= 1024*/) {
-    u64* mpart = reinterpret_cast<u64*>(wsb);
-    size_t off = align_up((size_t)3 * split64_lists(N) * MFMA_QB2 * SHADOW_KL * sizeof(u64), 256);
-    float* mq = reinterpret_cast<float*>(wsb + off);
-    off += align_up((size_t)MFMA_QB2 * d * sizeof(float), 256);
-    long long* cand_rows = reinterpret_cast<long long*>(wsb + off);
-    float* cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)MFMA_QB2 * SHADOW_KL * 8);
-    off += align_up((size_t)MFMA_QB2 * SHADOW_KL * 12, 256);
-    u64* tau0 = reinterpret_cast<u64*>(wsb + off);
-    off += 512;
-    int* gate = reinterpret_cast<int*>(wsb + off);
-    off += 256;
-    float* dump = reinterpret_cast<float*>(wsb + off);
-    off += align_up((size_t)MFMA_QB2 * 2 * g_scan_sample * sizeof(float), 256);
-    (void)off;   // (the rest of the workspace is spare)
-    hipError_t e = hipMemsetAsync(gate, 0, sizeof(int), st);
+    const PassWs w = pass_workspace(wsb, N, d, k);
+    u64* mpart = w.mpart;
+    float* mq = w.mq;
+    long long* cand_rows = w.cand_rows;
+    float* cand_scores = w.cand_scores;
+    u64* tau0 = w.tau0;
+    int* gate = w.gate;
+    hipError_t e = hipMemsetAsync(w.ctl, 0, MFMA_QB2 * 4 * sizeof(int) + sizeof(int), st);     // ctl and the pass gate behind it
     if (e == hipSuccess && nqa < QB) e = hipMemsetAsync(mq, 0, (size_t)QB * d * sizeof(float), st);
     if (e == hipSuccess) e = hipMemcpyAsync(mq, Q, (size_t)nqa * d * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) { set_error("ip_topk_shadow: query staging: %s", hipGetErrorString(e)); return (int)e; }
-    // threshold sample of the bf16 pass: 64K rows (twice the split scan's), second range 8 x that (tools: 2.34 ms per pass
-    // against 2.53 at 32K / x32)
+    // threshold sample of the fallback's own passes (split scan of the f32 rows)
     const long long ns = (g_scan_sample && N >= 16ll * g_scan_sample) ? 2 * g_scan_sample : 0;
     int rc;
-    // ---- stage 1 over the bf16 rows, in growing row ranges: each range runs under the threshold the ranges before it
-    // established (the candidate lists of a block only know that block's rows; without a good threshold a block
-    // inserts thousands of keys into 48-entry lists), and all ranges' lists are merged at the end
     {
-        const int kl = SHADOW_KL, cap = list_cap(kl);
-        int mwv = 8192 / cap;
-        if (mwv < 1) mwv = 1;
-        if (mwv > 16) mwv = 16;
-        // ranges: [0, ns) scored only (threshold pass: scores dumped, a per-query threshold from 1024 segment maxima),
-        // then [0, 32 ns) under that threshold, then the rest under the threshold the second range established
-        long long bounds[3] = {0, 0, 0};
-        int nb = 0;
-        if (ns > 0 && N >= 8ll * g_stage2_factor * ns) bounds[++nb] = (long long)g_stage2_factor * ns;
-        bounds[++nb] = N;
-        int plists = 0;
+        // ---- sample: SAMPLE_CHUNKS evenly spaced chunks of 512 rows, scores dumped; thresholds
+        const long long groups = N / 32, chunk_groups = 1ll << BATCH_SAMPLE_SHIFT;
+        const long long stride = (groups - chunk_groups) / (SAMPLE_CHUNKS - 1);
+        const long long nsample = (long long)SAMPLE_CHUNKS * chunk_groups * 32;
+        if ((rc = shadow64_scan_launch(Xb, nsample, d, mq, QB, nullptr, nullptr, nullptr, 0, st, w.dump, QB, BATCH_SAMPLE_SHIFT,
+                                       stride)))
+            return rc;
+        hipLaunchKernelGGL(batch_threshold_kernel, dim3(nqa), dim3(1024), 0, st, w.dump, nsample, k, mq, d, norms,
+                           BATCH_EXTRA_REL, w.thr);
+        WISE_LAUNCH_CHECK("batch_threshold_kernel");
+        // ---- collect over all rows
         {
             ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
-            if (ns > 0) {
-                if ((rc = shadow64_scan_launch(Xb, ns, 0, d, mq, QB, nullptr, nullptr, st, dump, QB))) return rc;
-                hipLaunchKernelGGL(segmax_threshold_kernel, dim3(QB), dim3(1024), 0, st, dump, ns, kl, tau0);
-                WISE_LAUNCH_CHECK("segmax_threshold_kernel");
-            }
-            for (int r = 0; r < nb; ++r) {
-                const long long lo = bounds[r], hi = bounds[r + 1];
-                if ((rc = shadow64_scan_launch(Xb + (size_t)lo * d, hi - lo, lo, d, mq, nqa, mpart + (size_t)plists * QB * kl,
-                                               (ns > 0) ? tau0 : nullptr, st, nullptr, QB)))
-                    return rc;
-                plists += split64_lists(hi - lo);
-                if (r + 1 < nb) {
-                    hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart, plists,
-                                       QB, kl, cap, (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
-                    WISE_LAUNCH_CHECK("merge_keys_kernel");
-                    if ((rc = sample_threshold_launch(cand_scores, cand_rows, tau0, st, kl))) return rc;
-                }
-            }
+            if ((rc = shadow64_scan_launch(Xb, N, d, mq, nqa, w.thr, w.ctl, w.cand, BATCH_CAP, st, nullptr, QB))) return rc;
         }
-        hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart, plists, QB, kl, cap,
-                           (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0);
-        WISE_LAUNCH_CHECK("merge_keys_kernel");
-        hipLaunchKernelGGL(rescore_certify_kernel, dim3(nqa), dim3(1024), 0, st, X, d, mq, cand_scores, cand_rows, kl, k, ids,
-                           id_base, max_norm, outD, outI, gate, stats, N <= (long long)kl ? 1 : 0);
-        WISE_LAUNCH_CHECK("rescore_certify_kernel");
+        hipLaunchKernelGGL(collect_refine_kernel, dim3(1, nqa), dim3(1024), 0, st, w.ctl, w.cand, BATCH_CAP, k, mq, d, norms,
+                           w.cand2, stats, gate, BATCH_EXTRA_REL);
+        WISE_LAUNCH_CHECK("collect_refine_kernel");
+        hipLaunchKernelGGL(collect_rescore_kernel, dim3(8, nqa), dim3(256), 0, st, X, d, mq, w.ctl, w.cand2, w.ekeys);
+        WISE_LAUNCH_CHECK("collect_rescore_kernel");
+        hipLaunchKernelGGL(collect_select_kernel, dim3(1, nqa), dim3(1024), 0, st, w.ctl, w.ekeys, k, ids, id_base, outD, outI,
+                           stats);
+        WISE_LAUNCH_CHECK("collect_select_kernel");
     }
     // ---- gated fallback over the f32 rows: every launch returns at once while *gate == 0
     if (QB != MFMA_QB2) {
@@ -1583,6 +1504,12 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
     // candidates), else one query at a time
     // (from two queries on: a 64-query pass costs 2.2 ms at 10M x 512 whatever it carries, two single-query searches
     // 3.4 ms; the VALU scan with 2 or 4 queries in registers is bound by its cross-lane reductions, 3.9 / 6.7 ms)
+    // an index too small for a sample (a few hundred MB at most) is answered by the f32 scans directly
+    if (N < COLLECT_MIN_ROWS) {
+        const size_t fneed = wise_ip_topk_workspace_bytes(N, d, nq, k);
+        if (fneed == 0 || fneed > workspace_bytes) { set_error("ip_topk_shadow: workspace %zu < %zu bytes", workspace_bytes, fneed); return WISE_E_WORKSPACE; }
+        return wise_ip_topk_f32(X, N, d, Q, nq, k, ids, id_base, outD, outI, workspace, workspace_bytes, stream);
+    }
     const bool batched = nq >= 2 && k <= MFMA_KC && shadow64_supported(d) && mfma_split_supported(d, 8, k) &&
                          split64_supported(d) && split_direct_enabled();
     // 512 < d <= 1024 (768: the ViT-L/14 dimension): 32 queries per pass, the f32 VALU scan as the gated fallback;
@@ -1598,13 +1525,7 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
         }
         return WISE_OK;
     }
-    // otherwise one query at a time in the threshold form; an index too small for a sample (a few hundred MB at most)
-    // is answered by the f32 scan directly
-    if (N < COLLECT_MIN_ROWS) {
-        const size_t fneed = wise_ip_topk_workspace_bytes(N, d, nq, k);
-        if (fneed == 0 || fneed > workspace_bytes) { set_error("ip_topk_shadow: workspace %zu < %zu bytes", workspace_bytes, fneed); return WISE_E_WORKSPACE; }
-        return wise_ip_topk_f32(X, N, d, Q, nq, k, ids, id_base, outD, outI, workspace, workspace_bytes, stream);
-    }
+    // otherwise one query at a time in the threshold form
     for (int q = 0; q < nq; ++q) {
         int rc = shadow_search_one(X, Xb, norms, N, d, Q + (size_t)q * d, k, lids, (long long)id_base,
                                    outD + (size_t)q * k, lI + (size_t)q * k, counters, wsb, st);

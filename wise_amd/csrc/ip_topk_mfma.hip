@@ -630,32 +630,34 @@ int split64_scan_launch(const float* X, long long N, long long row_offset, int d
 }
 
 // ------------------------------------------------------------------------------------------------
-// 64 queries per pass over the bf16 SHADOW of the index (wise_ip_topk_shadow_f32, nq >= 8): stage 1 of the batched
-// two-stage exact search.  The rows arrive as bf16, so they are MFMA A-operands as loaded (no split, no VALU work):
-// a lane's four 16-byte loads cover 32 columns of a 64-column chunk, and a product is x*(q_hi + q_lo): 16 MFMAs per
-// 4 KiB chunk and wave for the 64 queries.  Half the bytes of the f32 rows per pass; the approximate scores carry the
-// bf16 rounding of x (<= 2^-8 |x||q|), which the certificate of rescore_certify_kernel accounts for.  Lists hold
-// SHADOW_KL = 48 candidates per query (block-shared, locked, as in ip_scan_split64_kernel): LDS 128 KiB of Q images
-// + 24 KiB of lists at d = 512.  part [grid][64][SHADOW_KL].
+// 64 (or 32) queries per pass over the bf16 SHADOW of the index (wise_ip_topk_shadow_f32, two or more queries): the
+// pass over the bf16 rows of the batched two-stage exact search.  The rows arrive as bf16, so they are MFMA A-operands
+// as loaded (no split, no VALU work): a lane's four 16-byte loads cover 32 columns of a 64-column chunk, and a product is
+// x*(q_hi + q_lo): 16 MFMAs per 4 KiB chunk and wave for 64 queries.  Half the bytes of the f32 rows per pass; the
+// approximate scores carry the bf16 rounding of x and the 2^-17 left over by the two-piece query (shadow_eps).
+// Two modes (the threshold form of the single-query search, ip_topk.hip, for a whole batch):
+//   dump     the SAMPLE pass: evenly spaced chunks of 16 groups of 32 rows (chunk_shift = 4, chunk_stride in groups); the
+//            scores go to dump [QB][n sampled rows] and a per-query threshold comes out of them (batch_threshold_kernel);
+//   collect  the pass over all rows: every (query, row) whose score reaches thr[query] is appended to the query's list
+//            cand [QB][cap] (one atomic per hit; a hit is one score in several thousand), counts in ctl[4 q].
+// LDS: the Q images only (128 KiB at d = 512, 64 queries).
 // ------------------------------------------------------------------------------------------------
 constexpr int CW2 = 64;   // columns per chunk of the bf16 scan
 
 template <int PF, int QB>
 __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const bf16_t* __restrict__ Xb, long long N, int d,
-                                                                  const float* __restrict__ qpad /*[64][d]*/, int nq,
-                                                                  u64* __restrict__ part /*[grid][64][SHADOW_KL]*/,
-                                                                  long long row_offset,
-                                                                  const u64* __restrict__ tau0 /*[64] or null*/,
-                                                                  float* __restrict__ dump /*[64][N] or null*/, int abl) {
+                                                                  const float* __restrict__ qpad /*[QB][d]*/, int nq,
+                                                                  const float* __restrict__ thr /*[QB] (collect)*/,
+                                                                  int* __restrict__ ctl /*[QB][4] (collect)*/,
+                                                                  u64* __restrict__ cand /*[QB][cap] (collect)*/, int cap,
+                                                                  float* __restrict__ dump /*[QB][N] or null*/,
+                                                                  int chunk_shift, long long chunk_stride, int abl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int d4 = d >> 2, d8 = d >> 3;
     unsigned char* Qh = smem;
     unsigned char* Ql = smem + (size_t)QB * d * 2;
-    u64* lists = reinterpret_cast<u64*>(smem + (size_t)QB * d * 4);
-    int* locks = reinterpret_cast<int*>(lists + SHADOW_KL * QB);
-    constexpr int kl = SHADOW_KL;
 
     for (int idx = threadIdx.x; idx < QB * d4; idx += WAVES * 64) {
         const int j = idx / d4, c = idx - j * d4;
@@ -668,8 +670,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
         *reinterpret_cast<uint2*>(Qh + off) = make_uint2(h01, h23);
         *reinterpret_cast<uint2*>(Ql + off) = make_uint2(l01, l23);
     }
-    for (int e = threadIdx.x; e < kl * QB; e += WAVES * 64) lists[e] = 0;
-    if (threadIdx.x < QB) locks[threadIdx.x] = 0;
     __syncthreads();
 
     const int nch = d / CW2;
@@ -677,13 +677,18 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
     const long long gw = (long long)blockIdx.x * WAVES + wave, nw = (long long)gridDim.x * WAVES;
     const long long my_groups = gw < ngroups ? (ngroups - gw + nw - 1) / nw : 0;
     const long long steps = my_groups * nch;
+    // logical group -> first row it stands for (a sample visits evenly spaced chunks of 2^chunk_shift groups)
+    auto group_row = [&](long long g) {
+        return (chunk_shift >= 0 ? (g >> chunk_shift) * chunk_stride + (g & ((1ll << chunk_shift) - 1)) : g) * 32;
+    };
+    const long long row_limit = chunk_shift >= 0 ? (long long)1 << 62 : N;   // a sample holds whole groups only
 
     bf16x8 xq[PF][4];
     long long pg = gw, issued = 0;
     int pc = 0;
     auto prefetch = [&](bf16x8 (&dst)[4]) {
-        long long grow = pg * 32 + i;
-        if (grow >= N) grow = N - 1;
+        long long grow = group_row(pg) + i;
+        if (grow >= row_limit) grow = row_limit - 1;
         const bf16x8* src = reinterpret_cast<const bf16x8*>(Xb + grow * d + pc * CW2 + h * 32);
 #pragma unroll
         for (int t = 0; t < 4; ++t) dst[t] = src[t];
@@ -700,8 +705,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    u64 tau_a = tau0 ? tau0[i] : 0, tau_b = (tau0 && QB == 64) ? tau0[32 + i] : 0;
     const bool active_a = i < nq, active_b = QB == 64 && 32 + i < nq;
+    const float thr_a = (thr && active_a) ? thr[i] : 3.4028234663852886e38f;
+    const float thr_b = (thr && active_b) ? thr[32 + i] : 3.4028234663852886e38f;
     long long cg = gw;
     int cc = 0;
     const size_t ra = (size_t)i * d8 * 16, rb = (size_t)((QB == 64 ? 32 : 0) + i) * d8 * 16;
@@ -746,16 +752,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
         cc += PF;
         if (cc == nch) {
             cc = 0;
-            const long long row0 = cg * 32;
+            const long long lrow0 = cg * 32;            // logical (sample) position, for the dump
+            const long long row0 = group_row(cg);       // physical row
             cg += nw;
             if (dump) {
-                // threshold pass: no lists, the scores of this row range go to dump[q][row] for a per-query selection
+                // sample pass: the scores go to dump[q][logical row] for a per-query threshold
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < N) {
-                        dump[(size_t)i * N + row] = acc0[r];
-                        if constexpr (QB == 64) dump[(size_t)(32 + i) * N + row] = acc1[r];
+                    const long long lrow = lrow0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (lrow < N) {
+                        dump[(size_t)i * N + lrow] = acc0[r];
+                        if constexpr (QB == 64) dump[(size_t)(32 + i) * N + lrow] = acc1[r];
                     }
                     acc0[r] = 0.f; acc1[r] = 0.f;
                 }
@@ -763,29 +770,41 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
                 float t = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { t += acc0[r] + acc1[r]; acc0[r] = 0.f; acc1[r] = 0.f; }
-                if (t == 1.2345e-30f) lists[i] = 1;
+                if (t == 1.2345e-30f) ctl[0] = 1;
             } else {
-            select_group_shared<SHADOW_KL, QB>(acc0, tau_a, lists, locks, i, h, active_a, row0, N, row_offset);
-            if constexpr (QB == 64)
-                select_group_shared<SHADOW_KL, QB>(acc1, tau_b, lists, locks, 32 + i, h, active_b, row0, N, row_offset);
+                // collect: a lane holds query i (and 32 + i), 16 rows each
+                bool hit = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hit |= (acc0[r] >= thr_a) || (QB == 64 && acc1[r] >= thr_b);
+                if (__ballot(hit) != 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (row < N) {
+                            if (acc0[r] >= thr_a) {
+                                const int pos = atomicAdd(ctl + 4 * i, 1);
+                                if (pos < cap) cand[(size_t)i * cap + pos] = make_key(acc0[r], (unsigned)row);
+                            }
+                            if (QB == 64 && acc1[r] >= thr_b) {
+                                const int pos = atomicAdd(ctl + 4 * (32 + i), 1);
+                                if (pos < cap) cand[(size_t)(32 + i) * cap + pos] = make_key(acc1[r], (unsigned)row);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
             }
         }
-    }
-    if (dump) return;   // threshold pass: nothing to publish
-    __syncthreads();
-    u64* dst = part + (size_t)blockIdx.x * QB * kl;
-    for (int e = threadIdx.x; e < QB * kl; e += WAVES * 64) {
-        const int q = e / kl, r = e - q * kl;
-        dst[e] = q < nq ? lists[r * QB + q] : 0;
     }
 }
 
 bool shadow64_supported(int d) { return d % (4 * CW2) == 0 && d <= 512; }
 // 32 queries per pass: the Q images of 32 queries fit up to d = 1024 (the L/14 dimension, 768, included)
 bool shadow32_supported(int d) { return d % (4 * CW2) == 0 && d <= 1024; }
-int shadow64_scan_launch(const bf16_t* Xb, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
-                         const u64* tau0, hipStream_t st, float* dump, int qb) {
-    const size_t dl = (size_t)qb * d * 4 + (size_t)SHADOW_KL * qb * 8 + qb * 4;
+int shadow64_scan_launch(const bf16_t* Xb, long long N, int d, const float* qpad, int nq, const float* thr, int* ctl,
+                         u64* cand, int cap, hipStream_t st, float* dump, int qb, int chunk_shift, long long chunk_stride) {
+    const size_t dl = (size_t)qb * d * 4;
     static std::once_flag dattr;
     std::call_once(dattr, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 64>),
@@ -795,10 +814,10 @@ int shadow64_scan_launch(const bf16_t* Xb, long long N, long long row_offset, in
     });
     if (qb == 64)
         hipLaunchKernelGGL((ip_scan_shadow64_kernel<4, 64>), dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, Xb, N, d, qpad, nq,
-                           part, row_offset, tau0, dump, g_mfma_abl);
+                           thr, ctl, cand, cap, dump, chunk_shift, chunk_stride, g_mfma_abl);
     else
         hipLaunchKernelGGL((ip_scan_shadow64_kernel<4, 32>), dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, Xb, N, d, qpad, nq,
-                           part, row_offset, tau0, dump, g_mfma_abl);
+                           thr, ctl, cand, cap, dump, chunk_shift, chunk_stride, g_mfma_abl);
     WISE_LAUNCH_CHECK("ip_scan_shadow64_kernel");
     return WISE_OK;
 }

@@ -39,14 +39,15 @@ int split64_lists(long long N);
 bool split64_supported(int d);
 int split64_scan_launch(const float* X, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
                         const u64* tau0, hipStream_t st, const int* gate = nullptr);
-// the same over the bf16 shadow rows, SHADOW_KL candidates per query: part [split64_lists(N)][64][SHADOW_KL]
-constexpr int SHADOW_KL = 48;
+// the pass over the bf16 shadow rows, 64 or 32 queries at a time (d up to 512 / 1024): dump != null -> the scores of the
+// (sampled) rows go to dump [qb][N]; otherwise every (query, row) reaching thr[query] is appended to cand [qb][cap],
+// counts in ctl [qb][4].  chunk_shift >= 0: N counts SAMPLED rows, evenly spaced chunks of 2^chunk_shift groups of 32 rows,
+// chunk_stride groups apart
 bool shadow64_supported(int d);
-// dump != null: threshold pass — no lists; the scores of the N rows go to dump [64][N]
-// qb = 64 or 32 queries per pass (32: d up to 1024): part [split64_lists(N)][qb][SHADOW_KL], dump [qb][N]
 bool shadow32_supported(int d);
-int shadow64_scan_launch(const bf16_t* Xb, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
-                         const u64* tau0, hipStream_t st, float* dump = nullptr, int qb = 64);
+int shadow64_scan_launch(const bf16_t* Xb, long long N, int d, const float* qpad, int nq, const float* thr, int* ctl,
+                         u64* cand, int cap, hipStream_t st, float* dump = nullptr, int qb = 64, int chunk_shift = -1,
+                         long long chunk_stride = 0);
 int sample_threshold_launch(const float* cand_scores, const long long* cand_rows, u64* tau0, hipStream_t st,
                             int kl = MFMA_KL, const int* gate = nullptr);
 // exact f32 scores of cand_rows [nq][MFMA_KL], ordered, first k -> outD/outI [nq][k]
