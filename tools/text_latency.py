@@ -1,0 +1,19 @@
+"""single-query latency of the CLIP text tower (ViT-B/32 text), and a batch of 8 ViT-B/32 frames"""
+import sys, time
+from pathlib import Path
+import numpy as np, torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from wise_amd.feature.text import TextEngine, random_text_state_dict, text_spec_for
+from wise_amd.feature.vit import VitEngine, random_state_dict, spec_for
+tspec = text_spec_for("ViT-B-32", "openai")
+teng = TextEngine(tspec, random_text_state_dict(tspec, 0), max_batch=8)
+toks = torch.zeros(8, tspec.context, dtype=torch.int32, device="cuda"); toks[:, 0] = 49406; toks[:, 1:6] = 1234; toks[:, 6] = 49407
+spec = spec_for("ViT-B-32", "openai")
+eng = VitEngine(spec, random_state_dict(spec, 0), max_batch=8)
+x = torch.randn(8, 3, 224, 224, device="cuda")
+for name, fn in (("text tower, 1 query", lambda: teng.forward(toks[:1])), ("text tower, 8 queries", lambda: teng.forward(toks)),
+                 ("ViT-B/32, 8 frames (the reference's chunk)", lambda: eng.forward(x))):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50): fn()
+    torch.cuda.synchronize(); print(f"{name:45s} {(time.perf_counter() - t0) / 50 * 1e3:.4f} ms", flush=True)
