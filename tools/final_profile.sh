@@ -25,6 +25,13 @@ for C in FETCH_SIZE WRITE_SIZE; do
   cp "$(find $OUT/${TAG}_pmc_${L}_pre -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_pmc_${L}_pre_counter_collection.csv
   echo "$C passes done"
 done
+# HTSAT: every kernel of 3 whole forwards (the torch.randn fill is not a library kernel and is left out by name)
+for C in FETCH_SIZE WRITE_SIZE; do
+  L=$(echo $C | tr 'A-Z' 'a-z' | cut -d_ -f1)
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_${L}_htsat -- python3 tools/htsat_pmc.py 3 > $OUT/${TAG}_pmc_${L}_htsat.log 2>&1 || exit 1
+  cp "$(find $OUT/${TAG}_pmc_${L}_htsat -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_pmc_${L}_htsat_counter_collection.csv
+done
+echo "HTSAT PMC passes done"
 # matrix-core utilisation of the GEMM launches: busy cycles of the MFMA pipes over the launch's cycles (own pass)
 timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_mfma -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --roofline-only > $OUT/${TAG}_pmc_mfma.log 2>&1 || exit 1
 cp "$(find $OUT/${TAG}_pmc_mfma -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_pmc_mfma_counter_collection.csv

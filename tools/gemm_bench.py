@@ -31,8 +31,22 @@ SQUARE = [  # calibration against the guide's 256x256 8-phase figures (1320-1340
 ]
 
 
+HTSAT = [  # the Swin GEMMs of cfg-5 (128 clips): stage 2 (C=192), 3 (C=384), 4 (C=768); mode 2 = erf GELU
+    ("s2 qkv 131072x576x192", 131072, 576, 192, 0), ("s2 proj 131072x192x192", 131072, 192, 192, 3),
+    ("s2 fc1 131072x768x192", 131072, 768, 192, 2), ("s2 fc2 131072x192x768", 131072, 192, 768, 3),
+    ("s3 qkv 32768x1152x384", 32768, 1152, 384, 0), ("s3 proj 32768x384x384", 32768, 384, 384, 3),
+    ("s3 fc1 32768x1536x384", 32768, 1536, 384, 2), ("s3 fc2 32768x384x1536", 32768, 384, 1536, 3),
+    ("s4 qkv 8192x2304x768", 8192, 2304, 768, 0), ("s4 proj 8192x768x768", 8192, 768, 768, 3),
+    ("s4 fc1 8192x3072x768", 8192, 3072, 768, 2), ("s4 fc2 8192x768x3072", 8192, 768, 3072, 3),
+    ("merge1 131072x192x384", 131072, 192, 384, 4), ("merge2 32768x384x768", 32768, 384, 768, 4),
+]
+
+
 def main():
     args = sys.argv[1:]
+    if "--htsat" in args:
+        args.remove("--htsat")
+        SHAPES[:] = HTSAT
     if "--square" in args:
         args.remove("--square")
         SHAPES[:] = SQUARE
@@ -46,7 +60,7 @@ def main():
         bias = torch.randn(N, generator=g, device="cuda")
         ref = None
         if M <= 12800:
-            ref = A.float() @ W.float().t() + bias
+            ref = A.float() @ W.float().t() + bias   # (mode 3 adds into a zeroed output)
         res = {}
         outs = {}
         for v in variants:
@@ -57,7 +71,8 @@ def main():
             _lib.check(rc, "gemm")
             torch.cuda.synchronize()
             if ref is not None:
-                r = ref if mode == 3 else (ref * torch.sigmoid(1.702 * ref) if mode == 1 else ref)
+                r = ref if mode == 3 else (ref * torch.sigmoid(1.702 * ref) if mode == 1 else
+                                           (torch.nn.functional.gelu(ref) if mode == 2 else ref))
                 err = (out.float() - r).abs().max().item()
             else:
                 err = float("nan")

@@ -4,8 +4,9 @@ section prescribes) into profiles/pmc_traffic.json: HBM bytes per launch for the
 Corrections applied exactly as that guide states for gfx950:
   FETCH_SIZE counts 64 B per 128-B request for wide coalesced streaming reads -> doubled;
   WRITE_SIZE is exact for 16-B-per-lane streaming stores.  Both counters are in KiB.
-usage: python tools/pmc_traffic.py <fetch csv>[,<fetch csv>...] <write csv>[,<write csv>...]
-(comma-separated lists merge several profiled commands, e.g. bench.py --no-extra and tools/preproc_bench.py)
+usage: python tools/pmc_traffic.py <fetch csv>[,<fetch csv>...] <write csv>[,<write csv>...] [<htsat fetch csv> <htsat write csv> <forwards>]
+(comma-separated lists merge several profiled commands, e.g. bench.py --no-extra and tools/preproc_bench.py; the
+optional HTSAT pair comes from tools/htsat_pmc.py: ALL kernels of `forwards` whole forwards, summed -> "htsat_forward")
 """
 import csv
 import json
@@ -60,18 +61,29 @@ def main():
            "per_kernel": out}
     for key, prefix, per in (("gemm_bf16_kernel", "gemm_", 1), ("ip_scan_kernel", "ip_scan_kernel", 1),
                              ("ip_scan_mfma_kernel", "ip_scan_mfma_kernel", 1),
-                             ("ip_scan_bf16_kernel", "ip_scan_bf16_kernel", 1),
+                             ("ip_collect_bf16_kernel", "ip_collect_bf16_kernel", 1),
                              ("ip_scan_split_direct_kernel", "ip_scan_split_direct_kernel", 2),
                              ("ip_scan_split64_kernel", "ip_scan_split64_kernel", 2),
-                             ("ip_scan_shadow64_kernel", "ip_scan_shadow64_kernel", 3),
+                             ("ip_scan_shadow64_kernel", "ip_scan_shadow64_kernel", 2),
                              ("clip_resize_kernel", "clip_resize_kernel", 1), ("ivf_scan_kernel", "ivf_scan_kernel", 1),
                              ("attention_kernel", "attention_kernel", 1), ("layernorm_kernel", "layernorm_kernel", 1)):
         a = agg(prefix, per)
         if a:
             res[key] = a
+    if len(sys.argv) >= 6:
+        n_fwd = int(sys.argv[5])
+        tot_f = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(sys.argv[3])) if r["Counter_Name"] == "FETCH_SIZE"
+                    and "wise::" in r["Kernel_Name"])
+        tot_w = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(sys.argv[4])) if r["Counter_Name"] == "WRITE_SIZE"
+                    and "wise::" in r["Kernel_Name"])
+        res["htsat_forward"] = {"forwards": n_fwd, "hbm_read_bytes_per_launch": round(tot_f * 1024 * 2 / n_fwd),
+                                "hbm_write_bytes_per_launch": round(tot_w * 1024 / n_fwd),
+                                "hbm_bytes_per_launch": round((tot_f * 2 + tot_w) * 1024 / n_fwd),
+                                "note": "every kernel of a 128-clip forward summed (library kernels only)"}
+        print("htsat_forward", res["htsat_forward"]["hbm_bytes_per_launch"] / 1e9, "GB per forward")
     dst = Path(__file__).resolve().parent.parent / "profiles" / "pmc_traffic.json"
     dst.write_text(json.dumps(res, indent=1))
-    for k in ("gemm_bf16_kernel", "ip_scan_kernel", "ip_scan_bf16_kernel", "ip_scan_split_direct_kernel", "ip_scan_split64_kernel", "clip_resize_kernel"):
+    for k in ("gemm_bf16_kernel", "ip_scan_kernel", "ip_collect_bf16_kernel", "ip_scan_shadow64_kernel", "ip_scan_split_direct_kernel", "ip_scan_split64_kernel", "clip_resize_kernel"):
         if k in res:
             print(k, res[k]["hbm_bytes_per_launch"] / 1e6, "MB/launch over", res[k]["launches"], "launches")
     for k, v in out.items():

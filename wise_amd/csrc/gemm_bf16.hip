@@ -71,17 +71,17 @@ __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* lds_tile, int ro
 __device__ __forceinline__ float act_quickgelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
 }
-// erf GELU, 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 — the result is
-// rounded to bf16, 2^-9 relative, right after): one v_rcp_f32 and one v_exp_f32 plus a degree-5 Horner chain,
-// about a third of the instructions of the library erff, which matters because the epilogue applies it to
-// 64-160 values per thread (HTSAT's MLPs and the laion CLIP weights use this activation).
+// erf GELU, 0.5 x (1 + erf(x / sqrt 2)) = x Phi(x), as x * sigmoid(p(x)) with an odd degree-5 p fitted (minimax on
+// [-8, 8], tools/fit_gelu.py) to the erf form: |error| <= 2.6e-5 everywhere — a hundredth of the bf16 rounding the
+// result gets right after (2^-9 relative), and 20x closer than the tanh form (4.7e-4).  Six plain VALU operations,
+// one v_exp_f32 and one v_rcp_f32: half the issue slots of the Abramowitz-Stegun erf it replaces (|error| 5e-7, a
+// precision the bf16 output could not carry).  It matters: HTSAT applies GELU to 0.96 G values per forward — at 20
+// issue slots each that alone was ~0.6 ms of the 4.8 ms forward.  x^2 is clamped at 64 so that the x^5 term cannot turn
+// p around for |x| > 10; beyond |x| = 8 the sigmoid is saturated either way.  -log2(e) is folded into the coefficients.
 __device__ __forceinline__ float act_gelu(float x) {
-    const float z = x * 0.70710678118654752f, az = fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f),
-                                0.254829592f);
-    const float erf_abs = 1.f - poly * __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
-    return 0.5f * x * (1.f + copysignf(erf_abs, z));
+    const float x2 = fminf(x * x, 64.f);
+    const float p = x * fmaf(x2, fmaf(x2, 0.0010142630198970437f, -0.10677572339773178f), -2.301121234893799f);
+    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(p));
 }
 // GPT-2's gelu_new, 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x * sigmoid(2u): one exp2 and one rcp
 __device__ __forceinline__ float act_gelu_tanh(float x) {
@@ -1479,12 +1479,14 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
         const int tiles_m = M / 256, tiles_n = N / 256;
         const long long t256 = (long long)tiles_m * tiles_n;
         const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-        if (t256 >= 200 && (eff256 >= 0.85 || (K >= 2048 && eff256 >= 0.80)))
+        // (K < 512: a tile is 6-12 K-steps and its epilogue — the activation above all — is most of its life; the
+        // 128x128 kernel's second block per CU covers it: 131072x768x192 with GELU 120 -> 106 us, 32768x1536x384 79 -> 75)
+        if (t256 >= 200 && K >= 512 && (eff256 >= 0.85 || (K >= 2048 && eff256 >= 0.80)))
             return launch_mode(40, A, Wt, bias, M, N, K, mode, out, st);
         // (measured: worth it only when the ping-pong part spans several rounds; at 1-2 rounds the second
         // launch's own tail and the lost overlap cost more than the 128x128 kernel's slower main loop)
         // ... or from two rounds when what is left over is small (ViT-L/14 half batch: 129 x 4 tiles = 2 rounds + 4)
-        if (t256 >= 2 * 256 && g_split_m) {
+        if (t256 >= 2 * 256 && K >= 512 && g_split_m) {
             const int rounds = (int)(t256 / 256);
             const int m_pp = (rounds * 256) / tiles_n;  // m-tiles whose tiles fill `rounds` rounds (within one row)
             const bool small_rest = (tiles_m - m_pp) * 8 <= tiles_m;
