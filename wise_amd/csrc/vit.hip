@@ -136,10 +136,11 @@ using short4v = __attribute__((ext_vector_type(4))) short;
 // the FMA that subtracts the running maximum, 2^x is the bare v_exp_f32 (arguments are <= 0; results below
 // 2^-126 may flush), and the key-validity compare exists only in the MASK instantiation (the last, partial key
 // block, and causal attention).
-template <int QT, bool MASK>
-__device__ __forceinline__ void softmax_block(f32x4 (&sacc)[4][QT], bf16x8 (&pf)[2][QT], f32x4 (&oacc)[4][QT],
+template <int QT, bool MASK, int ND = 4>
+__device__ __forceinline__ void softmax_block(f32x4 (&sacc)[4][QT], bf16x8 (&pf)[2][QT], f32x4 (&oacc)[ND][QT],
                                               float (&mrun)[QT], float (&lrun)[QT], int kbase, const int (&klim)[QT]) {
-    const float sc = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+    // 1/sqrt(head dim) * log2(e); head dim = 16 ND (64, or 80 for ViT-H/14)
+    const float sc = (ND == 4 ? 0.125f : 0.11180339887498948f) * 1.4426950408889634f;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         float mx = -INFINITY;
@@ -166,7 +167,7 @@ __device__ __forceinline__ void softmax_block(f32x4 (&sacc)[4][QT], bf16x8 (&pf)
             }
         lrun[qt] = lrun[qt] * alpha + ps;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < ND; ++dt) {
             oacc[dt][qt][0] *= alpha; oacc[dt][qt][1] *= alpha;
             oacc[dt][qt][2] *= alpha; oacc[dt][qt][3] *= alpha;
         }
@@ -185,10 +186,13 @@ __device__ __forceinline__ void softmax_block(f32x4 (&sacc)[4][QT], bf16x8 (&pf)
 
 // (register budget stated explicitly: left alone the compiler spends 200-340 registers on load hoisting and the kernel,
 // which lives on latency hiding, drops to 1-2 waves per SIMD)
-template <int QT, bool CAUSAL>
-__global__ __launch_bounds__(256, QT == 2 ? 4 : 2) void attention_kernel(const bf16_t* __restrict__ qkv, int B, int T, int H,
+// DH = head dim: 64, or 80 (ViT-H/14: width 1280 over 16 heads) — then the QK^T contraction runs three 32-deep steps
+// with the last 16 channels zero, the PV product has five 16-channel output tiles and a V row is 160 bytes.
+template <int QT, bool CAUSAL, int DH = 64>
+__global__ __launch_bounds__(256, (QT == 2 && DH == 64) ? 4 : 2) void attention_kernel(const bf16_t* __restrict__ qkv, int B, int T, int H,
                                                         bf16_t* __restrict__ o) {
-    __shared__ __attribute__((aligned(16))) unsigned char v_all[4][64 * V_RS];
+    constexpr int NS = (DH + 31) / 32, ND = DH / 16, VRS = DH * 2 + 16;   // k-steps of QK^T, dh tiles of PV, V row stride
+    __shared__ __attribute__((aligned(16))) unsigned char v_all[4][64 * VRS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nqc = (T + 16 * QT - 1) / (16 * QT);
@@ -197,25 +201,27 @@ __global__ __launch_bounds__(256, QT == 2 ? 4 : 2) void attention_kernel(const b
     const int qc = (int)(item % nqc);
     const int h = (int)((item / nqc) % H);
     const int b = (int)(item / ((long long)nqc * H));
-    const int W = H * 64, W3 = 3 * W;
+    const int W = H * DH, W3 = 3 * W;
     const bf16_t* base = qkv + (size_t)b * T * W3;
     unsigned char* vimg = v_all[wave];
     const int l15 = lane & 15, g = lane >> 4;
 
     // Q fragments: B operand, lane holds Q[query = qt*16 + l15][dh = s*32 + 8g .. +7]
-    bf16x8 qf[QT][2];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 qf[QT][NS];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         int t = qc * (16 * QT) + qt * 16 + l15;
         if (t >= T) t = T - 1;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-            qf[qt][s] = *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + h * 64 + s * 32 + g * 8);
+        for (int s = 0; s < NS; ++s)
+            qf[qt][s] = (s * 32 + g * 8 < DH) ? *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + h * DH + s * 32 + g * 8)
+                                              : zero8;
     }
 
-    f32x4 oacc[4][QT];  // [dt][qt]: O^T[dh = dt*16 + g*4 + r][query = qt*16 + l15]
+    f32x4 oacc[ND][QT];  // [dt][qt]: O^T[dh = dt*16 + g*4 + r][query = qt*16 + l15]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < ND; ++i)
 #pragma unroll
         for (int j = 0; j < QT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float mrun[QT], lrun[QT];
@@ -230,15 +236,16 @@ __global__ __launch_bounds__(256, QT == 2 ? 4 : 2) void attention_kernel(const b
         //      the transpose the PV product needs is done by ds_read_b64_tr_b16 on the way out
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        constexpr int CPR = DH / 8;                     // 16-byte chunks per V row (8, or 10)
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int key = p * 8 + (lane >> 3);
+        for (int p = 0; p < CPR; ++p) {
+            const int c = p * 64 + lane, key = c / CPR, part = c - key * CPR;
             int t = kb * 64 + key;
             const bool valid = t < T;
             if (!valid) t = T - 1;
-            uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)t * W3 + 2 * W + h * 64 + (lane & 7) * 8);
+            uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)t * W3 + 2 * W + h * DH + part * 8);
             if (!valid) v = make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(vimg + key * V_RS + (lane & 7) * 16) = v;
+            *reinterpret_cast<uint4*>(vimg + key * VRS + part * 16) = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -250,13 +257,16 @@ __global__ __launch_bounds__(256, QT == 2 ? 4 : 2) void attention_kernel(const b
         for (int kt = 0; kt < 4; ++kt) {
             int t = kb * 64 + kt * 16 + l15;
             if (t >= T) t = T - 1;
-            bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + W + h * 64 + g * 8);
-            bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + W + h * 64 + 32 + g * 8);
+            bf16x8 kf[NS];
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2)
+                kf[s2] = (s2 * 32 + g * 8 < DH) ? *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + W + h * DH + s2 * 32 + g * 8)
+                                                : zero8;
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[qt][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[qt][1], c, 0, 0, 0);
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s2], qf[qt][s2], c, 0, 0, 0);
                 sacc[kt][qt] = c;
             }
         }
@@ -278,21 +288,21 @@ __global__ __launch_bounds__(256, QT == 2 ? 4 : 2) void attention_kernel(const b
                         for (int r = 0; r < 4; ++r)
                             if (kb * 64 + kt * 16 + g * 4 + r >= klim[qt]) sacc[kt][qt][r] = -INFINITY;
             }
-            softmax_block<QT, false>(sacc, pf, oacc, mrun, lrun, kb * 64 + g * 4, klim);
+            softmax_block<QT, false, ND>(sacc, pf, oacc, mrun, lrun, kb * 64 + g * 4, klim);
         }
         // ---- O^T += V^T P^T ; A operand: V^T[dh = dt*16 + l15][slot 8g + j] with
         //      slot j<4 -> key ks*32 + g*4 + j ; j>=4 -> key ks*32 + 16 + g*4 + (j-4)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < ND; ++dt) {
                 // transposed LDS read: the 16 lanes of group g fetch a 4-key x 16-dh block; lane 4q+p supplies
                 // the address of key row q, dh 4p..4p+3 and receives dh column (dt*16 + l15) of the 4 keys
-                const unsigned char* blk = vimg + (ks * 32 + g * 4 + (l15 >> 2)) * V_RS + (dt * 16 + (l15 & 3) * 4) * 2;
+                const unsigned char* blk = vimg + (ks * 32 + g * 4 + (l15 >> 2)) * VRS + (dt * 16 + (l15 & 3) * 4) * 2;
                 const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (__attribute__((address_space(3))) short4v*)(blk));
                 const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4v*)(blk + 16 * V_RS));
+                    (__attribute__((address_space(3))) short4v*)(blk + 16 * VRS));
                 union { short8 s; bf16x8 f; } cv;
                 cv.s = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
@@ -311,11 +321,11 @@ __global__ __launch_bounds__(256, QT == 2 ? 4 : 2) void attention_kernel(const b
         const int t = qc * (16 * QT) + qt * 16 + l15;
         if (t < T) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < ND; ++dt) {
                 uint2 pk;
                 pk.x = pack_bf16x2(oacc[dt][qt][0] * inv, oacc[dt][qt][1] * inv);
                 pk.y = pack_bf16x2(oacc[dt][qt][2] * inv, oacc[dt][qt][3] * inv);
-                *reinterpret_cast<uint2*>(o + ((size_t)b * T + t) * W + h * 64 + dt * 16 + g * 4) = pk;
+                *reinterpret_cast<uint2*>(o + ((size_t)b * T + t) * W + h * DH + dt * 16 + g * 4) = pk;
             }
         }
     }
@@ -323,9 +333,17 @@ __global__ __launch_bounds__(256, QT == 2 ? 4 : 2) void attention_kernel(const b
 
 static int g_attn_qt = 0;  // query tiles (of 16) per wave; 0 = by sequence length (debug knob overrides)
 
-int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st, bool causal) {
+int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st, bool causal, int dh) {
     WISE_CHECK_ARG(qkv && o && B > 0 && T > 0 && H > 0, "attention: bad argument");
+    WISE_CHECK_ARG(dh == 64 || (dh == 80 && !causal), "attention: head dim %d (64, or 80 without a mask)", dh);
     if (g_ablate & 4) return WISE_OK;
+    if (dh == 80) {   // ViT-H/14 (T = 257): 64 queries per wave
+        const int nqc = (T + 63) / 64;
+        const long long items = (long long)B * H * nqc;
+        hipLaunchKernelGGL((attention_kernel<4, false, 80>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, B, T, H, o);
+        WISE_LAUNCH_CHECK("attention_kernel");
+        return WISE_OK;
+    }
     // 32 queries per wave hides latency best when one key block covers T; longer sequences prefer 64 queries per
     // wave (K/V re-read half as often).  (Measured and dropped: a block-per-head kernel that stages K/V once in
     // LDS for all query chunks of a head — at T = 257 it was 5 % slower: the loop is bound by the softmax VALU work
@@ -522,7 +540,7 @@ int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int a
         const float* lpf = bw.pf + bw.per_layer_f * l;
         if ((rc = layernorm_f32_bf16(x, lpf + bw.ln1_w, lpf + bw.ln1_b, M, W, 1e-5f, h, st))) return rc;
         if ((rc = gemm_bf16(h, lwb + bw.in_proj, lpf + bw.in_b, Mp, 3 * W, W, 0, qkv, st))) return rc;
-        if ((rc = attention_bf16(qkv, batch, T, H, h, st, causal))) return rc;
+        if ((rc = attention_bf16(qkv, batch, T, H, h, st, causal, W / H))) return rc;
         if ((rc = gemm_bf16(h, lwb + bw.out_proj, lpf + bw.out_b, Mp, W, W, 3, x, st))) return rc;
         if ((rc = layernorm_f32_bf16(x, lpf + bw.ln2_w, lpf + bw.ln2_b, M, W, 1e-5f, h, st))) return rc;
         // act: 0 QuickGELU, 1 erf GELU, 2 gelu_new (tanh) -> epilogue modes 1, 2, 5
@@ -567,8 +585,8 @@ static int vit_dims(const wise_vit_config* c, VitDims* d) {
     d->S = c->image_size; d->P = c->patch; d->W = c->width; d->L = c->layers; d->H = c->heads;
     d->F = c->mlp; d->D = c->embed_dim;
     WISE_CHECK_ARG(d->P > 0 && d->S > 0 && d->S % d->P == 0, "vit: image_size %d not a multiple of patch %d", d->S, d->P);
-    WISE_CHECK_ARG(d->W > 0 && d->W % 128 == 0 && d->H * 64 == d->W, "vit: width %d must be heads*64 and a multiple of 128",
-                   d->W);
+    WISE_CHECK_ARG(d->W > 0 && d->W % 128 == 0 && (d->H * 64 == d->W || d->H * 80 == d->W),
+                   "vit: width %d must be heads * 64 (or heads * 80: ViT-H/14) and a multiple of 128", d->W);
     WISE_CHECK_ARG(d->F > 0 && d->F % 128 == 0, "vit: mlp %d must be a multiple of 128", d->F);
     WISE_CHECK_ARG(d->D > 0 && d->L >= 0 && d->W <= 4096 && d->W % 8 == 0, "vit: bad dims");
     WISE_CHECK_ARG(c->act == 0 || c->act == 1, "vit: act must be 0 (quick_gelu) or 1 (gelu)");
@@ -878,9 +896,9 @@ extern "C" int wise_layernorm_f32_bf16(const float* x, const float* w, const flo
 }
 
 extern "C" int wise_attention_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream) {
-    return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, false);
+    return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, false, 64);
 }
 
 extern "C" int wise_attention_causal_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream) {
-    return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, true);
+    return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, true, 64);
 }
