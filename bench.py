@@ -552,35 +552,39 @@ def main():
                                                    "share_of_forward": round(hg_ms / a_steps / (step_s * 1e3), 3)}}}
         del heng, wav
         torch.cuda.empty_cache()
-        # cfg-4 (image half): ViT-L/14 at bs=256 per GPU
-        lspec = spec_for("ViT-L-14", "openai")
-        leng = VitEngine(lspec, random_state_dict(lspec, 0), max_batch=args.batch)
+        # cfg-4 (image half): ViT-L/14 at bs=256 per GPU; and ViT-H/14 (head width 80), the image tower of the reference's
+        # default feature id (extract-features.py:192)
+        for key, lname, ltag, label in (("vit_l14", "ViT-L-14", "openai", "ViT-L/14"),
+                                        ("vit_h14", "ViT-H-14", "laion2b_s32b_b79k", "ViT-H/14")):
+            lspec = spec_for(lname, ltag)
+            leng = VitEngine(lspec, random_state_dict(lspec, 0), max_batch=args.batch)
 
-        def l14_step(i):
-            hold["l"] = leng.forward_pipelined(x)
+            def l14_step(i):
+                hold["l"] = leng.forward_pipelined(x)
 
-        def l14_step_serial(i):
-            hold["ls"] = leng.forward(x)
+            def l14_step_serial(i):
+                hold["ls"] = leng.forward(x)
 
-        l_steps = max(4, min(args.steps, 6))
-        for i in range(2):
-            l14_step_serial(i)
-        ldt_serial = timed_region(l14_step_serial, l_steps, world)
-        for i in range(2):
-            l14_step(i)
-        torch.cuda.synchronize()
-        ldt = timed_region(l14_step, l_steps, world)
-        assert torch.equal(hold["l"].result(), hold["ls"]), "ViT-L/14: in-flight and serial embeddings differ"
-        lfps = world * args.batch * l_steps / ldt
-        extra["vit_l14"] = {"value": round(lfps, 1), "unit": "frames/s", "ms_per_step": round(ldt / l_steps * 1e3, 3),
-                            "steps": l_steps, "batches_in_flight": 2,
-                            "one_batch_at_a_time_frames_per_s": round(world * args.batch * l_steps / ldt_serial, 1),
-                            "config": {"workload": "OpenCLIP ViT-L/14 image tower, bs=256 per GPU",
-                                                         "gflop_per_frame": round(lspec.flops_per_frame() / 1e9, 2)},
-                            "tflops": round(lfps / world * lspec.flops_per_frame() / 1e12, 2),
-                            "frac_of_bf16_peak": round(lfps / world * lspec.flops_per_frame() / 1e12 / PEAK_BF16_TFLOPS, 4)}
-        del leng
-        torch.cuda.empty_cache()
+            l_steps = max(4, min(args.steps, 6))
+            for i in range(2):
+                l14_step_serial(i)
+            ldt_serial = timed_region(l14_step_serial, l_steps, world)
+            for i in range(2):
+                l14_step(i)
+            torch.cuda.synchronize()
+            ldt = timed_region(l14_step, l_steps, world)
+            assert torch.equal(hold["l"].result(), hold["ls"]), f"{label}: in-flight and serial embeddings differ"
+            lfps = world * args.batch * l_steps / ldt
+            extra[key] = {"value": round(lfps, 1), "unit": "frames/s", "ms_per_step": round(ldt / l_steps * 1e3, 3),
+                          "steps": l_steps, "batches_in_flight": 2,
+                          "one_batch_at_a_time_frames_per_s": round(world * args.batch * l_steps / ldt_serial, 1),
+                          "config": {"workload": f"OpenCLIP {label} image tower, bs={args.batch} per GPU",
+                                     "gflop_per_frame": round(lspec.flops_per_frame() / 1e9, 2)},
+                          "tflops": round(lfps / world * lspec.flops_per_frame() / 1e12, 2),
+                          "frac_of_bf16_peak": round(lfps / world * lspec.flops_per_frame() / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            hold.pop("l", None); hold.pop("ls", None)
+            del leng
+            torch.cuda.empty_cache()
         # f2: decoded uint8 frames [256,3,240,320] resident in HBM -> GPU transform -> ViT-B/32 (uint8 in)
         from wise_amd.feature.preprocess import ClipPreprocessor, make_plan
 

@@ -285,7 +285,9 @@ int wise_layernorm_f32_bf16(const float* x, const float* w, const float* b, int 
                             float eps, uint16_t* y, void* stream);
 /* qkv [B*T, 3*H*64] bf16 (q|k|v packed like in_proj) -> o [B*T, H*64] bf16 ; softmax(QK^T/8)V */
 int wise_attention_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream);
-/* the same with the causal mask of the text tower: query t attends keys <= t */
+/* the same at head dim dh = 64 or 80 (ViT-H/14: width 1280 over 16 heads): qkv [B*T, 3*H*dh], softmax(QK^T/sqrt(dh))V */
+int wise_attention_dh_bf16(const uint16_t* qkv, int B, int T, int H, int dh, uint16_t* o, void* stream);
+/* head dim 64 with the causal mask of the text tower: query t attends keys <= t */
 int wise_attention_causal_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream);
 
 #ifdef __cplusplus

@@ -26,6 +26,8 @@ GOLD = ROOT / "tests" / "golden"
 
 TINY = VitSpec("tiny", 64, 32, 128, 2, 2, 512, 64, "quick_gelu")
 TINY_GELU = VitSpec("tiny-gelu", 56, 14, 128, 1, 2, 256, 32, "gelu")
+# head width 80 as in ViT-H/14 (width 640 over 8 heads), 9 x 9 patches + class token = 82 tokens: two key blocks
+TINY_H80 = VitSpec("tiny-h80", 126, 14, 640, 2, 8, 1280, 64, "gelu")
 
 
 def seeded_frames(n: int, S: int, seed: int) -> np.ndarray:
@@ -140,8 +142,10 @@ def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     golden_vit(TINY, 7, 3, 11, "vit_tiny.npz", full_taps=True, pin=True)
     golden_vit(TINY_GELU, 8, 2, 12, "vit_tiny_gelu.npz", full_taps=True, pin=True)
+    golden_vit(TINY_H80, 9, 2, 13, "vit_tiny_h80.npz", full_taps=True, pin=True)
     golden_vit(spec_for("ViT-B-32"), 0, 4, 1, "vit_b32.npz", full_taps=False, pin=True)
     golden_vit(spec_for("ViT-L-14"), 0, 2, 5, "vit_l14.npz", full_taps=False, pin=True)
+    golden_vit(spec_for("ViT-H-14", "laion2b_s32b_b79k"), 0, 2, 6, "vit_h14.npz", full_taps=False, pin=True)
     golden_ip()
 
 

@@ -113,13 +113,13 @@ def vit_forward(sd: Dict[str, torch.Tensor], images: torch.Tensor, *, patch: int
     return out
 
 
-def attention_ref(qkv: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
-    """qkv [B*T, 3*H*64] -> o [B*T, H*64]; the op wise_attention_bf16 computes."""
-    Wd = H * 64
+def attention_ref(qkv: torch.Tensor, B: int, T: int, H: int, dh: int = 64) -> torch.Tensor:
+    """qkv [B*T, 3*H*dh] -> o [B*T, H*dh]; the op wise_attention_bf16 / wise_attention_dh_bf16 computes."""
+    Wd = H * dh
     q, k, v = qkv.to(torch.float32).reshape(B, T, 3 * Wd).split(Wd, dim=-1)
-    q = q.reshape(B, T, H, 64).transpose(1, 2)
-    k = k.reshape(B, T, H, 64).transpose(1, 2)
-    v = v.reshape(B, T, H, 64).transpose(1, 2)
-    s = (q @ k.transpose(-1, -2)) / 8.0
+    q = q.reshape(B, T, H, dh).transpose(1, 2)
+    k = k.reshape(B, T, H, dh).transpose(1, 2)
+    v = v.reshape(B, T, H, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
     pr = torch.softmax(s, dim=-1)
     return (pr @ v).transpose(1, 2).reshape(B * T, Wd)

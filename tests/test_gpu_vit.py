@@ -109,6 +109,32 @@ def test_attention(B, T, H):
     assert cosine(got, ref) >= 1 - 1e-4
 
 
+@pytest.mark.parametrize("B,T,H", [(1, 1, 8), (2, 26, 8), (2, 82, 8), (1, 64, 16), (3, 257, 16), (1, 300, 8)])
+def test_attention_head_dim_80(B, T, H):
+    """ViT-H/14's head width: three 32-deep steps of QK^T with the tail zero, five 16-channel tiles of PV"""
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(B * 1000 + T + H)
+    W = H * 80
+    qkv = torch.randn(B * T, 3 * W, generator=g)
+    qkv[:, : 2 * W] *= 1.8
+    qkv = bf16_round(qkv)
+    o = torch.full((B * T, W), float("nan"), dtype=torch.bfloat16, device="cuda")
+    qd = qkv.to(torch.bfloat16).cuda()
+    _lib.check(lib.wise_attention_dh_bf16(qd.data_ptr(), B, T, H, 80, o.data_ptr(), _lib.stream_ptr()), "attn")
+    ref = vit_ref.attention_ref(qkv, B, T, H, 80)
+    got = o.float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 3e-2
+    assert cosine(got, ref) >= 1 - 1e-4
+    # head dim 64 through the same entry equals the plain one
+    qkv64 = bf16_round(torch.randn(B * T, 3 * H * 64, generator=g)).to(torch.bfloat16).cuda()
+    o1 = torch.empty(B * T, H * 64, dtype=torch.bfloat16, device="cuda"); o2 = torch.empty_like(o1)
+    _lib.check(lib.wise_attention_dh_bf16(qkv64.data_ptr(), B, T, H, 64, o1.data_ptr(), _lib.stream_ptr()), "attn")
+    _lib.check(lib.wise_attention_bf16(qkv64.data_ptr(), B, T, H, o2.data_ptr(), _lib.stream_ptr()), "attn")
+    assert torch.equal(o1, o2)
+    assert lib.wise_attention_dh_bf16(qkv64.data_ptr(), B, T, H, 72, o1.data_ptr(), _lib.stream_ptr()) != 0
+
+
 def load_golden(golden_dir, name):
     g = np.load(golden_dir / name)
     s = [int(v) for v in g["spec"]]
@@ -118,7 +144,8 @@ def load_golden(golden_dir, name):
     return spec, g, torch.from_numpy(frames)
 
 
-@pytest.mark.parametrize("name", ["vit_tiny.npz", "vit_tiny_gelu.npz", "vit_b32.npz", "vit_l14.npz"])
+@pytest.mark.parametrize("name", ["vit_tiny.npz", "vit_tiny_gelu.npz", "vit_tiny_h80.npz", "vit_b32.npz", "vit_l14.npz",
+                                  "vit_h14.npz"])
 def test_vit_golden(golden_dir, name):
     spec, g, frames = load_golden(golden_dir, name)
     sd = random_state_dict(spec, int(g["weight_seed"]))

@@ -101,6 +101,11 @@ def test_argument_validation_without_gpu():
     assert nb.value == 768 * 3072 + 12 * (3 * 768 * 768 + 768 * 768 + 2 * 3072 * 768) + 512 * 768
     bad = _lib.VitConfig(224, 32, 700, 12, 12, 3072, 512, 0)
     assert lib.wise_vit_layout(C.byref(bad), C.byref(nb), C.byref(nf)) == -1
+    h14 = spec_for("ViT-H-14", "laion2b_s32b_b79k").c_config()            # head width 80
+    assert lib.wise_vit_layout(C.byref(h14), C.byref(nb), C.byref(nf)) == 0
+    assert nb.value == 1280 * 640 + 32 * (4 * 1280 * 1280 + 2 * 5120 * 1280) + 1024 * 1280
+    bad = _lib.VitConfig(224, 14, 1280, 32, 10, 5120, 1024, 1)           # head width 128: not served
+    assert lib.wise_vit_layout(C.byref(bad), C.byref(nb), C.byref(nf)) == -1
 
 
 def test_weight_packing_layout():

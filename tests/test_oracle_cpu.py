@@ -20,7 +20,7 @@ def _golden(golden_dir, name):
     return spec, g, torch.from_numpy(frames)
 
 
-@pytest.mark.parametrize("name", ["vit_tiny.npz", "vit_tiny_gelu.npz", "vit_b32.npz"])
+@pytest.mark.parametrize("name", ["vit_tiny.npz", "vit_tiny_gelu.npz", "vit_tiny_h80.npz", "vit_b32.npz"])
 def test_vit_oracle_reproduces_golden(golden_dir, name):
     spec, g, frames = _golden(golden_dir, name)
     sd = random_state_dict(spec, int(g["weight_seed"]))
@@ -57,6 +57,13 @@ def test_reference_shape_contract():
     assert spec_for("ViT-B-32", "laion2b_s34b_b79k").act == "gelu"
     assert spec_for("ViT-B-32").flops_per_frame() == 8_817_623_040
     assert spec_for("ViT-L-14").flops_per_frame() == 162_025_537_536
+    # the reference's default feature id (extract-features.py:192): ViT-H/14 image tower, head width 80
+    from wise_amd.feature.mlfoundation_openclip import list_pretrained
+    assert ("xlm-roberta-large-ViT-H-14", "frozen_laion5b_s13b_b90k") in list_pretrained()
+    h = spec_for("xlm-roberta-large-ViT-H-14", "frozen_laion5b_s13b_b90k")
+    assert (h.width, h.heads, h.width // h.heads, h.layers, h.mlp, h.embed_dim, h.tokens, h.act) == \
+        (1280, 16, 80, 32, 5120, 1024, 257, "gelu")
+    assert spec_for("ViT-H-14-quickgelu", "dfn5b").act == "quick_gelu"
 
 
 def _c_oracle():

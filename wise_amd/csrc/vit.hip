@@ -337,10 +337,10 @@ int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_
     WISE_CHECK_ARG(qkv && o && B > 0 && T > 0 && H > 0, "attention: bad argument");
     WISE_CHECK_ARG(dh == 64 || (dh == 80 && !causal), "attention: head dim %d (64, or 80 without a mask)", dh);
     if (g_ablate & 4) return WISE_OK;
-    if (dh == 80) {   // ViT-H/14 (T = 257): 64 queries per wave
-        const int nqc = (T + 63) / 64;
+    if (dh == 80) {   // ViT-H/14 (T = 257): 48 queries per wave — 64 would spill (80 accumulator registers for O alone)
+        const int nqc = (T + 47) / 48;
         const long long items = (long long)B * H * nqc;
-        hipLaunchKernelGGL((attention_kernel<4, false, 80>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, B, T, H, o);
+        hipLaunchKernelGGL((attention_kernel<3, false, 80>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, B, T, H, o);
         WISE_LAUNCH_CHECK("attention_kernel");
         return WISE_OK;
     }
@@ -899,6 +899,9 @@ extern "C" int wise_attention_bf16(const uint16_t* qkv, int B, int T, int H, uin
     return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, false, 64);
 }
 
+extern "C" int wise_attention_dh_bf16(const uint16_t* qkv, int B, int T, int H, int dh, uint16_t* o, void* stream) {
+    return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, false, dh);
+}
 extern "C" int wise_attention_causal_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream) {
     return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, true, 64);
 }

@@ -30,6 +30,10 @@ KNOWN_PRETRAINED = {
     "ViT-B-32-quickgelu": ("openai", "laion400m_e31", "laion400m_e32"),
     "ViT-B-16": ("openai", "laion400m_e31", "laion400m_e32", "laion2b_s34b_b88k"),
     "ViT-L-14": ("openai", "laion400m_e31", "laion400m_e32", "laion2b_s32b_b82k"),
+    # head width 80; the multilingual pair is the reference's default feature id (extract-features.py:192)
+    "ViT-H-14": ("laion2b_s32b_b79k",),
+    "ViT-H-14-quickgelu": ("dfn5b",),
+    "xlm-roberta-large-ViT-H-14": ("frozen_laion5b_s13b_b90k",),
 }
 
 
@@ -118,7 +122,9 @@ class MlfoundationOpenClip(FeatureExtractor):
         self._gpu_preprocess = None
         # text tower (query side): built on first use; seeded models may run on the merge-less
         # byte tokenizer because open_clip's merge file does not exist offline
-        self.text_spec = text_spec_for(model, "openai" if seed is not None else tag)
+        # xlm-roberta-large-ViT-H-14: the image tower (the extraction hot path) is this library's; its text tower is
+        # HF XLM-RoBERTa-large with a sentencepiece vocabulary, which this build does not carry -> text queries raise
+        self.text_spec = None if model.startswith("xlm-roberta") else text_spec_for(model, "openai" if seed is not None else tag)
         self._seed = seed
         self._text_engine = None
         self._tokenizer = None
@@ -147,7 +153,8 @@ class MlfoundationOpenClip(FeatureExtractor):
         random_image = torch.rand((1, 3,) + self.input_image_size)
         feats = self.extract_image_features(self.preprocess_image(random_image))
         assert feats.shape[1] == self.output_dim
-        assert self.text_spec.embed_dim == self.output_dim  # both towers embed into the same space (:67-73)
+        # both towers embed into the same space (:67-73)
+        assert self.text_spec is None or self.text_spec.embed_dim == self.output_dim
 
     def get_output_dim(self):
         return self.output_dim
@@ -190,8 +197,14 @@ class MlfoundationOpenClip(FeatureExtractor):
         pending = self._get_engine().forward_pipelined(images.to(torch.float32) if images.dtype != torch.uint8 else images)
         return _AsyncFeatures(pending)
 
+    def _require_text_tower(self):
+        if self.text_spec is None:
+            raise NotImplementedError(f"{self.pretrained_model_name}: the XLM-RoBERTa text tower is not part of this "
+                                      "build (image features only); query it with a CLIP-text model's index")
+
     @property
     def tokenizer(self) -> ClipTokenizer:
+        self._require_text_tower()
         if self._tokenizer is None:
             self._tokenizer = ClipTokenizer.default(self.text_spec.context, allow_merge_less=self._seed is not None)
             if self._tokenizer.vocab_size > self.text_spec.vocab:
@@ -199,6 +212,7 @@ class MlfoundationOpenClip(FeatureExtractor):
         return self._tokenizer
 
     def _get_text_engine(self) -> TextEngine:
+        self._require_text_tower()
         if self._text_engine is None:
             sd = random_text_state_dict(self.text_spec, self._seed) if self._seed is not None else self._state_dict
             self._text_engine = TextEngine(self.text_spec, sd, device="cuda")

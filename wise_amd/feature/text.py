@@ -52,6 +52,7 @@ TEXT_SPECS: Dict[str, TextSpec] = {
     "ViT-B-32": TextSpec("ViT-B-32", 512, 8, 12, 512),
     "ViT-B-16": TextSpec("ViT-B-16", 512, 8, 12, 512),
     "ViT-L-14": TextSpec("ViT-L-14", 768, 12, 12, 768),
+    "ViT-H-14": TextSpec("ViT-H-14", 1024, 16, 24, 1024),
 }
 
 

@@ -47,7 +47,7 @@ class VitSpec:
     def flops_per_frame(self) -> int:
         """2*MAC of the contractions only."""
         g2, T, W, F, D = self.grid ** 2, self.tokens, self.width, self.mlp, self.embed_dim
-        per_layer = T * W * 3 * W * 2 + 2 * self.heads * T * T * 64 * 2 + T * W * W * 2 + 2 * T * W * F * 2
+        per_layer = T * W * 3 * W * 2 + 2 * self.heads * T * T * (W // self.heads) * 2 + T * W * W * 2 + 2 * T * W * F * 2
         return g2 * self.kdim * W * 2 + self.layers * per_layer + W * D * 2
 
     def c_config(self) -> _lib.VitConfig:
@@ -60,6 +60,9 @@ SPECS: Dict[str, VitSpec] = {
     "ViT-B-32": VitSpec("ViT-B-32", 224, 32, 768, 12, 12, 3072, 512),
     "ViT-B-16": VitSpec("ViT-B-16", 224, 16, 768, 12, 12, 3072, 512),
     "ViT-L-14": VitSpec("ViT-L-14", 224, 14, 1024, 24, 16, 4096, 768),
+    # head width 80 (open_clip model_configs/ViT-H-14.json); xlm-roberta-large-ViT-H-14 has the same image tower
+    "ViT-H-14": VitSpec("ViT-H-14", 224, 14, 1280, 32, 16, 5120, 1024),
+    "xlm-roberta-large-ViT-H-14": VitSpec("xlm-roberta-large-ViT-H-14", 224, 14, 1280, 32, 16, 5120, 1024),
 }
 
 
