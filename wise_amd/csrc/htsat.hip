@@ -36,7 +36,7 @@ int frontend(const float* wave, int B, int samples, int Fc, const float* hann, c
              const float* mel_len, const float* mel_wt, const float* bn_scale, const float* bn_shift, float* melbn,
              hipStream_t st);
 static int g_frontend_only = 0;  // (debug) stop after the front end: concurrency tests tap the log-mel
-static int g_fuse_ln = 3;  // bit 0: LayerNorm-in-GEMM fusion, bit 1: fused MLP (stage 1); wise_debug_set_htsat flips them off
+static int g_fuse_ln = 7;  // bit 0: LayerNorm-in-GEMM fusion, bit 1: fused MLP (stage 1), bit 2: fused attention half of a stage-1 block; wise_debug_set_htsat flips them off
 constexpr int N_FFT = 1024, HOP = 320, N_MELS = 64, MELW = 32, MAXF = 1024;
 constexpr int EMBED = 96, LATENT = 768, OUT = 1024;
 constexpr int DEPTHS[4] = {2, 2, 6, 2};
@@ -276,6 +276,271 @@ __global__ __launch_bounds__(256, 4) void swin_attention_kernel(const bf16_t* __
                 *reinterpret_cast<uint2*>(orow + dh) = pk;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 1 (C = 96, 4 heads of 24, 64 x 64 tokens per clip): the whole attention half of a Swin block in one kernel,
+//     x += proj( window_attention( LN1(x) W_qkv^T + b_qkv ) ) + b_proj          (in place; a window owns its 64 tokens)
+// so that per block the activations cross HBM once each way (24 KiB in, 24 KiB out per window) instead of four times
+// (LN-GEMM out 36 KiB, attention in 36 + out 12, projection in 12 + 24 + out 24).
+// A workgroup = 4 waves = the 4 heads of one window, persistent over windows (blockIdx, +gridDim, ...):
+//   1. all 256 threads: LayerNorm of the window's 64 rows (4 threads per row, exact two-pass statistics) -> bf16 image
+//      in LDS (the MFMA operand layout: row-major, 208-byte rows);
+//   2. wave h: q_h, k_h as TRANSPOSED products W x^T (lane = token, registers = head-dim) and v_h as x W^T (lane = head
+//      dim, registers = token): the accumulators, packed to bf16, ARE the operands of S^T = K Q^T and O^T = V^T P^T —
+//      the head-dim (resp. key) index is permuted the same way on both sides of each contraction, so nothing is
+//      exchanged.  W_{q,k,v} of the head stay in registers for the life of the workgroup (18 fragments);
+//   3. softmax with relative-position bias and shift mask exactly as swin_attention_kernel; O_h -> bf16 image in LDS;
+//   4. wave w: output projection of token tile w (W_proj image in LDS, loaded once per workgroup) + bias + residual,
+//      lane = token with 4 consecutive channels -> 16-byte read-modify-write of x.
+// ------------------------------------------------------------------------------------------------
+constexpr int SB_LD = 104;    // bf16 per LDS row: 96 + 8 (208 B = 13 x 16 B: rows fall on distinct 16-byte slots mod 256 B)
+
+__global__ __launch_bounds__(256, 2) void swin96_block_attn_kernel(float* __restrict__ x, int B, int shift,
+                                                                   const float* __restrict__ n1w, const float* __restrict__ n1b,
+                                                                   const bf16_t* __restrict__ wqkv /*[288][96]*/,
+                                                                   const float* __restrict__ qkvb /*[288]*/,
+                                                                   const float* __restrict__ bias /*[4][64][64]*/,
+                                                                   const bf16_t* __restrict__ wproj /*[96][96]*/,
+                                                                   const float* __restrict__ pb /*[96]*/) {
+    constexpr int H = 64, W = 64, C = 96;
+    __shared__ __attribute__((aligned(16))) bf16_t a_img[64 * SB_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t o_img[64 * SB_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t wp_img[96 * SB_LD];
+    __shared__ __attribute__((aligned(16))) float ln_g[96], ln_b[96];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int h = wv;                                  // this wave's head
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- once per workgroup: W_proj image, this head's weight fragments and biases
+    for (int c = tid; c < 96 * 12; c += 256) {
+        const int r = c / 12, part = c - r * 12;
+        *reinterpret_cast<uint4*>(wp_img + r * SB_LD + part * 8) = *reinterpret_cast<const uint4*>(wproj + r * 96 + part * 8);
+    }
+    bf16x8 wf[3][2][3];                                // [q,k,v][head-dim tile][k-step]: row = head dim dt*16+l15, 8 channels at ks*32+g*8
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int dh = dt * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+                wf[m][dt][ks] = dh < 24 ? *reinterpret_cast<const bf16x8*>(wqkv + (size_t)(m * C + h * 24 + dh) * C + ks * 32 + g * 8)
+                                        : zero8;
+        }
+    float bq[2][4], bk[2][4], bvv[2];                  // q/k: head dim dt*16+g*4+r (registers); v: head dim dt*16+l15 (lane)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int dh = dt * 16 + g * 4 + r;
+            bq[dt][r] = dh < 24 ? qkvb[h * 24 + dh] : 0.f;
+            bk[dt][r] = dh < 24 ? qkvb[C + h * 24 + dh] : 0.f;
+        }
+        bvv[dt] = (dt * 16 + l15) < 24 ? qkvb[2 * C + h * 24 + dt * 16 + l15] : 0.f;
+    }
+    // LayerNorm role of this thread: row tid>>2, channels (tid&3)*24 .. +23
+    const int lrow = tid >> 2, lq = tid & 3;
+    if (tid < 96) { ln_g[tid] = n1w[tid]; ln_b[tid] = n1b[tid]; }
+    const float scale = 0.20412414523193154f;  // 24^-0.5
+    const float LOG2E = 1.4426950408889634f;
+    const float* bh = bias + (size_t)h * 4096;
+
+    __syncthreads();                                   // wp_img, ln_g, ln_b
+    const int nwin_total = B * 64;
+    for (int item = blockIdx.x; item < nwin_total; item += gridDim.x) {
+        const int b = item >> 6, win = item & 63;
+        const int wy = win >> 3, wx = win & 7;
+        float* xb = x + (size_t)b * H * W * C;
+        // the bias table and b_proj do not change from window to window; reloading them (L1/L2 hits) is cheaper than the
+        // 88 registers the compiler would pin for them across the loop — so their addresses are made opaque per trip
+        const float* bhw = bh;
+        const float* pbw = pb;
+        asm volatile("" : "+v"(bhw), "+v"(pbw));
+        auto row_of = [&](int p) {
+            int y = wy * 8 + (p >> 3) + shift, xx = wx * 8 + (p & 7) + shift;
+            if (y >= H) y -= H;
+            if (xx >= W) xx -= W;
+            return y * W + xx;
+        };
+        auto region_of = [&](int p) {
+            const int ys = wy * 8 + (p >> 3), xs = wx * 8 + (p & 7);
+            const int ry = (ys >= H - 8) + (ys >= H - 4), rx = (xs >= W - 8) + (xs >= W - 4);
+            return ry * 3 + rx;
+        };
+        // ---- 1. LayerNorm of the window's rows -> a_img
+        {
+            const float* xr = xb + (size_t)row_of(lrow) * C + lq * 24;
+            float v[24];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(xr + i * 4);
+                v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+            }
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) sm += v[i];
+            sm += __shfl_xor(sm, 1, 64);
+            sm += __shfl_xor(sm, 2, 64);
+            const float mean = sm * (1.f / 96.f);
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) { v[i] -= mean; sq = fmaf(v[i], v[i], sq); }
+            sq += __shfl_xor(sq, 1, 64);
+            sq += __shfl_xor(sq, 2, 64);
+            const float rstd = rsqrtf(sq * (1.f / 96.f) + 1e-5f);
+            bf16_t* dst = a_img + lrow * SB_LD + lq * 24;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 gg = *reinterpret_cast<const float4*>(ln_g + lq * 24 + 8 * i + 4 * j);
+                    const float4 bb = *reinterpret_cast<const float4*>(ln_b + lq * 24 + 8 * i + 4 * j);
+                    y[4 * j] = fmaf(v[8 * i + 4 * j] * rstd, gg.x, bb.x);
+                    y[4 * j + 1] = fmaf(v[8 * i + 4 * j + 1] * rstd, gg.y, bb.y);
+                    y[4 * j + 2] = fmaf(v[8 * i + 4 * j + 2] * rstd, gg.z, bb.z);
+                    y[4 * j + 3] = fmaf(v[8 * i + 4 * j + 3] * rstd, gg.w, bb.w);
+                }
+                uint4 pk;
+                pk.x = pack_bf16x2(y[0], y[1]); pk.y = pack_bf16x2(y[2], y[3]);
+                pk.z = pack_bf16x2(y[4], y[5]); pk.w = pack_bf16x2(y[6], y[7]);
+                *reinterpret_cast<uint4*>(dst + 8 * i) = pk;
+            }
+        }
+        __syncthreads();
+        // ---- 2. q, k (transposed products) and v of this head, straight into operand form
+        bf16x8 qf[4], kf[4], vf[2][2];
+        {
+            f32x4 vacc[4][2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bf16x8 xf[3];
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks)
+                    xf[ks] = *reinterpret_cast<const bf16x8*>(a_img + (t * 16 + l15) * SB_LD + ks * 32 + g * 8);
+                f32x4 qa[2], ka[2];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    qa[dt] = f32x4{bq[dt][0], bq[dt][1], bq[dt][2], bq[dt][3]};
+                    ka[dt] = f32x4{bk[dt][0], bk[dt][1], bk[dt][2], bk[dt][3]};
+                    vacc[t][dt] = f32x4{bvv[dt], bvv[dt], bvv[dt], bvv[dt]};
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+                        qa[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][dt][ks], xf[ks], qa[dt], 0, 0, 0);
+                        ka[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][dt][ks], xf[ks], ka[dt], 0, 0, 0);
+                        vacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ks], wf[2][dt][ks], vacc[t][dt], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    qf[t][r] = (__bf16)qa[0][r]; qf[t][4 + r] = (__bf16)qa[1][r];
+                    kf[t][r] = (__bf16)ka[0][r]; kf[t][4 + r] = (__bf16)ka[1][r];
+                }
+            }
+            // V^T operand of k-step ks (key slots: registers 0-3 = keys (2ks)*16+g*4+r, 4-7 = keys (2ks+1)*16+g*4+r — the
+            // order the probabilities are packed in below)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        vf[ks][dt][r] = (__bf16)vacc[2 * ks][dt][r];
+                        vf[ks][dt][4 + r] = (__bf16)vacc[2 * ks + 1][dt][r];
+                    }
+        }
+        // ---- 3. per query tile: S^T = K Q^T, softmax (+ relative-position bias, shift mask), O^T = V^T P^T
+        unsigned long long regk = 0ull;                // shift-region id of key kt*16+g*4+r in nibble kt*4+r
+        if (shift > 0) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) regk |= (unsigned long long)region_of(kt * 16 + g * 4 + r) << (4 * (kt * 4 + r));
+        }
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            const int q = qt * 16 + l15;
+            const int regq = (shift > 0) ? region_of(q) : 0;
+            float mx = -INFINITY;
+            float s2[4][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const float4 bb = *reinterpret_cast<const float4*>(bhw + q * 64 + kt * 16 + g * 4);
+                const float bv4[4] = {bb.x, bb.y, bb.z, bb.w};
+                const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sv = sa[r] * scale + bv4[r];
+                    if (shift > 0 && (int)((regk >> (4 * (kt * 4 + r))) & 15ull) != regq) sv += -100.f;
+                    sv *= LOG2E;
+                    s2[kt][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float ps = 0.f;
+            float p[4][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[kt][r] = __builtin_amdgcn_exp2f(s2[kt][r] - mx);
+                    ps += p[kt][r];
+                }
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            const float linv = 1.f / ps;
+            f32x4 oa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 pf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[r] = (__bf16)p[2 * ks][r];
+                    pf[4 + r] = (__bf16)p[2 * ks + 1][r];
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) oa[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks][dt], pf, oa[dt], 0, 0, 0);
+            }
+            // lane (query l15, g): head dims dt*16 + g*4 + r
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int dh = dt * 16 + g * 4;
+                if (dh < 24) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(oa[dt][0] * linv, oa[dt][1] * linv);
+                    pk.y = pack_bf16x2(oa[dt][2] * linv, oa[dt][3] * linv);
+                    *reinterpret_cast<uint2*>(o_img + q * SB_LD + h * 24 + dh) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 4. projection of token tile wv, + bias + residual, in place
+        {
+            bf16x8 of[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+                of[ks] = *reinterpret_cast<const bf16x8*>(o_img + (wv * 16 + l15) * SB_LD + ks * 32 + g * 8);
+            float* xr = xb + (size_t)row_of(wv * 16 + l15) * C + g * 4;
+#pragma unroll
+            for (int nt = 0; nt < 6; ++nt) {
+                const float4 xv = *reinterpret_cast<const float4*>(xr + nt * 16);
+                const float4 pbv = *reinterpret_cast<const float4*>(pbw + nt * 16 + g * 4);
+                f32x4 acc = f32x4{xv.x + pbv.x, xv.y + pbv.y, xv.z + pbv.z, xv.w + pbv.w};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const bf16x8 wpf = *reinterpret_cast<const bf16x8*>(wp_img + (nt * 16 + l15) * SB_LD + ks * 32 + g * 8);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpf, of[ks], acc, 0, 0, 0);
+                }
+                *reinterpret_cast<float4*>(xr + nt * 16) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
+        // the next trip's LayerNorm writes a_img only after every wave has passed the barrier above (its a_img reads are
+        // long done), and its o_img writes come after the next trip's first barrier (this trip's o_img reads are done)
     }
 }
 
@@ -536,6 +801,14 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
             // At C = 192 the fused kernel (one block per CU) loses to LayerNorm + the tuned GEMMs (113 vs 93 us,
             // 173 vs 140 us), so stage 2 keeps the two-kernel form.
             const bool fuse_ln = (g_fuse_ln & 1) && C == 96 && gemm_ln_supported(3 * C, C, 0);
+            if (C == 96 && H == 64 && (g_fuse_ln & 4)) {
+                // stage 1: LayerNorm, QKV, window attention, projection and residual add in one kernel (2 workgroups per CU)
+                const int nwin = B * 64;
+                const int grid = nwin < 512 ? nwin : 512;
+                hipLaunchKernelGGL(swin96_block_attn_kernel, dim3(grid), dim3(256), 0, st, x, B, shift, n1w, n1b, wq, qb, rb,
+                                   wproj, pb);
+                WISE_LAUNCH_CHECK("htsat swin96_block_attn_kernel");
+            } else {
             if (fuse_ln) {
                 if ((rc = gemm_ln_bf16(x, n1w, n1b, wq, qb, Mp, 3 * C, C, 1e-5f, 0, qkv, st))) return rc;
             } else {
@@ -549,6 +822,7 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
                 WISE_LAUNCH_CHECK("htsat swin_attention_kernel");
             }
             if ((rc = gemm_bf16(h, wproj, pb, Mp, C, C, 3, x, st))) return rc;
+            }
             if (C == 96 && (g_fuse_ln & 2)) {
                 // the whole MLP in one kernel: the 384-wide hidden activations (403 MB at batch 128) stay on chip
                 if ((rc = mlp96_fused(x, n2w, n2b, wf1, f1b, wf2, f2b, Mp, 1e-5f, st))) return rc;
@@ -591,7 +865,7 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
 
 #ifdef WISE_DEBUG_KNOBS
 extern "C" int wise_debug_set_htsat(int flags) {
-    wise::htsat::g_fuse_ln = 3 & ~flags;   // flags bit 0: no LayerNorm fusion at all, bit 1: no fused MLP
+    wise::htsat::g_fuse_ln = 7 & ~(flags & 7);   // flags bit 0: no LayerNorm fusion at all, bit 1: no fused MLP, bit 2: no fused attention half
     wise::htsat::g_frontend_only = (flags >> 3) & 1;   // bit 3: front end only
     return 0;
 }
