@@ -15,6 +15,7 @@
 //              -> LN -> fc1 GEMM(+GELU) -> fc2 GEMM(+resid); PatchMerging = gather+LN kernel + GEMM
 //   head       final LN, token mean, Projection (linear1, GELU, linear2, LN(e1+e2)), L2 normalise
 #include "common.h"
+#include <type_traits>
 
 namespace wise {
 
@@ -40,6 +41,11 @@ static int g_fuse_ln = 7;  // bit 0: LayerNorm-in-GEMM fusion, bit 1: fused MLP 
 constexpr int N_FFT = 1024, HOP = 320, N_MELS = 64, MELW = 32, MAXF = 1024;
 constexpr int EMBED = 96, LATENT = 768, OUT = 1024;
 constexpr int DEPTHS[4] = {2, 2, 6, 2};
+// 16 bytes per lane from global memory straight into LDS (base wave-uniform, lane i lands at base + 16 i)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
 constexpr int HEADS[4] = {4, 8, 16, 32};
 
 // ------------------------------------------------------------------------------------------------
@@ -297,27 +303,63 @@ __global__ __launch_bounds__(256, 4) void swin_attention_kernel(const bf16_t* __
 // ------------------------------------------------------------------------------------------------
 constexpr int SB_LD = 104;    // bf16 per LDS row: 96 + 8 (208 B = 13 x 16 B: rows fall on distinct 16-byte slots mod 256 B)
 
-__global__ __launch_bounds__(256, 2) void swin96_block_attn_kernel(float* __restrict__ x, int B, int shift,
+template <int SHIFT /*0, or 4: the odd block of a stage*/>
+__global__ __launch_bounds__(256, 2) void swin96_block_attn_kernel(float* __restrict__ x, int B,
                                                                    const float* __restrict__ n1w, const float* __restrict__ n1b,
                                                                    const bf16_t* __restrict__ wqkv /*[288][96]*/,
                                                                    const float* __restrict__ qkvb /*[288]*/,
                                                                    const float* __restrict__ bias /*[4][64][64]*/,
                                                                    const bf16_t* __restrict__ wproj /*[96][96]*/,
                                                                    const float* __restrict__ pb /*[96]*/) {
-    constexpr int H = 64, W = 64, C = 96;
+    constexpr int H = 64, W = 64, C = 96, shift = SHIFT;
+    __shared__ __attribute__((aligned(16))) float x_img[64 * C];     // the window's rows as fetched (LDS-DMA, dense)
     __shared__ __attribute__((aligned(16))) bf16_t a_img[64 * SB_LD];
     __shared__ __attribute__((aligned(16))) bf16_t o_img[64 * SB_LD];
     __shared__ __attribute__((aligned(16))) bf16_t wp_img[96 * SB_LD];
     __shared__ __attribute__((aligned(16))) float ln_g[96], ln_b[96];
+    // relative-position bias, compact: the [64][64] table of a head is Toeplitz in (dy, dx), 15 x 15 distinct values;
+    // stored reversed and pre-multiplied by log2(e):  rpb[h][224 - ((dy+7)*15 + dx+7)] = bias_h(dy, dx) * log2(e)
+    __shared__ float rpb[4][228];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int h = wv;                                  // this wave's head
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float LOG2E = 1.4426950408889634f;
+    const int nwin_total = B * 64;
 
-    // ---- once per workgroup: W_proj image, this head's weight fragments and biases
+    // rows of window `it` (token p of the window -> row of the clip's 64 x 64 grid, cyclic shift by addressing)
+    auto row_of = [&](int it, int p) {
+        const int win = it & 63;
+        int y = (win >> 3) * 8 + (p >> 3) + shift, xx = (win & 7) * 8 + (p & 7) + shift;
+        if (y >= H) y -= H;
+        if (xx >= W) xx -= W;
+        return (it >> 6) * (H * W) + y * W + xx;
+    };
+    // fetch window `it` into x_img: 24 pieces of 1 KiB, 6 per wave, each lane 16 bytes of one row
+    auto fetch_window = [&](int it) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int c = wv * 6 + j;
+            const int off = c * 1024 + lane * 16;      // byte offset in the dense [64][384 B] image
+            const int row = off / 384, colb = off - row * 384;
+            glds16(reinterpret_cast<const unsigned char*>(x + (size_t)row_of(it, row) * C) + colb,
+                   reinterpret_cast<unsigned char*>(x_img) + c * 1024);
+        }
+    };
+    if ((int)blockIdx.x < nwin_total) fetch_window(blockIdx.x);
+
+    // ---- once per workgroup: W_proj image, LayerNorm affine terms, the compact bias tables; this head's weight
+    // fragments and biases
     for (int c = tid; c < 96 * 12; c += 256) {
         const int r = c / 12, part = c - r * 12;
         *reinterpret_cast<uint4*>(wp_img + r * SB_LD + part * 8) = *reinterpret_cast<const uint4*>(wproj + r * 96 + part * 8);
+    }
+    if (tid < 96) { ln_g[tid] = n1w[tid]; ln_b[tid] = n1b[tid]; }
+    for (int e = tid; e < 4 * 225; e += 256) {
+        const int hh = e / 225, j = e - hh * 225;
+        const int ti = 224 - j, dy = ti / 15 - 7, dx = ti % 15 - 7;
+        const int qy = dy > 0 ? dy : 0, qx = dx > 0 ? dx : 0, ky = qy - dy, kx = qx - dx;
+        rpb[hh][j] = bias[(size_t)hh * 4096 + (qy * 8 + qx) * 64 + ky * 8 + kx] * LOG2E;
     }
     bf16x8 wf[3][2][3];                                // [q,k,v][head-dim tile][k-step]: row = head dim dt*16+l15, 8 channels at ks*32+g*8
 #pragma unroll
@@ -341,38 +383,29 @@ __global__ __launch_bounds__(256, 2) void swin96_block_attn_kernel(float* __rest
         }
         bvv[dt] = (dt * 16 + l15) < 24 ? qkvb[2 * C + h * 24 + dt * 16 + l15] : 0.f;
     }
-    // LayerNorm role of this thread: row tid>>2, channels (tid&3)*24 .. +23
-    const int lrow = tid >> 2, lq = tid & 3;
-    if (tid < 96) { ln_g[tid] = n1w[tid]; ln_b[tid] = n1b[tid]; }
-    const float scale = 0.20412414523193154f;  // 24^-0.5
-    const float LOG2E = 1.4426950408889634f;
-    const float* bh = bias + (size_t)h * 4096;
+    const int lrow = tid >> 2, lq = tid & 3;           // LayerNorm role: row tid>>2, channels (tid&3)*24 .. +23
+    const float sc = 0.20412414523193154f * LOG2E;     // 24^-0.5, in the exp2 domain
+    // bias address of this lane: query (qt*2 + (l15>>3), l15&7), key (kt*2 + (g>>1), (g&1)*4 + r)
+    //   reversed index = 224 - ((qy-ky+7)*15 + qx-kx+7) = [22 - c_lane] + [90 - (qt-kt)*30 + r],  c_lane in [-19, 22]
+    const float* rp_lane = &rpb[h][22 - (((l15 >> 3) - (g >> 1)) * 15 + (l15 & 7) - (g & 1) * 4)];
 
-    __syncthreads();                                   // wp_img, ln_g, ln_b
-    const int nwin_total = B * 64;
     for (int item = blockIdx.x; item < nwin_total; item += gridDim.x) {
-        const int b = item >> 6, win = item & 63;
+        const int win = item & 63;
         const int wy = win >> 3, wx = win & 7;
-        float* xb = x + (size_t)b * H * W * C;
-        // the bias table and b_proj do not change from window to window; reloading them (L1/L2 hits) is cheaper than the
-        // 88 registers the compiler would pin for them across the loop — so their addresses are made opaque per trip
-        const float* bhw = bh;
-        const float* pbw = pb;
-        asm volatile("" : "+v"(bhw), "+v"(pbw));
-        auto row_of = [&](int p) {
-            int y = wy * 8 + (p >> 3) + shift, xx = wx * 8 + (p & 7) + shift;
-            if (y >= H) y -= H;
-            if (xx >= W) xx -= W;
-            return y * W + xx;
-        };
         auto region_of = [&](int p) {
             const int ys = wy * 8 + (p >> 3), xs = wx * 8 + (p & 7);
             const int ry = (ys >= H - 8) + (ys >= H - 4), rx = (xs >= W - 8) + (xs >= W - 4);
             return ry * 3 + rx;
         };
-        // ---- 1. LayerNorm of the window's rows -> a_img
+        // b_proj does not change from window to window; reloading it (cache hits) is cheaper than the registers the
+        // compiler would pin for it across the loop — so its address is made opaque per trip
+        const float* pbw = pb;
+        asm volatile("" : "+v"(pbw));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of x_img have landed
+        __syncthreads();                                   // ... and everybody else's (first trip: the setup above too)
+        // ---- 1. LayerNorm of the window's rows: x_img -> a_img
         {
-            const float* xr = xb + (size_t)row_of(lrow) * C + lq * 24;
+            const float* xr = x_img + lrow * C + lq * 24;
             float v[24];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -411,6 +444,8 @@ __global__ __launch_bounds__(256, 2) void swin96_block_attn_kernel(float* __rest
             }
         }
         __syncthreads();
+        // x_img is free: the next window's rows travel while this one is computed
+        if (item + (int)gridDim.x < nwin_total) fetch_window(item + gridDim.x);
         // ---- 2. q, k (transposed products) and v of this head, straight into operand form
         bf16x8 qf[4], kf[4], vf[2][2];
         {
@@ -453,8 +488,12 @@ __global__ __launch_bounds__(256, 2) void swin96_block_attn_kernel(float* __rest
                     }
         }
         // ---- 3. per query tile: S^T = K Q^T, softmax (+ relative-position bias, shift mask), O^T = V^T P^T
+        // Only the windows of the last row / column of a shifted block hold tokens of different regions: the mask is
+        // compiled into its own copy of the loop, chosen per window (uniform branch)
+        auto attend = [&](auto masked) {
+        constexpr bool MASK = decltype(masked)::value;
         unsigned long long regk = 0ull;                // shift-region id of key kt*16+g*4+r in nibble kt*4+r
-        if (shift > 0) {
+        if (MASK) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -463,19 +502,16 @@ __global__ __launch_bounds__(256, 2) void swin96_block_attn_kernel(float* __rest
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
             const int q = qt * 16 + l15;
-            const int regq = (shift > 0) ? region_of(q) : 0;
+            const int regq = MASK ? region_of(q) : 0;
             float mx = -INFINITY;
             float s2[4][4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const float4 bb = *reinterpret_cast<const float4*>(bhw + q * 64 + kt * 16 + g * 4);
-                const float bv4[4] = {bb.x, bb.y, bb.z, bb.w};
                 const f32x4 sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float sv = sa[r] * scale + bv4[r];
-                    if (shift > 0 && (int)((regk >> (4 * (kt * 4 + r))) & 15ull) != regq) sv += -100.f;
-                    sv *= LOG2E;
+                    float sv = fmaf(sa[r], sc, rp_lane[90 - (qt - kt) * 30 + r]);
+                    if (MASK && (int)((regk >> (4 * (kt * 4 + r))) & 15ull) != regq) sv += -100.f * LOG2E;
                     s2[kt][r] = sv;
                     mx = fmaxf(mx, sv);
                 }
@@ -518,14 +554,18 @@ __global__ __launch_bounds__(256, 2) void swin96_block_attn_kernel(float* __rest
                 }
             }
         }
+        };
+        if (shift > 0 && (wy == 7 || wx == 7)) attend(std::true_type{});
+        else attend(std::false_type{});
         __syncthreads();
-        // ---- 4. projection of token tile wv, + bias + residual, in place
+        // ---- 4. projection of token tile wv, + bias + residual, in place (the rows come from cache: they were fetched for
+        // x_img moments ago)
         {
             bf16x8 of[3];
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks)
                 of[ks] = *reinterpret_cast<const bf16x8*>(o_img + (wv * 16 + l15) * SB_LD + ks * 32 + g * 8);
-            float* xr = xb + (size_t)row_of(wv * 16 + l15) * C + g * 4;
+            float* xr = x + (size_t)row_of(item, wv * 16 + l15) * C + g * 4;
 #pragma unroll
             for (int nt = 0; nt < 6; ++nt) {
                 const float4 xv = *reinterpret_cast<const float4*>(xr + nt * 16);
@@ -539,8 +579,8 @@ __global__ __launch_bounds__(256, 2) void swin96_block_attn_kernel(float* __rest
                 *reinterpret_cast<float4*>(xr + nt * 16) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             }
         }
-        // the next trip's LayerNorm writes a_img only after every wave has passed the barrier above (its a_img reads are
-        // long done), and its o_img writes come after the next trip's first barrier (this trip's o_img reads are done)
+        // LDS reuse: a_img is rewritten only after the next trip's first barrier (its reads ended before the barrier above);
+        // o_img only after the next trip's second barrier (this trip's reads end before its first)
     }
 }
 
@@ -805,8 +845,12 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
                 // stage 1: LayerNorm, QKV, window attention, projection and residual add in one kernel (2 workgroups per CU)
                 const int nwin = B * 64;
                 const int grid = nwin < 512 ? nwin : 512;
-                hipLaunchKernelGGL(swin96_block_attn_kernel, dim3(grid), dim3(256), 0, st, x, B, shift, n1w, n1b, wq, qb, rb,
-                                   wproj, pb);
+                if (shift)
+                    hipLaunchKernelGGL(swin96_block_attn_kernel<4>, dim3(grid), dim3(256), 0, st, x, B, n1w, n1b, wq, qb, rb,
+                                       wproj, pb);
+                else
+                    hipLaunchKernelGGL(swin96_block_attn_kernel<0>, dim3(grid), dim3(256), 0, st, x, B, n1w, n1b, wq, qb, rb,
+                                       wproj, pb);
                 WISE_LAUNCH_CHECK("htsat swin96_block_attn_kernel");
             } else {
             if (fuse_ln) {
