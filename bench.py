@@ -519,9 +519,9 @@ def main():
         for depth, C_ in ((2, 96), (2, 192), (6, 384), (2, 768)):
             T = T0 // (C_ // 96) ** 2
             x32, a16 = T * C_ * 4, T * C_ * 2
-            ln_fused = C_ <= 192            # LayerNorm inside the GEMM's A-tile build (stages 1-2)
-            mlp_fused = C_ == 96            # the whole MLP in one kernel (stage 1)
-            attn_half = (x32 + 3 * a16 if ln_fused else x32 + a16 + a16 + 3 * a16) + (3 * a16 + a16) + (a16 + 2 * x32)
+            ln_fused = False                # (LayerNorm inside the GEMM's A-tile build: only stage 1 used it, and stage 1 is now
+            mlp_fused = C_ == 96            #  two kernels per block:) the attention half and the whole MLP, one kernel each
+            attn_half = 2 * x32 if C_ == 96 else (x32 + a16 + a16 + 3 * a16) + (3 * a16 + a16) + (a16 + 2 * x32)
             mlp_half = 2 * x32 if mlp_fused else ((x32 + 4 * a16 if ln_fused else x32 + a16 + a16 + 4 * a16) + 4 * a16 + 2 * x32)
             blocks += depth * (attn_half + mlp_half)
             fused_ideal += depth * 2 * x32

@@ -845,6 +845,8 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
                 // stage 1: LayerNorm, QKV, window attention, projection and residual add in one kernel (2 workgroups per CU)
                 const int nwin = B * 64;
                 const int grid = nwin < 512 ? nwin : 512;
+                // counted with the GEMM family: the QKV and projection products (the 64 x 64 attention products are not)
+                ProfScope prof(PROF_GEMM, 2.0 * (double)M * 96.0 * (288.0 + 96.0), st);
                 if (shift)
                     hipLaunchKernelGGL(swin96_block_attn_kernel<4>, dim3(grid), dim3(256), 0, st, x, B, n1w, n1b, wq, qb, rb,
                                        wproj, pb);
