@@ -232,6 +232,38 @@ int wise_text_forward(const wise_text_config* cfg, const uint16_t* wb, const flo
 int wise_text_tap_residual(const wise_text_config* cfg, int batch, const void* workspace, float* dst, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * HP-2 query side for open_clip models whose text tower wraps a Hugging Face encoder (`HFTextEncoder`):
+ *       XLM-RoBERTa with the mean pooler and the two-layer MLP projection — the text tower of
+ *       xlm-roberta-large-ViT-H-14/frozen_laion5b_s13b_b90k, the reference's DEFAULT feature id
+ *       (extract-features.py:192; reached from src/feature/mlfoundation_openclip.py:103-108 like wise_text_forward).
+ *       tokens int32 [batch, context], right-padded with pad_id (the HF tokenizer's padding='max_length').
+ * Weight layout (host packer: wise_amd/feature/xlmr_text.py):
+ *   wb bf16: per layer  W_qkv [3W,W] (query|key|value), W_out [W,W], W_fc1 [F,W], W_fc2 [W,F];  then the projection
+ *            W_p1 [Hd,W], W_p2 [D,Hd]  (open_clip 'mlp' proj, Hd = (W + D)/2, no biases)
+ *   pf fp32: word_emb [V,W], pos_emb [P,W], type_emb row 0 [W], embedding LayerNorm w,b;  per layer  b_qkv [3W],
+ *            b_out [W], attention-output LayerNorm w,b, b_fc1 [F], b_fc2 [W], output LayerNorm w,b
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct wise_xlmr_config {
+    int32_t context;        /* T: 77 (open_clip's context_length) */
+    int32_t vocab;          /* V: 250002 */
+    int32_t max_positions;  /* P: 514 */
+    int32_t width;          /* W: 1024; multiple of 128, head dim 64 */
+    int32_t layers;         /* L: 24 */
+    int32_t heads;          /* H = W/64 */
+    int32_t mlp;            /* F: 4096 */
+    int32_t proj_hidden;    /* Hd: (W + D)/2 */
+    int32_t embed_dim;      /* D: 1024 */
+    int32_t pad_id;         /* 1 */
+} wise_xlmr_config;
+int wise_xlmr_layout(const wise_xlmr_config* cfg, int64_t* wb_elems, int64_t* pf_elems);
+size_t wise_xlmr_workspace_bytes(const wise_xlmr_config* cfg, int batch);
+int wise_xlmr_forward(const wise_xlmr_config* cfg, const uint16_t* wb, const float* pf, const int32_t* tokens,
+                      int batch, float* out /* [batch, D] fp32, L2-normalised */, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* parity tap: residual stream fp32 [batch*context, W] of the last forward with the same batch */
+int wise_xlmr_tap_residual(const wise_xlmr_config* cfg, int batch, const void* workspace, float* dst, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HP-1  image transform on the GPU: replaces the per-frame CPU loop of
  *       MlfoundationOpenClip.preprocess_image, src/feature/mlfoundation_openclip.py:81-90, for uint8 frames
  *       [n,3,H,W] (the decoder's output, src/dataloader/dataset.py:298):
@@ -287,6 +319,9 @@ int wise_layernorm_f32_bf16(const float* x, const float* w, const float* b, int 
 int wise_attention_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream);
 /* the same at head dim dh = 64 or 80 (ViT-H/14: width 1280 over 16 heads): qkv [B*T, 3*H*dh], softmax(QK^T/sqrt(dh))V */
 int wise_attention_dh_bf16(const uint16_t* qkv, int B, int T, int H, int dh, uint16_t* o, void* stream);
+/* head dim 64, right-padded sequences: sequence b has lens[b] (device int32 [B], 1..T) keys; keys past it are masked for
+ * every query of that sequence (the BERT-family text towers, wise_xlmr_forward) */
+int wise_attention_lens_bf16(const uint16_t* qkv, int B, int T, int H, const int32_t* lens, uint16_t* o, void* stream);
 /* head dim 64 with the causal mask of the text tower: query t attends keys <= t */
 int wise_attention_causal_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream);
 

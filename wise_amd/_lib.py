@@ -30,6 +30,12 @@ class TextConfig(C.Structure):
                                           "pool", "head")]
 
 
+class XlmrConfig(C.Structure):
+    """wise_xlmr_config (include/wise_hip.h)"""
+    _fields_ = [(n, C.c_int32) for n in ("context", "vocab", "max_positions", "width", "layers", "heads", "mlp",
+                                         "proj_hidden", "embed_dim", "pad_id")]
+
+
 # every symbol include/wise_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 SIGNATURES = {
@@ -63,6 +69,10 @@ SIGNATURES = {
     "wise_text_workspace_bytes": (_sz, [_vp, _i]),
     "wise_text_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "wise_text_tap_residual": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "wise_xlmr_layout": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "wise_xlmr_workspace_bytes": (_sz, [_vp, _i]),
+    "wise_xlmr_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "wise_xlmr_tap_residual": (_i, [_vp, _i, _vp, _vp, _vp]),
     "wise_preproc_plan_init": (_i, [_i, _i, _i, _vp]),
     "wise_preproc_tables": (_i, [_vp, _vp]),
     "wise_preproc_u8": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
@@ -73,6 +83,7 @@ SIGNATURES = {
     "wise_layernorm_f32_bf16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "wise_attention_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "wise_attention_dh_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "wise_attention_lens_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "wise_attention_causal_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
 }
 

@@ -12,7 +12,12 @@ void gemm_set_overlapped(bool on);
 int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows, int W, float eps, bf16_t* y,
                        hipStream_t st);
 // head dim dh = 64, or 80 without a mask (ViT-H/14); causal = query t attends keys <= t (CLIP text tower)
-int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st, bool causal, int dh = 64);
+// lens != null (dh 64, no causal mask): sequence b has lens[b] keys, the rest of its T rows are padding
+int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st, bool causal, int dh = 64,
+                   const int* lens = nullptr);
+// LayerNorm with two outputs: xo fp32 (may alias x) and y bf16 — the post-LN blocks of the BERT-family text towers
+int layernorm_f32_dual(const float* x, const float* w, const float* b, int rows, int W, float eps, float* xo, bf16_t* y,
+                       hipStream_t st);
 
 // where one residual block's weights sit: bf16 blob (in_proj [3W,W], out_proj [W,W], c_fc [F,W], c_proj [W,F])
 // and fp32 blob (ln_1 w,b, in_proj bias, out_proj bias, ln_2 w,b, c_fc bias, c_proj bias); element offsets

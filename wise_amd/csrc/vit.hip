@@ -20,9 +20,9 @@ extern int g_ablate;  // timing-only ablation switches (wise_debug_set_gemm_flag
 // LayerNorm: one wave per row, row in registers, exact two-pass statistics in fp32
 // ------------------------------------------------------------------------------------------------
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x /* may be xo: no restrict */, const float* __restrict__ w,
                                                         const float* __restrict__ b, int rows, int W, float eps,
-                                                        bf16_t* __restrict__ y) {
+                                                        bf16_t* __restrict__ y, float* xo = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -55,9 +55,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const float4 ww = reinterpret_cast<const float4*>(w)[c];
             const float4 bb = reinterpret_cast<const float4*>(b)[c];
             uint2 pk;
-            pk.x = pack_bf16x2((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y);
-            pk.y = pack_bf16x2((v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+            const float y0 = (v[i].x - mean) * rstd * ww.x + bb.x, y1 = (v[i].y - mean) * rstd * ww.y + bb.y;
+            const float y2 = (v[i].z - mean) * rstd * ww.z + bb.z, y3 = (v[i].w - mean) * rstd * ww.w + bb.w;
+            pk.x = pack_bf16x2(y0, y1);
+            pk.y = pack_bf16x2(y2, y3);
             yr[c] = pk;
+            // post-LN blocks (BERT family): the normalised row is also the fp32 residual stream (xo may alias x: a wave
+            // owns its row and has read all of it)
+            if (xo) reinterpret_cast<float4*>(xo + (size_t)row * W)[c] = make_float4(y0, y1, y2, y3);
         }
     }
 }
@@ -109,13 +114,32 @@ int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows,
     const int nv = (W / 4 + 63) / 64;
     const dim3 grid((rows + 3) / 4), block(256);
 #define LN_CASE(n) \
-    case n: hipLaunchKernelGGL(layernorm_kernel<n>, grid, block, 0, st, x, w, b, rows, W, eps, y); break;
+    case n: hipLaunchKernelGGL(layernorm_kernel<n>, grid, block, 0, st, x, w, b, rows, W, eps, y, (float*)nullptr); break;
     switch (nv) {
         LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
         LN_CASE(9) LN_CASE(10) LN_CASE(11) LN_CASE(12) LN_CASE(13) LN_CASE(14) LN_CASE(15) LN_CASE(16)
     }
 #undef LN_CASE
     WISE_LAUNCH_CHECK("layernorm_kernel");
+    return WISE_OK;
+}
+
+// the same with a second output: xo fp32 [rows, W] = the normalised rows (may be x itself) — post-LN blocks
+int layernorm_f32_dual(const float* x, const float* w, const float* b, int rows, int W, float eps, float* xo, bf16_t* y,
+                       hipStream_t st) {
+    WISE_CHECK_ARG(x && w && b && y && xo, "layernorm_dual: null pointer");
+    WISE_CHECK_ARG(rows >= 0 && W > 128 && W % 4 == 0 && W <= 4096, "layernorm_dual: W=%d must be a multiple of 4 in (128, 4096]", W);
+    if (rows == 0) return WISE_OK;
+    const int nv = (W / 4 + 63) / 64;
+    const dim3 grid((rows + 3) / 4), block(256);
+#define LN_CASE(n) \
+    case n: hipLaunchKernelGGL(layernorm_kernel<n>, grid, block, 0, st, x, w, b, rows, W, eps, y, xo); break;
+    switch (nv) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+        LN_CASE(9) LN_CASE(10) LN_CASE(11) LN_CASE(12) LN_CASE(13) LN_CASE(14) LN_CASE(15) LN_CASE(16)
+    }
+#undef LN_CASE
+    WISE_LAUNCH_CHECK("layernorm_kernel (dual)");
     return WISE_OK;
 }
 
@@ -190,7 +214,7 @@ __device__ __forceinline__ void softmax_block(f32x4 (&sacc)[4][QT], bf16x8 (&pf)
 // with the last 16 channels zero, the PV product has five 16-channel output tiles and a V row is 160 bytes.
 template <int QT, bool CAUSAL, int DH = 64>
 __global__ __launch_bounds__(256, (QT == 2 && DH == 64) ? 4 : 2) void attention_kernel(const bf16_t* __restrict__ qkv, int B, int T, int H,
-                                                        bf16_t* __restrict__ o) {
+                                                        bf16_t* __restrict__ o, const int* __restrict__ lens = nullptr) {
     constexpr int NS = (DH + 31) / 32, ND = DH / 16, VRS = DH * 2 + 16;   // k-steps of QK^T, dh tiles of PV, V row stride
     __shared__ __attribute__((aligned(16))) unsigned char v_all[4][64 * VRS];
     const int lane = threadIdx.x & 63;
@@ -205,6 +229,9 @@ __global__ __launch_bounds__(256, (QT == 2 && DH == 64) ? 4 : 2) void attention_
     const bf16_t* base = qkv + (size_t)b * T * W3;
     unsigned char* vimg = v_all[wave];
     const int l15 = lane & 15, g = lane >> 4;
+    // keys the sequence has (right-padded batches of the BERT-family text towers: keys past lens[b] are masked for every
+    // query); everything key-side below runs on Tk, the query side on T
+    const int Tk = lens ? max(1, min(T, lens[b])) : T;
 
     // Q fragments: B operand, lane holds Q[query = qt*16 + l15][dh = s*32 + 8g .. +7]
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -230,7 +257,7 @@ __global__ __launch_bounds__(256, (QT == 2 && DH == 64) ? 4 : 2) void attention_
 
     // causal (text tower): query t sees keys <= t, so key blocks past the chunk's last query are skipped
     const int q_last = min(T, (qc + 1) * (16 * QT)) - 1;
-    const int nkb = CAUSAL ? (q_last >> 6) + 1 : (T + 63) >> 6;
+    const int nkb = CAUSAL ? (q_last >> 6) + 1 : (Tk + 63) >> 6;
     for (int kb = 0; kb < nkb; ++kb) {
         // ---- V image, row-major [64 keys][64 dh]: 8 passes, lane copies 16 B of V row key = p*8 + lane/8;
         //      the transpose the PV product needs is done by ds_read_b64_tr_b16 on the way out
@@ -241,8 +268,8 @@ __global__ __launch_bounds__(256, (QT == 2 && DH == 64) ? 4 : 2) void attention_
         for (int p = 0; p < CPR; ++p) {
             const int c = p * 64 + lane, key = c / CPR, part = c - key * CPR;
             int t = kb * 64 + key;
-            const bool valid = t < T;
-            if (!valid) t = T - 1;
+            const bool valid = t < Tk;
+            if (!valid) t = Tk - 1;
             uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)t * W3 + 2 * W + h * DH + part * 8);
             if (!valid) v = make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4*>(vimg + key * VRS + part * 16) = v;
@@ -256,7 +283,7 @@ __global__ __launch_bounds__(256, (QT == 2 && DH == 64) ? 4 : 2) void attention_
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             int t = kb * 64 + kt * 16 + l15;
-            if (t >= T) t = T - 1;
+            if (t >= Tk) t = Tk - 1;
             bf16x8 kf[NS];
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2)
@@ -275,11 +302,11 @@ __global__ __launch_bounds__(256, (QT == 2 && DH == 64) ? 4 : 2) void attention_
         {
             int klim[QT];  // keys this query sees
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) klim[qt] = CAUSAL ? min(T, qc * (16 * QT) + qt * 16 + l15 + 1) : T;
+            for (int qt = 0; qt < QT; ++qt) klim[qt] = CAUSAL ? min(T, qc * (16 * QT) + qt * 16 + l15 + 1) : Tk;
             // masking is a separate small pass (last, partial key block and causal attention only) so that the
             // softmax body is instantiated once: with both variants inlined the kernel needed 236 registers
             // instead of ~130 and lost half its occupancy
-            if (CAUSAL || kb * 64 + 64 > T) {
+            if (CAUSAL || kb * 64 + 64 > Tk) {
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
@@ -333,14 +360,15 @@ __global__ __launch_bounds__(256, (QT == 2 && DH == 64) ? 4 : 2) void attention_
 
 static int g_attn_qt = 0;  // query tiles (of 16) per wave; 0 = by sequence length (debug knob overrides)
 
-int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st, bool causal, int dh) {
+int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_t st, bool causal, int dh, const int* lens) {
     WISE_CHECK_ARG(qkv && o && B > 0 && T > 0 && H > 0, "attention: bad argument");
     WISE_CHECK_ARG(dh == 64 || (dh == 80 && !causal), "attention: head dim %d (64, or 80 without a mask)", dh);
+    WISE_CHECK_ARG(!lens || (dh == 64 && !causal), "attention: per-sequence key counts go with head dim 64 and no causal mask");
     if (g_ablate & 4) return WISE_OK;
     if (dh == 80) {   // ViT-H/14 (T = 257): 48 queries per wave — 64 would spill (80 accumulator registers for O alone)
         const int nqc = (T + 47) / 48;
         const long long items = (long long)B * H * nqc;
-        hipLaunchKernelGGL((attention_kernel<3, false, 80>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, B, T, H, o);
+        hipLaunchKernelGGL((attention_kernel<3, false, 80>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, B, T, H, o, (const int*)nullptr);
         WISE_LAUNCH_CHECK("attention_kernel");
         return WISE_OK;
     }
@@ -354,13 +382,13 @@ int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_
     const dim3 grid((unsigned)((items + 3) / 4)), block(256);
     if (causal) {
         if (qt == 4)
-            hipLaunchKernelGGL((attention_kernel<4, true>), grid, block, 0, st, qkv, B, T, H, o);
+            hipLaunchKernelGGL((attention_kernel<4, true>), grid, block, 0, st, qkv, B, T, H, o, (const int*)nullptr);
         else
-            hipLaunchKernelGGL((attention_kernel<2, true>), grid, block, 0, st, qkv, B, T, H, o);
+            hipLaunchKernelGGL((attention_kernel<2, true>), grid, block, 0, st, qkv, B, T, H, o, (const int*)nullptr);
     } else if (qt == 4)
-        hipLaunchKernelGGL((attention_kernel<4, false>), grid, block, 0, st, qkv, B, T, H, o);
+        hipLaunchKernelGGL((attention_kernel<4, false>), grid, block, 0, st, qkv, B, T, H, o, lens);
     else
-        hipLaunchKernelGGL((attention_kernel<2, false>), grid, block, 0, st, qkv, B, T, H, o);
+        hipLaunchKernelGGL((attention_kernel<2, false>), grid, block, 0, st, qkv, B, T, H, o, lens);
     WISE_LAUNCH_CHECK("attention_kernel");
     return WISE_OK;
 }
@@ -528,6 +556,12 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     for (int c = lane; c < D; c += 64) s += er[c] * er[c];
     const float nrm = sqrtf(wave_sum(s));
     for (int c = lane; c < D; c += 64) out[(size_t)r * D + c] = er[c] / nrm;
+}
+
+int l2norm_rows(const float* e, int rows, int D, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, e, rows, D, out);
+    WISE_LAUNCH_CHECK("l2norm_rows_kernel");
+    return WISE_OK;
 }
 
 // L pre-LN residual blocks over x fp32 [B*T (padded to 256), W]; h / qkv / a are the bf16 scratch operands
@@ -901,6 +935,10 @@ extern "C" int wise_attention_bf16(const uint16_t* qkv, int B, int T, int H, uin
 
 extern "C" int wise_attention_dh_bf16(const uint16_t* qkv, int B, int T, int H, int dh, uint16_t* o, void* stream) {
     return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, false, dh);
+}
+extern "C" int wise_attention_lens_bf16(const uint16_t* qkv, int B, int T, int H, const int32_t* lens, uint16_t* o, void* stream) {
+    WISE_CHECK_ARG(lens, "attention_lens: null pointer");
+    return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, false, 64, lens);
 }
 extern "C" int wise_attention_causal_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream) {
     return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, true, 64);

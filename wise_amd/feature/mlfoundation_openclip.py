@@ -17,6 +17,7 @@ from PIL import Image
 from .feature_extractor import FeatureExtractor
 from .clip_tokenizer import ClipTokenizer
 from .text import TextEngine, random_text_state_dict, text_spec_for
+from .xlmr_text import XLMR_SPECS, XlmrTextEngine, XlmrTokenizer, random_xlmr_state_dict
 from .vit import SPECS, VitEngine, random_state_dict, spec_for
 from .weights import load_state_dict_file, seeded_tag
 
@@ -34,6 +35,7 @@ KNOWN_PRETRAINED = {
     "ViT-H-14": ("laion2b_s32b_b79k",),
     "ViT-H-14-quickgelu": ("dfn5b",),
     "xlm-roberta-large-ViT-H-14": ("frozen_laion5b_s13b_b90k",),
+    "xlm-roberta-base-ViT-B-32": ("laion5b_s13b_b90k",),
 }
 
 
@@ -122,9 +124,9 @@ class MlfoundationOpenClip(FeatureExtractor):
         self._gpu_preprocess = None
         # text tower (query side): built on first use; seeded models may run on the merge-less
         # byte tokenizer because open_clip's merge file does not exist offline
-        # xlm-roberta-large-ViT-H-14: the image tower (the extraction hot path) is this library's; its text tower is
-        # HF XLM-RoBERTa-large with a sentencepiece vocabulary, which this build does not carry -> text queries raise
-        self.text_spec = None if model.startswith("xlm-roberta") else text_spec_for(model, "openai" if seed is not None else tag)
+        # xlm-roberta-*: the text tower is open_clip's HFTextEncoder over XLM-RoBERTa (xlmr_text.py), tokenised with the
+        # model's own sentencepiece vocabulary; every other model has the CLIP text transformer and its BPE tokenizer
+        self.text_spec = XLMR_SPECS[model] if model in XLMR_SPECS else text_spec_for(model, "openai" if seed is not None else tag)
         self._seed = seed
         self._text_engine = None
         self._tokenizer = None
@@ -153,8 +155,7 @@ class MlfoundationOpenClip(FeatureExtractor):
         random_image = torch.rand((1, 3,) + self.input_image_size)
         feats = self.extract_image_features(self.preprocess_image(random_image))
         assert feats.shape[1] == self.output_dim
-        # both towers embed into the same space (:67-73)
-        assert self.text_spec is None or self.text_spec.embed_dim == self.output_dim
+        assert self.text_spec.embed_dim == self.output_dim  # both towers embed into the same space (:67-73)
 
     def get_output_dim(self):
         return self.output_dim
@@ -197,25 +198,25 @@ class MlfoundationOpenClip(FeatureExtractor):
         pending = self._get_engine().forward_pipelined(images.to(torch.float32) if images.dtype != torch.uint8 else images)
         return _AsyncFeatures(pending)
 
-    def _require_text_tower(self):
-        if self.text_spec is None:
-            raise NotImplementedError(f"{self.pretrained_model_name}: the XLM-RoBERTa text tower is not part of this "
-                                      "build (image features only); query it with a CLIP-text model's index")
-
     @property
-    def tokenizer(self) -> ClipTokenizer:
-        self._require_text_tower()
+    def tokenizer(self):
         if self._tokenizer is None:
-            self._tokenizer = ClipTokenizer.default(self.text_spec.context, allow_merge_less=self._seed is not None)
+            if self.pretrained_model_name in XLMR_SPECS:
+                self._tokenizer = XlmrTokenizer.default(self.text_spec.context)     # needs sentencepiece.bpe.model
+            else:
+                self._tokenizer = ClipTokenizer.default(self.text_spec.context, allow_merge_less=self._seed is not None)
             if self._tokenizer.vocab_size > self.text_spec.vocab:
                 raise RuntimeError("tokenizer vocabulary larger than the model's token embedding")
         return self._tokenizer
 
-    def _get_text_engine(self) -> TextEngine:
-        self._require_text_tower()
+    def _get_text_engine(self):
         if self._text_engine is None:
-            sd = random_text_state_dict(self.text_spec, self._seed) if self._seed is not None else self._state_dict
-            self._text_engine = TextEngine(self.text_spec, sd, device="cuda")
+            if self.pretrained_model_name in XLMR_SPECS:
+                sd = random_xlmr_state_dict(self.text_spec, self._seed) if self._seed is not None else self._state_dict
+                self._text_engine = XlmrTextEngine(self.text_spec, sd, device="cuda")
+            else:
+                sd = random_text_state_dict(self.text_spec, self._seed) if self._seed is not None else self._state_dict
+                self._text_engine = TextEngine(self.text_spec, sd, device="cuda")
         return self._text_engine
 
     def preprocess_text(self, text: Union[str, List[str]]) -> torch.Tensor:

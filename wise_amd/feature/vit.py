@@ -63,6 +63,7 @@ SPECS: Dict[str, VitSpec] = {
     # head width 80 (open_clip model_configs/ViT-H-14.json); xlm-roberta-large-ViT-H-14 has the same image tower
     "ViT-H-14": VitSpec("ViT-H-14", 224, 14, 1280, 32, 16, 5120, 1024),
     "xlm-roberta-large-ViT-H-14": VitSpec("xlm-roberta-large-ViT-H-14", 224, 14, 1280, 32, 16, 5120, 1024),
+    "xlm-roberta-base-ViT-B-32": VitSpec("xlm-roberta-base-ViT-B-32", 224, 32, 768, 12, 12, 3072, 512),
 }
 
 
