@@ -83,3 +83,37 @@ def test_threshold_form_collects_every_row_of_the_exact_topk(layout):
         collected = np.where(approx >= s_a - 2 * eps)[0]
         assert set(top) <= set(collected)
         assert len(collected) >= k
+
+
+@pytest.mark.parametrize("kind", ["unit", "mixed_norms", "worst_case_mantissas"])
+@pytest.mark.parametrize("d", [512, 768])
+def test_one_piece_query_bound_of_the_batched_scan(kind, d):
+    """The batched shadow scan multiplies bf16 rows by ONE bf16 piece of the query (csrc/ip_topk_mfma.hip, LO = false);
+    csrc/ip_topk.hip `query_eps(QMODE_ONE_PIECE)` then adds (max|x| + max residual) |q - bf16 q| to the row-rounding bound:
+    |bf16(x) . bf16(q) - x . q| <= |bf16(x)| |q - bf16 q| + |x - bf16 x| |q|."""
+    rng = np.random.default_rng(3 + d)
+    n = 4096
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    if kind == "unit":
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+    elif kind == "mixed_norms":
+        X *= np.exp(rng.uniform(-6, 6, size=(n, 1))).astype(np.float32)
+    else:
+        e = rng.integers(-8, 4, size=X.shape)
+        X = (np.sign(X) * np.ldexp(1.0 + 2.0 ** -8 - 2.0 ** -20, e)).astype(np.float32)
+    for qkind in ("random", "worst_case_mantissas"):
+        q = rng.standard_normal(d).astype(np.float32)
+        if qkind == "worst_case_mantissas":
+            q = (np.sign(q) * np.ldexp(1.0 + 2.0 ** -8 - 2.0 ** -20, rng.integers(-6, 2, size=d))).astype(np.float32)
+        Xb, qb = bf16_round(X), bf16_round(q)
+        approx = (Xb * qb).sum(axis=1, dtype=np.float32)                     # products exact in f32, f32 accumulation
+        truth = X.astype(np.float64) @ q.astype(np.float64)
+        n0 = float(np.linalg.norm(X.astype(np.float64), axis=1).max())
+        n1 = float(np.linalg.norm(X.astype(np.float64) - Xb.astype(np.float64), axis=1).max())
+        qn = float(np.linalg.norm(q.astype(np.float64)))
+        qr = float(np.linalg.norm(q.astype(np.float64) - qb.astype(np.float64)))
+        eps = (n1 + d * 2.0 ** -23 * n0) * 1.0001 * qn + (n0 + n1) * qr * 1.0001 + 1e-6 * qn * n0
+        assert np.abs(approx.astype(np.float64) - truth).max() <= eps
+        # and it is not vacuous: within a factor of a few of the two-piece bound on unit data
+        if kind == "unit" and qkind == "random":
+            assert eps < 4 * (n1 + d * 2.0 ** -23 * n0) * qn

@@ -103,6 +103,14 @@ def test_feature_operators_equal_the_engines(golden_dir):
     c = teng.cfg
     tcfg = [c.context, c.vocab, c.width, c.layers, c.heads, c.mlp, c.embed_dim, c.act, c.pool, c.head]
     assert torch.equal(torch.ops.wise_hip.text_forward(toks, teng.wb, teng.pf, tcfg), teng.forward(toks))
+    from oracle.make_golden_xlmr import TINY as XT, seeded_tokens as xtok
+    from wise_amd.feature.xlmr_text import XlmrTextEngine, random_xlmr_state_dict
+    xeng = XlmrTextEngine(XT, random_xlmr_state_dict(XT, 1), max_batch=4)
+    xt = torch.from_numpy(xtok(3, XT, 4)).cuda()
+    xc = xeng.cfg
+    xcfg = [xc.context, xc.vocab, xc.max_positions, xc.width, xc.layers, xc.heads, xc.mlp, xc.proj_hidden, xc.embed_dim,
+            xc.pad_id]
+    assert torch.equal(torch.ops.wise_hip.xlmr_forward(xt, xeng.wb, xeng.pf, xcfg), xeng.forward(xt))
     raw = torch.from_numpy(np.random.default_rng(3).integers(0, 256, size=(2, 3, 120, 160), dtype=np.uint8)).cuda()
     from wise_amd.feature.preprocess import ClipPreprocessor
     assert torch.equal(torch.ops.wise_hip.clip_preprocess_u8(raw, 64), ClipPreprocessor(64)(raw))

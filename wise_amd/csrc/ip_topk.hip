@@ -456,6 +456,18 @@ __device__ __forceinline__ float shadow_eps(const float* __restrict__ norms, int
     return (norms[1] + (float)d * 1.1920929e-7f * norms[0]) * 1.0001f * sqrtf(qq);
 }
 
+// how the query entered the approximate scores: exactly (f32, the single-query scan), as two bf16 pieces (leaves
+// <= 2^-17 |q| of each score unaccounted), or as ONE bf16 piece — then |x_b . (q - bf16 q)| <=
+// (max|x| + max residual) |q - bf16 q|, with the rounding residual of the query measured (qr = its squared norm)
+enum : int { QMODE_F32 = 0, QMODE_TWO_PIECE = 1, QMODE_ONE_PIECE = 2 };
+__device__ __forceinline__ float query_eps(const float* __restrict__ norms, int d, float qq, float qr, int q_mode) {
+    float eps = shadow_eps(norms, d, qq);
+    if (q_mode == QMODE_TWO_PIECE) eps += 1.0e-5f * sqrtf(qq) * norms[0];
+    if (q_mode == QMODE_ONE_PIECE) eps += (norms[0] + norms[1]) * sqrtf(qr) * 1.0001f + 1.0e-6f * sqrtf(qq) * norms[0];
+    return eps;
+}
+__device__ __forceinline__ float bf16_round_residual(float v) { return v - bf16_to_f32(f32_to_bf16(v)); }
+
 // One group of R rows of the bf16 shadow against the query held in registers: every lane ends up with the score of row
 // `row0 + myr` (valid in the lanes with `owner`): 16-byte non-temporal loads, bf16 -> f32 by shift / mask, f32 fma chains,
 // butterfly transpose-reduce over the lanes.  NV8 = 16-byte chunks (8 bf16) per lane and row.
@@ -669,9 +681,9 @@ __global__ __launch_bounds__(1024) void collect_refine_kernel(int* __restrict__ 
                                                               int k, const float* __restrict__ Q, int d,
                                                               const float* __restrict__ norms, u64* __restrict__ cand2,
                                                               int* __restrict__ stats, int* __restrict__ pass_gate,
-                                                              float extra_rel /*score error beyond shadow_eps, x |q| max|x|*/) {
+                                                              int q_mode /*QMODE_*: how the query entered the scores*/) {
     __shared__ u64 wmax[16];
-    __shared__ float wsum[16];
+    __shared__ float wsum[16], wres[16];
     __shared__ int kept;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     ctl += 4 * blockIdx.y;
@@ -689,11 +701,15 @@ __global__ __launch_bounds__(1024) void collect_refine_kernel(int* __restrict__ 
         const u64 key = cand[i];
         mine = key > mine ? key : mine;
     }
-    float qq = 0.f;
-    for (int j = tid; j < d; j += 1024) qq = fmaf(Q[j], Q[j], qq);
+    float qq = 0.f, qr = 0.f;
+    for (int j = tid; j < d; j += 1024) {
+        qq = fmaf(Q[j], Q[j], qq);
+        const float rr = bf16_round_residual(Q[j]);
+        qr = fmaf(rr, rr, qr);
+    }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
-    if (lane == 0) wsum[wave] = qq;
+    for (int o = 32; o >= 1; o >>= 1) { qq += __shfl_xor(qq, o, 64); qr += __shfl_xor(qr, o, 64); }
+    if (lane == 0) { wsum[wave] = qq; wres[wave] = qr; }
     u64 L = 0;
     for (int r = 0; r < k; ++r) {
         u64 m = mine;
@@ -711,11 +727,11 @@ __global__ __launch_bounds__(1024) void collect_refine_kernel(int* __restrict__ 
         if (mine == g) mine = 0;
         __syncthreads();
     }
-    qq = 0.f;
+    qq = 0.f; qr = 0.f;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) qq += wsum[w];
+    for (int w = 0; w < 16; ++w) { qq += wsum[w]; qr += wres[w]; }
     // fewer than k non-empty slices (n < k cannot happen: the sampled rows themselves are collected): keep everything
-    const float eps = shadow_eps(norms, d, qq) + extra_rel * sqrtf(qq) * norms[0];
+    const float eps = query_eps(norms, d, qq, qr, q_mode);
     const float t2 = L != 0 ? f32_unorder((unsigned)(L >> 32)) - 2.f * eps : -3.4028234663852886e38f;
     for (int i0 = 0; i0 < n; i0 += 1024) {
         const int i = i0 + tid;
@@ -874,7 +890,7 @@ static long long g_scan_sample = 32768;                  // rows of the split sc
 static int g_stage2_factor = 8;                          // batched bf16 scan: second row range = factor x the threshold sample
 static int g_use_qb64 = 1;                               // 64 queries per pass when more than 32 are waiting
 static int g_use_split = 1;                             // ... as split-bf16 candidates + exact re-scoring (k <= MFMA_KC)
-extern int g_mfma_abl, g_split_direct;
+extern int g_mfma_abl, g_split_direct, g_shadow_one_piece;
 
 static ScanPlan plan_scan(long long N, int d, int nq, int k) {
     ScanPlan p;
@@ -962,6 +978,7 @@ extern "C" int wise_debug_set_scan(int rows, int blocks_per_cu) {
     g_split_direct = (rows >> 12) & 15 ? ((rows >> 12) & 15) % 8 : 4;   // bits 12-15: queue depth 3/4/6; 8 = DMA ring
     if (((rows >> 12) & 15) == 8) g_split_direct = 0;
     g_use_qb64 = (rows >> 25) & 1 ? 0 : 1;   // bit 25: never 64 queries per pass
+    g_shadow_one_piece = (rows >> 26) & 1 ? 0 : 1;   // bit 26: two-piece bf16 queries in the batched shadow scan
     g_scan_sample = (rows >> 16) & 1 ? 0 : ((rows >> 17) & 0xFF ? (long long)((rows >> 17) & 0xFF) * 16384 : 32768);  // bit 16: no sample pass; bits 17-24: sample rows / 16384  // bit 11: f32 matrix-core scan instead of the split-bf16 candidates
     return 0;
 }
@@ -1230,10 +1247,10 @@ namespace wise {
 // approximately.  thr[q] = L - 2 eps(q).  (A segment maximum costs a tenth of an exact selection: ~15 us against 176.)
 __global__ __launch_bounds__(1024) void batch_threshold_kernel(const float* __restrict__ scores, long long n, int k,
                                                                const float* __restrict__ Q, int d,
-                                                               const float* __restrict__ norms, float extra_rel,
+                                                               const float* __restrict__ norms, int q_mode,
                                                                float* __restrict__ thr) {
     __shared__ float mx[1024];
-    __shared__ float wsum[16];
+    __shared__ float wsum[16], wres[16];
     const int q = blockIdx.x, t = threadIdx.x;
     const float* sq = scores + (size_t)q * n;
     float m = -3.4028234663852886e38f;
@@ -1242,11 +1259,15 @@ __global__ __launch_bounds__(1024) void batch_threshold_kernel(const float* __re
         m = v > m ? v : m;
     }
     mx[t] = m;
-    float qq = 0.f;
-    for (int j = t; j < d; j += 1024) qq = fmaf(Q[(size_t)q * d + j], Q[(size_t)q * d + j], qq);
+    float qq = 0.f, qr = 0.f;
+    for (int j = t; j < d; j += 1024) {
+        const float qv = Q[(size_t)q * d + j], rr = bf16_round_residual(qv);
+        qq = fmaf(qv, qv, qq);
+        qr = fmaf(rr, rr, qr);
+    }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
-    if ((t & 63) == 0) wsum[t >> 6] = qq;
+    for (int o = 32; o >= 1; o >>= 1) { qq += __shfl_xor(qq, o, 64); qr += __shfl_xor(qr, o, 64); }
+    if ((t & 63) == 0) { wsum[t >> 6] = qq; wres[t >> 6] = qr; }
     __syncthreads();
     for (int size = 2; size <= 1024; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -1260,9 +1281,9 @@ __global__ __launch_bounds__(1024) void batch_threshold_kernel(const float* __re
             __syncthreads();
         }
     if (t == 0) {
-        qq = 0.f;
-        for (int w = 0; w < 16; ++w) qq += wsum[w];
-        const float eps = shadow_eps(norms, d, qq) + extra_rel * sqrtf(qq) * norms[0];
+        qq = 0.f; qr = 0.f;
+        for (int w = 0; w < 16; ++w) { qq += wsum[w]; qr += wres[w]; }
+        const float eps = query_eps(norms, d, qq, qr, q_mode);
         thr[q] = mx[k - 1] - 2.f * eps;     // n >= 1024 sampled rows (host check): every segment holds a row
     }
 }
@@ -1320,7 +1341,7 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norm
         WISE_LAUNCH_CHECK("ip_collect_bf16_kernel");
     }
     hipLaunchKernelGGL(collect_refine_kernel, dim3(1), dim3(1024), 0, st, counter, cand, COLLECT_CAP, k, q, d, norms, cand2,
-                       stats, (int*)nullptr, 0.f);
+                       stats, (int*)nullptr, (int)QMODE_F32);
     WISE_LAUNCH_CHECK("collect_refine_kernel");
     hipLaunchKernelGGL(collect_rescore_kernel, dim3(64), dim3(256), 0, st, X, d, q, counter, cand2, ekeys);
     WISE_LAUNCH_CHECK("collect_rescore_kernel");
@@ -1347,7 +1368,6 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norm
 }
 
 constexpr int BATCH_CAP = 65536;            // rows per query the batched collect pass may hand on
-constexpr float BATCH_EXTRA_REL = 1.0e-5f;  // the two-piece bf16 query of the MFMA scan leaves <= 2^-17 |q| of each score unaccounted
 constexpr int BATCH_SAMPLE_SHIFT = 4;       // a sample chunk = 16 groups of 32 rows = 512 rows
 
 struct PassWs {
@@ -1388,6 +1408,7 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* nor
                               int nqa, int k, const long long* ids, long long id_base, float* outD, long long* outI,
                               int* stats, unsigned char* wsb, hipStream_t st, int QB /*64, or 32 for 512 < d <= 1024*/) {
     const PassWs w = pass_workspace(wsb, N, d, k);
+    const int q_mode = shadow_one_piece() ? QMODE_ONE_PIECE : QMODE_TWO_PIECE;
     u64* mpart = w.mpart;
     float* mq = w.mq;
     long long* cand_rows = w.cand_rows;
@@ -1410,7 +1431,7 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* nor
                                        stride)))
             return rc;
         hipLaunchKernelGGL(batch_threshold_kernel, dim3(nqa), dim3(1024), 0, st, w.dump, nsample, k, mq, d, norms,
-                           BATCH_EXTRA_REL, w.thr);
+                           q_mode, w.thr);
         WISE_LAUNCH_CHECK("batch_threshold_kernel");
         // ---- collect over all rows
         {
@@ -1418,7 +1439,7 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* nor
             if ((rc = shadow64_scan_launch(Xb, N, d, mq, nqa, w.thr, w.ctl, w.cand, BATCH_CAP, st, nullptr, QB))) return rc;
         }
         hipLaunchKernelGGL(collect_refine_kernel, dim3(1, nqa), dim3(1024), 0, st, w.ctl, w.cand, BATCH_CAP, k, mq, d, norms,
-                           w.cand2, stats, gate, BATCH_EXTRA_REL);
+                           w.cand2, stats, gate, q_mode);
         WISE_LAUNCH_CHECK("collect_refine_kernel");
         hipLaunchKernelGGL(collect_rescore_kernel, dim3(8, nqa), dim3(256), 0, st, X, d, mq, w.ctl, w.cand2, w.ekeys);
         WISE_LAUNCH_CHECK("collect_rescore_kernel");
@@ -1427,7 +1448,7 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* nor
         WISE_LAUNCH_CHECK("collect_select_kernel");
     }
     // ---- gated fallback over the f32 rows: every launch returns at once while *gate == 0
-    if (QB != MFMA_QB2) {
+    if (d > 512) {
         // d > 512: the split-bf16 kernels do not reach; the f32 VALU scan redoes the pass, two queries per launch
         const ScanPlan p = plan_scan(N, d, 2, k);
         const int nv = (d / 4 + 63) / 64;
@@ -1510,13 +1531,14 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
         if (fneed == 0 || fneed > workspace_bytes) { set_error("ip_topk_shadow: workspace %zu < %zu bytes", workspace_bytes, fneed); return WISE_E_WORKSPACE; }
         return wise_ip_topk_f32(X, N, d, Q, nq, k, ids, id_base, outD, outI, workspace, workspace_bytes, stream);
     }
-    const bool batched = nq >= 2 && k <= MFMA_KC && shadow64_supported(d) && mfma_split_supported(d, 8, k) &&
+    const bool batched = d <= 512 && nq >= 2 && k <= MFMA_KC && shadow64_supported(d) && mfma_split_supported(d, 8, k) &&
                          split64_supported(d) && split_direct_enabled();
-    // 512 < d <= 1024 (768: the ViT-L/14 dimension): 32 queries per pass, the f32 VALU scan as the gated fallback;
-    // worth it from 3 queries on (a pass moves the bf16 rows once: 2.7 ms at 10M x 768, a single query 2.4 ms)
-    const bool batched32 = !batched && nq >= 3 && k <= 16 && d > 512 && shadow32_supported(d);
+    // 512 < d <= 1024 (768: the ViT-L/14 dimension): the f32 VALU scan as the gated fallback; 64 queries per pass with
+    // one-piece queries (their images fit LDS), 32 with two pieces; worth it from 3 queries on (a pass moves the bf16
+    // rows once: 2.7 ms at 10M x 768, a single query 2.4 ms)
+    const bool batched32 = !batched && nq >= 3 && k <= 16 && d > 512 && (shadow64_supported(d) || shadow32_supported(d));
     if (batched || batched32) {
-        const int qb = batched ? MFMA_QB2 : MFMA_QB;
+        const int qb = (batched || shadow64_supported(d)) ? MFMA_QB2 : MFMA_QB;
         for (int q0 = 0; q0 < nq; q0 += qb) {
             const int nqa = nq - q0 < qb ? nq - q0 : qb;
             int rc = shadow_search_pass(X, Xb, norms, N, d, Q + (size_t)q0 * d, nqa, k, lids, (long long)id_base,

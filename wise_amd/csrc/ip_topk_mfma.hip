@@ -644,7 +644,10 @@ int split64_scan_launch(const float* X, long long N, long long row_offset, int d
 // ------------------------------------------------------------------------------------------------
 constexpr int CW2 = 64;   // columns per chunk of the bf16 scan
 
-template <int PF, int QB>
+// LO: the query enters as two bf16 pieces (hi + lo: its rounding is negligible, 16 MFMAs per 4-KiB chunk); !LO: as ONE bf16
+// piece — half the MFMAs, half the LDS reads and half the LDS footprint (64 queries fit up to d = 1024); the rounding of
+// the query, ||q - bf16(q)|| (max||x|| + max residual), then enters the error bound of the threshold form (ip_topk.hip).
+template <int PF, int QB, bool LO>
 __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const bf16_t* __restrict__ Xb, long long N, int d,
                                                                   const float* __restrict__ qpad /*[QB][d]*/, int nq,
                                                                   const float* __restrict__ thr /*[QB] (collect)*/,
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
         const int c8 = c >> 1;
         const size_t off = ((size_t)j * d8 + ((c8 & ~15) | ((c8 & 15) ^ (j & 15)))) * 16 + (c & 1) * 8;
         *reinterpret_cast<uint2*>(Qh + off) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(Ql + off) = make_uint2(l01, l23);
+        if constexpr (LO) *reinterpret_cast<uint2*>(Ql + off) = make_uint2(l01, l23);
     }
     __syncthreads();
 
@@ -722,30 +725,30 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
             for (int j = 0; j < 4; ++j) {
                 const size_t o = (size_t)(((c8 + j) & ~15) | (((c8 + j) & 15) ^ (i & 15))) * 16;
                 qa[j] = *reinterpret_cast<const bf16x8*>(Qh + ra + o);
-                la[j] = *reinterpret_cast<const bf16x8*>(Ql + ra + o);
+                if constexpr (LO) la[j] = *reinterpret_cast<const bf16x8*>(Ql + ra + o);
                 if constexpr (QB == 64) {
                     qb[j] = *reinterpret_cast<const bf16x8*>(Qh + rb + o);
-                    lb[j] = *reinterpret_cast<const bf16x8*>(Ql + rb + o);
+                    if constexpr (LO) lb[j] = *reinterpret_cast<const bf16x8*>(Ql + rb + o);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             prefetch(xq[p]);
             __builtin_amdgcn_sched_barrier(0);
-            if (abl & 2) { acc0[0] += (float)x0[0] + (float)x1[1] + (float)x2[2] + (float)x3[3] + (float)qa[0][0] + (float)la[1][0] + (float)qb[2][0] + (float)lb[3][0] + (float)qa[1][0] + (float)qa[2][0] + (float)qa[3][0] + (float)la[0][0] + (float)la[2][0] + (float)la[3][0] + (float)qb[0][0] + (float)qb[1][0] + (float)qb[3][0] + (float)lb[0][0] + (float)lb[1][0] + (float)lb[2][0]; continue; }
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, la[0], acc0, 0, 0, 0);
-            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, lb[0], acc1, 0, 0, 0);
+            if (LO && (abl & 2)) { acc0[0] += (float)x0[0] + (float)x1[1] + (float)x2[2] + (float)x3[3] + (float)qa[0][0] + (float)la[1][0] + (float)qb[2][0] + (float)lb[3][0] + (float)qa[1][0] + (float)qa[2][0] + (float)qa[3][0] + (float)la[0][0] + (float)la[2][0] + (float)la[3][0] + (float)qb[0][0] + (float)qb[1][0] + (float)qb[3][0] + (float)lb[0][0] + (float)lb[1][0] + (float)lb[2][0]; continue; }
+            if constexpr (LO) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, la[0], acc0, 0, 0, 0);
+            if constexpr (LO && QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, lb[0], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, qa[0], acc0, 0, 0, 0);
             if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, qb[0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, la[1], acc0, 0, 0, 0);
-            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, lb[1], acc1, 0, 0, 0);
+            if constexpr (LO) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, la[1], acc0, 0, 0, 0);
+            if constexpr (LO && QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, lb[1], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, qa[1], acc0, 0, 0, 0);
             if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, qb[1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, la[2], acc0, 0, 0, 0);
-            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, lb[2], acc1, 0, 0, 0);
+            if constexpr (LO) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, la[2], acc0, 0, 0, 0);
+            if constexpr (LO && QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, lb[2], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, qa[2], acc0, 0, 0, 0);
             if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, qb[2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, la[3], acc0, 0, 0, 0);
-            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, lb[3], acc1, 0, 0, 0);
+            if constexpr (LO) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, la[3], acc0, 0, 0, 0);
+            if constexpr (LO && QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, lb[3], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, qa[3], acc0, 0, 0, 0);
             if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, qb[3], acc1, 0, 0, 0);
         }
@@ -799,25 +802,34 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
     }
 }
 
-bool shadow64_supported(int d) { return d % (4 * CW2) == 0 && d <= 512; }
-// 32 queries per pass: the Q images of 32 queries fit up to d = 1024 (the L/14 dimension, 768, included)
+int g_shadow_one_piece = 1;   // (debug knob) 0: two-piece bf16 query in the batched shadow scan
+bool shadow_one_piece() { return g_shadow_one_piece != 0; }
+// 64 queries per pass: their Q images must fit LDS — d <= 512 with two pieces per query, d <= 1024 with one
+bool shadow64_supported(int d) { return d % (4 * CW2) == 0 && d <= (g_shadow_one_piece ? 1024 : 512); }
+// 32 queries per pass (two-piece queries at 512 < d <= 1024, e.g. 768, the L/14 dimension)
 bool shadow32_supported(int d) { return d % (4 * CW2) == 0 && d <= 1024; }
 int shadow64_scan_launch(const bf16_t* Xb, long long N, int d, const float* qpad, int nq, const float* thr, int* ctl,
                          u64* cand, int cap, hipStream_t st, float* dump, int qb, int chunk_shift, long long chunk_stride) {
-    const size_t dl = (size_t)qb * d * 4;
+    const bool lo = !g_shadow_one_piece;
+    const size_t dl = (size_t)qb * d * (lo ? 4 : 2);
     static std::once_flag dattr;
     std::call_once(dattr, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 64>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 64, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 32>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 32, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 64, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 32, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    if (qb == 64)
-        hipLaunchKernelGGL((ip_scan_shadow64_kernel<4, 64>), dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, Xb, N, d, qpad, nq,
-                           thr, ctl, cand, cap, dump, chunk_shift, chunk_stride, g_mfma_abl);
-    else
-        hipLaunchKernelGGL((ip_scan_shadow64_kernel<4, 32>), dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, Xb, N, d, qpad, nq,
-                           thr, ctl, cand, cap, dump, chunk_shift, chunk_stride, g_mfma_abl);
+    WISE_CHECK_ARG(dl <= 160 * 1024, "shadow scan: the query images of %d queries at d=%d do not fit LDS", qb, d);
+#define SH_LAUNCH(QBV, LOV)                                                                                                  \
+    hipLaunchKernelGGL((ip_scan_shadow64_kernel<4, QBV, LOV>), dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, Xb, N, d, qpad, \
+                       nq, thr, ctl, cand, cap, dump, chunk_shift, chunk_stride, g_mfma_abl)
+    if (qb == 64) { if (lo) SH_LAUNCH(64, true); else SH_LAUNCH(64, false); }
+    else { if (lo) SH_LAUNCH(32, true); else SH_LAUNCH(32, false); }
+#undef SH_LAUNCH
     WISE_LAUNCH_CHECK("ip_scan_shadow64_kernel");
     return WISE_OK;
 }

@@ -45,6 +45,7 @@ int split64_scan_launch(const float* X, long long N, long long row_offset, int d
 // chunk_stride groups apart
 bool shadow64_supported(int d);
 bool shadow32_supported(int d);
+bool shadow_one_piece();   // the batched scan takes the query as one bf16 piece (its rounding enters the error bound)
 int shadow64_scan_launch(const bf16_t* Xb, long long N, int d, const float* qpad, int nq, const float* thr, int* ctl,
                          u64* cand, int cap, hipStream_t st, float* dump = nullptr, int qb = 64, int chunk_shift = -1,
                          long long chunk_stride = 0);

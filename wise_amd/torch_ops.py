@@ -41,6 +41,7 @@ SCHEMAS = {
     # HP-1 (open_clip encode_image / encode_text, msclap audio_encoder; src/feature/*.py)
     "vit_forward": "(Tensor images, Tensor wb, Tensor pf, int[] config) -> Tensor",
     "text_forward": "(Tensor tokens, Tensor wb, Tensor pf, int[] config) -> Tensor",
+    "xlmr_forward": "(Tensor tokens, Tensor wb, Tensor pf, int[] config) -> Tensor",
     "htsat_forward": "(Tensor wave, Tensor wb, Tensor pf) -> Tensor",
     "clip_preprocess_u8": "(Tensor frames, int size) -> Tensor",
 }
@@ -214,6 +215,22 @@ def _text_forward(tokens, wb, pf, config: List[int]):
     return out
 
 
+def _xlmr_forward(tokens, wb, pf, config: List[int]):
+    lib = _lib.lib()
+    _dev(tokens, wb, pf)
+    cfg = _lib.XlmrConfig(*config)
+    t = tokens.to(torch.int32).contiguous()
+    B = t.shape[0]
+    out = torch.empty(B, cfg.embed_dim, dtype=torch.float32, device=t.device)
+    need = lib.wise_xlmr_workspace_bytes(C.byref(cfg), B)
+    if need == 0:
+        raise ValueError("wise_hip::xlmr_forward: bad config")
+    ws = torch.empty(need, dtype=torch.uint8, device=t.device)
+    _check(lib.wise_xlmr_forward(C.byref(cfg), wb.data_ptr(), pf.data_ptr(), t.data_ptr(), B, out.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "wise_xlmr_forward")
+    return out
+
+
 def _htsat_forward(wave, wb, pf):
     lib = _lib.lib()
     _dev(wave, wb, pf)
@@ -254,6 +271,7 @@ _IMPLS = {
     "ivf_scan": (_ivf_scan, lambda X, lo, ids, Q, probes, k: _fake_pair(Q.shape[0], k, X)),
     "vit_forward": (_vit_forward, lambda im, wb, pf, cfg: im.new_empty((im.shape[0], cfg[6]), dtype=torch.float32)),
     "text_forward": (_text_forward, lambda t, wb, pf, cfg: t.new_empty((t.shape[0], cfg[6]), dtype=torch.float32)),
+    "xlmr_forward": (_xlmr_forward, lambda t, wb, pf, cfg: t.new_empty((t.shape[0], cfg[8]), dtype=torch.float32)),
     "htsat_forward": (_htsat_forward, lambda w, wb, pf: w.new_empty((w.shape[0], 1024), dtype=torch.float32)),
     "clip_preprocess_u8": (_clip_preprocess_u8, lambda f, s: f.new_empty((f.shape[0], 3, s, s), dtype=torch.uint8)),
 }
