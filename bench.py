@@ -418,16 +418,17 @@ def main():
             "batched_nq32_queries_per_s": round(32 * s_steps / sdt32, 2),
             "batched_nq32_ms_per_pass": round(sdt32 / s_steps * 1e3, 4),
             "batched_nq256_queries_per_s": round(256 * s256 / sdt256, 2),
-            "batched_nq256_roofline": {"kernel": "ip_scan_shadow64_kernel (stage 1 of the batched two-stage search)",
+            "batched_nq256_roofline": {"kernel": "ip_scan_shadow64_kernel<4,128,false> (stage 1 of the batched two-stage search)",
                                        "bound": "hbm",
-                                       "achieved": round(N * d * 2 / world / (sdt256 / s256 / 4) / 1e9, 1),
+                                       "achieved": round(N * d * 2 / world / (sdt256 / s256 / 2) / 1e9, 1),
                                        "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": round(N * d * 2 / world / (sdt256 / s256 / 4) / 1e9 / PEAK_HBM_GBS, 4),
-                                       "note": "bf16 shadow rows (N*d*2 bytes) per pass of 64 queries; whole call / 4 passes "
-                                               "(threshold pass, two scan ranges, merges, fp32 re-scoring + certificates, "
+                                       "frac": round(N * d * 2 / world / (sdt256 / s256 / 2) / 1e9 / PEAK_HBM_GBS, 4),
+                                       "note": "bf16 shadow rows (N*d*2 bytes) per pass of 128 queries (the query enters as one "
+                                               "bf16 piece, its rounding carried in the error bound); whole call / 2 passes "
+                                               "(sample, thresholds, collect, per-query refine + fp32 re-scoring + select, "
                                                "gated fallback launches), per GPU",
                                        "traffic": load_pmc_traffic("ip_scan_shadow64_kernel")},
-            "batched_nq32_roofline": {"kernel": "ip_scan_shadow64_kernel (one pass, half its 64 query slots used)",
+            "batched_nq32_roofline": {"kernel": "ip_scan_shadow64_kernel<4,64,false> (one pass, half its 64 query slots used)",
                                       "bound": "hbm",
                                       "achieved": round(N * d * 2 / world / (sdt32 / s_steps) / 1e9, 1),
                                       "peak": PEAK_HBM_GBS, "unit": "GB/s",

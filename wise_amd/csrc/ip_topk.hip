@@ -1369,6 +1369,7 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norm
 
 constexpr int BATCH_CAP = 65536;            // rows per query the batched collect pass may hand on
 constexpr int BATCH_SAMPLE_SHIFT = 4;       // a sample chunk = 16 groups of 32 rows = 512 rows
+constexpr int PASS_QMAX = 128;              // most queries one pass of the shadow scan carries (one-piece queries, d <= 512)
 
 struct PassWs {
     u64* mpart; float* mq; long long* cand_rows; float* cand_scores; u64* tau0; int* ctl; int* gate; float* thr;
@@ -1382,25 +1383,25 @@ static PassWs pass_workspace(unsigned char* wsb, long long N, int d, int k) {
     const size_t valu = (size_t)p2.grid * 4 * k * sizeof(u64);
     if (valu > lists) lists = valu;
     w.mpart = reinterpret_cast<u64*>(wsb + off); off += align_up(lists, 256);
-    w.mq = reinterpret_cast<float*>(wsb + off); off += align_up((size_t)MFMA_QB2 * d * sizeof(float), 256);
+    w.mq = reinterpret_cast<float*>(wsb + off); off += align_up((size_t)PASS_QMAX * d * sizeof(float), 256);
     w.cand_rows = reinterpret_cast<long long*>(wsb + off);
     w.cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)MFMA_QB2 * MFMA_KL * 8);
     off += align_up((size_t)MFMA_QB2 * MFMA_KL * 12, 256);
     w.tau0 = reinterpret_cast<u64*>(wsb + off); off += 512;
-    w.ctl = reinterpret_cast<int*>(wsb + off); off += MFMA_QB2 * 4 * sizeof(int);
+    w.ctl = reinterpret_cast<int*>(wsb + off); off += PASS_QMAX * 4 * sizeof(int);
     w.gate = reinterpret_cast<int*>(wsb + off); off += 256;
-    w.thr = reinterpret_cast<float*>(wsb + off); off += 256;
-    w.dump = reinterpret_cast<float*>(wsb + off); off += align_up((size_t)MFMA_QB2 * SAMPLE_CHUNKS * 512 * sizeof(float), 256);
-    w.cand = reinterpret_cast<u64*>(wsb + off); off += align_up((size_t)MFMA_QB2 * BATCH_CAP * sizeof(u64), 256);
-    w.cand2 = reinterpret_cast<u64*>(wsb + off); off += align_up((size_t)MFMA_QB2 * RESCORE_CAP * sizeof(u64), 256);
-    w.ekeys = reinterpret_cast<u64*>(wsb + off); off += align_up((size_t)MFMA_QB2 * RESCORE_CAP * sizeof(u64), 256);
+    w.thr = reinterpret_cast<float*>(wsb + off); off += align_up(PASS_QMAX * sizeof(float), 256);
+    w.dump = reinterpret_cast<float*>(wsb + off); off += align_up((size_t)PASS_QMAX * SAMPLE_CHUNKS * 512 * sizeof(float), 256);
+    w.cand = reinterpret_cast<u64*>(wsb + off); off += align_up((size_t)PASS_QMAX * BATCH_CAP * sizeof(u64), 256);
+    w.cand2 = reinterpret_cast<u64*>(wsb + off); off += align_up((size_t)PASS_QMAX * RESCORE_CAP * sizeof(u64), 256);
+    w.ekeys = reinterpret_cast<u64*>(wsb + off); off += align_up((size_t)PASS_QMAX * RESCORE_CAP * sizeof(u64), 256);
     w.total = off;
     return w;
 }
 
 static size_t pass_workspace_bytes(long long N, int d, int k) { return pass_workspace(nullptr, N, d, k).total; }
 
-// up to 64 queries (32 for 512 < d <= 1024) in the threshold form, the bf16 rows on the matrix cores: sample pass ->
+// up to QB queries (shadow_pass_queries(d): 128 / 64 / 32) in the threshold form, the bf16 rows on the matrix cores: sample pass ->
 // per-query thresholds -> one pass over all bf16 rows collecting every (query, row) that could matter -> per query:
 // refine, exact scores, the k best.  If any query's list overflows the pass gate is raised and the scan of the f32 rows
 // queued behind (split-bf16 candidates + exact re-scoring, or the f32 VALU scan for d > 512) redoes the pass.
@@ -1415,7 +1416,7 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* nor
     float* cand_scores = w.cand_scores;
     u64* tau0 = w.tau0;
     int* gate = w.gate;
-    hipError_t e = hipMemsetAsync(w.ctl, 0, MFMA_QB2 * 4 * sizeof(int) + sizeof(int), st);     // ctl and the pass gate behind it
+    hipError_t e = hipMemsetAsync(w.ctl, 0, PASS_QMAX * 4 * sizeof(int) + sizeof(int), st);     // ctl and the pass gate behind it
     if (e == hipSuccess && nqa < QB) e = hipMemsetAsync(mq, 0, (size_t)QB * d * sizeof(float), st);
     if (e == hipSuccess) e = hipMemcpyAsync(mq, Q, (size_t)nqa * d * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) { set_error("ip_topk_shadow: query staging: %s", hipGetErrorString(e)); return (int)e; }
@@ -1475,28 +1476,33 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* nor
         }
         return WISE_OK;
     }
-    {
-        const int kl = MFMA_KL, cap = list_cap(kl);
+    // d <= 512: the split-bf16 scan of the f32 rows, 64 queries per launch (a 128-query pass is redone in two halves)
+    for (int sub = 0; sub < nqa; sub += MFMA_QB2) {
+        const int nsub = nqa - sub < MFMA_QB2 ? nqa - sub : MFMA_QB2;
+        const float* sq = mq + (size_t)sub * d;       // mq is zero-padded to QB rows, QB a multiple of 64 here
+        float* sD = outD + (size_t)sub * k;
+        long long* sI = outI + (size_t)sub * k;
+        const int kl = MFMA_KL, cap = list_cap(kl), FQ = MFMA_QB2;
         int mwv = 8192 / cap;
         if (mwv < 1) mwv = 1;
         if (mwv > 16) mwv = 16;
         int p1 = 0;
         if (ns > 0) {
-            if ((rc = split64_scan_launch(X, ns, 0, d, mq, nqa, mpart, nullptr, st, gate))) return rc;
+            if ((rc = split64_scan_launch(X, ns, 0, d, sq, nsub, mpart, nullptr, st, gate))) return rc;
             p1 = split64_lists(ns);
-            hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart, p1, QB, kl, cap,
+            hipLaunchKernelGGL(merge_keys_kernel, dim3(nsub), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart, p1, FQ, kl, cap,
                                (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0, gate);
             WISE_LAUNCH_CHECK("merge_keys_kernel (gated)");
             if ((rc = sample_threshold_launch(cand_scores, cand_rows, tau0, st, kl, gate))) return rc;
         }
-        if ((rc = split64_scan_launch(X + (size_t)ns * d, N - ns, ns, d, mq, nqa, mpart + (size_t)p1 * QB * kl,
+        if ((rc = split64_scan_launch(X + (size_t)ns * d, N - ns, ns, d, sq, nsub, mpart + (size_t)p1 * FQ * kl,
                                       ns > 0 ? tau0 : nullptr, st, gate)))
             return rc;
-        hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart,
-                           p1 + split64_lists(N - ns), QB, kl, cap, (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0,
+        hipLaunchKernelGGL(merge_keys_kernel, dim3(nsub), dim3(mwv * 64), (size_t)mwv * cap * 8, st, mpart,
+                           p1 + split64_lists(N - ns), FQ, kl, cap, (const long long*)nullptr, 0ll, cand_scores, cand_rows, 0,
                            gate);
         WISE_LAUNCH_CHECK("merge_keys_kernel (gated)");
-        if ((rc = rescore_launch(X, d, mq, cand_rows, nqa, k, ids, id_base, outD, outI, st, gate))) return rc;
+        if ((rc = rescore_launch(X, d, sq, cand_rows, nsub, k, ids, id_base, sD, sI, st, gate))) return rc;
     }
     return WISE_OK;
 }
@@ -1538,8 +1544,9 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
     // rows once: 2.7 ms at 10M x 768, a single query 2.4 ms)
     const bool batched32 = !batched && nq >= 3 && k <= 16 && d > 512 && (shadow64_supported(d) || shadow32_supported(d));
     if (batched || batched32) {
-        const int qb = (batched || shadow64_supported(d)) ? MFMA_QB2 : MFMA_QB;
-        for (int q0 = 0; q0 < nq; q0 += qb) {
+        const int qmax = shadow_pass_queries(d);    // 128 (one-piece queries, d <= 512), 64 or 32
+        for (int q0 = 0, qb = qmax; q0 < nq; q0 += qb) {
+            qb = (qmax == 128 && nq - q0 <= 64) ? 64 : qmax;     // a half-empty 128-query pass costs 6 % more than a 64-query one
             const int nqa = nq - q0 < qb ? nq - q0 : qb;
             int rc = shadow_search_pass(X, Xb, norms, N, d, Q + (size_t)q0 * d, nqa, k, lids, (long long)id_base,
                                         outD + (size_t)q0 * k, lI + (size_t)q0 * k, counters, wsb, st, qb);

@@ -644,9 +644,10 @@ int split64_scan_launch(const float* X, long long N, long long row_offset, int d
 // ------------------------------------------------------------------------------------------------
 constexpr int CW2 = 64;   // columns per chunk of the bf16 scan
 
-// LO: the query enters as two bf16 pieces (hi + lo: its rounding is negligible, 16 MFMAs per 4-KiB chunk); !LO: as ONE bf16
-// piece — half the MFMAs, half the LDS reads and half the LDS footprint (64 queries fit up to d = 1024); the rounding of
-// the query, ||q - bf16(q)|| (max||x|| + max residual), then enters the error bound of the threshold form (ip_topk.hip).
+// LO: the query enters as two bf16 pieces (hi + lo: its rounding is negligible, 16 MFMAs per 4-KiB chunk at 64 queries);
+// !LO: as ONE bf16 piece — half the MFMAs, LDS reads and LDS footprint per query, so a pass carries 128 queries at
+// d <= 512 and 64 up to d = 1024; the rounding of the query, ||q - bf16(q)|| (max||x|| + max residual), then enters the
+// error bound of the threshold form (ip_topk.hip, query_eps).  NG = QB / 32 accumulator tiles of 32 rows x 32 queries.
 template <int PF, int QB, bool LO>
 __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const bf16_t* __restrict__ Xb, long long N, int d,
                                                                   const float* __restrict__ qpad /*[QB][d]*/, int nq,
@@ -655,6 +656,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
                                                                   u64* __restrict__ cand /*[QB][cap] (collect)*/, int cap,
                                                                   float* __restrict__ dump /*[QB][N] or null*/,
                                                                   int chunk_shift, long long chunk_stride, int abl) {
+    constexpr int NG = QB / 32;
+    static_assert(NG == 1 || NG == 2 || (NG == 4 && !LO), "query groups per pass");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -666,12 +669,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
         const int j = idx / d4, c = idx - j * d4;
         const float4 v = reinterpret_cast<const float4*>(qpad)[idx];
         const unsigned h01 = pack_bf16x2(v.x, v.y), h23 = pack_bf16x2(v.z, v.w);
-        const unsigned l01 = pack_bf16x2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xFFFF0000u));
-        const unsigned l23 = pack_bf16x2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xFFFF0000u));
         const int c8 = c >> 1;
         const size_t off = ((size_t)j * d8 + ((c8 & ~15) | ((c8 & 15) ^ (j & 15)))) * 16 + (c & 1) * 8;
         *reinterpret_cast<uint2*>(Qh + off) = make_uint2(h01, h23);
-        if constexpr (LO) *reinterpret_cast<uint2*>(Ql + off) = make_uint2(l01, l23);
+        if constexpr (LO) {
+            const unsigned l01 = pack_bf16x2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xFFFF0000u));
+            const unsigned l23 = pack_bf16x2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xFFFF0000u));
+            *reinterpret_cast<uint2*>(Ql + off) = make_uint2(l01, l23);
+        }
     }
     __syncthreads();
 
@@ -705,52 +710,56 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
         for (int p = 0; p < PF; ++p) prefetch(xq[p]);
     }
 
-    f32x16 acc0, acc1;
+    f32x16 acc[NG];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const bool active_a = i < nq, active_b = QB == 64 && 32 + i < nq;
-    const float thr_a = (thr && active_a) ? thr[i] : 3.4028234663852886e38f;
-    const float thr_b = (thr && active_b) ? thr[32 + i] : 3.4028234663852886e38f;
+    for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[gq][r] = 0.f;
+    float thr_g[NG];
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) thr_g[gq] = (thr && gq * 32 + i < nq) ? thr[gq * 32 + i] : 3.4028234663852886e38f;
     long long cg = gw;
     int cc = 0;
-    const size_t ra = (size_t)i * d8 * 16, rb = (size_t)((QB == 64 ? 32 : 0) + i) * d8 * 16;
     for (long long s0 = 0; s0 < steps; s0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             // nch % PF == 0 (host check): a group ends on the last slot of a trip
             const int c8 = ((cc + p) * CW2 >> 3) + h * 4;
-            bf16x8 x0 = xq[p][0], x1 = xq[p][1], x2 = xq[p][2], x3 = xq[p][3];
-            bf16x8 qa[4], la[4], qb[4], lb[4];
+            bf16x8 x[4] = {xq[p][0], xq[p][1], xq[p][2], xq[p][3]};
+            // Q fragments of k-step j+1 are fetched from LDS while the MFMAs of k-step j run (two register sets)
+            bf16x8 qf[2][NG], lf[2][LO ? NG : 1];
+            auto fetch_q = [&](int j, bf16x8 (&qd)[NG], bf16x8 (&ld)[LO ? NG : 1]) {
+                const size_t o = (size_t)(((c8 + j) & ~15) | (((c8 + j) & 15) ^ (i & 15))) * 16;
+#pragma unroll
+                for (int gq = 0; gq < NG; ++gq) {
+                    const size_t rq = (size_t)(gq * 32 + i) * d8 * 16;        // (gq*32 + i) & 15 == i & 15: one swizzle for all
+                    qd[gq] = *reinterpret_cast<const bf16x8*>(Qh + rq + o);
+                    if constexpr (LO) ld[gq] = *reinterpret_cast<const bf16x8*>(Ql + rq + o);
+                }
+            };
+            fetch_q(0, qf[0], lf[0]);
+            if (abl & 2) {   // timing ablation: loads and LDS reads without the matrix products
+                float t = (float)x[0][0] + (float)x[1][1] + (float)x[2][2] + (float)x[3][3];
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    fetch_q(j, qf[j & 1], lf[j & 1]);
+#pragma unroll
+                    for (int gq = 0; gq < NG; ++gq) { t += (float)qf[j & 1][gq][0]; if constexpr (LO) t += (float)lf[j & 1][gq][0]; }
+                }
+                prefetch(xq[p]);
+                acc[0][0] += t;
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const size_t o = (size_t)(((c8 + j) & ~15) | (((c8 + j) & 15) ^ (i & 15))) * 16;
-                qa[j] = *reinterpret_cast<const bf16x8*>(Qh + ra + o);
-                if constexpr (LO) la[j] = *reinterpret_cast<const bf16x8*>(Ql + ra + o);
-                if constexpr (QB == 64) {
-                    qb[j] = *reinterpret_cast<const bf16x8*>(Qh + rb + o);
-                    if constexpr (LO) lb[j] = *reinterpret_cast<const bf16x8*>(Ql + rb + o);
+                if (j < 3) fetch_q(j + 1, qf[(j + 1) & 1], lf[(j + 1) & 1]);
+                if (j == 0) prefetch(xq[p]);        // x[] holds this slot's rows: the slot can take the next chunk
+#pragma unroll
+                for (int gq = 0; gq < NG; ++gq) {
+                    if constexpr (LO) acc[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[j], lf[j & 1][gq], acc[gq], 0, 0, 0);
+                    acc[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[j], qf[j & 1][gq], acc[gq], 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            prefetch(xq[p]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (LO && (abl & 2)) { acc0[0] += (float)x0[0] + (float)x1[1] + (float)x2[2] + (float)x3[3] + (float)qa[0][0] + (float)la[1][0] + (float)qb[2][0] + (float)lb[3][0] + (float)qa[1][0] + (float)qa[2][0] + (float)qa[3][0] + (float)la[0][0] + (float)la[2][0] + (float)la[3][0] + (float)qb[0][0] + (float)qb[1][0] + (float)qb[3][0] + (float)lb[0][0] + (float)lb[1][0] + (float)lb[2][0]; continue; }
-            if constexpr (LO) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, la[0], acc0, 0, 0, 0);
-            if constexpr (LO && QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, lb[0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, qa[0], acc0, 0, 0, 0);
-            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0, qb[0], acc1, 0, 0, 0);
-            if constexpr (LO) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, la[1], acc0, 0, 0, 0);
-            if constexpr (LO && QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, lb[1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, qa[1], acc0, 0, 0, 0);
-            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, qb[1], acc1, 0, 0, 0);
-            if constexpr (LO) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, la[2], acc0, 0, 0, 0);
-            if constexpr (LO && QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, lb[2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, qa[2], acc0, 0, 0, 0);
-            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, qb[2], acc1, 0, 0, 0);
-            if constexpr (LO) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, la[3], acc0, 0, 0, 0);
-            if constexpr (LO && QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, lb[3], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, qa[3], acc0, 0, 0, 0);
-            if constexpr (QB == 64) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, qb[3], acc1, 0, 0, 0);
         }
         cc += PF;
         if (cc == nch) {
@@ -764,50 +773,57 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
                 for (int r = 0; r < 16; ++r) {
                     const long long lrow = lrow0 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (lrow < N) {
-                        dump[(size_t)i * N + lrow] = acc0[r];
-                        if constexpr (QB == 64) dump[(size_t)(32 + i) * N + lrow] = acc1[r];
+#pragma unroll
+                        for (int gq = 0; gq < NG; ++gq) dump[(size_t)(gq * 32 + i) * N + lrow] = acc[gq][r];
                     }
-                    acc0[r] = 0.f; acc1[r] = 0.f;
                 }
             } else if (abl & 1) {
                 float t = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { t += acc0[r] + acc1[r]; acc0[r] = 0.f; acc1[r] = 0.f; }
+                for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += acc[gq][r];
                 if (t == 1.2345e-30f) ctl[0] = 1;
             } else {
-                // collect: a lane holds query i (and 32 + i), 16 rows each
+                // collect: a lane holds queries gq*32 + i, 16 rows each
                 bool hit = false;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hit |= (acc0[r] >= thr_a) || (QB == 64 && acc1[r] >= thr_b);
+                for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hit |= acc[gq][r] >= thr_g[gq];
                 if (__ballot(hit) != 0) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (row < N) {
-                            if (acc0[r] >= thr_a) {
-                                const int pos = atomicAdd(ctl + 4 * i, 1);
-                                if (pos < cap) cand[(size_t)i * cap + pos] = make_key(acc0[r], (unsigned)row);
-                            }
-                            if (QB == 64 && acc1[r] >= thr_b) {
-                                const int pos = atomicAdd(ctl + 4 * (32 + i), 1);
-                                if (pos < cap) cand[(size_t)(32 + i) * cap + pos] = make_key(acc1[r], (unsigned)row);
+                    for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (row < N && acc[gq][r] >= thr_g[gq]) {
+                                const int q = gq * 32 + i;
+                                const int pos = atomicAdd(ctl + 4 * q, 1);
+                                if (pos < cap) cand[(size_t)q * cap + pos] = make_key(acc[gq][r], (unsigned)row);
                             }
                         }
-                    }
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
             }
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[gq][r] = 0.f;
         }
     }
 }
 
 int g_shadow_one_piece = 1;   // (debug knob) 0: two-piece bf16 query in the batched shadow scan
 bool shadow_one_piece() { return g_shadow_one_piece != 0; }
-// 64 queries per pass: their Q images must fit LDS — d <= 512 with two pieces per query, d <= 1024 with one
-bool shadow64_supported(int d) { return d % (4 * CW2) == 0 && d <= (g_shadow_one_piece ? 1024 : 512); }
-// 32 queries per pass (two-piece queries at 512 < d <= 1024, e.g. 768, the L/14 dimension)
-bool shadow32_supported(int d) { return d % (4 * CW2) == 0 && d <= 1024; }
+// queries per pass: their Q images must fit LDS (160 KiB) — two bf16 pieces per query: 64 up to d = 512, 32 up to 1024;
+// one piece: 128 up to d = 512, 64 up to d = 1024
+int shadow_pass_queries(int d) {
+    if (d % (4 * CW2) != 0 || d > 1024) return 0;
+    if (g_shadow_one_piece) return d <= 512 ? 128 : 64;
+    return d <= 512 ? 64 : 32;
+}
+bool shadow64_supported(int d) { return shadow_pass_queries(d) >= 64; }
+bool shadow32_supported(int d) { return shadow_pass_queries(d) >= 32; }
 int shadow64_scan_launch(const bf16_t* Xb, long long N, int d, const float* qpad, int nq, const float* thr, int* ctl,
                          u64* cand, int cap, hipStream_t st, float* dump, int qb, int chunk_shift, long long chunk_stride) {
     const bool lo = !g_shadow_one_piece;
@@ -818,16 +834,20 @@ int shadow64_scan_launch(const bf16_t* Xb, long long N, int d, const float* qpad
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 32, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 128, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 64, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 32, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    WISE_CHECK_ARG(dl <= 160 * 1024, "shadow scan: the query images of %d queries at d=%d do not fit LDS", qb, d);
+    WISE_CHECK_ARG(dl <= 160 * 1024 && (qb == 32 || qb == 64 || (qb == 128 && !lo)),
+                   "shadow scan: %d queries per pass at d=%d not served", qb, d);
 #define SH_LAUNCH(QBV, LOV)                                                                                                  \
     hipLaunchKernelGGL((ip_scan_shadow64_kernel<4, QBV, LOV>), dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, Xb, N, d, qpad, \
                        nq, thr, ctl, cand, cap, dump, chunk_shift, chunk_stride, g_mfma_abl)
-    if (qb == 64) { if (lo) SH_LAUNCH(64, true); else SH_LAUNCH(64, false); }
+    if (qb == 128) SH_LAUNCH(128, false);
+    else if (qb == 64) { if (lo) SH_LAUNCH(64, true); else SH_LAUNCH(64, false); }
     else { if (lo) SH_LAUNCH(32, true); else SH_LAUNCH(32, false); }
 #undef SH_LAUNCH
     WISE_LAUNCH_CHECK("ip_scan_shadow64_kernel");

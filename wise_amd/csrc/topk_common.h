@@ -45,6 +45,7 @@ int split64_scan_launch(const float* X, long long N, long long row_offset, int d
 // chunk_stride groups apart
 bool shadow64_supported(int d);
 bool shadow32_supported(int d);
+int shadow_pass_queries(int d);   // queries one pass of the shadow scan carries at this d (0: not served)
 bool shadow_one_piece();   // the batched scan takes the query as one bf16 piece (its rounding enters the error bound)
 int shadow64_scan_launch(const bf16_t* Xb, long long N, int d, const float* qpad, int nq, const float* thr, int* ctl,
                          u64* cand, int cap, hipStream_t st, float* dump = nullptr, int qb = 64, int chunk_shift = -1,
