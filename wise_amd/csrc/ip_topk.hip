@@ -973,7 +973,7 @@ extern "C" int wise_debug_set_scan(int rows, int blocks_per_cu) {
     g_scan_blocks_per_cu = blocks_per_cu & 0xFF;
     g_stage2_factor = (blocks_per_cu >> 8) & 0xFFF ? (blocks_per_cu >> 8) & 0xFFF : 8;
     g_use_mfma = (rows >> 8) & 1 ? 0 : 1;  // bit 8: force the VALU kernel for batched queries
-    g_mfma_abl = (rows >> 9) & 3;
+    g_mfma_abl = ((rows >> 9) & 3) | (((rows >> 27) & 1) << 2);   // bit 27: (timing experiment) tiled addressing in the shadow scan
     g_use_split = (rows >> 11) & 1 ? 0 : 1;
     g_split_direct = (rows >> 12) & 15 ? ((rows >> 12) & 15) % 8 : 4;   // bits 12-15: queue depth 3/4/6; 8 = DMA ring
     if (((rows >> 12) & 15) == 8) g_split_direct = 0;
@@ -1288,6 +1288,63 @@ __global__ __launch_bounds__(1024) void batch_threshold_kernel(const float* __re
     }
 }
 
+// Between the two ranges of the batched collect pass: the rows collected from the FIRST range bound the k-th best score
+// far better than the 64K-row sample did (k-th best of 1M rows instead of 64K), so the rest of the index runs under
+//     thr[q] = max(thr[q], L1 - 2 eps),   L1 = k-th largest of 1024 slice maxima of the collected approximate scores
+// (>= k distinct rows reach L1, the same argument as for the sample).  It matters because the collect kernel's hit path —
+// a pass over all of a lane's accumulators with atomics — is taken by nearly every 32-row group under the sample
+// threshold (128 queries x 32 rows x 3e-4), and by one group in thirty under the tightened one: 2.0 -> 1.75 ms per pass.
+// A query whose first-range list overflowed keeps its threshold (the refine step raises the gate for it later).
+__global__ __launch_bounds__(1024) void batch_tighten_kernel(const int* __restrict__ ctl, const u64* __restrict__ cand, int cap,
+                                                             int k, const float* __restrict__ Q, int d,
+                                                             const float* __restrict__ norms, int q_mode,
+                                                             float* __restrict__ thr) {
+    __shared__ u64 wmax[16];
+    __shared__ float wsum[16], wres[16];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = ctl[4 * q];
+    if (n > cap || n < k) return;                    // uniform: nothing to learn from an overflowed or a short list
+    cand += (size_t)q * cap;
+    Q += (size_t)q * d;
+    u64 mine = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const u64 key = cand[i];
+        mine = key > mine ? key : mine;
+    }
+    float qq = 0.f, qr = 0.f;
+    for (int j = tid; j < d; j += 1024) {
+        qq = fmaf(Q[j], Q[j], qq);
+        const float rr = bf16_round_residual(Q[j]);
+        qr = fmaf(rr, rr, qr);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { qq += __shfl_xor(qq, o, 64); qr += __shfl_xor(qr, o, 64); }
+    if (lane == 0) { wsum[wave] = qq; wres[wave] = qr; }
+    u64 L = 0;
+    for (int r = 0; r < k; ++r) {
+        u64 m = mine;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const u64 other = __shfl_xor(m, o, 64);
+            m = other > m ? other : m;
+        }
+        if (lane == 0) wmax[wave] = m;
+        __syncthreads();
+        u64 g = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) g = wmax[w] > g ? wmax[w] : g;
+        L = g;
+        if (mine == g) mine = 0;
+        __syncthreads();
+    }
+    if (tid == 0 && L != 0) {                        // L == 0: fewer than k non-empty slices
+        qq = 0.f; qr = 0.f;
+        for (int w = 0; w < 16; ++w) { qq += wsum[w]; qr += wres[w]; }
+        const float t2 = f32_unorder((unsigned)(L >> 32)) - 2.f * query_eps(norms, d, qq, qr, q_mode);
+        if (t2 > thr[q]) thr[q] = t2;
+    }
+}
+
 // One query (threshold form, see ip_collect_bf16_kernel): sample scan -> threshold -> collect every row that
 // could belong to the top-k -> exact scores -> the k best; the f32 scan queued behind runs only if the list overflowed.
 static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norms, long long N, int d, const float* q,
@@ -1369,6 +1426,7 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norm
 
 constexpr int BATCH_CAP = 65536;            // rows per query the batched collect pass may hand on
 constexpr int BATCH_SAMPLE_SHIFT = 4;       // a sample chunk = 16 groups of 32 rows = 512 rows
+constexpr long long BATCH_FIRST_RANGE = 1ll << 20;   // rows of the collect pass's first range (a multiple of 32)
 constexpr int PASS_QMAX = 128;              // most queries one pass of the shadow scan carries (one-piece queries, d <= 512)
 
 struct PassWs {
@@ -1434,10 +1492,20 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* nor
         hipLaunchKernelGGL(batch_threshold_kernel, dim3(nqa), dim3(1024), 0, st, w.dump, nsample, k, mq, d, norms,
                            q_mode, w.thr);
         WISE_LAUNCH_CHECK("batch_threshold_kernel");
-        // ---- collect over all rows
+        // ---- collect over all rows, in two ranges: [0, R1) under the sample's thresholds, the rest under thresholds
+        // tightened by what the first range collected (batch_tighten_kernel)
         {
             ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
-            if ((rc = shadow64_scan_launch(Xb, N, d, mq, nqa, w.thr, w.ctl, w.cand, BATCH_CAP, st, nullptr, QB))) return rc;
+            const long long R1 = N >= 4 * BATCH_FIRST_RANGE ? BATCH_FIRST_RANGE : N;
+            if ((rc = shadow64_scan_launch(Xb, R1, d, mq, nqa, w.thr, w.ctl, w.cand, BATCH_CAP, st, nullptr, QB))) return rc;
+            if (R1 < N) {
+                hipLaunchKernelGGL(batch_tighten_kernel, dim3(nqa), dim3(1024), 0, st, w.ctl, w.cand, BATCH_CAP, k, mq, d, norms,
+                                   q_mode, w.thr);
+                WISE_LAUNCH_CHECK("batch_tighten_kernel");
+                if ((rc = shadow64_scan_launch(Xb + (size_t)R1 * d, N - R1, d, mq, nqa, w.thr, w.ctl, w.cand, BATCH_CAP, st,
+                                               nullptr, QB, -1, 0, R1)))
+                    return rc;
+            }
         }
         hipLaunchKernelGGL(collect_refine_kernel, dim3(1, nqa), dim3(1024), 0, st, w.ctl, w.cand, BATCH_CAP, k, mq, d, norms,
                            w.cand2, stats, gate, q_mode);

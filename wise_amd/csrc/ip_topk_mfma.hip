@@ -655,7 +655,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
                                                                   int* __restrict__ ctl /*[QB][4] (collect)*/,
                                                                   u64* __restrict__ cand /*[QB][cap] (collect)*/, int cap,
                                                                   float* __restrict__ dump /*[QB][N] or null*/,
-                                                                  int chunk_shift, long long chunk_stride, int abl) {
+                                                                  int chunk_shift, long long chunk_stride, int abl,
+                                                                  long long row_base /*added to the rows recorded in cand*/) {
+#ifdef WISE_DEBUG_KNOBS
+    const int ab = abl;          // timing ablations exist in the debug library only: in the product build the hot loop has no
+#else                            // branches on them
+    constexpr int ab = 0;
+    (void)abl;
+#endif
     constexpr int NG = QB / 32;
     static_assert(NG == 1 || NG == 2 || (NG == 4 && !LO), "query groups per pass");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -698,8 +705,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
         long long grow = group_row(pg) + i;
         if (grow >= row_limit) grow = row_limit - 1;
         const bf16x8* src = reinterpret_cast<const bf16x8*>(Xb + grow * d + pc * CW2 + h * 32);
+        if (ab & 4) {
+            // (timing experiment, results meaningless) the same bytes read as a TILED shadow would be: the group's chunk
+            // as 4 KiB contiguous, each wave instruction 1 KiB contiguous
+            const bf16x8* tb = reinterpret_cast<const bf16x8*>(Xb + (group_row(pg) * d + (long long)pc * 2048)) + lane;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dst[t] = src[t];
+            for (int t = 0; t < 4; ++t) dst[t] = tb[t * 64];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dst[t] = src[t];      // (non-temporal loads measured no better here)
+        }
         if (issued + 1 < steps) {
             ++issued;
             if (++pc == nch) { pc = 0; pg += nw; }
@@ -738,7 +753,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
                 }
             };
             fetch_q(0, qf[0], lf[0]);
-            if (abl & 2) {   // timing ablation: loads and LDS reads without the matrix products
+            if (ab & 2) {   // timing ablation: loads and LDS reads without the matrix products
                 float t = (float)x[0][0] + (float)x[1][1] + (float)x[2][2] + (float)x[3][3];
 #pragma unroll
                 for (int j = 1; j < 4; ++j) {
@@ -777,7 +792,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
                         for (int gq = 0; gq < NG; ++gq) dump[(size_t)(gq * 32 + i) * N + lrow] = acc[gq][r];
                     }
                 }
-            } else if (abl & 1) {
+            } else if (ab & 1) {
                 float t = 0.f;
 #pragma unroll
                 for (int gq = 0; gq < NG; ++gq)
@@ -800,7 +815,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void ip_scan_shadow64_kernel(const b
                             if (row < N && acc[gq][r] >= thr_g[gq]) {
                                 const int q = gq * 32 + i;
                                 const int pos = atomicAdd(ctl + 4 * q, 1);
-                                if (pos < cap) cand[(size_t)q * cap + pos] = make_key(acc[gq][r], (unsigned)row);
+                                if (pos < cap) cand[(size_t)q * cap + pos] = make_key(acc[gq][r], (unsigned)(row_base + row));
                             }
                         }
                 }
@@ -825,7 +840,8 @@ int shadow_pass_queries(int d) {
 bool shadow64_supported(int d) { return shadow_pass_queries(d) >= 64; }
 bool shadow32_supported(int d) { return shadow_pass_queries(d) >= 32; }
 int shadow64_scan_launch(const bf16_t* Xb, long long N, int d, const float* qpad, int nq, const float* thr, int* ctl,
-                         u64* cand, int cap, hipStream_t st, float* dump, int qb, int chunk_shift, long long chunk_stride) {
+                         u64* cand, int cap, hipStream_t st, float* dump, int qb, int chunk_shift, long long chunk_stride,
+                         long long row_base) {
     const bool lo = !g_shadow_one_piece;
     const size_t dl = (size_t)qb * d * (lo ? 4 : 2);
     static std::once_flag dattr;
@@ -845,7 +861,7 @@ int shadow64_scan_launch(const bf16_t* Xb, long long N, int d, const float* qpad
                    "shadow scan: %d queries per pass at d=%d not served", qb, d);
 #define SH_LAUNCH(QBV, LOV)                                                                                                  \
     hipLaunchKernelGGL((ip_scan_shadow64_kernel<4, QBV, LOV>), dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, Xb, N, d, qpad, \
-                       nq, thr, ctl, cand, cap, dump, chunk_shift, chunk_stride, g_mfma_abl)
+                       nq, thr, ctl, cand, cap, dump, chunk_shift, chunk_stride, g_mfma_abl, row_base)
     if (qb == 128) SH_LAUNCH(128, false);
     else if (qb == 64) { if (lo) SH_LAUNCH(64, true); else SH_LAUNCH(64, false); }
     else { if (lo) SH_LAUNCH(32, true); else SH_LAUNCH(32, false); }

@@ -49,7 +49,7 @@ int shadow_pass_queries(int d);   // queries one pass of the shadow scan carries
 bool shadow_one_piece();   // the batched scan takes the query as one bf16 piece (its rounding enters the error bound)
 int shadow64_scan_launch(const bf16_t* Xb, long long N, int d, const float* qpad, int nq, const float* thr, int* ctl,
                          u64* cand, int cap, hipStream_t st, float* dump = nullptr, int qb = 64, int chunk_shift = -1,
-                         long long chunk_stride = 0);
+                         long long chunk_stride = 0, long long row_base = 0 /*Xb points at this row of the index*/);
 int sample_threshold_launch(const float* cand_scores, const long long* cand_rows, u64* tau0, hipStream_t st,
                             int kl = MFMA_KL, const int* gate = nullptr);
 // exact f32 scores of cand_rows [nq][MFMA_KL], ordered, first k -> outD/outI [nq][k]

@@ -143,6 +143,10 @@ class XlmrTextEngine:
         self._ws = None
         self._ws_batch = 0
         self.reserve(max_batch)
+        # One query is ~175 launches of a few microseconds each (24 layers x 7 + head): launch-bound.  Small batches are
+        # captured once into a hipGraph (the C ABI allocates and synchronises nothing) and replayed, as TextEngine does.
+        self.graph_max_batch = 4
+        self._graphs = {}
 
     def reserve(self, batch: int):
         if batch <= self._ws_batch:
@@ -152,6 +156,34 @@ class XlmrTextEngine:
             raise RuntimeError("wise_xlmr_workspace_bytes: bad config")
         self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
         self._ws_batch = batch
+        self._graphs = {}  # captured graphs hold the old workspace address
+
+    def _launch(self, t: torch.Tensor, out: torch.Tensor):
+        _lib.check(self.lib.wise_xlmr_forward(C.byref(self.cfg), self.wb.data_ptr(), self.pf.data_ptr(), t.data_ptr(),
+                                              t.shape[0], out.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                              _lib.stream_ptr()), "wise_xlmr_forward")
+
+    def _graph_for(self, B: int):
+        hit = self._graphs.get(B)
+        if hit is None:
+            s = self.spec
+            tok = torch.full((B, s.context), s.pad_id, dtype=torch.int32, device=self.device)
+            tok[:, 0] = 0
+            tok[:, 1] = 2
+            out = torch.empty(B, s.embed_dim, dtype=torch.float32, device=self.device)
+            self._launch(tok, out)  # warm-up outside the capture (first-call kernel attributes)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._launch(tok, out)
+            except RuntimeError:
+                self.graph_max_batch = 0   # capture not possible here: keep launching directly (same kernels)
+                torch.cuda.synchronize()
+                return None
+            hit = (g, tok, out)
+            self._graphs[B] = hit
+        return hit
 
     def forward(self, tokens: torch.Tensor) -> torch.Tensor:
         s = self.spec
@@ -166,10 +198,15 @@ class XlmrTextEngine:
         t = tokens.to(device=self.device, dtype=torch.int32).contiguous()
         B = t.shape[0]
         self.reserve(B)
+        if B <= self.graph_max_batch and not torch.cuda.is_current_stream_capturing():
+            hit = self._graph_for(B)
+            if hit is not None:
+                g, tok, gout = hit
+                tok.copy_(t)
+                g.replay()
+                return gout.clone()
         out = torch.empty(B, s.embed_dim, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.wise_xlmr_forward(C.byref(self.cfg), self.wb.data_ptr(), self.pf.data_ptr(), t.data_ptr(), B,
-                                              out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr()),
-                   "wise_xlmr_forward")
+        self._launch(t, out)
         return out
 
     def residual(self, batch: int) -> torch.Tensor:
