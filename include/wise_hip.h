@@ -28,7 +28,8 @@ extern "C" {
 
 const char* wise_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: per-index counters for the two-stage search,
- * the shadow's error norm, wise_build_flags). */
+ * the shadow's error norm, wise_build_flags; 3: wise_vit_config.arch, wise_text_config.no_causal / eps_e6 — the SigLIP
+ * towers — and the wise_xlmr_* entry points). */
 int wise_abi_version(void);
 /* The compiler flags the device code of this library was built with (wise_amd/build.py).  The product kernels must
  * be built without packed f32 VALU math ("-fno-slp-vectorize ... -packed-fp32-ops": DESIGN.md section 4, a gfx950
@@ -153,7 +154,12 @@ typedef struct wise_vit_config {
     int32_t heads;      /* H = W/64 */
     int32_t mlp;        /* F: 4W */
     int32_t embed_dim;  /* D: 512 / 768 */
-    int32_t act;        /* 0 = QuickGELU x*sigmoid(1.702x) (openai tags), 1 = erf GELU */
+    int32_t act;        /* 0 = QuickGELU x*sigmoid(1.702x) (openai tags), 1 = erf GELU, 2 = GELU tanh form */
+    int32_t arch;       /* 0 = open_clip VisionTransformer (class token, ln_pre, ln_post on the class row, linear projection);
+                           1 = timm ViT as open_clip's SigLIP towers use it (`TimmModel`, pool 'map'): no class token, no
+                           ln_pre, LayerNorm eps 1e-6, final norm over all tokens, attention-pool head (one latent query,
+                           projection, y + mlp(norm(y))), no projection (embed_dim == width); u8 input is normalised with
+                           mean = std = 0.5.  Weight layout of arch 1: wise_amd/feature/siglip.py:pack_siglip_vision */
 } wise_vit_config;
 
 #define WISE_VIT_IN_F32 0  /* images [B,3,S,S] fp32, already normalised (preprocess_image output) */
@@ -220,8 +226,12 @@ typedef struct wise_text_config {
     int32_t mlp;        /* F = 4W */
     int32_t embed_dim;  /* D: 512 / 768 (1024 with head = 1) */
     int32_t act;        /* 0 = QuickGELU, 1 = erf GELU, 2 = gelu_new (tanh form, GPT-2) */
-    int32_t pool;       /* pooled row: 0 = first argmax of the ids (open_clip), 1 = last id != 0 (msclap, pad id 0) */
-    int32_t head;       /* 0 = ln_final + linear projection; 1 = ln_f + msclap Projection (W1, GELU, W2, LayerNorm) */
+    int32_t pool;       /* pooled row: 0 = first argmax of the ids (open_clip), 1 = last id != 0 (msclap, pad id 0),
+                           2 = the last position of the context (open_clip pool_type 'last': SigLIP) */
+    int32_t head;       /* 0 = ln_final + linear projection; 1 = ln_f + msclap Projection (W1, GELU, W2, LayerNorm);
+                           2 = ln_final + Linear WITH bias (SigLIP: pf ends with the bias [D] after ln_final w,b) */
+    int32_t no_causal;  /* 0 = causal mask (CLIP, GPT-2); 1 = none (open_clip no_causal_mask: SigLIP) */
+    int32_t eps_e6;     /* LayerNorm epsilon: 0 = 1e-5, 1 = 1e-6 (SigLIP norm_kwargs) */
 } wise_text_config;
 int wise_text_layout(const wise_text_config* cfg, int64_t* wb_elems, int64_t* pf_elems);
 size_t wise_text_workspace_bytes(const wise_text_config* cfg, int batch);

@@ -22,12 +22,13 @@ EPI_BF16, EPI_QUICKGELU, EPI_GELU, EPI_RESID, EPI_F32 = range(5)
 
 
 class VitConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("image_size", "patch", "width", "layers", "heads", "mlp", "embed_dim", "act")]
+    _fields_ = [(n, C.c_int32) for n in ("image_size", "patch", "width", "layers", "heads", "mlp", "embed_dim", "act",
+                                          "arch")]
 
 
 class TextConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("context", "vocab", "width", "layers", "heads", "mlp", "embed_dim", "act",
-                                          "pool", "head")]
+                                          "pool", "head", "no_causal", "eps_e6")]
 
 
 class XlmrConfig(C.Structure):

@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__
         const float4 a = e[c], q = p[c];
         xr[c] = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
     }
-    if (t == 0 && pool == 1) {
+    if (t == 0 && pool == 2) {
+        if (lane == 0) eot[b] = T - 1;                 // SigLIP: the last position of the (padded) context
+    } else if (t == 0 && pool == 1) {
         // msclap: sequence_lengths = ne(input_ids, 0).sum(-1) - 1 (right-padded with id 0)
         int cnt = 0;
         for (int tt = lane; tt < T; tt += 64) cnt += tokens[b * T + tt] != 0 ? 1 : 0;
@@ -61,7 +63,8 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__
 }
 
 struct TextDims {
-    int T, V, W, L, H, F, D, act, pool, head;
+    int T, V, W, L, H, F, D, act, pool, head, no_causal;
+    float eps;
 };
 static int text_dims(const wise_text_config* c, TextDims* d) {
     WISE_CHECK_ARG(c, "text: null config");
@@ -74,9 +77,10 @@ static int text_dims(const wise_text_config* c, TextDims* d) {
     WISE_CHECK_ARG(d->F > 0 && d->F % 128 == 0, "text: mlp %d must be a multiple of 128", d->F);
     WISE_CHECK_ARG(d->D > 0 && d->D % 4 == 0 && d->L >= 0, "text: bad dims");
     WISE_CHECK_ARG(c->act >= 0 && c->act <= 2, "text: act must be 0 (quick_gelu), 1 (gelu) or 2 (gelu_new)");
-    WISE_CHECK_ARG((c->pool == 0 || c->pool == 1) && (c->head == 0 || c->head == 1), "text: pool/head must be 0 or 1");
-    WISE_CHECK_ARG(c->head == 0 || d->D == 1024, "text: the msclap Projection head is 1024 wide");
-    d->act = c->act; d->pool = c->pool; d->head = c->head;
+    WISE_CHECK_ARG(c->pool >= 0 && c->pool <= 2 && c->head >= 0 && c->head <= 2, "text: pool/head must be 0, 1 or 2");
+    WISE_CHECK_ARG(c->head != 1 || d->D == 1024, "text: the msclap Projection head is 1024 wide");
+    WISE_CHECK_ARG((c->no_causal == 0 || c->no_causal == 1) && (c->eps_e6 == 0 || c->eps_e6 == 1), "text: no_causal / eps_e6 must be 0 or 1");
+    d->act = c->act; d->pool = c->pool; d->head = c->head; d->no_causal = c->no_causal; d->eps = c->eps_e6 ? 1e-6f : 1e-5f;
     return WISE_OK;
 }
 
@@ -100,7 +104,7 @@ static TextOffsets text_offsets(const TextDims& d) {
     o.per_layer_f = o.proj_b + W;
     o.lnf_w = o.layer0_f + o.per_layer_f * d.L; o.lnf_b = o.lnf_w + W;
     o.pj_lw = o.lnf_b + W; o.pj_lb = o.pj_lw + d.D;            // head 1: LayerNorm of the Projection
-    o.total_f = d.head == 1 ? o.pj_lb + d.D : o.pj_lw;
+    o.total_f = d.head == 1 ? o.pj_lb + d.D : (d.head == 2 ? o.pj_lw + d.D : o.pj_lw);   // head 2: the projection's bias [D]
     return o;
 }
 
@@ -172,10 +176,10 @@ extern "C" int wise_text_forward(const wise_text_config* cfg, const uint16_t* wb
     const BlockWeights bw = {wb + o.layer0_b, o.per_layer_b, o.in_proj, o.out_proj, o.c_fc, o.c_proj,
                              pf + o.layer0_f, o.per_layer_f, o.ln1_w, o.ln1_b, o.in_b, o.out_b, o.ln2_w, o.ln2_b,
                              o.fc_b, o.proj_b};
-    if ((rc = transformer_blocks(bw, d.L, d.W, d.H, d.F, d.act, batch, d.T, true, x, h, qkv, a, st))) return rc;
-    if (d.head == 0)
+    if ((rc = transformer_blocks(bw, d.L, d.W, d.H, d.F, d.act, batch, d.T, d.no_causal == 0, x, h, qkv, a, st, d.eps))) return rc;
+    if (d.head == 0 || d.head == 2)
         return pooled_head(x, pf + o.lnf_w, pf + o.lnf_b, wb + o.projT, batch, d.T, d.W, d.D, eot, h,
-                           reinterpret_cast<float*>(qkv), out, st);
+                           reinterpret_cast<float*>(qkv), out, st, d.eps, d.head == 2 ? pf + o.pj_lw : nullptr);
     // msclap: ln_f on the pooled row -> Projection(W1, GELU, W2, LayerNorm(e1 + e2)) -> L2 normalise
     if ((rc = pooled_ln(x, pf + o.lnf_w, pf + o.lnf_b, batch, d.T, d.W, eot, h, st))) return rc;
     return clap_projection(h, wb + o.projT, wb + o.proj2, pf + o.pj_lw, pf + o.pj_lb, batch, d.W,

@@ -26,12 +26,14 @@ struct BlockWeights {
     const float* pf; size_t per_layer_f, ln1_w, ln1_b, in_b, out_b, ln2_w, ln2_b, fc_b, proj_b;
 };
 int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int act, int batch, int T, bool causal,
-                       float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st);
+                       float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st, float eps = 1e-5f);
+int l2norm_rows(const float* e, int rows, int D, float* out, hipStream_t st);
 // LayerNorm of row pos[b] (or 0) of every sequence -> hb bf16 [batch, W]
 int pooled_ln(const float* x, const float* ln_w, const float* ln_b, int batch, int T, int W, const int* pos,
-              bf16_t* hb, hipStream_t st);
+              bf16_t* hb, hipStream_t st, float eps = 1e-5f);
 int pooled_head(const float* x, const float* ln_w, const float* ln_b, const bf16_t* projT, int batch, int T, int W,
-                int D, const int* pos, bf16_t* hb, float* e, float* out, hipStream_t st);
+                int D, const int* pos, bf16_t* hb, float* e, float* out, hipStream_t st, float eps = 1e-5f,
+                const float* proj_bias = nullptr /*[D]: text_projection as a Linear with bias (SigLIP)*/);
 
 // msclap Projection head (htsat.hip): lat bf16 [Bp, d_in] -> out fp32 [B, 1024], L2-normalised
 int clap_projection(const bf16_t* lat, const bf16_t* W1, const bf16_t* W2, const float* lw, const float* lb, int B,

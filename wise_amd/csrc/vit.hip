@@ -397,11 +397,18 @@ int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_
 // patch gather (im2col): images [B,3,S,S] fp32 or u8 -> patches bf16 [B*g*g, Kp], k = c*P*P + py*P + px
 // u8 input applies (x/255 - mean)/std of the OpenAI CLIP transform (mlfoundation_openclip.py:81-90)
 // ------------------------------------------------------------------------------------------------
+// (u8 input) Normalize constants: OpenAI CLIP's for the CLIP towers, 0.5 / 0.5 for the SigLIP towers (open_clip preprocess_cfg)
+struct NormConst { float mean[3], stdv[3]; };
+static NormConst norm_const(int arch) {
+    if (arch == 1) return NormConst{{0.5f, 0.5f, 0.5f}, {0.5f, 0.5f, 0.5f}};
+    return NormConst{{0.48145466f, 0.4578275f, 0.40821073f}, {0.26862954f, 0.26130258f, 0.27577711f}};
+}
+
 template <typename TIN>
 __global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ img, int B, int S, int P, int g,
-                                                       int Kp, bf16_t* __restrict__ patches) {
-    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
-    const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+                                                       int Kp, bf16_t* __restrict__ patches, NormConst nc) {
+    const float* mean = nc.mean;
+    const float* stdv = nc.stdv;
     const int prow = blockIdx.x;  // b*g*g + gy*g + gx
     const int b = prow / (g * g), gy = (prow / g) % g, gx = prow % g;
     const int K = 3 * P * P;
@@ -411,7 +418,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ i
             const int c = k / (P * P), py = (k / P) % P, px = k % P;
             const size_t src = (((size_t)b * 3 + c) * S + gy * P + py) * S + gx * P + px;
             if (sizeof(TIN) == 1)
-                v = ((float)img[src] / 255.f - mean[c]) / stdv[c];  // ToTensor's true division, then Normalize
+                v = ((float)img[src] / 255.f - (c == 0 ? mean[0] : c == 1 ? mean[1] : mean[2])) /
+                    (c == 0 ? stdv[0] : c == 1 ? stdv[1] : stdv[2]);  // ToTensor's true division, then Normalize
             else
                 v = (float)img[src];
         }
@@ -423,9 +431,9 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ i
 // aligned input): two 16-byte loads (fp32) or one 8-byte load (u8) and one 16-byte store
 template <typename TIN>
 __global__ __launch_bounds__(256) void patchify8_kernel(const TIN* __restrict__ img, long long total8, int S, int P, int g,
-                                                        bf16_t* __restrict__ patches) {
-    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
-    const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+                                                        bf16_t* __restrict__ patches, NormConst nc) {
+    const float* mean = nc.mean;
+    const float* stdv = nc.stdv;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total8) return;
     const int K8 = 3 * P * P / 8;
@@ -440,7 +448,8 @@ __global__ __launch_bounds__(256) void patchify8_kernel(const TIN* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const unsigned byte = ((e < 4 ? raw.x : raw.y) >> (8 * (e & 3))) & 0xFFu;
-            v[e] = ((float)byte / 255.f - mean[c]) / stdv[c];  // ToTensor's true division, then Normalize
+            v[e] = ((float)byte / 255.f - (c == 0 ? mean[0] : c == 1 ? mean[1] : mean[2])) /
+                   (c == 0 ? stdv[0] : c == 1 ? stdv[1] : stdv[2]);  // ToTensor's true division, then Normalize
         }
     } else {
         const float4 a = *reinterpret_cast<const float4*>(img + src), bq = *reinterpret_cast<const float4*>(img + src + 4);
@@ -449,6 +458,93 @@ __global__ __launch_bounds__(256) void patchify8_kernel(const TIN* __restrict__ 
     uint4 o;
     o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
     *reinterpret_cast<uint4*>(patches + (size_t)prow * (3 * P * P) + k) = o;
+}
+
+// timm towers without a class token and without ln_pre (SigLIP): x[row, :] = patch_out[row, :] + pos[row % T, :]
+// (the patch embedding's bias is folded into pos by the packer).  float4 per thread.
+__global__ __launch_bounds__(256) void embed_pos_kernel(const float* __restrict__ patch_out, const float* __restrict__ pos,
+                                                        long long total4, int T, int W, float* __restrict__ x) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int w4 = W >> 2;
+    const long long row = idx / w4;
+    const int c = (int)(idx - row * w4);
+    const float4 a = reinterpret_cast<const float4*>(patch_out)[idx];
+    const float4 p = reinterpret_cast<const float4*>(pos)[(size_t)(row % T) * w4 + c];
+    reinterpret_cast<float4*>(x)[idx] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+}
+
+// Attention pooling with one latent query (timm AttentionPoolLatent, the 'map' head of the SigLIP towers): per (image,
+// head) o = softmax(q_h . K_h^T / 8) V_h over the image's T tokens, head dim 64.  kv bf16 [B*T, 2W] (keys | values),
+// qv fp32 [W] = q(latent) (constant: computed by the packer).  One wave per (image, head); lane = token slice.
+__global__ __launch_bounds__(64) void map_pool_kernel(const bf16_t* __restrict__ kv, const float* __restrict__ qv, int T, int W,
+                                                      bf16_t* __restrict__ o /*[B, W]*/) {
+    const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int W2 = 2 * W;
+    float q[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) q[j] = qv[h * 64 + j] * 0.125f;
+    const bf16_t* base = kv + (size_t)b * T * W2 + h * 64;
+    float mx = -INFINITY;
+    constexpr int MAXT = 16;                       // tokens per lane: T <= 1024
+    float sc[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int t = i * 64 + lane;
+        float sdot = -INFINITY;
+        if (t < T) {
+            const uint4* kr = reinterpret_cast<const uint4*>(base + (size_t)t * W2);
+            sdot = 0.f;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const uint4 u = kr[c8];
+                const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sdot = fmaf(__uint_as_float(w4[e] << 16), q[c8 * 8 + 2 * e], sdot);
+                    sdot = fmaf(__uint_as_float(w4[e] & 0xFFFF0000u), q[c8 * 8 + 2 * e + 1], sdot);
+                }
+            }
+        }
+        sc[i] = sdot;
+        mx = fmaxf(mx, sdot);
+    }
+    mx = wave_max(mx);
+    float ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        sc[i] = (i * 64 + lane < T) ? __expf(sc[i] - mx) : 0.f;
+        ps += sc[i];
+    }
+    ps = wave_sum(ps);
+    float acc[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int t = i * 64 + lane;
+        if (t < T) {
+            const uint4* vr = reinterpret_cast<const uint4*>(base + (size_t)t * W2 + W);
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const uint4 u = vr[c8];
+                const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[c8 * 8 + 2 * e] = fmaf(sc[i], __uint_as_float(w4[e] << 16), acc[c8 * 8 + 2 * e]);
+                    acc[c8 * 8 + 2 * e + 1] = fmaf(sc[i], __uint_as_float(w4[e] & 0xFFFF0000u), acc[c8 * 8 + 2 * e + 1]);
+                }
+            }
+        }
+    }
+    const float inv = 1.f / ps;
+    float mine = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const float tot = wave_sum(acc[j]);
+        if (lane == j) mine = tot * inv;
+    }
+    o[(size_t)b * W + h * 64 + lane] = f32_to_bf16(mine);
 }
 
 // x[b*T + t, :] = ln_pre( (t == 0 ? cls : patch_out[b*g*g + t-1, :]) + pos[t, :] ), one wave per row
@@ -566,17 +662,17 @@ int l2norm_rows(const float* e, int rows, int D, float* out, hipStream_t st) {
 
 // L pre-LN residual blocks over x fp32 [B*T (padded to 256), W]; h / qkv / a are the bf16 scratch operands
 int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int act, int batch, int T, bool causal,
-                       float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st) {
+                       float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st, float eps) {
     const int M = batch * T, Mp = (M + 255) / 256 * 256;
     int rc;
     for (int l = 0; l < L; ++l) {
         const bf16_t* lwb = bw.wb + bw.per_layer_b * l;
         const float* lpf = bw.pf + bw.per_layer_f * l;
-        if ((rc = layernorm_f32_bf16(x, lpf + bw.ln1_w, lpf + bw.ln1_b, M, W, 1e-5f, h, st))) return rc;
+        if ((rc = layernorm_f32_bf16(x, lpf + bw.ln1_w, lpf + bw.ln1_b, M, W, eps, h, st))) return rc;
         if ((rc = gemm_bf16(h, lwb + bw.in_proj, lpf + bw.in_b, Mp, 3 * W, W, 0, qkv, st))) return rc;
         if ((rc = attention_bf16(qkv, batch, T, H, h, st, causal, W / H))) return rc;
         if ((rc = gemm_bf16(h, lwb + bw.out_proj, lpf + bw.out_b, Mp, W, W, 3, x, st))) return rc;
-        if ((rc = layernorm_f32_bf16(x, lpf + bw.ln2_w, lpf + bw.ln2_b, M, W, 1e-5f, h, st))) return rc;
+        if ((rc = layernorm_f32_bf16(x, lpf + bw.ln2_w, lpf + bw.ln2_b, M, W, eps, h, st))) return rc;
         // act: 0 QuickGELU, 1 erf GELU, 2 gelu_new (tanh) -> epilogue modes 1, 2, 5
         if ((rc = gemm_bf16(h, lwb + bw.c_fc, lpf + bw.fc_b, Mp, F, W, act == 0 ? 1 : (act == 1 ? 2 : 5), a, st))) return rc;
         if ((rc = gemm_bf16(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, W, F, 3, x, st))) return rc;
@@ -586,10 +682,10 @@ int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int a
 
 // out[b,:] = normalize( LN(x[b*T + pos[b], :]) @ proj ), projT bf16 [D,W]; hb bf16 [Bp,W] and e fp32 [Bp,D] scratch
 int pooled_ln(const float* x, const float* ln_w, const float* ln_b, int batch, int T, int W, const int* pos,
-              bf16_t* hb, hipStream_t st) {
+              bf16_t* hb, hipStream_t st, float eps) {
     const int nv = (W / 4 + 63) / 64;
     const dim3 grid((batch + 3) / 4), block(256);
-#define CLS_CASE(n) case n: hipLaunchKernelGGL(cls_ln_kernel<n>, grid, block, 0, st, x, ln_w, ln_b, batch, T, W, 1e-5f, \
+#define CLS_CASE(n) case n: hipLaunchKernelGGL(cls_ln_kernel<n>, grid, block, 0, st, x, ln_w, ln_b, batch, T, W, eps, \
                                                hb, pos); break;
     switch (nv) {
         CLS_CASE(1) CLS_CASE(2) CLS_CASE(3) CLS_CASE(4) CLS_CASE(5) CLS_CASE(6) CLS_CASE(7) CLS_CASE(8)
@@ -601,18 +697,18 @@ int pooled_ln(const float* x, const float* ln_w, const float* ln_b, int batch, i
 }
 
 int pooled_head(const float* x, const float* ln_w, const float* ln_b, const bf16_t* projT, int batch, int T, int W,
-                int D, const int* pos, bf16_t* hb, float* e, float* out, hipStream_t st) {
+                int D, const int* pos, bf16_t* hb, float* e, float* out, hipStream_t st, float eps, const float* proj_bias) {
     const int Bp = (batch + 255) / 256 * 256;
     int rc;
-    if ((rc = pooled_ln(x, ln_w, ln_b, batch, T, W, pos, hb, st))) return rc;
-    if ((rc = gemm_bf16(hb, projT, nullptr, Bp, D, W, 4, e, st))) return rc;
+    if ((rc = pooled_ln(x, ln_w, ln_b, batch, T, W, pos, hb, st, eps))) return rc;
+    if ((rc = gemm_bf16(hb, projT, proj_bias, Bp, D, W, 4, e, st))) return rc;
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, st, e, batch, D, out);
     WISE_LAUNCH_CHECK("l2norm_rows_kernel");
     return WISE_OK;
 }
 
 struct VitDims {
-    int S, P, W, L, H, F, D, g, T, K, Kp;
+    int S, P, W, L, H, F, D, g, T, K, Kp, arch;
 };
 static int vit_dims(const wise_vit_config* c, VitDims* d) {
     WISE_CHECK_ARG(c, "vit: null config");
@@ -623,8 +719,12 @@ static int vit_dims(const wise_vit_config* c, VitDims* d) {
                    "vit: width %d must be heads * 64 (or heads * 80: ViT-H/14) and a multiple of 128", d->W);
     WISE_CHECK_ARG(d->F > 0 && d->F % 128 == 0, "vit: mlp %d must be a multiple of 128", d->F);
     WISE_CHECK_ARG(d->D > 0 && d->L >= 0 && d->W <= 4096 && d->W % 8 == 0, "vit: bad dims");
-    WISE_CHECK_ARG(c->act == 0 || c->act == 1, "vit: act must be 0 (quick_gelu) or 1 (gelu)");
-    d->g = d->S / d->P; d->T = d->g * d->g + 1; d->K = 3 * d->P * d->P; d->Kp = (d->K + 63) / 64 * 64;
+    WISE_CHECK_ARG(c->act >= 0 && c->act <= 2, "vit: act must be 0 (quick_gelu), 1 (gelu) or 2 (gelu, tanh form)");
+    WISE_CHECK_ARG(c->arch == 0 || c->arch == 1, "vit: arch must be 0 (CLIP) or 1 (timm SigLIP: no class token, attention-pool head)");
+    d->arch = c->arch;
+    WISE_CHECK_ARG(d->arch == 0 || (d->D == d->W && d->H * 64 == d->W), "vit: the attention-pool head has no projection (embed_dim == width) and head dim 64");
+    d->g = d->S / d->P; d->T = d->g * d->g + (d->arch == 0 ? 1 : 0); d->K = 3 * d->P * d->P; d->Kp = (d->K + 63) / 64 * 64;
+    WISE_CHECK_ARG(d->arch == 0 || d->T <= 1024, "vit: the attention-pool head serves up to 1024 tokens");
     return WISE_OK;
 }
 
@@ -634,6 +734,9 @@ struct VitOffsets {
     // fp32 blob (elements)
     size_t cls, pos, ln_pre_w, ln_pre_b, layer0_f, per_layer_f, ln1_w, ln1_b, in_b, out_b, ln2_w, ln2_b, fc_b, proj_b,
         ln_post_w, ln_post_b, total_f;
+    // arch 1 (attention-pool head): bf16 W_kv [2W,W], W_proj [W,W], W_fc1 [F,W], W_fc2 [W,F] from projT on; fp32 after the
+    // final norm (ln_post_w/b): q(latent) [W], b_kv [2W], b_proj [W], head norm w,b, b_fc1 [F], b_fc2 [W]
+    size_t h_kv, h_proj, h_fc1, h_fc2, hq, h_kvb, h_projb, hn_w, hn_b, h_fc1b, h_fc2b;
 };
 static VitOffsets vit_offsets(const VitDims& d) {
     VitOffsets o;
@@ -646,11 +749,21 @@ static VitOffsets vit_offsets(const VitDims& d) {
     o.total_b = o.projT + (size_t)d.D * W;
     o.cls = 0; o.pos = W; o.ln_pre_w = o.pos + (size_t)d.T * W; o.ln_pre_b = o.ln_pre_w + W;
     o.layer0_f = o.ln_pre_b + W;
+    if (d.arch == 1) {   // no class token, no ln_pre
+        o.pos = 0; o.layer0_f = (size_t)d.T * W;
+        o.h_kv = o.projT; o.h_proj = o.h_kv + 2 * W * W; o.h_fc1 = o.h_proj + W * W; o.h_fc2 = o.h_fc1 + F * W;
+        o.total_b = o.h_fc2 + W * F;
+    }
     o.ln1_w = 0; o.ln1_b = W; o.in_b = 2 * W; o.out_b = 5 * W; o.ln2_w = 6 * W; o.ln2_b = 7 * W; o.fc_b = 8 * W;
     o.proj_b = o.fc_b + F;
     o.per_layer_f = o.proj_b + W;
     o.ln_post_w = o.layer0_f + o.per_layer_f * d.L; o.ln_post_b = o.ln_post_w + W;
     o.total_f = o.ln_post_b + W;
+    if (d.arch == 1) {
+        o.hq = o.ln_post_b + W; o.h_kvb = o.hq + W; o.h_projb = o.h_kvb + 2 * W; o.hn_w = o.h_projb + W; o.hn_b = o.hn_w + W;
+        o.h_fc1b = o.hn_b + W; o.h_fc2b = o.h_fc1b + F;
+        o.total_f = o.h_fc2b + W;
+    }
     return o;
 }
 
@@ -669,7 +782,10 @@ static VitWs vit_ws(const VitDims& d, int B) {
     size_t qkv_b = (size_t)w.Mp * 3 * d.W * 2, po_b = (size_t)w.Mpp * d.W * 4;
     w.qkv = off; off += align_up(qkv_b > po_b ? qkv_b : po_b, 256);
     size_t a_b = (size_t)w.Mp * d.F * 2, pa_b = (size_t)w.Mpp * d.Kp * 2;
-    w.a = off; off += align_up(a_b > pa_b ? a_b : pa_b, 256);
+    const size_t head_b = (size_t)((B + 255) / 256 * 256) * (d.W + d.F) * 2;      // arch 1: the head's bf16 rows live here too
+    if (pa_b > a_b) a_b = pa_b;
+    if (d.arch == 1 && head_b > a_b) a_b = head_b;
+    w.a = off; off += align_up(a_b, 256);
     w.total = off;
     return w;
 }
@@ -696,27 +812,34 @@ static int vit_forward_part(const wise_vit_config* cfg, const VitDims& d, const 
     int rc;
 
     // 1. patch gather + conv1-as-GEMM (no bias)
+    const NormConst nc = norm_const(d.arch);
     const bool fast_gather = d.P % 8 == 0 && d.S % 8 == 0 && d.Kp == 3 * d.P * d.P && ((uintptr_t)images & 15) == 0;
     if (fast_gather) {
         const long long total8 = (long long)ws.Mpatch * (d.Kp / 8);
         const unsigned blocks = (unsigned)((total8 + 255) / 256);
         if (in_kind == WISE_VIT_IN_U8)
             hipLaunchKernelGGL(patchify8_kernel<unsigned char>, dim3(blocks), dim3(256), 0, st,
-                               reinterpret_cast<const unsigned char*>(images), total8, d.S, d.P, d.g, patches);
+                               reinterpret_cast<const unsigned char*>(images), total8, d.S, d.P, d.g, patches, nc);
         else
             hipLaunchKernelGGL(patchify8_kernel<float>, dim3(blocks), dim3(256), 0, st,
-                               reinterpret_cast<const float*>(images), total8, d.S, d.P, d.g, patches);
+                               reinterpret_cast<const float*>(images), total8, d.S, d.P, d.g, patches, nc);
     } else if (in_kind == WISE_VIT_IN_U8)
         hipLaunchKernelGGL(patchify_kernel<unsigned char>, dim3(ws.Mpatch), dim3(256), 0, st,
-                           reinterpret_cast<const unsigned char*>(images), batch, d.S, d.P, d.g, d.Kp, patches);
+                           reinterpret_cast<const unsigned char*>(images), batch, d.S, d.P, d.g, d.Kp, patches, nc);
     else
         hipLaunchKernelGGL(patchify_kernel<float>, dim3(ws.Mpatch), dim3(256), 0, st,
-                           reinterpret_cast<const float*>(images), batch, d.S, d.P, d.g, d.Kp, patches);
+                           reinterpret_cast<const float*>(images), batch, d.S, d.P, d.g, d.Kp, patches, nc);
     WISE_LAUNCH_CHECK("patchify_kernel");
     rc = gemm_bf16(patches, wb + o.conv1, nullptr, ws.Mpp, W, d.Kp, 4, patch_out, st);
     if (rc) return rc;
-    // 2. cls + pos + ln_pre -> x
-    {
+    // 2. cls + pos + ln_pre -> x   (arch 1: patch rows + pos, nothing else)
+    if (d.arch == 1) {
+        const long long total4 = (long long)ws.M * (W >> 2);
+        hipLaunchKernelGGL(embed_pos_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, patch_out, pf + o.pos,
+                           total4, d.T, W, x);
+        WISE_LAUNCH_CHECK("embed_pos_kernel");
+    } else {
+
         const int nv = (W / 4 + 63) / 64;
         const float* cls = pf + o.cls; const float* pos = pf + o.pos;
         const float* lw = pf + o.ln_pre_w; const float* lb = pf + o.ln_pre_b;
@@ -737,7 +860,27 @@ static int vit_forward_part(const wise_vit_config* cfg, const VitDims& d, const 
     const BlockWeights bw = {wb + o.layer0_b, o.per_layer_b, o.in_proj, o.out_proj, o.c_fc, o.c_proj,
                              pf + o.layer0_f, o.per_layer_f, o.ln1_w, o.ln1_b, o.in_b, o.out_b, o.ln2_w, o.ln2_b,
                              o.fc_b, o.proj_b};
-    if ((rc = transformer_blocks(bw, d.L, W, d.H, d.F, cfg->act, batch, d.T, false, x, h, qkv, a, st))) return rc;
+    if ((rc = transformer_blocks(bw, d.L, W, d.H, d.F, cfg->act, batch, d.T, false, x, h, qkv, a, st,
+                                 d.arch == 1 ? 1e-6f : 1e-5f)))
+        return rc;
+    if (d.arch == 1) {
+        // 4'. timm 'map' head: final norm over every token -> keys | values GEMM -> one latent query per head attends the
+        // image's tokens -> projection -> y + mlp(norm(y)) -> L2 normalise (the tower has no further projection)
+        const int Bp = (batch + 255) / 256 * 256;
+        if ((rc = layernorm_f32_bf16(x, pf + o.ln_post_w, pf + o.ln_post_b, ws.M, W, 1e-6f, h, st))) return rc;
+        if ((rc = gemm_bf16(h, wb + o.h_kv, pf + o.h_kvb, ws.Mp, 2 * W, W, 0, qkv, st))) return rc;
+        bf16_t* pooled = h;                                    // [Bp, W] bf16 (h is free once the kv GEMM has read it)
+        hipLaunchKernelGGL(map_pool_kernel, dim3(batch, d.H), dim3(64), 0, st, qkv, pf + o.hq, d.T, W, pooled);
+        WISE_LAUNCH_CHECK("map_pool_kernel");
+        float* y = reinterpret_cast<float*>(qkv);              // [Bp, W] fp32 (keys | values are consumed; x stays for the parity tap)
+        bf16_t* yn = a;                                        // [Bp, W] bf16, then the hidden rows [Bp, F] behind it
+        bf16_t* hid = a + (size_t)Bp * W;
+        if ((rc = gemm_bf16(pooled, wb + o.h_proj, pf + o.h_projb, Bp, W, W, 4, y, st))) return rc;
+        if ((rc = layernorm_f32_bf16(y, pf + o.hn_w, pf + o.hn_b, batch, W, 1e-6f, yn, st))) return rc;
+        if ((rc = gemm_bf16(yn, wb + o.h_fc1, pf + o.h_fc1b, Bp, d.F, W, 2, hid, st))) return rc;     // timm Mlp: erf GELU
+        if ((rc = gemm_bf16(hid, wb + o.h_fc2, pf + o.h_fc2b, Bp, W, d.F, 3, y, st))) return rc;
+        return l2norm_rows(y, batch, W, out, st);
+    }
     // 4. ln_post(cls) -> bf16 [Bp,W] (aliases h) ; @ proj -> fp32 [Bp,D] (aliases qkv) ; L2 normalise rows
     if ((rc = pooled_head(x, pf + o.ln_post_w, pf + o.ln_post_b, wb + o.projT, batch, d.T, W, d.D, nullptr, h,
                           reinterpret_cast<float*>(qkv), out, st)))

@@ -17,9 +17,6 @@
 
 namespace wise {
 
-// l2norm_rows_kernel lives in vit.hip
-int l2norm_rows(const float* e, int rows, int D, float* out, hipStream_t st);
-
 // x[row, :] = word[tokens[row]] + pos[position(row)] + type0 ; lens[b] = number of non-pad tokens.  Wave per row.
 __global__ __launch_bounds__(256) void xlmr_embed_kernel(const int* __restrict__ tokens, const float* __restrict__ word,
                                                          const float* __restrict__ pos, const float* __restrict__ type0,

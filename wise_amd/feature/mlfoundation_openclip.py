@@ -17,6 +17,8 @@ from PIL import Image
 from .feature_extractor import FeatureExtractor
 from .clip_tokenizer import ClipTokenizer
 from .text import TextEngine, random_text_state_dict, text_spec_for
+from .siglip import (SIGLIP_MEAN, SIGLIP_STD, SIGLIP_TEXT, SIGLIP_VISION, SiglipTokenizer, pack_siglip_text,
+                     random_siglip_text_state_dict, random_siglip_vision_state_dict)
 from .xlmr_text import XLMR_SPECS, XlmrTextEngine, XlmrTokenizer, random_xlmr_state_dict
 from .vit import SPECS, VitEngine, random_state_dict, spec_for
 from .weights import load_state_dict_file, seeded_tag
@@ -36,6 +38,8 @@ KNOWN_PRETRAINED = {
     "ViT-H-14-quickgelu": ("dfn5b",),
     "xlm-roberta-large-ViT-H-14": ("frozen_laion5b_s13b_b90k",),
     "xlm-roberta-base-ViT-B-32": ("laion5b_s13b_b90k",),
+    # SigLIP (timm image tower, attention-pool head; tests/test-kinetics-6.sh:91 extracts with ViT-L-16-SigLIP-384)
+    **{name: ("webli",) for name in SIGLIP_VISION},
 }
 
 
@@ -45,14 +49,23 @@ def list_pretrained():
 
 class ClipImageTransform:
     """open_clip's eval transform for PIL input, restated without torchvision:
-    Resize(S, bicubic, shorter side) -> CenterCrop(S) -> RGB -> ToTensor -> Normalize(mean, std)."""
+    Resize(S, bicubic, shorter side) -> CenterCrop(S) -> RGB -> ToTensor -> Normalize(mean, std);
+    resize_mode 'squash' (the SigLIP models' preprocess_cfg): Resize((S, S), bicubic) without regard to aspect, no crop."""
 
-    def __init__(self, size: int):
+    def __init__(self, size: int, mean=CLIP_MEAN, std=CLIP_STD, resize_mode: str = "shortest"):
         self.size = int(size)
+        self.mean, self.std, self.resize_mode = tuple(mean), tuple(std), resize_mode
 
     def __call__(self, img: Image.Image) -> torch.Tensor:
         S = self.size
         w, h = img.size
+        if self.resize_mode == "squash":
+            if (w, h) != (S, S):
+                img = img.resize((S, S), Image.BICUBIC)
+            img = img.convert("RGB")
+            x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).to(torch.float32) / 255.0
+            return (x - torch.tensor(self.mean, dtype=torch.float32).view(3, 1, 1)) / \
+                torch.tensor(self.std, dtype=torch.float32).view(3, 1, 1)
         if w <= h:
             nw, nh = S, int(S * h / w)
         else:
@@ -63,8 +76,8 @@ class ClipImageTransform:
         top = int(round((nh - S) / 2.0))
         img = img.crop((left, top, left + S, top + S)).convert("RGB")
         x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).to(torch.float32) / 255.0
-        mean = torch.tensor(CLIP_MEAN, dtype=torch.float32).view(3, 1, 1)
-        std = torch.tensor(CLIP_STD, dtype=torch.float32).view(3, 1, 1)
+        mean = torch.tensor(self.mean, dtype=torch.float32).view(3, 1, 1)
+        std = torch.tensor(self.std, dtype=torch.float32).view(3, 1, 1)
         return (x - mean) / std
 
 
@@ -112,21 +125,33 @@ class MlfoundationOpenClip(FeatureExtractor):
         assert len(id_tokens) == 4
         model, tag = id_tokens[2], id_tokens[3]
         seed = seeded_tag(tag)
-        if model.replace("-quickgelu", "") not in SPECS or (seed is None and (model, tag) not in list_pretrained()):
+        self._siglip = model in SIGLIP_VISION
+        if (model.replace("-quickgelu", "") not in SPECS and not self._siglip) or \
+                (seed is None and (model, tag) not in list_pretrained()):
             raise ValueError(f'Model ({model}, {tag}) not available in {self.ID_PREFIX}')
         self.pretrained_model_name = model
         self.pretraining_dataset = tag
         self.DEVICE = "cuda" if torch.cuda.is_available() else "cpu"
-        self.spec = spec_for(model, "openai" if seed is not None else tag)
-        self._state_dict = random_state_dict(self.spec, seed) if seed is not None else load_state_dict_file(model, tag)
-        self.preprocess = ClipImageTransform(self.spec.image_size)
+        if self._siglip:
+            # timm image tower with the attention-pool head; squash resize, mean = std = 0.5 (open_clip preprocess_cfg)
+            self.spec = SIGLIP_VISION[model]
+            self._state_dict = random_siglip_vision_state_dict(self.spec, seed) if seed is not None \
+                else load_state_dict_file(model, tag)
+            self.preprocess = ClipImageTransform(self.spec.image_size, SIGLIP_MEAN, SIGLIP_STD, "squash")
+        else:
+            self.spec = spec_for(model, "openai" if seed is not None else tag)
+            self._state_dict = random_state_dict(self.spec, seed) if seed is not None else load_state_dict_file(model, tag)
+            self.preprocess = ClipImageTransform(self.spec.image_size)
         self._engine = None
         self._gpu_preprocess = None
         # text tower (query side): built on first use; seeded models may run on the merge-less
         # byte tokenizer because open_clip's merge file does not exist offline
         # xlm-roberta-*: the text tower is open_clip's HFTextEncoder over XLM-RoBERTa (xlmr_text.py), tokenised with the
         # model's own sentencepiece vocabulary; every other model has the CLIP text transformer and its BPE tokenizer
-        self.text_spec = XLMR_SPECS[model] if model in XLMR_SPECS else text_spec_for(model, "openai" if seed is not None else tag)
+        if self._siglip:
+            self.text_spec = SIGLIP_TEXT[model]
+        else:
+            self.text_spec = XLMR_SPECS[model] if model in XLMR_SPECS else text_spec_for(model, "openai" if seed is not None else tag)
         self._seed = seed
         self._text_engine = None
         self._tokenizer = None
@@ -177,6 +202,9 @@ class MlfoundationOpenClip(FeatureExtractor):
         device.  ToTensor + Normalize are applied by the tower when extract_image_features receives uint8."""
         if not isinstance(images, torch.Tensor) or len(images.shape) != 4 or images.dtype != torch.uint8:
             raise ValueError('input to preprocess_image_device() must be a uint8 torch.Tensor [n,3,H,W]')
+        if self._siglip:
+            raise NotImplementedError("the GPU image transform serves Resize(shorter side) + CenterCrop; the SigLIP models' "
+                                      "squash resize runs through preprocess_image (PIL), as in the reference")
         if self._gpu_preprocess is None:
             from .preprocess import ClipPreprocessor
             self._gpu_preprocess = ClipPreprocessor(self.spec.image_size, device="cuda")
@@ -203,6 +231,8 @@ class MlfoundationOpenClip(FeatureExtractor):
         if self._tokenizer is None:
             if self.pretrained_model_name in XLMR_SPECS:
                 self._tokenizer = XlmrTokenizer.default(self.text_spec.context)     # needs sentencepiece.bpe.model
+            elif self._siglip:
+                self._tokenizer = SiglipTokenizer.default(self.text_spec.context)   # needs the model's spiece.model
             else:
                 self._tokenizer = ClipTokenizer.default(self.text_spec.context, allow_merge_less=self._seed is not None)
             if self._tokenizer.vocab_size > self.text_spec.vocab:
@@ -214,6 +244,9 @@ class MlfoundationOpenClip(FeatureExtractor):
             if self.pretrained_model_name in XLMR_SPECS:
                 sd = random_xlmr_state_dict(self.text_spec, self._seed) if self._seed is not None else self._state_dict
                 self._text_engine = XlmrTextEngine(self.text_spec, sd, device="cuda")
+            elif self._siglip:
+                sd = random_siglip_text_state_dict(self.text_spec, self._seed) if self._seed is not None else self._state_dict
+                self._text_engine = TextEngine(self.text_spec, sd, device="cuda", pack=pack_siglip_text)
             else:
                 sd = random_text_state_dict(self.text_spec, self._seed) if self._seed is not None else self._state_dict
                 self._text_engine = TextEngine(self.text_spec, sd, device="cuda")

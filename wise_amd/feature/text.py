@@ -29,8 +29,10 @@ class TextSpec:
     context: int = 77
     vocab: int = 49408
     act: str = "quick_gelu"   # 'quick_gelu' | 'gelu' | 'gelu_new' (GPT-2's tanh form)
-    pool: str = "argmax"      # pooled row: 'argmax' of the ids (open_clip) | 'last_nonzero' id (msclap, pad id 0)
-    head: str = "linear"      # 'linear' projection [W,D] | 'clap' = msclap Projection (W1, GELU, W2, LayerNorm)
+    pool: str = "argmax"      # pooled row: 'argmax' of the ids (open_clip) | 'last_nonzero' id (msclap, pad id 0) | 'last' position
+    head: str = "linear"      # 'linear' projection [W,D] | 'clap' = msclap Projection (W1, GELU, W2, LayerNorm) | 'linear_bias'
+    causal: bool = True       # False: open_clip no_causal_mask (SigLIP)
+    ln_eps: float = 1e-5      # 1e-6 for the SigLIP text tower (norm_kwargs)
 
     @property
     def mlp(self) -> int:
@@ -44,7 +46,9 @@ class TextSpec:
     def c_config(self) -> _lib.TextConfig:
         return _lib.TextConfig(self.context, self.vocab, self.width, self.layers, self.heads, self.mlp, self.embed_dim,
                                {"quick_gelu": 0, "gelu": 1, "gelu_new": 2}[self.act],
-                               {"argmax": 0, "last_nonzero": 1}[self.pool], {"linear": 0, "clap": 1}[self.head])
+                               {"argmax": 0, "last_nonzero": 1, "last": 2}[self.pool],
+                               {"linear": 0, "clap": 1, "linear_bias": 2}[self.head], 0 if self.causal else 1,
+                               {1e-5: 0, 1e-6: 1}[self.ln_eps])
 
 
 # text towers of the open_clip models in wise_amd/feature/vit.py:SPECS (open_clip model configs)

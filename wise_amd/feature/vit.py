@@ -26,7 +26,8 @@ class VitSpec:
     heads: int
     mlp: int
     embed_dim: int
-    act: str = "quick_gelu"  # 'quick_gelu' (openai tags) | 'gelu' (laion tags)
+    act: str = "quick_gelu"  # 'quick_gelu' (openai tags) | 'gelu' (laion tags) | 'gelu_tanh'
+    arch: int = 0            # 0 = open_clip VisionTransformer; 1 = timm ViT of the SigLIP towers (wise_amd/feature/siglip.py)
 
     @property
     def grid(self) -> int:
@@ -34,7 +35,7 @@ class VitSpec:
 
     @property
     def tokens(self) -> int:
-        return self.grid * self.grid + 1
+        return self.grid * self.grid + (1 if self.arch == 0 else 0)
 
     @property
     def kdim(self) -> int:
@@ -52,7 +53,7 @@ class VitSpec:
 
     def c_config(self) -> _lib.VitConfig:
         return _lib.VitConfig(self.image_size, self.patch, self.width, self.layers, self.heads, self.mlp,
-                              self.embed_dim, 0 if self.act == "quick_gelu" else 1)
+                              self.embed_dim, {"quick_gelu": 0, "gelu": 1, "gelu_tanh": 2}[self.act], self.arch)
 
 
 # open_clip model names WISE passes as id token [2]
@@ -179,7 +180,11 @@ class VitEngine:
         self.cfg = spec.c_config()
         nb, nf = C.c_int64(), C.c_int64()
         _lib.check(self.lib.wise_vit_layout(C.byref(self.cfg), C.byref(nb), C.byref(nf)), "wise_vit_layout")
-        wb, pf = pack_weights(spec, sd)
+        if spec.arch == 1:
+            from .siglip import pack_siglip_vision
+            wb, pf = pack_siglip_vision(spec, sd)
+        else:
+            wb, pf = pack_weights(spec, sd)
         if wb.numel() != nb.value or pf.numel() != nf.value:
             raise RuntimeError(f"weight blob size mismatch: packed {wb.numel()}/{pf.numel()}, "
                                f"library expects {nb.value}/{nf.value}")
