@@ -555,16 +555,26 @@ def main():
         torch.cuda.empty_cache()
         # cfg-4 (image half): ViT-L/14 at bs=256 per GPU; and ViT-H/14 (head width 80), the image tower of the reference's
         # default feature id (extract-features.py:192)
+        from wise_amd.feature.siglip import SIGLIP_VISION, random_siglip_vision_state_dict
         for key, lname, ltag, label in (("vit_l14", "ViT-L-14", "openai", "ViT-L/14"),
-                                        ("vit_h14", "ViT-H-14", "laion2b_s32b_b79k", "ViT-H/14")):
-            lspec = spec_for(lname, ltag)
-            leng = VitEngine(lspec, random_state_dict(lspec, 0), max_batch=args.batch)
+                                        ("vit_h14", "ViT-H-14", "laion2b_s32b_b79k", "ViT-H/14"),
+                                        ("siglip_l16_384", "ViT-L-16-SigLIP-384", "webli", "ViT-L/16 SigLIP 384 px (timm tower, "
+                                         "attention-pool head; the video model of the reference's tests/test-kinetics-6.sh)")):
+            if lname in SIGLIP_VISION:
+                lspec = SIGLIP_VISION[lname]
+                leng = VitEngine(lspec, random_siglip_vision_state_dict(lspec, 0), max_batch=args.batch)
+                x_l = torch.randn(args.batch, 3, lspec.image_size, lspec.image_size, device="cuda",
+                                  generator=torch.Generator(device="cuda").manual_seed(11 + rank)).clamp_(-1, 1)
+            else:
+                lspec = spec_for(lname, ltag)
+                leng = VitEngine(lspec, random_state_dict(lspec, 0), max_batch=args.batch)
+                x_l = x
 
             def l14_step(i):
-                hold["l"] = leng.forward_pipelined(x)
+                hold["l"] = leng.forward_pipelined(x_l)
 
             def l14_step_serial(i):
-                hold["ls"] = leng.forward(x)
+                hold["ls"] = leng.forward(x_l)
 
             l_steps = max(4, min(args.steps, 6))
             for i in range(2):
@@ -584,7 +594,7 @@ def main():
                           "tflops": round(lfps / world * lspec.flops_per_frame() / 1e12, 2),
                           "frac_of_bf16_peak": round(lfps / world * lspec.flops_per_frame() / 1e12 / PEAK_BF16_TFLOPS, 4)}
             hold.pop("l", None); hold.pop("ls", None)
-            del leng
+            del leng, x_l
             torch.cuda.empty_cache()
         # f2: decoded uint8 frames [256,3,240,320] resident in HBM -> GPU transform -> ViT-B/32 (uint8 in)
         from wise_amd.feature.preprocess import ClipPreprocessor, make_plan

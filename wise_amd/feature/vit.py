@@ -49,6 +49,8 @@ class VitSpec:
         """2*MAC of the contractions only."""
         g2, T, W, F, D = self.grid ** 2, self.tokens, self.width, self.mlp, self.embed_dim
         per_layer = T * W * 3 * W * 2 + 2 * self.heads * T * T * (W // self.heads) * 2 + T * W * W * 2 + 2 * T * W * F * 2
+        if self.arch == 1:   # attention-pool head: kv over every token, one query, projection, MLP on the pooled row
+            return g2 * self.kdim * W * 2 + self.layers * per_layer + T * W * 2 * W * 2 + 2 * T * W * 2 + W * W * 2 + 2 * W * F * 2
         return g2 * self.kdim * W * 2 + self.layers * per_layer + W * D * 2
 
     def c_config(self) -> _lib.VitConfig:
