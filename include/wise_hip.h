@@ -294,10 +294,13 @@ typedef struct wise_preproc_plan {
     int32_t ndh, ndv;           /* dwords of padded taps per output column / row */
     int32_t max_cols4, max_rows4; /* staged input rectangle of the worst tile: column dwords, rows / 4 */
     int32_t lds_bytes;
-    int32_t reserved;
+    int32_t reserved;           /* geometry: 0 = Resize(shorter side) + CenterCrop, 1 = squash (set by the _init functions) */
     uint64_t table_bytes;       /* size of the tap-table blob */
 } wise_preproc_plan;
 int wise_preproc_plan_init(int H, int W, int S, wise_preproc_plan* plan);
+/* the same for open_clip's resize_mode 'squash' (the SigLIP models' preprocess_cfg): Resize((S, S), BICUBIC) without
+ * regard to the aspect ratio, no crop — new_w = new_h = S, left = top = 0; same tables, same kernel */
+int wise_preproc_plan_init_squash(int H, int W, int S, wise_preproc_plan* plan);
 int wise_preproc_tables(const wise_preproc_plan* plan, void* host_tables);
 /* frames uint8 [n,3,H,W] (device) -> out uint8 [n,3,S,S] (device, 4-byte aligned). */
 int wise_preproc_u8(const wise_preproc_plan* plan, const void* dev_tables, const uint8_t* frames, int n,

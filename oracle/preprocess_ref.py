@@ -126,6 +126,12 @@ def clip_preprocess_u8(frames: np.ndarray, S: int) -> np.ndarray:
     return np.ascontiguousarray(r[:, :, top:top + S, left:left + S])
 
 
+def squash_preprocess_u8(frames: np.ndarray, S: int) -> np.ndarray:
+    """uint8 [n,3,H,W] -> uint8 [n,3,S,S]: open_clip resize_mode 'squash' (the SigLIP models' preprocess_cfg) —
+    Resize((S, S), BICUBIC) without regard to the aspect ratio, no crop."""
+    return pil_resize_bicubic_u8(frames, S, S)
+
+
 def clip_preprocess(frames: np.ndarray, S: int) -> np.ndarray:
     """Full transform: uint8 [n,3,H,W] -> fp32 [n,3,S,S] = (u8/255 - mean)/std in fp32 (ToTensor, Normalize)."""
     u = clip_preprocess_u8(frames, S).astype(np.float32) / np.float32(255.0)

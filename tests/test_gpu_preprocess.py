@@ -76,3 +76,16 @@ def test_uint8_frames_to_embeddings_match_the_cpu_pil_path():
     assert cos.min() > 1 - 1e-4, cos
     with pytest.raises(ValueError):
         fx.preprocess_image_device(frames.float())
+
+
+@pytest.mark.parametrize("H,W,S,n", [(240, 320, 384, 5), (720, 1280, 384, 3), (97, 211, 224, 4), (384, 384, 384, 2),
+                                      (600, 450, 256, 3), (1080, 1920, 384, 2)])
+def test_squash_transform_is_bit_exact(H, W, S, n):
+    """the SigLIP models' transform (Resize((S, S)), no crop) on the same kernel: equal to the Pillow-pinned oracle"""
+    from wise_amd.feature.preprocess import ClipPreprocessor
+
+    frames = np.random.default_rng(H + 3 * W + S).integers(0, 256, (n, 3, H, W), dtype=np.uint8)
+    got = ClipPreprocessor(S, squash=True)(torch.from_numpy(frames).cuda())
+    torch.cuda.synchronize()
+    want = ref.squash_preprocess_u8(frames, S)
+    assert np.array_equal(got.cpu().numpy(), want), f"{int((got.cpu().numpy() != want).sum())} bytes differ"

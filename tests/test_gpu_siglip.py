@@ -110,5 +110,10 @@ def test_reference_test_model_end_to_end(tmp_path, monkeypatch):
     with torch.no_grad():
         want = siglip_ref.siglip_text_forward(rtsd(fx.text_spec, 0), tok, heads=fx.text_spec.heads, act=fx.text_spec.act)
     assert cosine(torch.from_numpy(tfe), want) > 1 - COS_TOL
-    with pytest.raises(NotImplementedError):
-        fx.preprocess_image_device(torch.zeros(1, 3, 240, 320, dtype=torch.uint8, device="cuda"))
+    # decoded uint8 frames through the GPU transform (squash) and the u8 input of the tower == the PIL path above
+    raw = torch.from_numpy(np.stack([np.asarray(im) for im in imgs])).permute(0, 3, 1, 2).contiguous().cuda()
+    u8 = fx.preprocess_image_device(raw)
+    assert tuple(u8.shape) == (2, 3, 384, 384) and u8.dtype == torch.uint8
+    assert torch.equal(((u8.cpu().float() / 255.0) - 0.5) / 0.5, x.cpu())
+    feats_u8 = fx.extract_image_features(u8)
+    assert cosine(torch.from_numpy(feats_u8), torch.from_numpy(feats)) > 1 - 1e-5

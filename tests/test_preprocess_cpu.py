@@ -96,3 +96,21 @@ def test_plan_rejects_what_the_kernel_cannot_do():
         pp.make_plan(16384, 16384, 224)    # 73x downscale: a tile's input does not fit LDS
     with pytest.raises(ValueError):
         pp.make_plan(0, 10, 224)
+
+
+def test_squash_oracle_against_live_pillow_and_plan_geometry():
+    """open_clip resize_mode 'squash' (the SigLIP models): Resize((S, S), BICUBIC), no crop — the oracle equals Pillow bit
+    for bit, and the library's squash plan has new size S x S with no crop offset"""
+    Image = pytest.importorskip("PIL.Image")
+    from wise_amd.feature.preprocess import make_plan
+
+    rng = np.random.default_rng(6)
+    for H, W, S in [(240, 320, 384), (720, 1280, 384), (97, 211, 224), (384, 384, 384), (600, 450, 256), (384, 500, 384)]:
+        frame = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+        im = Image.fromarray(np.ascontiguousarray(frame.transpose(1, 2, 0)), mode="RGB")
+        want = np.asarray(im.resize((S, S), Image.BICUBIC) if (W, H) != (S, S) else im).transpose(2, 0, 1)
+        assert np.array_equal(ref.squash_preprocess_u8(frame[None], S)[0], want)
+        p = make_plan(H, W, S, squash=True)
+        assert (p.new_w, p.new_h, p.left, p.top, p.reserved) == (S, S, 0, 0, 1)
+    q = make_plan(240, 320, 224)
+    assert q.reserved == 0 and (q.new_w, q.new_h) == (298, 224)

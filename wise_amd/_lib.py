@@ -75,6 +75,7 @@ SIGNATURES = {
     "wise_xlmr_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "wise_xlmr_tap_residual": (_i, [_vp, _i, _vp, _vp, _vp]),
     "wise_preproc_plan_init": (_i, [_i, _i, _i, _vp]),
+    "wise_preproc_plan_init_squash": (_i, [_i, _i, _i, _vp]),
     "wise_preproc_tables": (_i, [_vp, _vp]),
     "wise_preproc_u8": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "wise_preproc_taps": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i]),

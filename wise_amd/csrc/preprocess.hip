@@ -150,18 +150,24 @@ struct HostPlan {
     AxisTables h, v;
 };
 
-static int build_plan(int H, int W, int S, HostPlan& hp) {
+static int build_plan(int H, int W, int S, int squash, HostPlan& hp) {
     WISE_CHECK_ARG(H >= 1 && W >= 1 && H <= 16384 && W <= 16384, "preproc: frame %dx%d out of range", H, W);
     WISE_CHECK_ARG(S >= 4 && S <= 1024 && S % 4 == 0, "preproc: output edge %d must be a multiple of 4 in [4,1024]", S);
     wise_preproc_plan& p = hp.p;
     p = wise_preproc_plan{};
     p.H = H; p.W = W; p.S = S;
-    // torchvision Resize(S): shorter side -> S, longer side -> int(S * long / short)
-    if (W <= H) { p.new_w = S; p.new_h = (int)((double)((long long)S * H) / (double)W); }
-    else        { p.new_w = (int)((double)((long long)S * W) / (double)H); p.new_h = S; }
-    WISE_CHECK_ARG(p.new_w <= 65536 && p.new_h <= 65536, "preproc: aspect ratio of %dx%d too extreme", H, W);
-    p.left = half_round_even(p.new_w - S);
-    p.top = half_round_even(p.new_h - S);
+    p.reserved = squash ? 1 : 0;
+    if (squash) {
+        // open_clip resize_mode 'squash' (the SigLIP models): Resize((S, S)) without regard to aspect, no crop
+        p.new_w = S; p.new_h = S; p.left = 0; p.top = 0;
+    } else {
+        // torchvision Resize(S): shorter side -> S, longer side -> int(S * long / short)
+        if (W <= H) { p.new_w = S; p.new_h = (int)((double)((long long)S * H) / (double)W); }
+        else        { p.new_w = (int)((double)((long long)S * W) / (double)H); p.new_h = S; }
+        WISE_CHECK_ARG(p.new_w <= 65536 && p.new_h <= 65536, "preproc: aspect ratio of %dx%d too extreme", H, W);
+        p.left = half_round_even(p.new_w - S);
+        p.top = half_round_even(p.new_h - S);
+    }
     Taps th, tv;
     pillow_taps(W, p.new_w, th);
     pillow_taps(H, p.new_h, tv);
@@ -192,7 +198,16 @@ using namespace wise;
 extern "C" int wise_preproc_plan_init(int H, int W, int S, wise_preproc_plan* plan) {
     WISE_CHECK_ARG(plan, "preproc: null plan");
     HostPlan hp;
-    const int rc = build_plan(H, W, S, hp);
+    const int rc = build_plan(H, W, S, 0, hp);
+    if (rc) return rc;
+    *plan = hp.p;
+    return WISE_OK;
+}
+
+extern "C" int wise_preproc_plan_init_squash(int H, int W, int S, wise_preproc_plan* plan) {
+    WISE_CHECK_ARG(plan, "preproc: null plan");
+    HostPlan hp;
+    const int rc = build_plan(H, W, S, 1, hp);
     if (rc) return rc;
     *plan = hp.p;
     return WISE_OK;
@@ -202,7 +217,7 @@ extern "C" int wise_preproc_plan_init(int H, int W, int S, wise_preproc_plan* pl
 extern "C" int wise_preproc_tables(const wise_preproc_plan* plan, void* host_tables) {
     WISE_CHECK_ARG(plan && host_tables, "preproc: null argument");
     HostPlan hp;
-    const int rc = build_plan(plan->H, plan->W, plan->S, hp);
+    const int rc = build_plan(plan->H, plan->W, plan->S, plan->reserved, hp);
     if (rc) return rc;
     WISE_CHECK_ARG(hp.p.table_bytes == plan->table_bytes && hp.p.tile == plan->tile, "preproc: plan does not match");
     int* o = static_cast<int*>(host_tables);
@@ -370,7 +385,7 @@ extern "C" int wise_preproc_u8(const wise_preproc_plan* plan, const void* dev_ta
     WISE_CHECK_ARG(plan && dev_tables && frames && out, "preproc: null argument");
     WISE_CHECK_ARG(n >= 1 && n <= (1 << 20), "preproc: n=%d", n);
     HostPlan hp;
-    int rc = build_plan(plan->H, plan->W, plan->S, hp);
+    int rc = build_plan(plan->H, plan->W, plan->S, plan->reserved, hp);
     if (rc) return rc;
     const wise_preproc_plan& p = hp.p;
     WISE_CHECK_ARG(p.table_bytes == plan->table_bytes && p.tile == plan->tile && p.lds_bytes == plan->lds_bytes,

@@ -202,12 +202,11 @@ class MlfoundationOpenClip(FeatureExtractor):
         device.  ToTensor + Normalize are applied by the tower when extract_image_features receives uint8."""
         if not isinstance(images, torch.Tensor) or len(images.shape) != 4 or images.dtype != torch.uint8:
             raise ValueError('input to preprocess_image_device() must be a uint8 torch.Tensor [n,3,H,W]')
-        if self._siglip:
-            raise NotImplementedError("the GPU image transform serves Resize(shorter side) + CenterCrop; the SigLIP models' "
-                                      "squash resize runs through preprocess_image (PIL), as in the reference")
         if self._gpu_preprocess is None:
             from .preprocess import ClipPreprocessor
-            self._gpu_preprocess = ClipPreprocessor(self.spec.image_size, device="cuda")
+            # the SigLIP models squash the frame to S x S (open_clip resize_mode 'squash'); the others resize the shorter
+            # side and crop the centre — same kernel, different tap tables
+            self._gpu_preprocess = ClipPreprocessor(self.spec.image_size, device="cuda", squash=self._siglip)
         return self._gpu_preprocess(images)
 
     def extract_image_features(self, images: torch.Tensor) -> np.ndarray:

@@ -24,11 +24,13 @@ class PreprocPlan(C.Structure):
                [("table_bytes", C.c_uint64)]
 
 
-def make_plan(H: int, W: int, S: int) -> PreprocPlan:
-    """Geometry + table sizes for one (H, W, S); host-only (works without a GPU)."""
+def make_plan(H: int, W: int, S: int, squash: bool = False) -> PreprocPlan:
+    """Geometry + table sizes for one (H, W, S); host-only (works without a GPU).  squash: open_clip's resize_mode of the
+    SigLIP models — Resize((S, S)) without regard to aspect and no crop — instead of Resize(shorter side) + CenterCrop."""
     lib = _lib.load()
     plan = PreprocPlan()
-    rc = lib.wise_preproc_plan_init(int(H), int(W), int(S), C.byref(plan))
+    init = lib.wise_preproc_plan_init_squash if squash else lib.wise_preproc_plan_init
+    rc = init(int(H), int(W), int(S), C.byref(plan))
     if rc != 0:
         raise ValueError(lib.wise_last_error().decode())
     return plan
@@ -64,16 +66,17 @@ class ClipPreprocessor:
     """Callable: device uint8 [n,3,H,W] -> device uint8 [n,3,S,S].  Plans and device tables are cached per
     frame geometry (a video collection has a handful of distinct sizes)."""
 
-    def __init__(self, size: int, device: str = "cuda"):
+    def __init__(self, size: int, device: str = "cuda", squash: bool = False):
         self.size = int(size)
         self.device = device
+        self.squash = bool(squash)     # the SigLIP models' transform: Resize((S, S)), no crop
         self._plans: Dict[Tuple[int, int], Tuple[PreprocPlan, torch.Tensor]] = {}
 
     def _plan(self, H: int, W: int):
         key = (H, W)
         hit = self._plans.get(key)
         if hit is None:
-            plan = make_plan(H, W, self.size)
+            plan = make_plan(H, W, self.size, self.squash)
             tables = torch.from_numpy(plan_tables(plan)).to(self.device)
             hit = (plan, tables)
             self._plans[key] = hit
