@@ -78,11 +78,13 @@ def test_padding_batch_independence_and_argument_checks():
         want = xlmr_text_ref.xlmr_text_forward(sd, t, heads=spec.heads, pad_id=spec.pad_id)
     got = eng.forward(t).cpu()
     assert cosine(got, want) > 1 - COS_TOL
-    # a row's embedding does not depend on its neighbours in the batch
+    # a row's embedding does not depend on its neighbours in the batch (a single query takes the split-K kernels, whose
+    # fixed summation order differs from the batched tiles': equal to rounding, and bit-stable from call to call)
     alone = torch.cat([eng.forward(t[i:i + 1]).cpu() for i in range(4)])
-    assert torch.equal(alone, got)
+    assert cosine(alone, got) > 1 - 1e-5 and (alone - got).abs().max() < 1e-3      # bf16 roundings flip here and there
+    assert torch.equal(torch.cat([eng.forward(t[i:i + 1]).cpu() for i in range(4)]), alone)
     big = eng.forward(t.repeat(70, 1)).cpu()           # 280 rows: more than one 256-row GEMM tile of pooled rows
-    assert torch.equal(big[:4], got) and torch.equal(big[-4:], got)
+    assert cosine(big[:4], got) > 1 - 1e-5 and torch.equal(big[:4], big[-4:])
     # bidirectional: a later token matters to the whole sequence
     tok2 = tok.copy(); tok2[3, 7] = 11
     assert (eng.forward(torch.from_numpy(tok2)).cpu()[3] - got[3]).abs().max() > 1e-3

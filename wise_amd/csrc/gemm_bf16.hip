@@ -14,6 +14,9 @@
 // fragment reads conflict-free.  The product is computed transposed (weights as the MFMA A
 // operand, activations as B) so that each lane ends up holding 4 consecutive output columns of one
 // row: 8-byte bf16 / 16-byte fp32 epilogue accesses, and the bias is one float4 per lane.
+#include <utility>
+#include <vector>
+
 #include "common.h"
 
 namespace wise {
@@ -527,6 +530,111 @@ __global__ __launch_bounds__(256, MINB) void gemm_ring_kernel(const bf16_t* __re
                                      smem + wave * 16384);
     } else {
         epilogue<MODE>(acc, bias, out, N, m0, n0, wm, wn, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinny problems — one text query is 77 rows against [N, K] weights (K up to 4096) — as split-K: the grid is
+// (N / 128 column slabs) x (S slices of K), every block runs the ring kernel's loop over ITS slice for rows 0..127 and
+// stores the fp32 partial tile; splitk_reduce_kernel adds the S partials in a fixed order (deterministic), then bias and
+// the epilogue, for the rows that matter.  256x1024x4096 (XLM-R fc2 of one query): 16 blocks x 64 K-tiles = 57 us as an
+// ordinary launch; 128 blocks x 4 K-tiles + the reduction: see tools/text_latency.py.
+// ------------------------------------------------------------------------------------------------
+template <int STAGES>
+__global__ __launch_bounds__(256, 1) void gemm_splitk_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt, int N,
+                                                             int K, int k_len, float* __restrict__ part /*[S][128][N]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BKT = 64;
+    constexpr int TB = 128 * BKT * 2, SB = 2 * TB, GPS = 2 * (TB / 1024 / 4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * BN, k0 = blockIdx.y * k_len;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = k_len / BKT;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) {
+        if (s < nk) {
+            stage_tile_ring<BKT>(A, K, 0, k0 + s * BKT, smem + s * SB, wave, lane, 127);
+            stage_tile_ring<BKT>(Wt, K, n0, k0 + s * BKT, smem + s * SB + TB, wave, lane, N - 1);
+        }
+    }
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + STAGES - 2 < nk)
+            wait_vmcnt<(STAGES - 2) * GPS>();
+        else
+            wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const int nt = kt + STAGES - 1;
+            if (nt < nk) {
+                int ns = cur + STAGES - 1;
+                if (ns >= STAGES) ns -= STAGES;
+                stage_tile_ring<BKT>(A, K, 0, k0 + nt * BKT, smem + ns * SB, wave, lane, 127);
+                stage_tile_ring<BKT>(Wt, K, n0, k0 + nt * BKT, smem + ns * SB + TB, wave, lane, N - 1);
+            }
+        }
+        const unsigned char* At = smem + cur * SB;
+        const unsigned char* Bt = At + TB;
+#pragma unroll
+        for (int s = 0; s < BKT / 32; ++s) {
+            const int chunk = s * 4 + (lane >> 4);
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = lds_frag_ring<BKT>(At, wm * 64 + i * 16 + (lane & 15), chunk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = lds_frag_ring<BKT>(Bt, wn * 64 + j * 16 + (lane & 15), chunk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+    }
+    // partial tile, fp32, row-major [128][N] of slice blockIdx.y: lane owns 4 consecutive columns of 16 rows
+    float* ps = part + (size_t)blockIdx.y * 128 * N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        if (n >= N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = wm * 64 + i * 16 + (lane & 15);
+            *reinterpret_cast<float4*>(ps + (size_t)m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+// out[m, n..n+3] = epi( sum_s part[s][m][n..] + bias ) for m < rows; thread per 4 columns
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int rows, int N,
+                                                            const float* __restrict__ bias, void* __restrict__ out) {
+    const int n4 = N >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * n4) return;
+    const int m = idx / n4, c = idx - m * n4;
+    float4 v = bias ? reinterpret_cast<const float4*>(bias)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+        const float4 p = reinterpret_cast<const float4*>(part + ((size_t)s * 128 + m) * N)[c];
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (MODE == EPI_RESID) {
+        float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * N) + c;
+        const float4 r = *o;
+        *o = make_float4(r.x + v.x, r.y + v.y, r.z + v.z, r.w + v.w);
+    } else if (MODE == EPI_F32) {
+        reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * N)[c] = v;
+    } else {
+        uint2 pk;
+        pk.x = pack_bf16x2(act_apply<MODE>(v.x), act_apply<MODE>(v.y));
+        pk.y = pack_bf16x2(act_apply<MODE>(v.z), act_apply<MODE>(v.w));
+        reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)m * N)[c] = pk;
     }
 }
 
@@ -1346,6 +1454,7 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
     // Shapes a variant cannot tile fall back to variant 0.
     switch (variant) {
         case 1: launch_ring<MODE, 32, 4, 2>(A, Wt, bias, M, N, K, out, st); break;
+        case 2: launch_ring<MODE, 64, 4, 1>(A, Wt, bias, M, N, K, out, st); break;   // skinny problems: 4 K-tiles of 64 in flight per block
         case 5: if (M % 256 == 0 && N % 192 == 0) { launch_big<MODE, 3>(A, Wt, bias, M, N, K, out, st); break; }
                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 6: if (MODE == EPI_RESID && M % 256 == 0 && N % 192 == 0) { launch_big_pre<MODE, 3>(A, Wt, bias, M, N, K, out, st); break; }
@@ -1394,6 +1503,10 @@ static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bi
 // shape heuristic (measured with tools/gemm_bench.py on MI355X)
 static int auto_variant(int M, int N, int K) {
     if (K % 64 != 0) return 1;  // K multiple of 32 only (HTSAT C=96): the BK=32 ring kernel
+    // Skinny problems (a text query: 77 rows against [N, K] weights; the heads of the towers): fewer blocks than CUs, each
+    // streaming its own slab of the weights from HBM over a long K — latency-bound with one K-tile in flight (12800x...
+    // shapes never come here).  The ring kernel keeps four 64-deep K-tiles in flight per block: 256x1024x4096 57 -> 19 us.
+    if ((long long)(M / 128) * ((N + 127) / 128) <= 128 && K >= 512) return 2;
     // when a 256x192 tiling fits the chip in ONE well-filled round it beats 128x128 (fewer staged bytes, no
     // second-round tail); otherwise the 128x128 tile at two blocks per CU wins because its epilogue overlaps
     // the other block's main loop
@@ -1441,6 +1554,92 @@ int gemm_ln_bf16(const float* x, const float* lnw, const float* lnb, const bf16_
 #undef LN_CASE
     WISE_LAUNCH_CHECK("gemm_ln_kernel");
     return WISE_OK;
+}
+
+// fp32 scratch of the split-K path: a pool of four buffers allocated together on the first skinny launch of the process
+// (outside any graph capture: the engines warm up before they capture); a stream is bound to one of them the first time it
+// takes the path — no allocation then, so a capture stream may be new — and a fifth stream gets the ordinary kernels.
+constexpr size_t SPLITK_SCRATCH_BYTES = (size_t)24 << 20;
+constexpr int SPLITK_POOL = 4;
+static std::mutex g_splitk_mu;
+static float* g_splitk_pool[SPLITK_POOL] = {nullptr, nullptr, nullptr, nullptr};
+static hipStream_t g_splitk_owner[SPLITK_POOL] = {nullptr, nullptr, nullptr, nullptr};
+static int g_splitk_bound = 0, g_splitk_state = 0;   // state: 0 = not yet allocated, 1 = pool ready, -1 = allocation failed
+static float* splitk_scratch(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_splitk_mu);
+    if (g_splitk_state == 0) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+        unsigned char* base = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&base), SPLITK_SCRATCH_BYTES * SPLITK_POOL) != hipSuccess) {
+            (void)hipGetLastError();
+            g_splitk_state = -1;
+            return nullptr;
+        }
+        for (int i = 0; i < SPLITK_POOL; ++i) g_splitk_pool[i] = reinterpret_cast<float*>(base + SPLITK_SCRATCH_BYTES * i);
+        g_splitk_state = 1;
+    }
+    if (g_splitk_state != 1) return nullptr;
+    for (int i = 0; i < g_splitk_bound; ++i)
+        if (g_splitk_owner[i] == st) return g_splitk_pool[i];
+    if (g_splitk_bound == SPLITK_POOL) return nullptr;
+    g_splitk_owner[g_splitk_bound] = st;
+    return g_splitk_pool[g_splitk_bound++];
+}
+
+template <int MODE>
+static void launch_reduce(const float* part, int S, int rows, int N, const float* bias, void* out, hipStream_t st) {
+    const int total = rows * (N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel<MODE>, dim3((total + 255) / 256), dim3(256), 0, st, part, S, rows, N, bias, out);
+}
+
+// rows 0..m_valid-1 (<= 128) of A @ Wt^T through the split-K pair of kernels; false = not applicable here
+static bool gemm_splitk(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int N, int K, int mode,
+                        void* out, hipStream_t st) {
+    if (m_valid < 1 || m_valid > 128 || M < 128 || K < 512 || K % 128 != 0 || N % 128 != 0 || N < 128) return false;
+    const int slabs = N / 128;
+    int S = 1;
+    for (int c : {2, 4, 8, 16, 32}) {     // slices: enough blocks for the chip, at least two K-tiles per slice
+        if (K % (c * 64) != 0 || K / c < 128) break;
+        S = c;
+        if (slabs * c >= 160) break;
+    }
+    if (S < 2 || (size_t)S * 128 * N * sizeof(float) > SPLITK_SCRATCH_BYTES) return false;
+    float* part = splitk_scratch(st);
+    if (!part) return false;
+    ProfScope prof(PROF_GEMM, 2.0 * (double)m_valid * (double)N * (double)K, st);
+    constexpr int STAGES = 4;
+    const size_t lds = (size_t)STAGES * 2 * 128 * 64 * 2;
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_splitk_kernel<STAGES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    hipLaunchKernelGGL(gemm_splitk_kernel<STAGES>, dim3(slabs, S), dim3(256), lds, st, A, Wt, N, K, K / S, part);
+    switch (mode) {
+        case EPI_BF16: launch_reduce<EPI_BF16>(part, S, m_valid, N, bias, out, st); break;
+        case EPI_QUICKGELU: launch_reduce<EPI_QUICKGELU>(part, S, m_valid, N, bias, out, st); break;
+        case EPI_GELU: launch_reduce<EPI_GELU>(part, S, m_valid, N, bias, out, st); break;
+        case EPI_GELU_TANH: launch_reduce<EPI_GELU_TANH>(part, S, m_valid, N, bias, out, st); break;
+        case EPI_RESID: launch_reduce<EPI_RESID>(part, S, m_valid, N, bias, out, st); break;
+        default: launch_reduce<EPI_F32>(part, S, m_valid, N, bias, out, st); break;
+    }
+    return true;
+}
+
+int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out, hipStream_t st);
+
+// m_valid: the rows of A that carry data (the rest of the M rows are padding whose results nobody reads)
+int gemm_bf16_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int N, int K, int mode,
+                   void* out, hipStream_t st) {
+    WISE_CHECK_ARG(A && Wt && out, "gemm_bf16: null pointer");
+    WISE_CHECK_ARG(M > 0 && M % BM == 0 && N > 0 && N % 4 == 0 && K > 0 && K % 32 == 0 && mode >= 0 && mode <= 5,
+                   "gemm_bf16: M=%d must be a multiple of %d, N=%d of 4, K=%d of 32", M, BM, N, K);
+    if (g_gemm_variant == 0 && m_valid <= 128 && gemm_splitk(A, Wt, bias, M, m_valid, N, K, mode, out, st)) {
+        WISE_LAUNCH_CHECK("gemm_splitk_kernel");
+        return WISE_OK;
+    }
+    return gemm_bf16(A, Wt, bias, M, N, K, mode, out, st);
 }
 
 int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out,

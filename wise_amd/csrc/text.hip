@@ -176,7 +176,7 @@ extern "C" int wise_text_forward(const wise_text_config* cfg, const uint16_t* wb
     const BlockWeights bw = {wb + o.layer0_b, o.per_layer_b, o.in_proj, o.out_proj, o.c_fc, o.c_proj,
                              pf + o.layer0_f, o.per_layer_f, o.ln1_w, o.ln1_b, o.in_b, o.out_b, o.ln2_w, o.ln2_b,
                              o.fc_b, o.proj_b};
-    if ((rc = transformer_blocks(bw, d.L, d.W, d.H, d.F, d.act, batch, d.T, d.no_causal == 0, x, h, qkv, a, st, d.eps))) return rc;
+    if ((rc = transformer_blocks(bw, d.L, d.W, d.H, d.F, d.act, batch, d.T, d.no_causal == 0, x, h, qkv, a, st, d.eps, true))) return rc;
     if (d.head == 0 || d.head == 2)
         return pooled_head(x, pf + o.lnf_w, pf + o.lnf_b, wb + o.projT, batch, d.T, d.W, d.D, eot, h,
                            reinterpret_cast<float*>(qkv), out, st, d.eps, d.head == 2 ? pf + o.pj_lw : nullptr);

@@ -6,6 +6,10 @@ namespace wise {
 
 int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode, void* out,
               hipStream_t st);
+// the same when only the first m_valid of the M rows carry data (a single text query: 77 of 256): skinny problems go
+// through a split-K pair of kernels instead of leaving most of the chip idle
+int gemm_bf16_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int N, int K, int mode,
+                   void* out, hipStream_t st);
 // hint for the tile heuristic: the caller is about to enqueue GEMMs on several streams that overlap in time
 // (host-side state; the library is single-threaded by contract)
 void gemm_set_overlapped(bool on);
@@ -26,7 +30,8 @@ struct BlockWeights {
     const float* pf; size_t per_layer_f, ln1_w, ln1_b, in_b, out_b, ln2_w, ln2_b, fc_b, proj_b;
 };
 int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int act, int batch, int T, bool causal,
-                       float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st, float eps = 1e-5f);
+                       float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st, float eps = 1e-5f,
+                       bool skinny = false /*text towers: calls of <= 128 rows may take the split-K kernels*/);
 int l2norm_rows(const float* e, int rows, int D, float* out, hipStream_t st);
 // LayerNorm of row pos[b] (or 0) of every sequence -> hb bf16 [batch, W]
 int pooled_ln(const float* x, const float* ln_w, const float* ln_b, int batch, int T, int W, const int* pos,

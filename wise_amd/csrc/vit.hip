@@ -662,20 +662,24 @@ int l2norm_rows(const float* e, int rows, int D, float* out, hipStream_t st) {
 
 // L pre-LN residual blocks over x fp32 [B*T (padded to 256), W]; h / qkv / a are the bf16 scratch operands
 int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int act, int batch, int T, bool causal,
-                       float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st, float eps) {
+                       float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st, float eps, bool skinny) {
+    // skinny (the text towers): a call of <= 128 rows may take the split-K kernels.  The image towers do not: their
+    // one-stream, two-half-batch and two-batches-in-flight forms must return the same bits, and a half batch could fall
+    // under 128 rows where the whole batch does not.
     const int M = batch * T, Mp = (M + 255) / 256 * 256;
+    const int Mv = skinny ? M : Mp;
     int rc;
     for (int l = 0; l < L; ++l) {
         const bf16_t* lwb = bw.wb + bw.per_layer_b * l;
         const float* lpf = bw.pf + bw.per_layer_f * l;
         if ((rc = layernorm_f32_bf16(x, lpf + bw.ln1_w, lpf + bw.ln1_b, M, W, eps, h, st))) return rc;
-        if ((rc = gemm_bf16(h, lwb + bw.in_proj, lpf + bw.in_b, Mp, 3 * W, W, 0, qkv, st))) return rc;
+        if ((rc = gemm_bf16_rows(h, lwb + bw.in_proj, lpf + bw.in_b, Mp, Mv, 3 * W, W, 0, qkv, st))) return rc;
         if ((rc = attention_bf16(qkv, batch, T, H, h, st, causal, W / H))) return rc;
-        if ((rc = gemm_bf16(h, lwb + bw.out_proj, lpf + bw.out_b, Mp, W, W, 3, x, st))) return rc;
+        if ((rc = gemm_bf16_rows(h, lwb + bw.out_proj, lpf + bw.out_b, Mp, Mv, W, W, 3, x, st))) return rc;
         if ((rc = layernorm_f32_bf16(x, lpf + bw.ln2_w, lpf + bw.ln2_b, M, W, eps, h, st))) return rc;
         // act: 0 QuickGELU, 1 erf GELU, 2 gelu_new (tanh) -> epilogue modes 1, 2, 5
-        if ((rc = gemm_bf16(h, lwb + bw.c_fc, lpf + bw.fc_b, Mp, F, W, act == 0 ? 1 : (act == 1 ? 2 : 5), a, st))) return rc;
-        if ((rc = gemm_bf16(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, W, F, 3, x, st))) return rc;
+        if ((rc = gemm_bf16_rows(h, lwb + bw.c_fc, lpf + bw.fc_b, Mp, Mv, F, W, act == 0 ? 1 : (act == 1 ? 2 : 5), a, st))) return rc;
+        if ((rc = gemm_bf16_rows(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, Mv, W, F, 3, x, st))) return rc;
     }
     return WISE_OK;
 }

@@ -179,12 +179,12 @@ extern "C" int wise_xlmr_forward(const wise_xlmr_config* cfg, const uint16_t* wb
     for (int l = 0; l < d.L; ++l) {
         const bf16_t* lw = wb + o.per_layer_b * l;
         const float* lp = pf + o.layer0_f + o.per_layer_f * l;
-        if ((rc = gemm_bf16(h, lw + o.qkv, lp + o.qkv_b, Mp, 3 * W, W, 0, qkv, st))) return rc;
+        if ((rc = gemm_bf16_rows(h, lw + o.qkv, lp + o.qkv_b, Mp, M, 3 * W, W, 0, qkv, st))) return rc;
         if ((rc = attention_bf16(qkv, batch, d.T, d.H, h, st, false, 64, lens))) return rc;
-        if ((rc = gemm_bf16(h, lw + o.out, lp + o.out_b, Mp, W, W, 3, x, st))) return rc;
+        if ((rc = gemm_bf16_rows(h, lw + o.out, lp + o.out_b, Mp, M, W, W, 3, x, st))) return rc;
         if ((rc = layernorm_f32_dual(x, lp + o.ln1_w, lp + o.ln1_b, M, W, eps, x, h, st))) return rc;
-        if ((rc = gemm_bf16(h, lw + o.fc1, lp + o.fc1_b, Mp, d.F, W, 2, a, st))) return rc;
-        if ((rc = gemm_bf16(a, lw + o.fc2, lp + o.fc2_b, Mp, W, d.F, 3, x, st))) return rc;
+        if ((rc = gemm_bf16_rows(h, lw + o.fc1, lp + o.fc1_b, Mp, M, d.F, W, 2, a, st))) return rc;
+        if ((rc = gemm_bf16_rows(a, lw + o.fc2, lp + o.fc2_b, Mp, M, W, d.F, 3, x, st))) return rc;
         if ((rc = layernorm_f32_dual(x, lp + o.ln2_w, lp + o.ln2_b, M, W, eps, x, h, st))) return rc;
     }
     // mean over the sequence's own tokens -> MLP projection (no biases) -> L2 normalise
@@ -192,8 +192,8 @@ extern "C" int wise_xlmr_forward(const wise_xlmr_config* cfg, const uint16_t* wb
     hipLaunchKernelGGL(xlmr_meanpool_kernel, dim3(batch), dim3(256), 0, st, x, lens, d.T, W, h);
     WISE_LAUNCH_CHECK("xlmr_meanpool_kernel");
     float* e = reinterpret_cast<float*>(qkv);
-    if ((rc = gemm_bf16(h, wb + o.proj1, nullptr, Bp, d.Hd, W, 2, a, st))) return rc;
-    if ((rc = gemm_bf16(a, wb + o.proj2, nullptr, Bp, d.D, d.Hd, 4, e, st))) return rc;
+    if ((rc = gemm_bf16_rows(h, wb + o.proj1, nullptr, Bp, batch, d.Hd, W, 2, a, st))) return rc;
+    if ((rc = gemm_bf16_rows(a, wb + o.proj2, nullptr, Bp, batch, d.D, d.Hd, 4, e, st))) return rc;
     return l2norm_rows(e, batch, d.D, out, st);
 }
 
