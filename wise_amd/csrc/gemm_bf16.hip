@@ -1443,6 +1443,7 @@ static void launch_pp(const bf16_t* A, const bf16_t* Wt, const float* bias, int 
 static int g_gemm_variant = 0;
 static int g_tile320 = 1;  // allow the 320x256 ping-pong tiling (wise_debug_set_gemm_flags bit 0 turns it off)
 static int g_overlapped = 0;  // the caller is running another stream's kernels beside this one (gemm_set_overlapped)
+static int g_overlap_policy = 0;  // (debug knob) tiles under overlap: 0 = as for a lone stream minus the 320-row tilings (the product), 1 = 128x128 only, 2 = 128x128 except the QKV-shaped launches, 3 = hint ignored
 static int g_split_m = 1;  // split M between the ping-pong kernel and the 128x128 kernel (bit 29 of the knob: off)
   // 0: 2-stage BK=64 ; 1: ring BK=32 x4 (2 blocks/CU) ; 2: ring BK=64 x4 (1 block/CU) ; 3: ring BK=64 x3
 
@@ -1651,6 +1652,20 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
     int v = g_gemm_variant;
     if (v == 100) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);  // force 128x128 (A/B runs)
     if (v != 0) return launch_mode(v, A, Wt, bias, M, N, K, mode, out, st);
+    // Two whole batches in flight on two streams (VitEngine.forward_pipelined -> wise_vit_forward_single sets the hint):
+    // measured in one process (tools/vit_variant_pipe.py, ViT-B/32 bs=256): hint ignored 3.28 ms per step; the lone-stream
+    // heuristic minus the 320-row tilings (policy 0, what follows below) 3.16; 128x128 everywhere (policy 1) 3.20.
+    if (g_overlap_policy == 3) {   // (debug) ignore the hint altogether
+        const int keep = g_overlapped;
+        g_overlapped = 0;
+        g_overlap_policy = 0;
+        const int rc3 = gemm_bf16(A, Wt, bias, M, N, K, mode, out, st);
+        g_overlap_policy = 3;
+        g_overlapped = keep;
+        return rc3;
+    }
+    if (g_overlapped && g_overlap_policy == 1) return launch_mode(auto_variant(M, N, K) == 2 ? 2 : 0, A, Wt, bias, M, N, K, mode, out, st);
+    if (g_overlapped && g_overlap_policy == 2 && !(bf16_out(mode) && N >= 3 * K)) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);
 
     // Tile quantisation decides between the ping-pong tilings: 6400 x 3072 is 300 tiles of 256x256 (two rounds
     // at 59 %) but 240 tiles of 320x256 (one round at 94 %); measured 694 -> 799 TFLOP/s on that shape.
@@ -1729,6 +1744,7 @@ extern "C" int wise_debug_set_gemm_stamps(unsigned long long* buf /*device, 8192
 }
 extern "C" int wise_debug_set_gemm_flags(int flags) {
     wise::g_tile320 = (flags & 1) ? 0 : 1;
+    wise::g_overlap_policy = (flags >> 4) & 3;     // bits 4-5: tiles under overlap (0 lone-stream tiles, 1 = 128x128, 2 = mixed)
     wise::g_ablate = flags & 6;
     return 0;
 }

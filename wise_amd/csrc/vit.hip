@@ -1044,8 +1044,12 @@ extern "C" int wise_vit_forward_single(const wise_vit_config* cfg, const uint16_
     }
     WISE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wb & 15) == 0 && ((uintptr_t)pf & 15) == 0,
                    "vit_forward: workspace must be 256-byte and weight blobs 16-byte aligned");
-    return vit_forward_part(cfg, d, vit_offsets(d), wb, pf, images, in_kind, batch, out,
-                            reinterpret_cast<unsigned char*>(workspace), (hipStream_t)stream);
+    // this entry point exists for callers that keep two whole batches in flight on two streams: tile for co-residency
+    gemm_set_overlapped(true);
+    rc = vit_forward_part(cfg, d, vit_offsets(d), wb, pf, images, in_kind, batch, out,
+                          reinterpret_cast<unsigned char*>(workspace), (hipStream_t)stream);
+    gemm_set_overlapped(false);
+    return rc;
 }
 
 extern "C" int wise_vit_tap_residual(const wise_vit_config* cfg, int batch, const void* workspace, float* dst,
