@@ -31,6 +31,10 @@ const char* wise_last_error(void);
  * the shadow's error norm, wise_build_flags; 3: wise_vit_config.arch, wise_text_config.no_causal / eps_e6 — the SigLIP
  * towers — and the wise_xlmr_* entry points). */
 int wise_abi_version(void);
+/* Host-side hint for the GEMM tile heuristic (no device work): on != 0 while the caller enqueues batches that will run
+ * beside another stream's (two batches in flight); one-block-per-CU tilings are then avoided where they measured slower.
+ * wise_vit_forward / _single set it themselves; HtsatEngine.forward_pipelined brackets its call with it. */
+void wise_overlap_hint(int on);
 /* The compiler flags the device code of this library was built with (wise_amd/build.py).  The product kernels must
  * be built without packed f32 VALU math ("-fno-slp-vectorize ... -packed-fp32-ops": DESIGN.md section 4, a gfx950
  * wait-state hazard); __graft_entry__.smoke() and the tests assert it on the library that is actually loaded. */

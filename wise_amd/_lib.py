@@ -42,6 +42,7 @@ _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 SIGNATURES = {
     "wise_last_error": (C.c_char_p, []),
     "wise_abi_version": (_i, []),
+    "wise_overlap_hint": (None, [_i]),
     "wise_build_flags": (C.c_char_p, []),
     "wise_device_ok": (_i, []),
     "wise_prof_begin": (_i, [_i]),

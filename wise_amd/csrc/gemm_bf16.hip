@@ -1729,6 +1729,8 @@ extern "C" int wise_gemm_ln_bf16(const float* x, const float* lnw, const float* 
     return wise::gemm_ln_bf16(x, lnw, lnb, Wt, bias, M, N, K, eps, mode, out, (hipStream_t)stream);
 }
 
+extern "C" void wise_overlap_hint(int on) { wise::gemm_set_overlapped(on != 0); }
+
 extern "C" int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, int mode,
                               void* out, void* stream) {
     return wise::gemm_bf16(A, Wt, bias, M, N, K, mode, out, (hipStream_t)stream);

@@ -154,8 +154,10 @@ class HtsatEngine:
         out = torch.empty(B, OUT_DIM, dtype=torch.float32, device=self.device)
         x.record_stream(slot["stream"])
         out.record_stream(slot["stream"])
+        self.lib.wise_overlap_hint(1)      # this batch runs beside the other slot's: tile for co-residency
         rc = self.lib.wise_htsat_forward(self.wb.data_ptr(), self.pf.data_ptr(), x.data_ptr(), B, N, out.data_ptr(),
                                          slot["ws"].data_ptr(), slot["ws"].numel(), slot["stream"].cuda_stream)
+        self.lib.wise_overlap_hint(0)
         _lib.check(rc, "wise_htsat_forward")
         done = torch.cuda.Event()
         done.record(slot["stream"])
