@@ -410,6 +410,28 @@ def test_batched_two_stage_search_with_threshold_passes():
     check_against_oracle(X, Q, k, ids, D, I)
 
 
+@pytest.mark.parametrize("d,nq", [(512, 65), (512, 128), (512, 129), (512, 200), (512, 257), (768, 65), (768, 130), (256, 300)])
+def test_batched_pass_sizes_and_remainders(d, nq):
+    """passes of 128 queries at d <= 512 (64 at d = 768), a remainder of <= 64 through the 64-query kernel, single-query
+    remainders; two collect ranges (N >= 4M rows) — ids and scores equal the f32 scan's for every query"""
+    N, k = 4_300_000, 10
+    g = torch.Generator(device="cuda").manual_seed(d + nq)
+    X = torch.empty(N, d, device="cuda")
+    for s0 in range(0, N, 1_000_000):
+        n = min(1_000_000, N - s0)
+        X[s0:s0 + n] = torch.nn.functional.normalize(torch.randn(n, d, device="cuda", generator=g), dim=1)
+    Q = torch.nn.functional.normalize(torch.randn(nq, d, device="cuda", generator=g), dim=1)
+    ref = FlatIPIndex(d, shadow=False).adopt(X)
+    D0, I0 = ref.search_device(Q, k)
+    del ref
+    idx = FlatIPIndex(d, shadow=True).adopt(X)
+    before = idx.shadow_counts()
+    D, I = idx.search_device(Q, k)
+    certified, fallback = counts_since(idx, before)
+    assert certified + fallback == nq and fallback == 0
+    assert torch.equal(I, I0) and torch.equal(D, D0)
+
+
 def test_full_size_two_stage_against_the_f32_scan():
     """BASELINE cfg-3 size (10M x 512): the two-stage searches (one query; batches of 64 on the matrix cores, with
     the threshold pass and both row ranges) return exactly what the f32 scans of the same index return, and what

@@ -13,8 +13,8 @@ B = 256
 eng = VitEngine(spec, random_state_dict(spec, 0), max_batch=B)
 x = torch.randn(B, 3, 224, 224, device="cuda")
 for rep in range(2):
-    for name, v, pol in (("overlap policy 0 (lone-stream tiles)", 0, 0), ("overlap policy 1 (128x128)", 0, 1),
-                         ("overlap policy 2 (128x128, QKV ping-pong)", 0, 2), ("hint ignored (round-1 behaviour)", 0, 3)):
+    for name, v, pol in (("overlap policy 0 (lone-stream tiles minus 320-row)", 0, 0), ("policy 7: QKV and fc1 128x128", 0, 7),
+                         ("policy 5: fc1 128x128", 0, 5), ("policy 6: QKV 128x128", 0, 6), ("hint ignored (round-1 behaviour)", 0, 3)):
         lib.wise_debug_set_gemm_variant(v)
         lib.wise_debug_set_gemm_flags(pol << 4)
         for _ in range(4): eng.forward_pipelined(x)

@@ -1666,6 +1666,10 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
     }
     if (g_overlapped && g_overlap_policy == 1) return launch_mode(auto_variant(M, N, K) == 2 ? 2 : 0, A, Wt, bias, M, N, K, mode, out, st);
     if (g_overlapped && g_overlap_policy == 2 && !(bf16_out(mode) && N >= 3 * K)) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);
+    if (g_overlapped && g_overlap_policy == 4 && (mode == EPI_RESID || mode == EPI_F32)) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);
+    if (g_overlapped && g_overlap_policy == 5 && bf16_out(mode) && N == 4 * K) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);
+    if (g_overlapped && g_overlap_policy == 6 && bf16_out(mode) && N == 3 * K) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);
+    if (g_overlapped && g_overlap_policy == 7 && bf16_out(mode) && N >= 3 * K) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);
 
     // Tile quantisation decides between the ping-pong tilings: 6400 x 3072 is 300 tiles of 256x256 (two rounds
     // at 59 %) but 240 tiles of 320x256 (one round at 94 %); measured 694 -> 799 TFLOP/s on that shape.
@@ -1746,7 +1750,7 @@ extern "C" int wise_debug_set_gemm_stamps(unsigned long long* buf /*device, 8192
 }
 extern "C" int wise_debug_set_gemm_flags(int flags) {
     wise::g_tile320 = (flags & 1) ? 0 : 1;
-    wise::g_overlap_policy = (flags >> 4) & 3;     // bits 4-5: tiles under overlap (0 lone-stream tiles, 1 = 128x128, 2 = mixed)
+    wise::g_overlap_policy = (flags >> 4) & 7;     // bits 4-6: tiles under overlap (0 lone-stream tiles, 1 = 128x128, 2 = mixed, 3 = hint ignored, 4/5/6 = 128x128 for the residual / fc1 / QKV launches only)
     wise::g_ablate = flags & 6;
     return 0;
 }
