@@ -681,6 +681,40 @@ def main():
             "tflops_batch256": round(256 * t_steps / tdt256 * tspec.flops_per_query() / 1e12, 2)}
         del teng, toks
         torch.cuda.empty_cache()
+        # the query side of the reference's DEFAULT model pair (xlm-roberta-large-ViT-H-14, extract-features.py:192)
+        from wise_amd.feature.xlmr_text import XLMR_SPECS, XlmrTextEngine, random_xlmr_state_dict
+        xspec = XLMR_SPECS["xlm-roberta-large-ViT-H-14"]
+        xeng = XlmrTextEngine(xspec, random_xlmr_state_dict(xspec, 0), max_batch=256)
+        if world > 1:
+            xeng.graph_max_batch = 0
+        xt = np.full((256, xspec.context), xspec.pad_id, dtype=np.int32)
+        for i in range(256):
+            kx = int(trng.integers(3, 24))
+            xt[i, 0] = 0
+            xt[i, 1:1 + kx] = trng.integers(4, xspec.vocab, kx)
+            xt[i, 1 + kx] = 2
+        xt = torch.from_numpy(xt).cuda()
+
+        def xtext1(i):
+            hold["t"] = xeng.forward(xt[i % 256:i % 256 + 1])
+
+        def xtext256(i):
+            hold["t"] = xeng.forward(xt)
+
+        for i in range(3):
+            xtext1(i); xtext256(i)
+        x_steps = max(5, min(args.steps, 20))
+        xdt1 = timed_region(xtext1, x_steps, world)
+        xdt256 = timed_region(xtext256, x_steps, world)
+        extra["xlmr_text_tower"] = {
+            "value": round(world * 256 * x_steps / xdt256, 1), "unit": "queries/s (batches of 256)",
+            "single_query_ms": round(xdt1 / x_steps * 1e3, 4), "ms_per_batch256": round(xdt256 / x_steps * 1e3, 3),
+            "config": {"workload": "XLM-RoBERTa-large text tower of xlm-roberta-large-ViT-H-14 (open_clip HFTextEncoder: mean "
+                                   "pooler + MLP projection): token ids [n,77] resident in HBM -> unit vectors [n,1024]; seeded "
+                                   "weights", "gflop_per_query": round(xspec.flops_per_query() / 1e9, 3)},
+            "tflops_batch256": round(256 * x_steps / xdt256 * xspec.flops_per_query() / 1e12, 2)}
+        del xeng, xt
+        torch.cuda.empty_cache()
         # f4: IndexIVFFlat at the reference's geometry for 10M rows (nlist = 10 * round(sqrt(N)) = 31620, nprobe 32 =
         # the REST default, routes.py:902).  The lists are synthesised (equal sizes, rows = list direction + noise,
         # centroid = normalised list mean): training 31620 cells on 3.2M rows is hours of k-means and is not what
