@@ -33,7 +33,7 @@ const char* wise_last_error(void);
 int wise_abi_version(void);
 /* Host-side hint for the GEMM tile heuristic (no device work): on != 0 while the caller enqueues batches that will run
  * beside another stream's (two batches in flight); one-block-per-CU tilings are then avoided where they measured slower.
- * wise_vit_forward / _single set it themselves; HtsatEngine.forward_pipelined brackets its call with it. */
+ * wise_vit_forward sets it itself for its half batches; the engines' forward_pipelined bracket their calls with it. */
 void wise_overlap_hint(int on);
 /* The compiler flags the device code of this library was built with (wise_amd/build.py).  The product kernels must
  * be built without packed f32 VALU math ("-fno-slp-vectorize ... -packed-fp32-ops": DESIGN.md section 4, a gfx950

@@ -1652,7 +1652,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
     int v = g_gemm_variant;
     if (v == 100) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);  // force 128x128 (A/B runs)
     if (v != 0) return launch_mode(v, A, Wt, bias, M, N, K, mode, out, st);
-    // Two whole batches in flight on two streams (VitEngine.forward_pipelined -> wise_vit_forward_single sets the hint):
+    // Two whole batches in flight on two streams (VitEngine.forward_pipelined brackets its calls with wise_overlap_hint):
     // measured in one process (tools/vit_variant_pipe.py, ViT-B/32 bs=256): hint ignored 3.28 ms per step; the lone-stream
     // heuristic minus the 320-row tilings (policy 0, what follows below) 3.16; 128x128 everywhere (policy 1) 3.20.
     if (g_overlap_policy == 3) {   // (debug) ignore the hint altogether

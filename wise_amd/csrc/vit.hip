@@ -1044,12 +1044,10 @@ extern "C" int wise_vit_forward_single(const wise_vit_config* cfg, const uint16_
     }
     WISE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wb & 15) == 0 && ((uintptr_t)pf & 15) == 0,
                    "vit_forward: workspace must be 256-byte and weight blobs 16-byte aligned");
-    // this entry point exists for callers that keep two whole batches in flight on two streams: tile for co-residency
-    gemm_set_overlapped(true);
-    rc = vit_forward_part(cfg, d, vit_offsets(d), wb, pf, images, in_kind, batch, out,
-                          reinterpret_cast<unsigned char*>(workspace), (hipStream_t)stream);
-    gemm_set_overlapped(false);
-    return rc;
+    // (a caller that keeps two whole batches in flight on two streams brackets this call with wise_overlap_hint so that
+    // the GEMMs tile for co-residency; a lone stream gets the lone-stream tiles)
+    return vit_forward_part(cfg, d, vit_offsets(d), wb, pf, images, in_kind, batch, out,
+                            reinterpret_cast<unsigned char*>(workspace), (hipStream_t)stream);
 }
 
 extern "C" int wise_vit_tap_residual(const wise_vit_config* cfg, int batch, const void* workspace, float* dst,

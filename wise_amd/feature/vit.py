@@ -260,9 +260,11 @@ class VitEngine:
         out = torch.empty(B, self.spec.embed_dim, dtype=torch.float32, device=self.device)
         x.record_stream(slot["stream"])
         out.record_stream(slot["stream"])
+        self.lib.wise_overlap_hint(1)   # this batch runs beside the other slot's: GEMM tiles chosen for co-residency
         rc = self.lib.wise_vit_forward_single(C.byref(self.cfg), self.wb.data_ptr(), self.pf.data_ptr(), x.data_ptr(),
                                               kind, B, out.data_ptr(), slot["ws"].data_ptr(), slot["ws"].numel(),
                                               slot["stream"].cuda_stream)
+        self.lib.wise_overlap_hint(0)
         _lib.check(rc, "wise_vit_forward_single")
         done = torch.cuda.Event()
         done.record(slot["stream"])
