@@ -145,6 +145,7 @@ def main():
     golden_vit(TINY_H80, 9, 2, 13, "vit_tiny_h80.npz", full_taps=True, pin=True)
     golden_vit(spec_for("ViT-B-32"), 0, 4, 1, "vit_b32.npz", full_taps=False, pin=True)
     golden_vit(spec_for("ViT-L-14"), 0, 2, 5, "vit_l14.npz", full_taps=False, pin=True)
+    golden_vit(spec_for("ViT-B-16", "laion2b_s34b_b88k"), 0, 2, 14, "vit_b16.npz", full_taps=False, pin=True)   # 197 tokens, erf GELU
     golden_vit(spec_for("ViT-H-14", "laion2b_s32b_b79k"), 0, 2, 6, "vit_h14.npz", full_taps=False, pin=True)
     golden_ip()
 

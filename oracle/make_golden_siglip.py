@@ -167,6 +167,7 @@ def main():
     golden_vision(TINY_V, 3, 3, 31, "siglip_v_tiny.npz")
     golden_vision(TINY_V_TANH, 4, 2, 32, "siglip_v_tiny100.npz")
     golden_text(TINY_T, 3, 5, 33, "siglip_t_tiny.npz")
+    golden_vision(SIGLIP_VISION["ViT-B-16-SigLIP-256"], 0, 2, 36, "siglip_v_b16_256.npz")     # the id the factory docstring names
     golden_vision(SIGLIP_VISION["ViT-L-16-SigLIP-384"], 0, 2, 34, "siglip_v_l16_384.npz")
     golden_text(SIGLIP_TEXT["ViT-L-16-SigLIP-384"], 0, 3, 35, "siglip_t_l16_384.npz")
 

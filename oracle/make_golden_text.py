@@ -105,6 +105,7 @@ def main():
     golden(TINY_GELU, 1, 5, 32, "text_tiny_gelu.npz")
     golden(text_spec_for("ViT-B-32", "openai"), 0, 6, 33, "text_b32.npz")
     golden(text_spec_for("ViT-L-14", "openai"), 0, 3, 34, "text_l14.npz")
+    golden(text_spec_for("ViT-H-14", "laion2b_s32b_b79k"), 0, 3, 35, "text_h14.npz")     # 24 layers x 1024, erf GELU
 
 
 if __name__ == "__main__":

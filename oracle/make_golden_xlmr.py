@@ -87,6 +87,7 @@ def main():
     golden(TINY, 5, 6, 21, "xlmr_tiny.npz")
     golden(TINY_SHORT, 6, 4, 22, "xlmr_tiny_short.npz")
     golden(XLMR_SPECS["xlm-roberta-large-ViT-H-14"], 0, 3, 23, "xlmr_large.npz")
+    golden(XLMR_SPECS["xlm-roberta-base-ViT-B-32"], 0, 3, 24, "xlmr_base.npz")
 
 
 if __name__ == "__main__":

@@ -26,6 +26,7 @@ def cosine(a, b):
 
 
 @pytest.mark.parametrize("spec,fname", [(TINY_V, "siglip_v_tiny.npz"), (TINY_V_TANH, "siglip_v_tiny100.npz"),
+                                        (SIGLIP_VISION["ViT-B-16-SigLIP-256"], "siglip_v_b16_256.npz"),
                                         (SIGLIP_VISION["ViT-L-16-SigLIP-384"], "siglip_v_l16_384.npz")])
 def test_vision_tower_matches_golden(spec, fname):
     g = np.load(GOLD / fname)

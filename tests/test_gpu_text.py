@@ -41,7 +41,8 @@ def test_causal_attention(B, T, H):
 
 @pytest.mark.parametrize("spec,fname", [(TINY, "text_tiny.npz"), (TINY_GELU, "text_tiny_gelu.npz"),
                                         (text_spec_for("ViT-B-32", "openai"), "text_b32.npz"),
-                                        (text_spec_for("ViT-L-14", "openai"), "text_l14.npz")])
+                                        (text_spec_for("ViT-L-14", "openai"), "text_l14.npz"),
+                                        (text_spec_for("ViT-H-14", "laion2b_s32b_b79k"), "text_h14.npz")])
 def test_text_forward_matches_golden(spec, fname):
     gold = np.load(GOLD / fname)
     seed, n, tok_seed = (int(v) for v in gold["meta"][:3])

@@ -144,8 +144,8 @@ def load_golden(golden_dir, name):
     return spec, g, torch.from_numpy(frames)
 
 
-@pytest.mark.parametrize("name", ["vit_tiny.npz", "vit_tiny_gelu.npz", "vit_tiny_h80.npz", "vit_b32.npz", "vit_l14.npz",
-                                  "vit_h14.npz"])
+@pytest.mark.parametrize("name", ["vit_tiny.npz", "vit_tiny_gelu.npz", "vit_tiny_h80.npz", "vit_b32.npz", "vit_b16.npz",
+                                  "vit_l14.npz", "vit_h14.npz"])
 def test_vit_golden(golden_dir, name):
     spec, g, frames = load_golden(golden_dir, name)
     sd = random_state_dict(spec, int(g["weight_seed"]))

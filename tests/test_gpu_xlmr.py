@@ -46,7 +46,8 @@ def test_attention_with_padded_keys(B, T, H):
 
 
 @pytest.mark.parametrize("spec,fname", [(TINY, "xlmr_tiny.npz"), (TINY_SHORT, "xlmr_tiny_short.npz"),
-                                        (XLMR_SPECS["xlm-roberta-large-ViT-H-14"], "xlmr_large.npz")])
+                                        (XLMR_SPECS["xlm-roberta-large-ViT-H-14"], "xlmr_large.npz"),
+                                        (XLMR_SPECS["xlm-roberta-base-ViT-B-32"], "xlmr_base.npz")])
 def test_xlmr_forward_matches_golden(spec, fname):
     gold = np.load(GOLD / fname)
     seed, n, tok_seed = (int(v) for v in gold["meta"][:3])
