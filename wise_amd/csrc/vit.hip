@@ -212,8 +212,11 @@ __device__ __forceinline__ void softmax_block(f32x4 (&sacc)[4][QT], bf16x8 (&pf)
 // which lives on latency hiding, drops to 1-2 waves per SIMD)
 // DH = head dim: 64, or 80 (ViT-H/14: width 1280 over 16 heads) — then the QK^T contraction runs three 32-deep steps
 // with the last 16 channels zero, the PV product has five 16-channel output tiles and a V row is 160 bytes.
-template <int QT, bool CAUSAL, int DH = 64>
-__global__ __launch_bounds__(256, (QT == 2 && DH == 64) ? 4 : 2) void attention_kernel(const bf16_t* __restrict__ qkv, int B, int T, int H,
+// PF: the K fragments and the V rows of the NEXT key block travel while the current one is computed (64 more registers:
+// the kernel is bound by the latency of those loads, block after block — a wave holding ONE query took as long over a
+// sequence as a wave holding 64).
+template <int QT, bool CAUSAL, int DH = 64, bool PF = false>
+__global__ __launch_bounds__(256, (QT == 2 && DH == 64 && !PF) ? 4 : 2) void attention_kernel(const bf16_t* __restrict__ qkv, int B, int T, int H,
                                                         bf16_t* __restrict__ o, const int* __restrict__ lens = nullptr) {
     constexpr int NS = (DH + 31) / 32, ND = DH / 16, VRS = DH * 2 + 16;   // k-steps of QK^T, dh tiles of PV, V row stride
     __shared__ __attribute__((aligned(16))) unsigned char v_all[4][64 * VRS];
@@ -258,12 +261,20 @@ __global__ __launch_bounds__(256, (QT == 2 && DH == 64) ? 4 : 2) void attention_
     // causal (text tower): query t sees keys <= t, so key blocks past the chunk's last query are skipped
     const int q_last = min(T, (qc + 1) * (16 * QT)) - 1;
     const int nkb = CAUSAL ? (q_last >> 6) + 1 : (Tk + 63) >> 6;
-    for (int kb = 0; kb < nkb; ++kb) {
-        // ---- V image, row-major [64 keys][64 dh]: 8 passes, lane copies 16 B of V row key = p*8 + lane/8;
-        //      the transpose the PV product needs is done by ds_read_b64_tr_b16 on the way out
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        constexpr int CPR = DH / 8;                     // 16-byte chunks per V row (8, or 10)
+    constexpr int CPR = DH / 8;                         // 16-byte chunks per V row (8, or 10)
+    // loads of one key block: K fragments [kt][k-step] (A operand of S^T = K Q^T) and the lane's share of the V rows
+    auto load_k = [&](int kb, bf16x8 (&kf)[4][NS]) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            int t = kb * 64 + kt * 16 + l15;
+            if (t >= Tk) t = Tk - 1;
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2)
+                kf[kt][s2] = (s2 * 32 + g * 8 < DH) ? *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + W + h * DH + s2 * 32 + g * 8)
+                                                    : zero8;
+        }
+    };
+    auto load_v = [&](int kb, uint4 (&vr)[CPR]) {
 #pragma unroll
         for (int p = 0; p < CPR; ++p) {
             const int c = p * 64 + lane, key = c / CPR, part = c - key * CPR;
@@ -272,7 +283,54 @@ __global__ __launch_bounds__(256, (QT == 2 && DH == 64) ? 4 : 2) void attention_
             if (!valid) t = Tk - 1;
             uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)t * W3 + 2 * W + h * DH + part * 8);
             if (!valid) v = make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(vimg + key * VRS + part * 16) = v;
+            vr[p] = v;
+        }
+    };
+    // HOIST (without PF): all of a block's V rows and K fragments are requested before the first is used — more loads in
+    // flight per wave (T = 576: 960 -> 700 us per launch).  Not where registers are the budget: 32 queries per wave at four
+    // waves per SIMD (T <= 64) and head width 80 keep the load-use-load-use form.
+    constexpr bool HOIST = PF || (QT != 2 && DH == 64 && !CAUSAL);
+    bf16x8 kf_n[PF ? 4 : 1][NS];
+    uint4 vr_n[PF ? CPR : 1];
+    if constexpr (PF) { load_k(0, kf_n); load_v(0, vr_n); }
+    for (int kb = 0; kb < nkb; ++kb) {
+        // ---- V image, row-major [64 keys][64 dh]: 8 passes, lane copies 16 B of V row key = p*8 + lane/8;
+        //      the transpose the PV product needs is done by ds_read_b64_tr_b16 on the way out
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 kf[HOIST ? 4 : 1][NS];
+        if constexpr (HOIST) {
+            uint4 vr[CPR];
+            if constexpr (PF) {
+#pragma unroll
+                for (int p = 0; p < CPR; ++p) vr[p] = vr_n[p];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) kf[kt][s2] = kf_n[kt][s2];
+            } else {
+                load_v(kb, vr);
+                load_k(kb, kf);
+            }
+#pragma unroll
+            for (int p = 0; p < CPR; ++p) {
+                const int c = p * 64 + lane, key = c / CPR, part = c - key * CPR;
+                *reinterpret_cast<uint4*>(vimg + key * VRS + part * 16) = vr[p];
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < CPR; ++p) {
+                const int c = p * 64 + lane, key = c / CPR, part = c - key * CPR;
+                int t = kb * 64 + key;
+                const bool valid = t < Tk;
+                if (!valid) t = Tk - 1;
+                uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)t * W3 + 2 * W + h * DH + part * 8);
+                if (!valid) v = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(vimg + key * VRS + part * 16) = v;
+            }
+        }
+        if constexpr (PF) {
+            if (kb + 1 < nkb) { load_k(kb + 1, kf_n); load_v(kb + 1, vr_n); }   // in flight through this block's MFMAs and softmax
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -282,18 +340,20 @@ __global__ __launch_bounds__(256, (QT == 2 && DH == 64) ? 4 : 2) void attention_
         f32x4 sacc[4][QT];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            int t = kb * 64 + kt * 16 + l15;
-            if (t >= Tk) t = Tk - 1;
-            bf16x8 kf[NS];
+            constexpr int KI = HOIST ? 1 : 0;          // kf row of this tile: kt (hoisted) or the single scratch row
+            if constexpr (!HOIST) {
+                int t = kb * 64 + kt * 16 + l15;
+                if (t >= Tk) t = Tk - 1;
 #pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2)
-                kf[s2] = (s2 * 32 + g * 8 < DH) ? *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + W + h * DH + s2 * 32 + g * 8)
-                                                : zero8;
+                for (int s2 = 0; s2 < NS; ++s2)
+                    kf[0][s2] = (s2 * 32 + g * 8 < DH) ? *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + W + h * DH + s2 * 32 + g * 8)
+                                                       : zero8;
+            }
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s2 = 0; s2 < NS; ++s2) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s2], qf[qt][s2], c, 0, 0, 0);
+                for (int s2 = 0; s2 < NS; ++s2) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt * KI][s2], qf[qt][s2], c, 0, 0, 0);
                 sacc[kt][qt] = c;
             }
         }
@@ -376,6 +436,20 @@ int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_
     // wave (K/V re-read half as often).  (Measured and dropped: a block-per-head kernel that stages K/V once in
     // LDS for all query chunks of a head — at T = 257 it was 5 % slower: the loop is bound by the softmax VALU work
     // and by latency at 2-3 waves per SIMD, not by the K/V re-reads, which hit L2.)
+    // measured per launch (bs 256): T = 257: 64 queries/wave 327 us as it was, 290 with the hoisted loads, 48 queries +
+    // prefetch 248; T = 576: 960 / 700 / 717; T = 197: 147 / 133 / 132 (tools/attn_bench.py)
+    if (!causal && (g_attn_qt == 3 || (g_attn_qt == 0 && T > 64 && T <= 320))) {   // 48 queries per wave, next key block prefetched
+        const long long it3 = (long long)B * H * ((T + 47) / 48);
+        hipLaunchKernelGGL((attention_kernel<3, false, 64, true>), dim3((unsigned)((it3 + 3) / 4)), dim3(256), 0, st, qkv, B, T, H, o, lens);
+        WISE_LAUNCH_CHECK("attention_kernel");
+        return WISE_OK;
+    }
+    if (!causal && g_attn_qt == 5) {   // 32 queries per wave, next key block prefetched
+        const long long it2 = (long long)B * H * ((T + 31) / 32);
+        hipLaunchKernelGGL((attention_kernel<2, false, 64, true>), dim3((unsigned)((it2 + 3) / 4)), dim3(256), 0, st, qkv, B, T, H, o, lens);
+        WISE_LAUNCH_CHECK("attention_kernel");
+        return WISE_OK;
+    }
     const int qt = g_attn_qt ? (g_attn_qt == 4 ? 4 : 2) : (T <= 64 ? 2 : 4);
     const int nqc = (T + 16 * qt - 1) / (16 * qt);
     const long long items = (long long)B * H * nqc;
@@ -946,7 +1020,7 @@ using namespace wise;
 #ifdef WISE_DEBUG_KNOBS
 extern "C" int wise_debug_set_vit_streams(int n) {
     g_vit_streams = n & 0xFF;
-    if (n >> 8) g_attn_qt = n >> 8;  // bits 8..: attention query tiles per wave (2 or 4)
+    if (n >> 8) g_attn_qt = (n >> 8) == 255 ? 0 : (n >> 8);  // bits 8..: attention variant (2 / 4: 32 / 64 queries per wave; 3 / 5: 48 / 32 with prefetch; 255: heuristic)
     return 0;
 }
 #endif
