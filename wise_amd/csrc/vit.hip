@@ -439,7 +439,7 @@ int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_
     // and by latency at 2-3 waves per SIMD, not by the K/V re-reads, which hit L2.)
     // measured per launch (bs 256): T = 257: 64 queries/wave 327 us as it was, 290 with the hoisted loads, 48 queries +
     // prefetch 248; T = 576: 960 / 700 / 717; T = 197: 147 / 133 / 132 (tools/attn_bench.py)
-    if (!causal && (g_attn_qt == 3 || (g_attn_qt == 0 && T > 64 && T <= 320))) {   // 48 queries per wave, next key block prefetched
+    if (!causal && g_attn_qt == 3) {   // (debug variant) 48 queries per wave, next key block prefetched
         const long long it3 = (long long)B * H * ((T + 47) / 48);
         hipLaunchKernelGGL((attention_kernel<3, false, 64, true>), dim3((unsigned)((it3 + 3) / 4)), dim3(256), 0, st, qkv, B, T, H, o, lens);
         WISE_LAUNCH_CHECK("attention_kernel");
