@@ -1557,14 +1557,14 @@ int gemm_ln_bf16(const float* x, const float* lnw, const float* lnb, const bf16_
     return WISE_OK;
 }
 
-// fp32 scratch of the split-K path: a pool of four buffers allocated together on the first skinny launch of the process
+// fp32 scratch of the split-K path: a pool of eight buffers allocated together on the first skinny launch of the process
 // (outside any graph capture: the engines warm up before they capture); a stream is bound to one of them the first time it
-// takes the path — no allocation then, so a capture stream may be new — and a fifth stream gets the ordinary kernels.
+// takes the path — no allocation then, so a capture stream may be new — and a ninth stream gets the ordinary kernels.
 constexpr size_t SPLITK_SCRATCH_BYTES = (size_t)24 << 20;
-constexpr int SPLITK_POOL = 4;
+constexpr int SPLITK_POOL = 8;
 static std::mutex g_splitk_mu;
-static float* g_splitk_pool[SPLITK_POOL] = {nullptr, nullptr, nullptr, nullptr};
-static hipStream_t g_splitk_owner[SPLITK_POOL] = {nullptr, nullptr, nullptr, nullptr};
+static float* g_splitk_pool[SPLITK_POOL] = {};
+static hipStream_t g_splitk_owner[SPLITK_POOL] = {};
 static int g_splitk_bound = 0, g_splitk_state = 0;   // state: 0 = not yet allocated, 1 = pool ready, -1 = allocation failed
 static float* splitk_scratch(hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_splitk_mu);
