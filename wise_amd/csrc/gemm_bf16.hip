@@ -865,6 +865,166 @@ __global__ __launch_bounds__(256, 2) void mlp96_kernel(float* __restrict__ x, co
     epilogue_f32_lds_piece<EPI_RESID, 4, 3>(acc2, b2, x, C, m0 + wm * 64, wn * 48, lane, w_img + wave * 12288);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same MLP with BOTH weight matrices resident in LDS and nothing else going through it: a persistent workgroup (one per CU,
+// 8 waves) stages W1 [384][96] and W2 [96][384] once as MFMA operand images (147 KiB), and every wave takes 32 tokens at a
+// time through the whole MLP in registers:
+//   x rows -> LayerNorm (4 lanes per token, two-pass) -> bf16 B-operand fragments;
+//   per pair of 16-row hidden tiles: h^T = W1 x^T (transposed product: lane = token, registers = hidden rows), + b1, GELU,
+//   packed to bf16 — which IS the B operand of the second product y^T += W2 h^T for that 32-deep k-step, because W2's
+//   image is stored with its k index permuted the way the first product's accumulators come out;
+//   + b2 + x, stored as 16-byte pieces.
+// No barrier after the prologue, no LDS write, no staging latency in the loop; what remains is the GELU's VALU work
+// (192 values per lane and 32 tokens).  mlp96_kernel above re-stages the weight tiles for every 128 rows (600 MB of
+// L2 -> LDS traffic per launch) and waits for them four times per block.
+// ------------------------------------------------------------------------------------------------
+constexpr int MLPR_W1_BYTES = 3 * 384 * 64, MLPR_W2_BYTES = 12 * 96 * 64;
+
+__global__ __launch_bounds__(512, 1) void mlp96r_kernel(float* __restrict__ x, const float* __restrict__ lnw,
+                                                        const float* __restrict__ lnb, const bf16_t* __restrict__ W1,
+                                                        const float* __restrict__ b1, const bf16_t* __restrict__ W2,
+                                                        const float* __restrict__ b2, long long units /*of 32 tokens*/, float eps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int C = 96, HID = 384;
+    unsigned char* w1_img = smem;                                  // [ks 3][384 hidden rows][64 B], 16-byte chunks swizzled
+    unsigned char* w2_img = smem + MLPR_W1_BYTES;                  // [hp 12][96 out rows][64 B]: chunk g = hidden (2hp)*16+4g..+3 | (2hp+1)*16+4g..+3
+    float* fb = reinterpret_cast<float*>(smem + MLPR_W1_BYTES + MLPR_W2_BYTES);   // b1[384] | b2[96] | ln_w[96] | ln_b[96]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    // ---- prologue: the weight images (each 16-byte chunk once)
+    for (int c = tid; c < 3 * HID * 4; c += 512) {
+        const int ks = c / (HID * 4), rem = c - ks * (HID * 4), row = rem >> 2, ch = rem & 3;
+        const uint4 v = *reinterpret_cast<const uint4*>(W1 + (size_t)row * C + ks * 32 + ch * 8);
+        *reinterpret_cast<uint4*>(w1_img + ks * (HID * 64) + row * 64 + (swz_chunk<32>(row, ch) << 4)) = v;
+    }
+    for (int c = tid; c < 12 * C * 4; c += 512) {
+        const int hp = c / (C * 4), rem = c - hp * (C * 4), row = rem >> 2, ch = rem & 3;
+        const uint2 lo = *reinterpret_cast<const uint2*>(W2 + (size_t)row * HID + (2 * hp) * 16 + ch * 4);
+        const uint2 hi = *reinterpret_cast<const uint2*>(W2 + (size_t)row * HID + (2 * hp + 1) * 16 + ch * 4);
+        *reinterpret_cast<uint4*>(w2_img + hp * (C * 64) + row * 64 + (swz_chunk<32>(row, ch) << 4)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    for (int c = tid; c < HID + 3 * C; c += 512)
+        fb[c] = c < HID ? b1[c] : (c < HID + C ? b2[c - HID] : (c < HID + 2 * C ? lnw[c - HID - C] : lnb[c - HID - 2 * C]));
+    __syncthreads();
+    const float* b1s = fb;
+    const float* b2s = fb + HID;
+    const float* gws = fb + HID + C;
+    const float* gbs = fb + HID + 2 * C;
+
+    const long long gw = (long long)blockIdx.x * 8 + wave, nw = (long long)gridDim.x * 8;
+    // the rows of the NEXT unit travel while the current one is computed (48 registers)
+    float4 xn[2][3][2];
+    auto fetch = [&](long long u) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const float* xr = x + ((size_t)u * 32 + tt * 16 + l15) * C + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                xn[tt][ks][0] = *reinterpret_cast<const float4*>(xr + ks * 32);
+                xn[tt][ks][1] = *reinterpret_cast<const float4*>(xr + ks * 32 + 4);
+            }
+        }
+    };
+    if (gw < units) fetch(gw);
+    for (long long u = gw; u < units; u += nw) {
+        float* xu = x + (size_t)u * 32 * C;
+        // ---- LayerNorm -> B-operand fragments af[tt][ks]: lane (token tt*16 + l15, channels ks*32 + g*8 .. +7)
+        bf16x8 af[2][3];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float v[3][8];
+            float sm = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const float4 a = xn[tt][ks][0], bq = xn[tt][ks][1];
+                v[ks][0] = a.x; v[ks][1] = a.y; v[ks][2] = a.z; v[ks][3] = a.w;
+                v[ks][4] = bq.x; v[ks][5] = bq.y; v[ks][6] = bq.z; v[ks][7] = bq.w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm += v[ks][e];
+            }
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            const float mean = sm * (1.f / 96.f);
+            float sq = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[ks][e] -= mean; sq = fmaf(v[ks][e], v[ks][e], sq); }
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            const float rstd = rsqrtf(sq * (1.f / 96.f) + eps);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const float4 w0 = *reinterpret_cast<const float4*>(gws + ks * 32 + g * 8), w1v = *reinterpret_cast<const float4*>(gws + ks * 32 + g * 8 + 4);
+                const float4 c0 = *reinterpret_cast<const float4*>(gbs + ks * 32 + g * 8), c1v = *reinterpret_cast<const float4*>(gbs + ks * 32 + g * 8 + 4);
+                const float gw8[8] = {w0.x, w0.y, w0.z, w0.w, w1v.x, w1v.y, w1v.z, w1v.w};
+                const float gb8[8] = {c0.x, c0.y, c0.z, c0.w, c1v.x, c1v.y, c1v.z, c1v.w};
+                bf16x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (__bf16)((v[ks][e] * rstd) * gw8[e] + gb8[e]);
+                af[tt][ks] = f;
+            }
+        }
+        if (u + nw < units) fetch(u + nw);
+        // ---- the two products, one 32-deep hidden k-step at a time
+        f32x4 acc2[6][2];
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) acc2[ct][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int hp = 0; hp < 12; ++hp) {
+            bf16x8 hf[2];
+            f32x4 a1[2][2];                                    // [hidden tile of the pair][token tile]
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int hrow = (2 * hp + hh) * 16 + l15;
+                const float4 bv = *reinterpret_cast<const float4*>(b1s + (2 * hp + hh) * 16 + g * 4);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) a1[hh][tt] = f32x4{bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w1_img + ks * (HID * 64) + hrow * 64 + (swz_chunk<32>(hrow, g) << 4));
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        a1[hh][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[tt][ks], a1[hh][tt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                bf16x8 f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f[r] = (__bf16)act_gelu(a1[0][tt][r]);
+                    f[4 + r] = (__bf16)act_gelu(a1[1][tt][r]);
+                }
+                hf[tt] = f;
+            }
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct) {
+                const int orow = ct * 16 + l15;
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w2_img + hp * (C * 64) + orow * 64 + (swz_chunk<32>(orow, g) << 4));
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    acc2[ct][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hf[tt], acc2[ct][tt], 0, 0, 0);
+            }
+        }
+        // ---- + b2 + residual: lane (token tt*16 + l15): channels ct*16 + g*4 .. +3
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float* xr = xu + (size_t)(tt * 16 + l15) * C + g * 4;
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct) {
+                const float4 r = *reinterpret_cast<const float4*>(xr + ct * 16);
+                const float4 bb = *reinterpret_cast<const float4*>(b2s + ct * 16 + g * 4);
+                *reinterpret_cast<float4*>(xr + ct * 16) = make_float4(r.x + bb.x + acc2[ct][tt][0], r.y + bb.y + acc2[ct][tt][1],
+                                                                         r.z + bb.z + acc2[ct][tt][2], r.w + bb.w + acc2[ct][tt][3]);
+            }
+        }
+    }
+}
+
 template <int MODE, int NF>
 static void launch_gemm_ln(const float* x, const float* lnw, const float* lnb, const bf16_t* Wt, const float* bias,
                            int M, int N, float eps, bf16_t* out, hipStream_t st) {
@@ -1442,6 +1602,7 @@ static void launch_pp(const bf16_t* A, const bf16_t* Wt, const float* bias, int 
 
 static int g_gemm_variant = 0;
 static int g_tile320 = 1;  // allow the 320x256 ping-pong tiling (wise_debug_set_gemm_flags bit 0 turns it off)
+static int g_mlp96_resident = 1;  // (debug knob) 0: the staged mlp96_kernel
 static int g_overlapped = 0;  // the caller is running another stream's kernels beside this one (gemm_set_overlapped)
 static int g_overlap_policy = 0;  // (debug knob) tiles under overlap: 0 = as for a lone stream minus the 320-row tilings (the product), 1 = 128x128 only, 2 = 128x128 except the QKV-shaped launches, 3 = hint ignored
 static int g_split_m = 1;  // split M between the ping-pong kernel and the 128x128 kernel (bit 29 of the knob: off)
@@ -1523,6 +1684,19 @@ int mlp96_fused(float* x, const float* lnw, const float* lnb, const bf16_t* W1, 
                 const float* b2, int M, float eps, hipStream_t st) {
     WISE_CHECK_ARG(x && lnw && lnb && W1 && b1 && W2 && b2 && M > 0 && M % 128 == 0, "mlp96: bad argument (M=%d)", M);
     ProfScope prof(PROF_GEMM, 4.0 * (double)M * 96.0 * 384.0, st);
+    if (g_mlp96_resident) {
+        const size_t ldsr = (size_t)MLPR_W1_BYTES + MLPR_W2_BYTES + (384 + 3 * 96) * sizeof(float);   // 150 KiB
+        static std::once_flag attr_r;
+        std::call_once(attr_r, [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp96r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)ldsr);
+        });
+        const long long units = M / 32;
+        const int grid = units < 8 * 256 ? (int)((units + 7) / 8) : 256;
+        hipLaunchKernelGGL(mlp96r_kernel, dim3(grid), dim3(512), ldsr, st, x, lnw, lnb, W1, b1, W2, b2, units, eps);
+        WISE_LAUNCH_CHECK("mlp96r_kernel");
+        return WISE_OK;
+    }
     const size_t lds = (size_t)9 * 128 * 64;  // 72 KiB
     static std::once_flag attr_set;
     std::call_once(attr_set, [&] {
@@ -1750,6 +1924,7 @@ extern "C" int wise_debug_set_gemm_stamps(unsigned long long* buf /*device, 8192
 }
 extern "C" int wise_debug_set_gemm_flags(int flags) {
     wise::g_tile320 = (flags & 1) ? 0 : 1;
+    wise::g_mlp96_resident = (flags >> 7) & 1 ? 0 : 1;   // bit 7: the staged MLP kernel instead of the weight-resident one
     wise::g_overlap_policy = (flags >> 4) & 7;     // bits 4-6: tiles under overlap (0 lone-stream tiles, 1 = 128x128, 2 = mixed, 3 = hint ignored, 4/5/6 = 128x128 for the residual / fc1 / QKV launches only)
     wise::g_ablate = flags & 6;
     return 0;
