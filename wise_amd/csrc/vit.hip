@@ -433,8 +433,8 @@ int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_
         WISE_LAUNCH_CHECK("attention_kernel");
         return WISE_OK;
     }
-    // 32 queries per wave hides latency best when one key block covers T; longer sequences prefer 64 queries per
-    // wave (K/V re-read half as often).  (Measured and dropped: a block-per-head kernel that stages K/V once in
+    // 64 queries per wave with a block's loads hoisted from T = 33 on (T = 50, ViT-B/32: 24.4 -> 21.9 us per launch: K and
+    // V are read once per head instead of twice); 32 queries per wave below that.  (Measured and dropped: a block-per-head kernel that stages K/V once in
     // LDS for all query chunks of a head — at T = 257 it was 5 % slower: the loop is bound by the softmax VALU work
     // and by latency at 2-3 waves per SIMD, not by the K/V re-reads, which hit L2.)
     // measured per launch (bs 256): T = 257: 64 queries/wave 327 us as it was, 290 with the hoisted loads, 48 queries +
@@ -451,7 +451,7 @@ int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_
         WISE_LAUNCH_CHECK("attention_kernel");
         return WISE_OK;
     }
-    const int qt = g_attn_qt ? (g_attn_qt == 4 ? 4 : 2) : (T <= 64 ? 2 : 4);
+    const int qt = g_attn_qt ? (g_attn_qt == 4 ? 4 : 2) : (T <= 32 ? 2 : 4);
     const int nqc = (T + 16 * qt - 1) / (16 * qt);
     const long long items = (long long)B * H * nqc;
     const dim3 grid((unsigned)((items + 3) / 4)), block(256);
