@@ -206,6 +206,25 @@ int wise_htsat_tap(int what, const void* workspace, int batch, int samples, floa
                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * HP-1 audio  MS-CLAP (version 2022) audio encoder: PANNs Cnn14 + projection — the same reference call site
+ *       (src/feature/microsoft_clap.py:49-50) when the feature id's version token is '2022'
+ *       (:20-31: every key of msclap's CLAP.model_name is accepted).  Fixed architecture (msclap config_2022:
+ *       n_fft 1024, hop 320, 64 mel bands 50..14000 Hz at sr 44100; six ConvBlocks 64..2048 channels of two
+ *       3x3 convolutions + BatchNorm + ReLU, 2x2 average pooling after the first five; mean over mel, max + mean over
+ *       time; fc1 2048->2048 + ReLU; projection 2048->1024).  wave [B, samples] fp32, any length of at least 32 STFT
+ *       frames (the whole clip enters the model).  out [B,1024] fp32, unit rows.
+ * Weight blobs: layout in wise_amd/feature/cnn14.py:pack_cnn14_weights (msclap state-dict keys; BatchNorm folded).
+ * ---------------------------------------------------------------------------------------------- */
+int wise_cnn14_layout(int64_t* wb_elems, int64_t* pf_elems);
+size_t wise_cnn14_workspace_bytes(int batch, int samples);
+int wise_cnn14_forward(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
+                       float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* parity tap after a forward with the same (batch, samples): what 0 = BatchNorm'd log-mel fp32 [B*frames*64],
+ * 1 = pooled latent bf16 [B*2048], 2 = fc1 output bf16 [B*2048]; copies `bytes` bytes. */
+int wise_cnn14_tap(int what, const void* workspace, int batch, int samples, void* dst, int64_t bytes,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HP-2 query side: OpenCLIP text tower — replaces `self.model.encode_text(tokens)` + L2
  *       normalise, reference call site src/feature/mlfoundation_openclip.py:103-108 (reached from
  *       FeatureSearchIndex.search, src/index/feature_search_index.py:112).  Token ids in, unit vectors out;
@@ -318,9 +337,16 @@ int wise_preproc_taps(int in_size, int out_size, int* ksize, int* first, int* co
 /* C[M,N] = epilogue(A[M,K] bf16 @ Wt[N,K]^T bf16 + bias[N]) ; M%128==0 rows must be readable
  * (callers pad), N%4==0, K%32==0.
  * mode: 0 -> out_bf16 = acc+bias ; 1 -> out_bf16 = quickgelu(acc+bias) ; 2 -> out_bf16 = gelu(acc+bias)
- *       3 -> resid_f32 += acc+bias (in place, fp32 residual stream) ; 4 -> out_f32 = acc+bias */
+ *       3 -> resid_f32 += acc+bias (in place, fp32 residual stream) ; 4 -> out_f32 = acc+bias
+ *       5 -> out_bf16 = gelu_tanh(acc+bias) ; 6 -> out_bf16 = relu(acc+bias) */
 int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K,
                    int mode, void* out, void* stream);
+/* out[ceil128(B*T*F), cout] bf16 = relu(conv3x3(x [B,T,F,cin] bf16, position-major ("NHWC"), stride 1, zero padding 1)
+ * + bias[cout]); wt [cout, 9*cin] bf16 with k = (kh*3 + kw)*cin + c (BatchNorm folded by the caller); cin, cout
+ * multiples of 64; zeros = at least 16 bytes of zeros on the device (what every out-of-image tap reads).  The implicit
+ * GEMM behind the ConvBlocks of wise_cnn14_forward (torch: F.relu(bn(F.conv2d(x, w, padding=1)))). */
+int wise_conv3x3_relu_bf16(const uint16_t* x, const uint16_t* wt, const float* bias, const uint16_t* zeros, int batch,
+                           int T, int F, int cin, int cout, uint16_t* out, void* stream);
 /* LayerNorm fused into the GEMM's A operand: out_bf16[M,N] = epi( LN(x_f32[M,K]; lnw, lnb, eps) @ Wt[N,K]^T + bias ),
  * for K in {96, 192} (HTSAT stages 1-2), N % 8 == 0, M % 128 == 0, bf16 output modes (0, 1, 2, 5). */
 int wise_gemm_ln_bf16(const float* x, const float* lnw, const float* lnb, const uint16_t* Wt, const float* bias,

@@ -141,11 +141,12 @@ def test_feature_extractor_base_and_factory_errors():
         FeatureExtractorFactory("mlfoundations/open_clip/ViT-Z-99/openai")
     with pytest.raises(ValueError, match="not available"):
         FeatureExtractorFactory("microsoft/clap/1999/Not-Applicable")
-    # msclap's other two model keys (microsoft_clap.py:20-31) are different architectures (Cnn14 + BERT; clapcap):
-    # refused at construction, never served by the 2023 kernels under their id
-    for version in ("2022", "clapcap"):
-        with pytest.raises(NotImplementedError, match="only the 2023 model"):
-            FeatureExtractorFactory(f"microsoft/clap/{version}/seeded-0")
+    # msclap's other two model keys (microsoft_clap.py:20-31): '2022' (Cnn14 + BERT) is its own pair of engines;
+    # 'clapcap' cannot produce embeddings in the reference either (microsoft_clap.py:49 reads `.clap`, which msclap's
+    # clapcap wrapper does not have) and is refused at construction, never served by another model's kernels
+    assert FeatureExtractorFactory("microsoft/clap/2022/seeded-0").version == "2022"
+    with pytest.raises(NotImplementedError, match="captioning model"):
+        FeatureExtractorFactory("microsoft/clap/clapcap/seeded-0")
 
 
 def test_openclip_preprocess_matches_reference_transform():

@@ -50,6 +50,9 @@ def main():
     if "--square" in args:
         args.remove("--square")
         SHAPES[:] = SQUARE
+    library = "--library" in args   # calibration only: time torch.mm (hipBLASLt / rocBLAS) on the same operands
+    if library:
+        args.remove("--library")
     variants = [int(v) for v in args] or [0, 1, 2, 3]
     lib = _lib.lib()
     lib.wise_debug_set_gemm_variant.argtypes = [C.c_int]
@@ -95,6 +98,23 @@ def main():
                 torch.cuda.synchronize()
                 res[v].append(e0.elapsed_time(e1) / iters * 1e-3)
         line = f"{name:26s}"
+        if library:   # plain bf16 product, no bias / activation / residual: an upper bound for the library's epilogues
+            Wt = W.t()
+            for backend in ("cublaslt", "cublas"):
+                torch.backends.cuda.preferred_blas_library(backend)
+                for _ in range(5):
+                    o = torch.mm(A, Wt)
+                ts = []
+                for rnd in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20):
+                        o = torch.mm(A, Wt)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) / 20 * 1e-3)
+                ts.sort()
+                line += f" | {backend}: {2.0 * M * N * K / ts[2] / 1e12:7.1f} TF {ts[2]*1e6:7.1f}us"
         for v in variants:
             ts = sorted(res[v])
             tf = 2.0 * M * N * K / ts[len(ts) // 2] / 1e12

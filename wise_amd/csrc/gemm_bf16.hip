@@ -21,8 +21,8 @@
 
 namespace wise {
 
-enum : int { EPI_BF16 = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4, EPI_GELU_TANH = 5 };
-constexpr bool bf16_out(int mode) { return mode == EPI_BF16 || mode == EPI_QUICKGELU || mode == EPI_GELU || mode == EPI_GELU_TANH; }
+enum : int { EPI_BF16 = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4, EPI_GELU_TANH = 5, EPI_RELU = 6 };
+constexpr bool bf16_out(int mode) { return mode == EPI_BF16 || mode == EPI_QUICKGELU || mode == EPI_GELU || mode == EPI_GELU_TANH || mode == EPI_RELU; }
 
 // Tuning / ablation switches.  They exist only in the debug build (libwise_hip_debug.so, -DWISE_DEBUG_KNOBS: tools/ and
 // wise_debug_set_gemm_variant); in the product library they are compile-time constants and the branches fold away.
@@ -96,6 +96,7 @@ __device__ __forceinline__ float act_apply(float x) {
     if (MODE == EPI_QUICKGELU) return act_quickgelu(x);
     if (MODE == EPI_GELU) return act_gelu(x);
     if (MODE == EPI_GELU_TANH) return act_gelu_tanh(x);
+    if (MODE == EPI_RELU) return fmaxf(x, 0.f);
     return x;
 }
 
@@ -407,6 +408,119 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
                                      smem + wave * 16384);
     } else {
         epilogue<MODE>(acc, bias, out, N, m0, n0, wm, wn, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 convolution, stride 1, zero padding 1, over an NHWC bf16 image, as an implicit GEMM on the same 128-row tile:
+//   out[p, n] = relu( sum_{tap, c} X[p + dy(tap)*F + dx(tap), c] * Wt[n, tap*Cin + c] + bias[n] ),   p = (b*T + t)*F + f
+// (the ConvBlocks of PANNs Cnn14, the audio encoder of MS-CLAP '2022'; BatchNorm is folded into Wt and bias by the
+// packer).  There is no im2col buffer: a K-tile is 64 input channels of ONE tap (Cin % 64 == 0), so the A tile of a
+// K-step is 128 row segments of 128 bytes whose source addresses differ from the plain GEMM's only by the tap's shift
+// — each lane of the LDS-DMA supplies its own source address, and a lane whose neighbour falls outside the image (or
+// whose row is past M) points at a 16-byte page of zeros instead.  Per lane the four rows it stages never change, so
+// their (t, f) coordinates are divided out once, before the loop.  Everything else — LDS image, swizzle, fragment
+// reads, transposed product, epilogue through LDS — is gemm_bf16_kernel's.  NTJ = column tiles per wave: 4 -> 128
+// output channels per block, 2 -> 64 (the first block of Cnn14).  Rows are padded: out has ceil128(M) rows.
+// ------------------------------------------------------------------------------------------------
+template <int NTJ>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
+                                                         const float* __restrict__ bias,
+                                                         const bf16_t* __restrict__ zeros, int T, int F, int Cin, int M,
+                                                         int Cout, bf16_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BNC = 32 * NTJ;                     // output channels per block
+    constexpr int TW = BNC * BK * 2;                  // bytes of a W tile
+    constexpr int SBC = TILE_BYTES + TW;              // bytes of a stage
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = Cout / BNC;
+    int tm, tn;
+    tile_coords((M + BM - 1) / BM, tiles_n, 8, &tm, &tn);
+    const int m0 = tm * BM, n0 = tn * BNC;
+    const int K = 9 * Cin, ck = Cin / BK, nk = 9 * ck;
+
+    // the four rows this lane stages: position, coordinates, element offset of its 16-byte chunk at tap (0, 0)
+    int pt[4], pf[4];
+    long long poff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = (t * 4 + wave) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (r & 7);
+        const int p = m0 + r;
+        const int q = p / F;
+        pf[t] = p - q * F;
+        pt[t] = (p < M) ? q % T : -4;                 // rows past M: every tap is "outside"
+        poff[t] = (long long)p * Cin + c * 8;
+    }
+    auto stage = [&](int tap, int cc, unsigned char* dst) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const long long shift = (long long)(dy * F + dx) * Cin + cc * BK;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool in = (unsigned)(pt[t] + dy) < (unsigned)T && (unsigned)(pf[t] + dx) < (unsigned)F;
+            glds16(in ? X + poff[t] + shift : zeros, dst + (t * 4 + wave) * 1024);
+        }
+#pragma unroll
+        for (int t = 0; t < NTJ; ++t) {               // W tile: 32*NTJ rows of 128 bytes
+            const int r = (t * 4 + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            glds16(Wt + (size_t)(n0 + r) * K + (size_t)(tap * ck + cc) * BK + c * 8, dst + TILE_BYTES + (t * 4 + wave) * 1024);
+        }
+    };
+
+    f32x4 acc[4][NTJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int tap = 0, cc = 0;                              // of the K-tile staged NEXT
+    stage(0, 0, smem);
+    if (++cc == ck) { cc = 0; ++tap; }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();  // waits vmcnt(0): tile kt landed; everyone done reading buffer cur^1
+        if (kt + 1 < nk) {
+            stage(tap, cc, smem + (cur ^ 1) * SBC);
+            if (++cc == ck) { cc = 0; ++tap; }
+        }
+        const unsigned char* At = smem + cur * SBC;
+        const unsigned char* Bt = At + TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int chunk = s * 4 + (lane >> 4);
+            bf16x8 af[4], wf[NTJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = lds_frag(At, wm * 64 + i * 16 + (lane & 15), chunk);
+#pragma unroll
+            for (int j = 0; j < NTJ; ++j) wf[j] = lds_frag(Bt, wn * (16 * NTJ) + j * 16 + (lane & 15), chunk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NTJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    if constexpr (NTJ == 4) {
+        __syncthreads();  // staging buffers are dead from here on
+        epilogue_lds<EPI_RELU>(acc, bias, out, Cout, m0, n0, wm, wn, lane, wave, smem);
+    } else {
+        // 64 x 32 per wave: a lane's 4 consecutive channels of one position, 8 bytes at a time
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j) {
+            const int n = n0 + wn * (16 * NTJ) + j * 16 + (lane >> 4) * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+                uint2 pk;
+                pk.x = pack_bf16x2(fmaxf(acc[i][j][0] + bv.x, 0.f), fmaxf(acc[i][j][1] + bv.y, 0.f));
+                pk.y = pack_bf16x2(fmaxf(acc[i][j][2] + bv.z, 0.f), fmaxf(acc[i][j][3] + bv.w, 0.f));
+                *reinterpret_cast<uint2*>(out + (size_t)m * Cout + n) = pk;
+            }
+        }
     }
 }
 
@@ -1654,6 +1768,7 @@ static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bi
         case EPI_QUICKGELU: launch_variant<EPI_QUICKGELU>(v, A, Wt, bias, M, N, K, out, st); break;
         case EPI_GELU: launch_variant<EPI_GELU>(v, A, Wt, bias, M, N, K, out, st); break;
         case EPI_GELU_TANH: launch_variant<EPI_GELU_TANH>(v, A, Wt, bias, M, N, K, out, st); break;
+        case EPI_RELU: launch_variant<EPI_RELU>(v, A, Wt, bias, M, N, K, out, st); break;
         case EPI_RESID: launch_variant<EPI_RESID>(v, A, Wt, bias, M, N, K, out, st); break;
         case EPI_F32: launch_variant<EPI_F32>(v, A, Wt, bias, M, N, K, out, st); break;
         default: set_error("gemm_bf16: unknown mode %d", mode); return WISE_E_INVALID;
@@ -1808,7 +1923,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
 int gemm_bf16_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int N, int K, int mode,
                    void* out, hipStream_t st) {
     WISE_CHECK_ARG(A && Wt && out, "gemm_bf16: null pointer");
-    WISE_CHECK_ARG(M > 0 && M % BM == 0 && N > 0 && N % 4 == 0 && K > 0 && K % 32 == 0 && mode >= 0 && mode <= 5,
+    WISE_CHECK_ARG(M > 0 && M % BM == 0 && N > 0 && N % 4 == 0 && K > 0 && K % 32 == 0 && mode >= 0 && mode <= 6,
                    "gemm_bf16: M=%d must be a multiple of %d, N=%d of 4, K=%d of 32", M, BM, N, K);
     if (g_gemm_variant == 0 && m_valid <= 128 && gemm_splitk(A, Wt, bias, M, m_valid, N, K, mode, out, st)) {
         WISE_LAUNCH_CHECK("gemm_splitk_kernel");
@@ -1893,6 +2008,40 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
         }
     }
     return launch_mode(auto_variant(M, N, K), A, Wt, bias, M, N, K, mode, out, st);
+}
+
+// out[ceil128(M), Cout] bf16 = relu(conv3x3(X [B, T, F, Cin] bf16 NHWC) + bias); M = B*T*F, Cin % 64 == 0, Cout % 64 == 0.
+// `zeros`: at least 16 readable bytes of zeros on the device (the padding every out-of-image tap reads).
+int conv3x3_bf16(const bf16_t* X, const bf16_t* Wt, const float* bias, const bf16_t* zeros, int B, int T, int F, int Cin,
+                 int Cout, bf16_t* out, hipStream_t st) {
+    WISE_CHECK_ARG(X && Wt && bias && zeros && out, "conv3x3: null pointer");
+    const long long M = (long long)B * T * F;
+    WISE_CHECK_ARG(B > 0 && T > 0 && F > 0 && Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % 64 == 0 &&
+                       (M + 127) / 128 * 128 * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 40) && M < (1ll << 31) - 128,
+                   "conv3x3: B=%d T=%d F=%d Cin=%d Cout=%d unsupported", B, T, F, Cin, Cout);
+    ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)Cout * 9.0 * (double)Cin, st);
+    const int tiles_m = (int)((M + 127) / 128);
+    if (Cout % 128 == 0) {
+        auto kern = conv3x3_kernel<4>;
+        const size_t lds = 2 * (TILE_BYTES + 128 * BK * 2);   // 64 KiB
+        static std::once_flag attr4;
+        std::call_once(attr4, [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
+        hipLaunchKernelGGL(kern, dim3(tiles_m * (Cout / 128)), dim3(256), lds, st, X, Wt, bias, zeros, T, F, Cin, (int)M,
+                           Cout, out);
+    } else {
+        auto kern = conv3x3_kernel<2>;
+        const size_t lds = 2 * (TILE_BYTES + 64 * BK * 2);    // 48 KiB
+        static std::once_flag attr2;
+        std::call_once(attr2, [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
+        hipLaunchKernelGGL(kern, dim3(tiles_m * (Cout / 64)), dim3(256), lds, st, X, Wt, bias, zeros, T, F, Cin, (int)M,
+                           Cout, out);
+    }
+    WISE_LAUNCH_CHECK("conv3x3_kernel");
+    return WISE_OK;
 }
 
 }  // namespace wise

@@ -15,6 +15,7 @@
 //              -> LN -> fc1 GEMM(+GELU) -> fc2 GEMM(+resid); PatchMerging = gather+LN kernel + GEMM
 //   head       final LN, token mean, Projection (linear1, GELU, linear2, LN(e1+e2)), L2 normalise
 #include "common.h"
+#include "transformer.h"
 #include <type_traits>
 
 namespace wise {
@@ -38,7 +39,7 @@ int frontend(const float* wave, int B, int samples, int Fc, const float* hann, c
              hipStream_t st);
 static int g_frontend_only = 0;  // (debug) stop after the front end: concurrency tests tap the log-mel
 static int g_fuse_ln = 7;  // bit 0: LayerNorm-in-GEMM fusion, bit 1: fused MLP (stage 1), bit 2: fused attention half of a stage-1 block; wise_debug_set_htsat flips them off
-constexpr int N_FFT = 1024, HOP = 320, N_MELS = 64, MELW = 32, MAXF = 1024;
+constexpr int N_FFT = 1024, HOP = 320, N_MELS = 64, MELW = FRONT_MELW, MAXF = 1024;
 constexpr int EMBED = 96, LATENT = 768, OUT = 1024;
 constexpr int DEPTHS[4] = {2, 2, 6, 2};
 // 16 bytes per lane from global memory straight into LDS (base wave-uniform, lane i lands at base + 16 i)

@@ -12,10 +12,11 @@
 #include <mutex>
 
 #include "common.h"
+#include "transformer.h"
 
 namespace wise {
 namespace htsat {
-constexpr int N_FFT = 1024, HOP = 320, MELW = 32;
+constexpr int N_FFT = 1024, HOP = 320, MELW = FRONT_MELW;
 
 // ------------------------------------------------------------------------------------------------
 // frontend: a wave computes one STFT frame at a time and loops over frames (persistent grid)

@@ -10,6 +10,10 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
 // through a split-K pair of kernels instead of leaving most of the chip idle
 int gemm_bf16_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int N, int K, int mode,
                    void* out, hipStream_t st);
+// relu(conv3x3(X [B, T, F, Cin] bf16 NHWC, zero padding 1) + bias) -> out [ceil128(B*T*F), Cout] bf16 (implicit GEMM, Wt [Cout, 9*Cin] with
+// k = (kh*3 + kw)*Cin + c); zeros = 16 bytes of zeros on the device
+int conv3x3_bf16(const bf16_t* X, const bf16_t* Wt, const float* bias, const bf16_t* zeros, int B, int T, int F, int Cin,
+                 int Cout, bf16_t* out, hipStream_t st);
 // hint for the tile heuristic: the caller is about to enqueue GEMMs on several streams that overlap in time
 // (host-side state; the library is single-threaded by contract)
 void gemm_set_overlapped(bool on);
@@ -43,5 +47,13 @@ int pooled_head(const float* x, const float* ln_w, const float* ln_b, const bf16
 // msclap Projection head (htsat.hip): lat bf16 [Bp, d_in] -> out fp32 [B, 1024], L2-normalised
 int clap_projection(const bf16_t* lat, const bf16_t* W1, const bf16_t* W2, const float* lw, const float* lb, int B,
                     int d_in, float* e, bf16_t* g, float* out, hipStream_t st);
+
+namespace htsat {
+// mel + bn0 of the first Fc frames of every clip (htsat_frontend.hip): melbn fp32 [B, Fc, 64]
+int frontend(const float* wave, int B, int samples, int Fc, const float* hann, const float* mel_start,
+             const float* mel_len, const float* mel_wt, const float* bn_scale, const float* bn_shift, float* melbn,
+             hipStream_t st);
+constexpr int FRONT_MELW = 36;   // most FFT bins a mel band may span in the sparse table (2023 config: 16, 2022: 35)
+}  // namespace htsat
 
 }  // namespace wise

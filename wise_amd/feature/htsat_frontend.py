@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 N_FFT, N_MELS, SR, FMIN, FMAX = 1024, 64, 44100, 50.0, 8000.0
-MELW = 32  # max non-zero FFT bins per band kept in the sparse table (asserted below)
+MELW = 36  # max non-zero FFT bins per band kept in the sparse table (asserted below; csrc/transformer.h FRONT_MELW)
 
 
 def hann_periodic(n: int = N_FFT) -> torch.Tensor:
@@ -35,10 +35,11 @@ def _mel_to_hz(m):
     return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
 
 
-def mel_filterbank() -> np.ndarray:
-    """[64, 513] float32: triangular filters on the Slaney mel scale, area-normalised (librosa.filters.mel)."""
+def mel_filterbank(fmax: float = FMAX) -> np.ndarray:
+    """[64, 513] float32: triangular filters on the Slaney mel scale, area-normalised (librosa.filters.mel).
+    fmax: 8000 in msclap's 2023 config (HTSAT), 14000 in the 2022 config (Cnn14)."""
     fftfreqs = np.linspace(0, SR / 2.0, 1 + N_FFT // 2)
-    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(FMIN), _hz_to_mel(FMAX), N_MELS + 2))
+    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(FMIN), _hz_to_mel(fmax), N_MELS + 2))
     fdiff = np.diff(mel_f)
     ramps = mel_f[:, None] - fftfreqs[None, :]
     w = np.zeros((N_MELS, 1 + N_FFT // 2))
@@ -48,9 +49,9 @@ def mel_filterbank() -> np.ndarray:
     return (w * enorm[:, None]).astype(np.float32)
 
 
-def sparse_mel():
+def sparse_mel(fmax: float = FMAX):
     """-> (start int32[64], length int32[64], weights float32[64, MELW]) with weights[b, j] = fb[b, start[b]+j]."""
-    fb = mel_filterbank()
+    fb = mel_filterbank(fmax)
     start = np.zeros(N_MELS, np.int32)
     length = np.zeros(N_MELS, np.int32)
     wts = np.zeros((N_MELS, MELW), np.float32)

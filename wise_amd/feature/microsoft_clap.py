@@ -29,12 +29,13 @@ class MicrosoftClap(FeatureExtractor):
         assert len(id_tokens) == 4
         if id_tokens[2] not in CLAP_MODEL_NAMES:
             raise ValueError(f'Model version {id_tokens[2]} is not available. Available models are {CLAP_MODEL_NAMES}')
-        if id_tokens[2] != '2023':
-            # msclap builds a Cnn14 audio encoder + BERT for '2022' and HTSAT + GPT-2 (+ a caption decoder) for 'clapcap'
-            # (src/feature/microsoft_clap.py:20-31 accepts all three keys); only the 2023 pair exists here, and an
-            # embedding from the wrong architecture must never be returned under another model's id
-            raise NotImplementedError(f"MS-CLAP version {id_tokens[2]!r}: only the 2023 model (HTSAT audio encoder, GPT-2 "
-                                      f"caption encoder) is built as MI355X kernels")
+        if id_tokens[2] == 'clapcap':
+            # msclap's 'clapcap' wrapper holds its model under `.clapcap`, not `.clap`: the reference's own
+            # extract_audio_features (`self.model.clap.audio_encoder`, microsoft_clap.py:49) raises AttributeError for
+            # it, so there is no embedding behaviour to reproduce; an embedding from another architecture must never be
+            # returned under this id
+            raise NotImplementedError("MS-CLAP version 'clapcap' is a captioning model: the reference's extractor cannot "
+                                      "produce embeddings with it either (microsoft_clap.py:49 reads `.clap`)")
         self.version = id_tokens[2]
         self.weights_tag = id_tokens[3]
         self.DEVICE = "cuda" if torch.cuda.is_available() else "cpu"
@@ -88,18 +89,21 @@ class MicrosoftClap(FeatureExtractor):
         return self._text_engine
 
     def _get_engine(self):
+        """the audio encoder msclap builds for this version: HTSAT for '2023', PANNs Cnn14 for '2022'"""
         if self._engine is None:
-            try:
-                from .htsat import HtsatEngine, random_htsat_state_dict
-            except ImportError as e:  # pragma: no cover
-                raise NotImplementedError("HTSAT audio kernels are not part of this build yet") from e
             seed = seeded_tag(self.weights_tag)
+            sd = None
             if seed is None:
                 from .weights import load_state_dict_file
                 sd = load_state_dict_file(f"clap-{self.version}", self.weights_tag)
+                if any(k.startswith("audio_encoder.") for k in sd):
+                    sd = {k[len("audio_encoder."):]: v for k, v in sd.items() if k.startswith("audio_encoder.")}
+            if self.version == '2022':
+                from .cnn14 import Cnn14Engine, random_cnn14_state_dict
+                self._engine = Cnn14Engine(sd if sd is not None else random_cnn14_state_dict(seed), device="cuda")
             else:
-                sd = random_htsat_state_dict(seed)
-            self._engine = HtsatEngine(sd, device="cuda")
+                from .htsat import HtsatEngine, random_htsat_state_dict
+                self._engine = HtsatEngine(sd if sd is not None else random_htsat_state_dict(seed), device="cuda")
         return self._engine
 
     def extract_audio_features(self, preprocessed_audio: torch.Tensor) -> np.ndarray:

@@ -1,2 +1,2 @@
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWISE_BUILD_FLAGS="-O3 --offload-arch=gfx950 -fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops" -DWISE_DEBUG_KNOBS -c /root/repo/wise_amd/csrc/common.hip -o /root/repo/wise_amd/lib/obj_debug/common.o -fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops
-# build.py 1a5c56517f2f4c61
+# build.py 73eb202ec08d3603
