@@ -29,7 +29,8 @@ extern "C" {
 const char* wise_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: per-index counters for the two-stage search,
  * the shadow's error norm, wise_build_flags; 3: wise_vit_config.arch, wise_text_config.no_causal / eps_e6 — the SigLIP
- * towers — and the wise_xlmr_* entry points). */
+ * towers — and the wise_xlmr_* entry points; 4: wise_xlmr_config.pos_mode / pool / head / eps_e12 — MS-CLAP 2022's BERT
+ * caption encoder — and the wise_cnn14_* entry points). */
 int wise_abi_version(void);
 /* Host-side hint for the GEMM tile heuristic (no device work): on != 0 while the caller enqueues batches that will run
  * beside another stream's (two batches in flight); one-block-per-CU tilings are then avoided where they measured slower.
@@ -286,7 +287,14 @@ typedef struct wise_xlmr_config {
     int32_t mlp;            /* F: 4096 */
     int32_t proj_hidden;    /* Hd: (W + D)/2 */
     int32_t embed_dim;      /* D: 1024 */
-    int32_t pad_id;         /* 1 */
+    int32_t pad_id;         /* 1 (XLM-R <pad>); 0 for BERT's [PAD] */
+    /* ABI 4: the BERT-family switches (all 0 = XLM-RoBERTa under open_clip's HFTextEncoder) */
+    int32_t pos_mode;       /* 0: position = cumsum(mask)*mask + pad (RoBERTa); 1: position = 0..T-1 (BERT) */
+    int32_t pool;           /* 0: mean over the sequence's own tokens; 1: the first row ([CLS]) */
+    int32_t head;           /* 0: W -> Hd -> D, GELU between, no biases (open_clip 'mlp'); 1: msclap Projection
+                             *    (e1 = W1 x, e2 = W2 gelu(e1), LayerNorm(e1 + e2); Hd = D = 1024; the fp32 blob then
+                             *    ends with that LayerNorm's w, b [D]) — MS-CLAP 2022's caption encoder */
+    int32_t eps_e12;        /* LayerNorm eps in units of 1e-12 (BERT: 1); 0 = 1e-5 */
 } wise_xlmr_config;
 int wise_xlmr_layout(const wise_xlmr_config* cfg, int64_t* wb_elems, int64_t* pf_elems);
 size_t wise_xlmr_workspace_bytes(const wise_xlmr_config* cfg, int batch);

@@ -34,7 +34,7 @@ class TextConfig(C.Structure):
 class XlmrConfig(C.Structure):
     """wise_xlmr_config (include/wise_hip.h)"""
     _fields_ = [(n, C.c_int32) for n in ("context", "vocab", "max_positions", "width", "layers", "heads", "mlp",
-                                         "proj_hidden", "embed_dim", "pad_id")]
+                                         "proj_hidden", "embed_dim", "pad_id", "pos_mode", "pool", "head", "eps_e12")]
 
 
 # every symbol include/wise_hip.h declares: name -> (restype, argtypes)

@@ -9,6 +9,10 @@
 //   L POST-LN blocks: x = LN(x + Wo attn(x W_qkv^T + b) + bo) ; x = LN(x + W2 gelu(W1 x + b1) + b2),
 //     attention bidirectional, padded keys masked
 //   pooled = sum_t mask x / sum_t mask ; out = normalize( W_p2 gelu(W_p1 pooled) )   (both projections without bias)
+// The same encoder family with other switches is MS-CLAP 2022's caption encoder (msclap TextEncoder over bert-base-uncased,
+// reference call site src/feature/microsoft_clap.py:53-58): absolute positions 0..T-1 (pos_mode 1), LayerNorm eps 1e-12,
+// the [CLS] row as the pooled vector (pool 1) and msclap's Projection as the head (head 1: e1 = W1 x, e2 = W2 gelu(e1),
+// LayerNorm(e1 + e2), L2 normalise — clap_projection of htsat.hip); restated in oracle/clap_bert_ref.py.
 // GEMMs, attention and LayerNorm are the image tower's kernels (vit.hip, gemm_bf16.hip): attention takes the
 // per-sequence key count, LayerNorm writes the fp32 residual stream and the bf16 GEMM operand in one pass.
 #include <algorithm>
@@ -21,7 +25,7 @@ namespace wise {
 __global__ __launch_bounds__(256) void xlmr_embed_kernel(const int* __restrict__ tokens, const float* __restrict__ word,
                                                          const float* __restrict__ pos, const float* __restrict__ type0,
                                                          int B, int T, int W, int vocab, int max_pos, int pad,
-                                                         float* __restrict__ x, int* __restrict__ lens) {
+                                                         int pos_abs, float* __restrict__ x, int* __restrict__ lens) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * T) return;
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(256) void xlmr_embed_kernel(const int* __restrict__
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { upto += __shfl_xor(upto, off, 64); all += __shfl_xor(all, off, 64); }
-    int p = live ? upto + pad : pad;
+    int p = pos_abs ? t : (live ? upto + pad : pad);   // BERT: arange(T); RoBERTa: cumsum(mask) * mask + pad
     p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // ids are validated on the host; stay in bounds regardless
     const float4* e = reinterpret_cast<const float4*>(word + (size_t)id * W);
@@ -52,10 +56,11 @@ __global__ __launch_bounds__(256) void xlmr_embed_kernel(const int* __restrict__
 }
 
 // pooled[b, :] = sum_{t < lens[b]} x[b, t, :] / lens[b]  -> bf16 ; block per sequence, thread per 4 channels
+// (first_only: the first row alone — BERT's [CLS] pooling)
 __global__ __launch_bounds__(256) void xlmr_meanpool_kernel(const float* __restrict__ x, const int* __restrict__ lens, int T,
-                                                            int W, bf16_t* __restrict__ pooled) {
+                                                            int W, int first_only, bf16_t* __restrict__ pooled) {
     const int b = blockIdx.x;
-    const int n = max(1, min(T, lens[b]));
+    const int n = first_only ? 1 : max(1, min(T, lens[b]));
     const float inv = 1.f / (float)n;
     for (int c = threadIdx.x; c < (W >> 2); c += 256) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -71,15 +76,22 @@ __global__ __launch_bounds__(256) void xlmr_meanpool_kernel(const float* __restr
 }
 
 struct XlmrDims {
-    int T, V, P, W, L, H, F, Hd, D, pad;
+    int T, V, P, W, L, H, F, Hd, D, pad, pos_abs, pool, head;
+    float eps;
 };
 static int xlmr_dims(const wise_xlmr_config* c, XlmrDims* d) {
     WISE_CHECK_ARG(c, "xlmr: null config");
     d->T = c->context; d->V = c->vocab; d->P = c->max_positions; d->W = c->width; d->L = c->layers; d->H = c->heads;
     d->F = c->mlp; d->Hd = c->proj_hidden; d->D = c->embed_dim; d->pad = c->pad_id;
+    d->pos_abs = c->pos_mode; d->pool = c->pool; d->head = c->head;
+    d->eps = c->eps_e12 > 0 ? (float)((double)c->eps_e12 * 1e-12) : 1e-5f;
+    WISE_CHECK_ARG((d->pos_abs == 0 || d->pos_abs == 1) && (d->pool == 0 || d->pool == 1) && (d->head == 0 || d->head == 1) &&
+                       c->eps_e12 >= 0, "xlmr: pos_mode %d / pool %d / head %d / eps_e12 %d", c->pos_mode, c->pool, c->head, c->eps_e12);
+    WISE_CHECK_ARG(d->head == 0 || (d->D == 1024 && d->Hd == d->D), "xlmr: the msclap projection head is W -> 1024 -> 1024 (got %d, %d)",
+                   d->Hd, d->D);
     WISE_CHECK_ARG(d->T >= 1 && d->T <= 128, "xlmr: context %d must be in [1,128]", d->T);
     WISE_CHECK_ARG(d->V >= 4 && d->pad >= 0 && d->pad < d->V, "xlmr: vocab %d / pad id %d", d->V, d->pad);
-    WISE_CHECK_ARG(d->P >= d->T + d->pad + 1, "xlmr: %d position rows cannot hold %d tokens after pad id %d", d->P, d->T, d->pad);
+    WISE_CHECK_ARG(d->P >= (c->pos_mode ? d->T : d->T + d->pad + 1), "xlmr: %d position rows cannot hold %d tokens (pad id %d)", d->P, d->T, d->pad);
     WISE_CHECK_ARG(d->W > 128 && d->W % 128 == 0 && d->H * 64 == d->W && d->W <= 4096,
                    "xlmr: width %d must be heads*64 and a multiple of 128", d->W);
     WISE_CHECK_ARG(d->F > 0 && d->F % 128 == 0 && d->Hd > 0 && d->Hd % 32 == 0, "xlmr: mlp %d must be a multiple of 128, projection hidden %d of 32",
@@ -91,7 +103,7 @@ static int xlmr_dims(const wise_xlmr_config* c, XlmrDims* d) {
 struct XlmrOffsets {
     size_t per_layer_b, qkv, out, fc1, fc2, proj1, proj2, total_b;                          // bf16 blob
     size_t word, pos, type0, eln_w, eln_b, layer0_f, per_layer_f, qkv_b, out_b, ln1_w, ln1_b, fc1_b, fc2_b, ln2_w, ln2_b,
-        total_f;                                                                            // fp32 blob
+        head_ln, total_f;                                                                   // fp32 blob
 };
 static XlmrOffsets xlmr_offsets(const XlmrDims& d) {
     XlmrOffsets o;
@@ -105,7 +117,8 @@ static XlmrOffsets xlmr_offsets(const XlmrDims& d) {
     o.qkv_b = 0; o.out_b = 3 * W; o.ln1_w = 4 * W; o.ln1_b = 5 * W; o.fc1_b = 6 * W; o.fc2_b = o.fc1_b + F;
     o.ln2_w = o.fc2_b + W; o.ln2_b = o.ln2_w + W;
     o.per_layer_f = o.ln2_b + W;
-    o.total_f = o.layer0_f + o.per_layer_f * d.L;
+    o.head_ln = o.layer0_f + o.per_layer_f * d.L;                                           // head 1: LayerNorm w, b [D]
+    o.total_f = o.head_ln + (d.head == 1 ? 2 * (size_t)d.D : 0);
     return o;
 }
 
@@ -170,10 +183,10 @@ extern "C" int wise_xlmr_forward(const wise_xlmr_config* cfg, const uint16_t* wb
     bf16_t* a = reinterpret_cast<bf16_t*>(wsb + ws.a);
     int* lens = reinterpret_cast<int*>(wsb + ws.lens);
     const int M = ws.M, Mp = ws.Mp, W = d.W;
-    const float eps = 1e-5f;                                  // XLM-RoBERTa's layer_norm_eps
+    const float eps = d.eps;                                  // layer_norm_eps: 1e-5 XLM-RoBERTa, 1e-12 BERT
 
     hipLaunchKernelGGL(xlmr_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tokens, pf + o.word, pf + o.pos, pf + o.type0,
-                       batch, d.T, W, d.V, d.P, d.pad, x, lens);
+                       batch, d.T, W, d.V, d.P, d.pad, d.pos_abs, x, lens);
     WISE_LAUNCH_CHECK("xlmr_embed_kernel");
     if ((rc = layernorm_f32_dual(x, pf + o.eln_w, pf + o.eln_b, M, W, eps, x, h, st))) return rc;
     for (int l = 0; l < d.L; ++l) {
@@ -189,9 +202,15 @@ extern "C" int wise_xlmr_forward(const wise_xlmr_config* cfg, const uint16_t* wb
     }
     // mean over the sequence's own tokens -> MLP projection (no biases) -> L2 normalise
     const int Bp = (batch + 255) / 256 * 256;
-    hipLaunchKernelGGL(xlmr_meanpool_kernel, dim3(batch), dim3(256), 0, st, x, lens, d.T, W, h);
+    if (d.head == 1) {   // rows past the batch feed the head's 128-row GEMM tiles: keep them finite
+        hipError_t me = hipMemsetAsync(h, 0, (size_t)Bp * W * 2, st);
+        if (me != hipSuccess) { set_error("xlmr_forward: hipMemsetAsync: %s", hipGetErrorString(me)); return (int)me; }
+    }
+    hipLaunchKernelGGL(xlmr_meanpool_kernel, dim3(batch), dim3(256), 0, st, x, lens, d.T, W, d.pool, h);
     WISE_LAUNCH_CHECK("xlmr_meanpool_kernel");
     float* e = reinterpret_cast<float*>(qkv);
+    if (d.head == 1)
+        return clap_projection(h, wb + o.proj1, wb + o.proj2, pf + o.head_ln, pf + o.head_ln + d.D, batch, W, e, a, out, st);
     if ((rc = gemm_bf16_rows(h, wb + o.proj1, nullptr, Bp, batch, d.Hd, W, 2, a, st))) return rc;
     if ((rc = gemm_bf16_rows(a, wb + o.proj2, nullptr, Bp, batch, d.D, d.Hd, 4, e, st))) return rc;
     return l2norm_rows(e, batch, d.D, out, st);

@@ -1,9 +1,10 @@
 """MicrosoftClap — drop-in surface for the reference's src/feature/microsoft_clap.py:9-58.
 
 `preprocess_audio` reproduces the reference exactly (transpose when shape[0] > 2, mono mix,
-default_collate([audio])).  `extract_audio_features` drives the HTSAT HIP kernels
-(wise_amd/feature/htsat.py); `preprocess_text` / `extract_text_features` drive the caption encoder of the 2023
-model (GPT-2 base + msclap Projection, wise_amd/feature/clap_text.py) on the HIP text-tower kernels.
+default_collate([audio])).  Version '2023': `extract_audio_features` drives the HTSAT HIP kernels
+(wise_amd/feature/htsat.py), `preprocess_text` / `extract_text_features` the caption encoder GPT-2 base + msclap
+Projection (wise_amd/feature/clap_text.py).  Version '2022': PANNs Cnn14 (wise_amd/feature/cnn14.py) and
+bert-base-uncased + msclap Projection (wise_amd/feature/clap_bert.py on the XLM-RoBERTa tower's kernels).
 """
 from __future__ import annotations
 
@@ -20,7 +21,7 @@ CLAP_MODEL_NAMES = ('2022', '2023', 'clapcap')  # msclap 1.3.3 CLAP.model_name k
 
 class MicrosoftClap(FeatureExtractor):
     ID_PREFIX = 'microsoft/clap/'
-    DESCRIPTION = 'MS-CLAP HTSAT audio encoder as MI355X HIP kernels; see https://github.com/microsoft/CLAP'
+    DESCRIPTION = 'MS-CLAP audio / caption encoders (2023: HTSAT + GPT-2, 2022: Cnn14 + BERT) as MI355X HIP kernels; see https://github.com/microsoft/CLAP'
 
     def __init__(self, id):
         if not id.startswith(self.ID_PREFIX):
@@ -65,27 +66,41 @@ class MicrosoftClap(FeatureExtractor):
     @property
     def tokenizer(self):
         if self._tokenizer is None:
-            from .gpt2_tokenizer import Gpt2Tokenizer
-            self._tokenizer = Gpt2Tokenizer.default(77, allow_merge_less=seeded_tag(self.weights_tag) is not None)
+            seeded = seeded_tag(self.weights_tag) is not None
+            if self.version == '2022':      # msclap config_2022: text_model bert-base-uncased, text_len 100
+                from .bert_tokenizer import BertTokenizer
+                self._tokenizer = BertTokenizer.default(100, allow_synthetic=seeded)
+            else:                           # config_2023: gpt2, text_len 77
+                from .gpt2_tokenizer import Gpt2Tokenizer
+                self._tokenizer = Gpt2Tokenizer.default(77, allow_merge_less=seeded)
         return self._tokenizer
 
     def preprocess_text(self, text):
-        """msclap `preprocess_text`: GPT-2 ids of `text + ' <|endoftext|>'`, padded with id 0 to 77 (the reference
-        returns msclap's dict of tensors; here the ids alone, which is all the encoder consumes)."""
+        """msclap `preprocess_text`: 2023 — GPT-2 ids of `text + ' <|endoftext|>'`, padded with id 0 to 77; 2022 — BERT
+        WordPiece ids `[CLS] … [SEP]` padded with [PAD] to 100 (the reference returns msclap's dict of tensors; here the
+        ids alone, which is all the encoders consume: the attention mask is `ids != pad`, token types are zero)."""
         return self.tokenizer(text)
 
     def _get_text_engine(self):
         if self._text_engine is None:
-            from .clap_text import CAPTION_SPEC, pack_caption_weights, random_caption_state_dict
-            from .text import TextEngine
             seed = seeded_tag(self.weights_tag)
+            sd = None
             if seed is None:
                 from .weights import load_state_dict_file
                 full = load_state_dict_file(f"clap-{self.version}", self.weights_tag)
                 sd = {k[len("caption_encoder."):]: v for k, v in full.items() if k.startswith("caption_encoder.")}
+            if self.version == '2022':
+                from .clap_bert import CLAP_BERT_SPEC, pack_clap_bert_weights, random_clap_bert_state_dict
+                from .xlmr_text import XlmrTextEngine
+                self._text_engine = XlmrTextEngine(CLAP_BERT_SPEC, sd if sd is not None else
+                                                   random_clap_bert_state_dict(CLAP_BERT_SPEC, seed), device="cuda",
+                                                   pack=pack_clap_bert_weights)
             else:
-                sd = random_caption_state_dict(CAPTION_SPEC, seed)
-            self._text_engine = TextEngine(CAPTION_SPEC, sd, device="cuda", pack=pack_caption_weights)
+                from .clap_text import CAPTION_SPEC, pack_caption_weights, random_caption_state_dict
+                from .text import TextEngine
+                self._text_engine = TextEngine(CAPTION_SPEC, sd if sd is not None else
+                                               random_caption_state_dict(CAPTION_SPEC, seed), device="cuda",
+                                               pack=pack_caption_weights)
         return self._text_engine
 
     def _get_engine(self):

@@ -45,7 +45,7 @@ class XlmrSpec:
 
     def c_config(self) -> _lib.XlmrConfig:
         return _lib.XlmrConfig(self.context, self.vocab, self.max_positions, self.width, self.layers, self.heads, self.mlp,
-                               self.proj_hidden, self.embed_dim, self.pad_id)
+                               self.proj_hidden, self.embed_dim, self.pad_id, 0, 0, 0, 0)
 
 
 # open_clip model configs whose text_cfg names a Hugging Face XLM-RoBERTa (model_configs/xlm-roberta-*-ViT-*.json)
@@ -127,14 +127,17 @@ class XlmrTextEngine:
     """Device copies of the weight blobs + a workspace; `forward(tokens)` launches the HIP pipeline on the current torch
     stream and returns a device tensor [B, D] fp32 (L2-normalised)."""
 
-    def __init__(self, spec: XlmrSpec, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 8):
+    def __init__(self, spec: XlmrSpec, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 8,
+                 pack=None):
+        """`spec`: anything with the XlmrSpec surface (`c_config`, context, vocab, pad_id, embed_dim, width);
+        `pack(spec, sd)` -> (bf16 blob, fp32 blob), default pack_xlmr_weights"""
         self.spec = spec
         self.lib = _lib.lib()
         self.device = torch.device(device)
         self.cfg = spec.c_config()
         nb, nf = C.c_int64(), C.c_int64()
         _lib.check(self.lib.wise_xlmr_layout(C.byref(self.cfg), C.byref(nb), C.byref(nf)), "wise_xlmr_layout")
-        wb, pf = pack_xlmr_weights(spec, sd)
+        wb, pf = (pack or pack_xlmr_weights)(spec, sd)
         if wb.numel() != nb.value or pf.numel() != nf.value:
             raise RuntimeError(f"weight blob size mismatch: packed {wb.numel()}/{pf.numel()}, "
                                f"library expects {nb.value}/{nf.value}")
