@@ -349,12 +349,14 @@ int wise_preproc_taps(int in_size, int out_size, int* ksize, int* first, int* co
  *       5 -> out_bf16 = gelu_tanh(acc+bias) ; 6 -> out_bf16 = relu(acc+bias) */
 int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K,
                    int mode, void* out, void* stream);
-/* out[ceil128(B*T*F), cout] bf16 = relu(conv3x3(x [B,T,F,cin] bf16, position-major ("NHWC"), stride 1, zero padding 1)
- * + bias[cout]); wt [cout, 9*cin] bf16 with k = (kh*3 + kw)*cin + c (BatchNorm folded by the caller); cin, cout
- * multiples of 64; zeros = at least 16 bytes of zeros on the device (what every out-of-image tap reads).  The implicit
- * GEMM behind the ConvBlocks of wise_cnn14_forward (torch: F.relu(bn(F.conv2d(x, w, padding=1)))). */
+/* out[ceil256(B*T*F), cout] bf16 = relu(conv3x3(x [B,T,F,cin] bf16, position-major ("NHWC"), stride 1, zero padding 1)
+ * + bias[cout]); with pool != 0 its 2x2 average pooling (floor) instead, out [B*(T/2)*(F/2), cout], computed in the same
+ * kernel (the unpooled tensor is never written).  wt [cout, 9*cin] bf16 with k = (kh*3 + kw)*cin + c (BatchNorm folded
+ * by the caller); cin, cout multiples of 64; zeros = at least 16 bytes of zeros on the device (what every out-of-image
+ * tap reads).  The implicit GEMM behind the ConvBlocks of wise_cnn14_forward
+ * (torch: F.avg_pool2d(F.relu(bn(F.conv2d(x, w, padding=1))), 2)). */
 int wise_conv3x3_relu_bf16(const uint16_t* x, const uint16_t* wt, const float* bias, const uint16_t* zeros, int batch,
-                           int T, int F, int cin, int cout, uint16_t* out, void* stream);
+                           int T, int F, int cin, int cout, int pool, uint16_t* out, void* stream);
 /* LayerNorm fused into the GEMM's A operand: out_bf16[M,N] = epi( LN(x_f32[M,K]; lnw, lnb, eps) @ Wt[N,K]^T + bias ),
  * for K in {96, 192} (HTSAT stages 1-2), N % 8 == 0, M % 128 == 0, bf16 output modes (0, 1, 2, 5). */
 int wise_gemm_ln_bf16(const float* x, const float* lnw, const float* lnb, const uint16_t* Wt, const float* bias,

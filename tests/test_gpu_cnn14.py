@@ -28,19 +28,27 @@ def engine():
     return Cnn14Engine(random_cnn14_state_dict(0), max_batch=4, max_samples=192000)
 
 
-@pytest.mark.parametrize("B,T,Fq,cin,cout", [(1, 8, 8, 64, 64), (3, 7, 4, 64, 128), (2, 21, 2, 128, 128),
-                                              (1, 5, 3, 256, 512), (2, 33, 16, 64, 64), (1, 1, 1, 128, 256)])
-def test_conv3x3_building_block(B, T, Fq, cin, cout):
+@pytest.mark.parametrize("B,T,Fq,cin,cout,pool", [
+    (1, 8, 8, 64, 64, False), (3, 7, 4, 64, 128, False), (2, 21, 2, 128, 128, False), (1, 5, 3, 256, 512, False),
+    (2, 33, 16, 64, 64, False), (1, 1, 1, 128, 256, False),
+    (1, 8, 8, 64, 64, True), (3, 7, 5, 64, 128, True), (2, 21, 2, 128, 128, True), (2, 33, 16, 64, 64, True),
+    (1, 2, 2, 128, 256, True),
+    (1, 331, 128, 64, 256, False), (1, 331, 128, 64, 256, True),      # >= 160 tiles of 256 x 256: the ping-pong kernels
+    (2, 93, 4, 128, 512, True)])
+def test_conv3x3_building_block(B, T, Fq, cin, cout, pool):
     """the implicit-GEMM convolution alone against torch's conv2d on the same bf16-rounded operands: edges (zero
-    padding at every border, rows past the last tile), both tile widths (64 and 128 output channels)"""
+    padding at every border, rows past the last tile), both tile widths (64 and 128 output channels), the ping-pong
+    tile, and the fused 2x2 average pooling (floor: odd leftovers dropped) in each of them"""
     g = torch.Generator().manual_seed(B * 1000 + T * 10 + cin)
     x = torch.randn(B, T, Fq, cin, generator=g).to(torch.bfloat16)
     w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(torch.bfloat16)
     bias = 0.2 * torch.randn(cout, generator=g)
     ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), padding=1) + bias[None, :, None, None])
-    ref = ref.permute(0, 2, 3, 1)                                     # [B, T, F, Cout]
+    if pool:
+        ref = F.avg_pool2d(ref, kernel_size=2)
+    ref = ref.permute(0, 2, 3, 1)                                     # [B, T', F', Cout]
     wt = w.permute(0, 2, 3, 1).contiguous().reshape(cout, 9 * cin)    # k = (kh*3 + kw)*cin + c
-    got = conv3x3_relu(x.cuda(), wt.cuda(), bias.cuda()).float().cpu()
+    got = conv3x3_relu(x.cuda(), wt.cuda(), bias.cuda(), pool=pool).float().cpu()
     assert got.shape == ref.shape
     # bf16 output rounding (2^-9 relative) + fp32 summation order
     assert torch.allclose(got, ref, rtol=8e-3, atol=2e-3), (got - ref).abs().max()

@@ -71,7 +71,7 @@ SIGNATURES = {
     "wise_cnn14_workspace_bytes": (_sz, [_i, _i]),
     "wise_cnn14_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "wise_cnn14_tap": (_i, [_i, _vp, _i, _i, _vp, _i64, _vp]),
-    "wise_conv3x3_relu_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "wise_conv3x3_relu_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "wise_text_layout": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "wise_text_workspace_bytes": (_sz, [_vp, _i]),
     "wise_text_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),

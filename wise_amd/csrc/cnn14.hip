@@ -10,13 +10,14 @@
 //   conv3x3       the other eleven convolutions as implicit GEMMs on the matrix cores (gemm_bf16.hip:
 //                 no im2col buffer — a K-tile is 64 channels of one tap, gathered by the LDS-DMA);
 //                 BatchNorm folded into the weights and a bias by the packer, ReLU in the epilogue     bf16 NHWC
-//   avgpool2      2x2 average pooling (floor) after blocks 1-5
+//   avgpool2      2x2 average pooling (floor) after blocks 1-5: fused into the second convolution of the block (the tile's
+//                 rows are the members of pooling windows; see conv3x3_kernel), the unpooled tensor is never written
 //   head_pool     mean over the mel axis, max over time + mean over time                               bf16 [Bp, 2048]
 //   fc1 + ReLU    gemm_bf16 (mode 6), then msclap's Projection (clap_projection, htsat.hip) and the L2 normalisation
 //
 // Layout: activations are position-major ("NHWC"): row p = (b*T + t)*F + f holds the C channels of one
 // time-frequency cell, so a convolution's A operand rows are contiguous channel vectors.  Two activation buffers
-// alternate; rows are padded to the 128-row tile (padding rows are written, never read as data).
+// alternate; rows are padded to the 256-row tile (padding rows are written, never read as data).
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -29,42 +30,47 @@ constexpr int NBLK = 6, EMB = 2048, OUT = 1024, MIN_FRAMES = 32;
 constexpr int CH[NBLK] = {64, 128, 256, 512, 1024, 2048};
 
 // ------------------------------------------------------------------------------------------------
-// block 1, conv 1: 1 -> 64 channels.  Thread = (cell, group of 8 channels): eight neighbouring threads write the 128
-// bytes of one cell.  Weights [64][9] (BatchNorm scale folded) and the shift sit in LDS.
+// block 1, conv 1: 1 -> 64 channels.  A thread owns ONE group of 8 output channels (lane & 7) for the life of the
+// kernel — its 72 weights (BatchNorm scale folded) and 8 shifts stay in registers — and walks cells with a grid
+// stride; the eight threads of a cell write its 128 bytes together.  Nine input values per cell come from the log-mel
+// (cache hits: neighbouring cells share them).  Bound by the bf16 tensor it writes (787 MB at 64 clips x 10 s).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ mel /*[B,T,64]*/,
                                                          const float* __restrict__ w /*[64][9]*/,
                                                          const float* __restrict__ shift /*[64]*/, int T, long long cells,
                                                          bf16_t* __restrict__ out /*[cells, 64]*/) {
-    __shared__ float sw[9][64], sb[64];
-    for (int i = threadIdx.x; i < 576; i += 256) sw[i % 9][i / 9] = w[i];
-    if (threadIdx.x < 64) sb[threadIdx.x] = shift[threadIdx.x];
-    __syncthreads();
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long p = idx >> 3;
-    if (p >= cells) return;
-    const int g = (int)(idx & 7);
-    const int f = (int)(p & 63);
-    const int t = (int)((p >> 6) % T);
-    float x[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const bool in = (unsigned)(t + dy) < (unsigned)T && (unsigned)(f + dx) < 64u;
-        x[tap] = in ? mel[p + dy * 64 + dx] : 0.f;
-    }
-    float v[8];
+    const int g = threadIdx.x & 7;
+    float wr[8][9], sh[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        float a = 0.f;
+        sh[c] = shift[g * 8 + c];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) a = fmaf(x[tap], sw[tap][g * 8 + c], a);
-        v[c] = fmaxf(a + sb[g * 8 + c], 0.f);
+        for (int tap = 0; tap < 9; ++tap) wr[c][tap] = w[(g * 8 + c) * 9 + tap];
     }
-    uint4 pk;
-    pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
-    pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
-    *reinterpret_cast<uint4*>(out + p * 64 + g * 8) = pk;
+    const long long stride = (long long)gridDim.x * 32;
+    for (long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); p < cells; p += stride) {
+        const int f = (int)(p & 63);
+        const int t = (int)((p >> 6) % T);
+        float x[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const bool in = (unsigned)(t + dy) < (unsigned)T && (unsigned)(f + dx) < 64u;
+            x[tap] = in ? mel[p + dy * 64 + dx] : 0.f;
+        }
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) a = fmaf(x[tap], wr[c][tap], a);
+            v[c] = fmaxf(a + sh[c], 0.f);
+        }
+        uint4 pk;
+        pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+        pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(out + p * 64 + g * 8) = pk;
+    }
 }
 
 __device__ __forceinline__ void unpack8(const uint4 v, float* f) {
@@ -72,32 +78,6 @@ __device__ __forceinline__ void unpack8(const uint4 v, float* f) {
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
     f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
     f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
-}
-
-// 2x2 average pooling, floor: [B, T, F, C] -> [B, T/2, F/2, C]; thread = (output cell, 8 channels)
-__global__ __launch_bounds__(256) void avgpool2_kernel(const bf16_t* __restrict__ x, int T, int F, int C, long long units,
-                                                       bf16_t* __restrict__ y) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= units) return;
-    const int cg = C >> 3, T2 = T >> 1, F2 = F >> 1;
-    const int g = (int)(idx % cg);
-    const long long q = idx / cg;
-    const int f2 = (int)(q % F2);
-    const long long r = q / F2;
-    const int t2 = (int)(r % T2);
-    const long long b = r / T2;
-    const bf16_t* src = x + (((b * T + 2 * t2) * F + 2 * f2) * (long long)C + g * 8);
-    float a[8], s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        unpack8(*reinterpret_cast<const uint4*>(src + ((k >> 1) * (long long)F + (k & 1)) * C), a);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) s[c] += a[c];
-    }
-    uint4 pk;
-    pk.x = pack_bf16x2(0.25f * s[0], 0.25f * s[1]); pk.y = pack_bf16x2(0.25f * s[2], 0.25f * s[3]);
-    pk.z = pack_bf16x2(0.25f * s[4], 0.25f * s[5]); pk.w = pack_bf16x2(0.25f * s[6], 0.25f * s[7]);
-    *reinterpret_cast<uint4*>(y + q * C + g * 8) = pk;
 }
 
 // [B, T, F, C] -> lat [B, C]: mean over F, then max over T + mean over T; thread = (clip, 8 channels)
@@ -169,7 +149,7 @@ static Ws workspace(int B, int samples) {
     Ws w{};
     w.T = samples / HOP + 1;
     const size_t Bp = (size_t)(B + 127) / 128 * 128;
-    const size_t rows1 = ((size_t)B * w.T * 64 + 127) / 128 * 128;     // block 1 holds the largest tensors
+    const size_t rows1 = ((size_t)B * w.T * 64 + 255) / 256 * 256;     // block 1 holds the largest tensors (rows padded to the 256-row tile)
     size_t off = 0;
     w.zeros = off; off += 256;
     w.mel = off; off += up256((size_t)B * w.T * 64 * 4);
@@ -209,26 +189,22 @@ static int forward(const bf16_t* wb, const float* pf, const float* wave, int B, 
         return rc;
     {
         const long long cells = (long long)B * T * 64;
-        hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)((cells * 8 + 255) / 256)), dim3(256), 0, st, mel, pf + o.c0_w,
-                           pf + o.c0_b, T, cells, cur);
+        const long long want = (cells + 31) / 32;
+        hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(want < 256 * 16 ? want : 256 * 16)), dim3(256), 0, st, mel,
+                           pf + o.c0_w, pf + o.c0_b, T, cells, cur);
         WISE_LAUNCH_CHECK("cnn14 conv_first_kernel");
     }
     for (int i = 0; i < NBLK; ++i) {
         const int cin = i ? CH[i - 1] : 1, cout = CH[i];
         for (int j = 0; j < 2; ++j) {
             if (i == 0 && j == 0) continue;
-            if ((rc = conv3x3_bf16(cur, wb + o.cw[i][j], pf + o.cb[i][j], zeros, B, T, F, j ? cout : cin, cout, nxt, st)))
+            // the block's second convolution carries the 2x2 average pooling that follows it (blocks 1-5)
+            if ((rc = conv3x3_bf16(cur, wb + o.cw[i][j], pf + o.cb[i][j], zeros, B, T, F, j ? cout : cin, cout,
+                                   j == 1 && i < NBLK - 1, nxt, st)))
                 return rc;
             bf16_t* t = cur; cur = nxt; nxt = t;
         }
-        if (i < NBLK - 1) {
-            const long long units = (long long)B * (T / 2) * (F / 2) * (cout / 8);
-            hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, cur, T, F, cout, units,
-                               nxt);
-            WISE_LAUNCH_CHECK("cnn14 avgpool2_kernel");
-            bf16_t* t = cur; cur = nxt; nxt = t;
-            T /= 2; F /= 2;
-        }
+        if (i < NBLK - 1) { T /= 2; F /= 2; }
     }
     hipLaunchKernelGGL(head_pool_kernel, dim3((B * (EMB / 8) + 255) / 256), dim3(256), 0, st, cur, B, T, F, EMB, lat);
     WISE_LAUNCH_CHECK("cnn14 head_pool_kernel");
@@ -280,10 +256,11 @@ extern "C" int wise_cnn14_tap(int what, const void* workspace_ptr, int batch, in
     return WISE_OK;
 }
 
-// relu(conv3x3(x [B, T, F, Cin] bf16 NHWC, padding 1) + bias) -> out [ceil128(B*T*F), Cout] bf16; wt [Cout, 9*Cin],
+// relu(conv3x3(x [B, T, F, Cin] bf16 NHWC, padding 1) + bias) -> out [ceil256(B*T*F), Cout] bf16, or (pool != 0) its 2x2
+// average pooling [B*(T/2)*(F/2), Cout]; wt [Cout, 9*Cin],
 // k = (kh*3 + kw)*Cin + c; zeros = 16 bytes of zeros on the device.  The building block above, exposed for parity tests
 // and for callers with other convolutional encoders.
 extern "C" int wise_conv3x3_relu_bf16(const uint16_t* x, const uint16_t* wt, const float* bias, const uint16_t* zeros,
-                                      int batch, int T, int F, int cin, int cout, uint16_t* out, void* stream) {
-    return conv3x3_bf16(x, wt, bias, zeros, batch, T, F, cin, cout, out, (hipStream_t)stream);
+                                      int batch, int T, int F, int cin, int cout, int pool, uint16_t* out, void* stream) {
+    return conv3x3_bf16(x, wt, bias, zeros, batch, T, F, cin, cout, pool != 0, out, (hipStream_t)stream);
 }

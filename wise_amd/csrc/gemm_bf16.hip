@@ -422,8 +422,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
 // their (t, f) coordinates are divided out once, before the loop.  Everything else — LDS image, swizzle, fragment
 // reads, transposed product, epilogue through LDS — is gemm_bf16_kernel's.  NTJ = column tiles per wave: 4 -> 128
 // output channels per block, 2 -> 64 (the first block of Cnn14).  Rows are padded: out has ceil128(M) rows.
+//
+// POOL: the 2x2 average pooling (floor) that follows the second convolution of a ConvBlock, fused.  Because every A
+// row is gathered by address anyway, the tile's rows need not be consecutive cells: row wm*64 + i*16 + l of a tile is
+// member i (dt = i >> 1, df = i & 1) of the pooling window of output cell q = 32*tile + 16*wm + l.  The four members
+// of a window are then the four row tiles acc[0..3][j] of ONE lane — pooling is three adds per value after bias and
+// ReLU, no shuffle, no LDS — and the full-resolution tensor is never written (block 1 of Cnn14 at 64 clips x 10 s:
+// 787 MB not written and not read back).  M counts window members (4 per output cell); out [B, T/2, F/2, Cout].
 // ------------------------------------------------------------------------------------------------
-template <int NTJ>
+template <int NTJ, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                          const float* __restrict__ bias,
                                                          const bf16_t* __restrict__ zeros, int T, int F, int Cin, int M,
@@ -444,15 +451,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const bf16_t* __restric
     // the four rows this lane stages: position, coordinates, element offset of its 16-byte chunk at tap (0, 0)
     int pt[4], pf[4];
     long long poff[4];
+    const int T2 = T >> 1, F2 = F >> 1;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int r = (t * 4 + wave) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (r & 7);
-        const int p = m0 + r;
-        const int q = p / F;
-        pf[t] = p - q * F;
-        pt[t] = (p < M) ? q % T : -4;                 // rows past M: every tap is "outside"
-        poff[t] = (long long)p * Cin + c * 8;
+        if constexpr (POOL) {
+            const int mem = (r >> 4) & 3;
+            const int q = tm * 32 + (r >> 6) * 16 + (r & 15);          // output cell of this row's window
+            const int qf = q / F2, f2 = q - qf * F2, b = qf / T2, t2 = qf - b * T2;
+            const int tt = 2 * t2 + (mem >> 1), ff = 2 * f2 + (mem & 1);
+            pf[t] = ff;
+            pt[t] = (4 * q < M) ? tt : -4;
+            poff[t] = ((long long)(b * T + tt) * F + ff) * Cin + c * 8;
+        } else {
+            const int p = m0 + r;
+            const int q = p / F;
+            pf[t] = p - q * F;
+            pt[t] = (p < M) ? q % T : -4;             // rows past M: every tap is "outside"
+            poff[t] = (long long)p * Cin + c * 8;
+        }
     }
     auto stage = [&](int tap, int cc, unsigned char* dst) {
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
@@ -503,7 +521,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const bf16_t* __restric
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
-    if constexpr (NTJ == 4) {
+    if constexpr (POOL) {
+        const int q = tm * 32 + wm * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j) {
+            const int n = n0 + wn * (16 * NTJ) + j * 16 + (lane >> 4) * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v0 += fmaxf(acc[i][j][0] + bv.x, 0.f); v1 += fmaxf(acc[i][j][1] + bv.y, 0.f);
+                v2 += fmaxf(acc[i][j][2] + bv.z, 0.f); v3 += fmaxf(acc[i][j][3] + bv.w, 0.f);
+            }
+            uint2 pk;
+            pk.x = pack_bf16x2(0.25f * v0, 0.25f * v1);
+            pk.y = pack_bf16x2(0.25f * v2, 0.25f * v3);
+            if (4 * q < M) *reinterpret_cast<uint2*>(out + (size_t)q * Cout + n) = pk;
+        }
+    } else if constexpr (NTJ == 4) {
         __syncthreads();  // staging buffers are dead from here on
         epilogue_lds<EPI_RELU>(acc, bias, out, Cout, m0, n0, wm, wn, lane, wave, smem);
     } else {
@@ -1555,6 +1590,154 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 3x3 convolution (conv3x3_kernel above) on the ping-pong kernel's tile, ring and schedule: 256 x 256 output
+// tile (WROWS 128) or 256 x 128 (WROWS 64), K-tiles of 32 input channels of one tap (Cin % 32 == 0).  Only the A
+// staging differs from gemm_pp_kernel: the two (or, never here, three) rows a lane stages keep their (t, f) coordinates
+// in registers, the tap of the K-tile being staged shifts the source address, and a row whose neighbour lies outside
+// the image reads the page of zeros.  Same vmcnt counts (same number of LDS-DMA instructions per K-tile), same RAW / WAR
+// argument.  out has ceil256(M) rows.
+// ------------------------------------------------------------------------------------------------
+// POOL (WROWS 128): as in conv3x3_kernel — row wm*128 + i*16 + l is member i & 3 of the window of output cell
+// 64*tile + 32*wm + 16*(i >> 2) + l, so a window is acc[4h .. 4h+3][j] of one lane.
+template <int WROWS, bool POOL>
+__global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
+                                                            const float* __restrict__ bias,
+                                                            const bf16_t* __restrict__ zeros, int T, int F, int Cin,
+                                                            int M, int Cout, bf16_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BKT = 32, NT = 4, MI = WROWS / 16;
+    constexpr int BMB = 256;
+    constexpr int WM_WAVES = BMB / WROWS, WN_WAVES = 8 / WM_WAVES, BNB = WN_WAVES * 64;
+    constexpr int STAGES = (WROWS == 64) ? 5 : 4;
+    constexpr int TA = BMB * BKT * 2, TBt = BNB * BKT * 2, SB = TA + TBt;
+    constexpr int GPS = TA / 8192 + TBt / 8192;
+    constexpr int INFL = (STAGES - 2) * GPS;
+    constexpr int RA = TA / 8192;                      // A rows a lane stages (2)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
+    const bool late = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+
+    const int tiles_n = Cout / BNB;
+    int tm, tn;
+    tile_coords((M + BMB - 1) / BMB, tiles_n, 4, &tm, &tn);
+    const int m0 = tm * BMB, n0 = tn * BNB;
+    const int K = 9 * Cin, ck = Cin / BKT, nk = 9 * ck;
+
+    static_assert(!POOL || WROWS == 128, "fused pooling: 256 x 256 tile only");
+    int pt[RA], pf[RA];
+    long long poff[RA];
+    const int T2 = T >> 1, F2 = F >> 1;
+#pragma unroll
+    for (int t = 0; t < RA; ++t) {
+        const int r = (t * 8 + wave) * 16 + (lane >> 2);
+        const int c = swz_chunk<BKT>(r, lane & 3);
+        if constexpr (POOL) {
+            const int i = (r >> 4) & 7, mem = i & 3;
+            const int q = tm * 64 + (r >> 7) * 32 + (i >> 2) * 16 + (r & 15);
+            const int qf = q / F2, f2 = q - qf * F2, b = qf / T2, t2 = qf - b * T2;
+            const int tt = 2 * t2 + (mem >> 1), ff = 2 * f2 + (mem & 1);
+            pf[t] = ff;
+            pt[t] = (4 * q < M) ? tt : -4;
+            poff[t] = ((long long)(b * T + tt) * F + ff) * Cin + c * 8;
+        } else {
+            const int p = m0 + r;
+            const int q = p / F;
+            pf[t] = p - q * F;
+            pt[t] = (p < M) ? q % T : -4;
+            poff[t] = (long long)p * Cin + c * 8;
+        }
+    }
+    int tap = 0, cc = 0;                               // of the K-tile staged next
+    auto stage_next = [&](int kt_stage, unsigned char* dst) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const long long shift = (long long)(dy * F + dx) * Cin + cc * BKT;
+#pragma unroll
+        for (int t = 0; t < RA; ++t) {
+            const bool in = (unsigned)(pt[t] + dy) < (unsigned)T && (unsigned)(pf[t] + dx) < (unsigned)F;
+            glds16(in ? X + poff[t] + shift : zeros, dst + (t * 8 + wave) * 1024);
+        }
+        stage_rows8_ring<BNB, BKT>(Wt, K, n0, kt_stage * BKT, dst + TA, wave, lane);
+        if (++cc == ck) { cc = 0; ++tap; }
+    };
+
+    f32x4 acc[MI][NT];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) stage_next(s, smem + s * SB);       // nk >= 18 > STAGES - 1 always (Cin >= 64)
+    if (late) {
+        wait_vmcnt<INFL>();
+        __builtin_amdgcn_s_barrier();
+    }
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + STAGES - 2 < nk) wait_vmcnt<INFL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + STAGES - 1 < nk) {
+            int ns = cur + STAGES - 1;
+            if (ns >= STAGES) ns -= STAGES;
+            stage_next(kt + STAGES - 1, smem + ns * SB);
+        }
+        const unsigned char* At = smem + cur * SB;
+        const unsigned char* Bt = At + TA;
+        const int chunk = lane >> 4;
+        bf16x8 wf[NT], af[MI];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = lds_frag_ring<BKT>(Bt, wn * 64 + j * 16 + (lane & 15), chunk);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = lds_frag_ring<BKT>(At, wm * WROWS + i * 16 + (lane & 15), chunk);
+        if (kt + STAGES - 1 < nk) wait_vmcnt<INFL>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+    if constexpr (POOL) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = tm * 64 + wm * 32 + h * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+                const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+                for (int i = 4 * h; i < 4 * h + 4; ++i) {
+                    v0 += fmaxf(acc[i][j][0] + bv.x, 0.f); v1 += fmaxf(acc[i][j][1] + bv.y, 0.f);
+                    v2 += fmaxf(acc[i][j][2] + bv.z, 0.f); v3 += fmaxf(acc[i][j][3] + bv.w, 0.f);
+                }
+                uint2 pk;
+                pk.x = pack_bf16x2(0.25f * v0, 0.25f * v1);
+                pk.y = pack_bf16x2(0.25f * v2, 0.25f * v3);
+                if (4 * q < M) *reinterpret_cast<uint2*>(out + (size_t)q * Cout + n) = pk;
+            }
+        }
+        return;
+    }
+    __syncthreads();  // both groups are past their last fragment read: the ring is dead
+    if constexpr (WROWS == 64)
+        epilogue_lds<EPI_RELU>(acc, bias, out, Cout, m0, n0, wm, wn, lane, wave, smem);
+    else if constexpr (!POOL)
+        epilogue_big_lds<EPI_RELU, MI>(acc, bias, out, Cout, m0, n0, wm, wn, lane, wave, smem);
+}
+
 #ifdef WISE_DEBUG_KNOBS
 // ------------------------------------------------------------------------------------------------
 // Ping-pong kernel, second form: the fragment reads ride inside the MFMA cluster.  (MEASURED SLOWER — round 2, kept in
@@ -2010,35 +2193,72 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
     return launch_mode(auto_variant(M, N, K), A, Wt, bias, M, N, K, mode, out, st);
 }
 
-// out[ceil128(M), Cout] bf16 = relu(conv3x3(X [B, T, F, Cin] bf16 NHWC) + bias); M = B*T*F, Cin % 64 == 0, Cout % 64 == 0.
+static int g_conv_variant = 0;   // (debug knob) 0 = by shape, 1 = the 128-row tile everywhere, 2 = ping-pong wherever it tiles
+
+template <typename K>
+static void conv_launch(K kern, size_t lds, int grid, int threads, const bf16_t* X, const bf16_t* Wt, const float* bias,
+                        const bf16_t* zeros, int T, int F, int Cin, int M, int Cout, bf16_t* out, hipStream_t st) {
+    static std::mutex mu;
+    static std::vector<const void*> configured;   // kernels whose dynamic-LDS limit has been raised (a handful)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        const void* id = reinterpret_cast<const void*>(kern);
+        bool seen = false;
+        for (const void* c : configured) seen = seen || c == id;
+        if (!seen) {
+            (void)hipFuncSetAttribute(id, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            configured.push_back(id);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, X, Wt, bias, zeros, T, F, Cin, M, Cout, out);
+}
+
+// relu(conv3x3(X [B, T, F, Cin] bf16 NHWC) + bias), Cin % 64 == 0, Cout % 64 == 0:
+//   pool == false: out [ceil256(B*T*F), Cout] bf16 (rows padded to the tile)
+//   pool == true:  avg_pool2d(., 2) (floor) of it, out [B*(T/2)*(F/2), Cout] bf16 — the full-resolution tensor is never written
 // `zeros`: at least 16 readable bytes of zeros on the device (the padding every out-of-image tap reads).
 int conv3x3_bf16(const bf16_t* X, const bf16_t* Wt, const float* bias, const bf16_t* zeros, int B, int T, int F, int Cin,
-                 int Cout, bf16_t* out, hipStream_t st) {
+                 int Cout, bool pool, bf16_t* out, hipStream_t st) {
     WISE_CHECK_ARG(X && Wt && bias && zeros && out, "conv3x3: null pointer");
-    const long long M = (long long)B * T * F;
-    WISE_CHECK_ARG(B > 0 && T > 0 && F > 0 && Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % 64 == 0 &&
-                       (M + 127) / 128 * 128 * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 40) && M < (1ll << 31) - 128,
+    WISE_CHECK_ARG(B > 0 && T > 0 && F > 0 && Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % 64 == 0 && (!pool || (T >= 2 && F >= 2)),
                    "conv3x3: B=%d T=%d F=%d Cin=%d Cout=%d unsupported", B, T, F, Cin, Cout);
+    // rows the tiles walk: every cell, or the four members of every pooling window (floor: odd leftovers are not computed)
+    const long long M = pool ? 4ll * B * (T / 2) * (F / 2) : (long long)B * T * F;
+    WISE_CHECK_ARG((long long)B * T * F * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 40) && (long long)B * T * F < (1ll << 31) - 256,
+                   "conv3x3: B=%d T=%d F=%d too large", B, T, F);
     ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)Cout * 9.0 * (double)Cin, st);
+    const int tiles256 = (int)((M + 255) / 256);
+    // The ping-pong tile (one block per CU) where its tiles fill the chip in well-used rounds — measured per layer with
+    // tools/conv_bench.py (64 clips x 10 s): 1006-1162 against 904-1037 TFLOP/s on blocks 3 and 4 (6 and 3 rounds), 1031-1057
+    // against 978-996 on block 6 (184 tiles, one round), but 947-971 against 1049-1088 on block 5 (372 tiles = 1.45 rounds);
+    // its 256 x 128 form lost everywhere it was tried (block 2: 539-679 against 681-857) and is not used.
+    const long long tpp = (long long)tiles256 * (Cout / 256);
+    const double eff = tpp > 0 ? (double)tpp / (double)(((tpp + 255) / 256) * 256) : 0.0;
+    const bool pp256 = Cout % 256 == 0 && (g_conv_variant == 2 || (g_conv_variant == 0 && tpp >= 160 && eff >= 0.70 && (tpp <= 256 || eff >= 0.85)));
+    if (pp256) {
+        const size_t lds = (size_t)4 * (256 + 256) * 64;   // 128 KiB
+        if (pool) conv_launch(conv3x3_pp_kernel<128, true>, lds, (int)tpp, 512, X, Wt, bias, zeros, T, F, Cin, (int)M, Cout, out, st);
+        else conv_launch(conv3x3_pp_kernel<128, false>, lds, (int)tpp, 512, X, Wt, bias, zeros, T, F, Cin, (int)M, Cout, out, st);
+        WISE_LAUNCH_CHECK("conv3x3_pp_kernel");
+        return WISE_OK;
+    }
+#ifdef WISE_DEBUG_KNOBS
+    if (g_conv_variant == 2 && Cout % 128 == 0 && !pool) {   // the 256 x 128 form (measured slower; debug library only)
+        conv_launch(conv3x3_pp_kernel<64, false>, (size_t)5 * (256 + 128) * 64, tiles256 * (Cout / 128), 512, X, Wt, bias, zeros, T, F,
+                    Cin, (int)M, Cout, out, st);
+        WISE_LAUNCH_CHECK("conv3x3_pp_kernel");
+        return WISE_OK;
+    }
+#endif
     const int tiles_m = (int)((M + 127) / 128);
     if (Cout % 128 == 0) {
-        auto kern = conv3x3_kernel<4>;
         const size_t lds = 2 * (TILE_BYTES + 128 * BK * 2);   // 64 KiB
-        static std::once_flag attr4;
-        std::call_once(attr4, [&] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        });
-        hipLaunchKernelGGL(kern, dim3(tiles_m * (Cout / 128)), dim3(256), lds, st, X, Wt, bias, zeros, T, F, Cin, (int)M,
-                           Cout, out);
+        if (pool) conv_launch(conv3x3_kernel<4, true>, lds, tiles_m * (Cout / 128), 256, X, Wt, bias, zeros, T, F, Cin, (int)M, Cout, out, st);
+        else conv_launch(conv3x3_kernel<4, false>, lds, tiles_m * (Cout / 128), 256, X, Wt, bias, zeros, T, F, Cin, (int)M, Cout, out, st);
     } else {
-        auto kern = conv3x3_kernel<2>;
         const size_t lds = 2 * (TILE_BYTES + 64 * BK * 2);    // 48 KiB
-        static std::once_flag attr2;
-        std::call_once(attr2, [&] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        });
-        hipLaunchKernelGGL(kern, dim3(tiles_m * (Cout / 64)), dim3(256), lds, st, X, Wt, bias, zeros, T, F, Cin, (int)M,
-                           Cout, out);
+        if (pool) conv_launch(conv3x3_kernel<2, true>, lds, tiles_m * (Cout / 64), 256, X, Wt, bias, zeros, T, F, Cin, (int)M, Cout, out, st);
+        else conv_launch(conv3x3_kernel<2, false>, lds, tiles_m * (Cout / 64), 256, X, Wt, bias, zeros, T, F, Cin, (int)M, Cout, out, st);
     }
     WISE_LAUNCH_CHECK("conv3x3_kernel");
     return WISE_OK;
@@ -2076,6 +2296,7 @@ extern "C" int wise_debug_set_gemm_flags(int flags) {
     wise::g_mlp96_resident = (flags >> 7) & 1 ? 0 : 1;   // bit 7: the staged MLP kernel instead of the weight-resident one
     wise::g_overlap_policy = (flags >> 4) & 7;     // bits 4-6: tiles under overlap (0 lone-stream tiles, 1 = 128x128, 2 = mixed, 3 = hint ignored, 4/5/6 = 128x128 for the residual / fc1 / QKV launches only)
     wise::g_ablate = flags & 6;
+    wise::g_conv_variant = (flags >> 8) & 3;       // bits 8-9: convolution tile (0 by shape, 1 = 128-row tile, 2 = ping-pong)
     return 0;
 }
 

@@ -10,10 +10,11 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
 // through a split-K pair of kernels instead of leaving most of the chip idle
 int gemm_bf16_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int N, int K, int mode,
                    void* out, hipStream_t st);
-// relu(conv3x3(X [B, T, F, Cin] bf16 NHWC, zero padding 1) + bias) -> out [ceil128(B*T*F), Cout] bf16 (implicit GEMM, Wt [Cout, 9*Cin] with
-// k = (kh*3 + kw)*Cin + c); zeros = 16 bytes of zeros on the device
+// relu(conv3x3(X [B, T, F, Cin] bf16 NHWC, zero padding 1) + bias) as an implicit GEMM (Wt [Cout, 9*Cin] with
+// k = (kh*3 + kw)*Cin + c): out [ceil256(B*T*F), Cout] bf16, or with pool its 2x2 average pooling (floor),
+// out [B*(T/2)*(F/2), Cout], fused; zeros = 16 bytes of zeros on the device
 int conv3x3_bf16(const bf16_t* X, const bf16_t* Wt, const float* bias, const bf16_t* zeros, int B, int T, int F, int Cin,
-                 int Cout, bf16_t* out, hipStream_t st);
+                 int Cout, bool pool, bf16_t* out, hipStream_t st);
 // hint for the tile heuristic: the caller is about to enqueue GEMMs on several streams that overlap in time
 // (host-side state; the library is single-threaded by contract)
 void gemm_set_overlapped(bool on);

@@ -71,6 +71,17 @@ def random_cnn14_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
     return sd
 
 
+def flops_per_clip(samples: int) -> int:
+    """multiply-adds x 2 of the twelve convolutions, fc1 and the projection for one clip of `samples` samples"""
+    T, F, cin, total = samples // HOP + 1, N_MELS, 1, 0
+    for i, cout in enumerate(CHANNELS):
+        total += 2 * T * F * 9 * (cin * cout + cout * cout)
+        if i < len(CHANNELS) - 1:
+            T, F = T // 2, F // 2
+        cin = cout
+    return total + 2 * (EMB * EMB + EMB * OUT_DIM + OUT_DIM * OUT_DIM)
+
+
 def _fold(sd, p: str, conv: str, bn: str):
     """conv weight [Cout, Cin, 3, 3] and its BatchNorm -> ([Cout, 9, Cin] scaled, shift [Cout]); k = (kh*3 + kw)*Cin + c"""
     f32 = lambda k: sd[k].detach().to(torch.float32).cpu()
@@ -202,16 +213,18 @@ class Cnn14Engine:
         return out
 
 
-def conv3x3_relu(x: torch.Tensor, wt: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-    """relu(conv3x3(x) + bias) through `wise_conv3x3_relu_bf16`: x [B, T, F, Cin] bf16 (position-major), wt [Cout, 9*Cin]
-    bf16, bias [Cout] fp32 -> [B, T, F, Cout] bf16.  The building block of the engine, for parity tests."""
+def conv3x3_relu(x: torch.Tensor, wt: torch.Tensor, bias: torch.Tensor, pool: bool = False) -> torch.Tensor:
+    """relu(conv3x3(x) + bias), optionally followed by the fused 2x2 average pooling, through `wise_conv3x3_relu_bf16`:
+    x [B, T, F, Cin] bf16 (position-major), wt [Cout, 9*Cin] bf16, bias [Cout] fp32 -> [B, T, F, Cout] bf16 (or
+    [B, T//2, F//2, Cout]).  The building block of the engine, for parity tests."""
     B, T, F, Cin = x.shape
     Cout = wt.shape[0]
-    rows = (B * T * F + 127) // 128 * 128
+    To, Fo = (T // 2, F // 2) if pool else (T, F)
+    rows = (B * To * Fo + 255) // 256 * 256
     out = torch.empty(rows, Cout, dtype=torch.bfloat16, device=x.device)
     zeros = torch.zeros(64, dtype=torch.bfloat16, device=x.device)
     rc = _lib.lib().wise_conv3x3_relu_bf16(x.contiguous().data_ptr(), wt.contiguous().data_ptr(),
-                                          bias.contiguous().data_ptr(), zeros.data_ptr(), B, T, F, Cin, Cout,
+                                          bias.contiguous().data_ptr(), zeros.data_ptr(), B, T, F, Cin, Cout, int(pool),
                                           out.data_ptr(), _lib.stream_ptr())
     _lib.check(rc, "wise_conv3x3_relu_bf16")
-    return out[: B * T * F].reshape(B, T, F, Cout)
+    return out[: B * To * Fo].reshape(B, To, Fo, Cout)
