@@ -551,7 +551,51 @@ def main():
                                                    "launches_per_forward": int(hg_n // a_steps),
                                                    "ms_per_forward": round(hg_ms / a_steps, 3),
                                                    "share_of_forward": round(hg_ms / a_steps / (step_s * 1e3), 3)}}}
-        del heng, wav
+        del heng
+        # MS-CLAP 2022's audio encoder (PANNs Cnn14), same clips, bs=64 per GPU: convolutions as implicit GEMMs
+        from wise_amd.feature.cnn14 import Cnn14Engine, flops_per_clip, random_cnn14_state_dict
+
+        cb = 64
+        ceng = Cnn14Engine(random_cnn14_state_dict(0), max_batch=cb, max_samples=480000)
+        cwav = wav[:cb]
+
+        def cnn_step_serial(i):
+            hold["co"] = ceng.forward(cwav)
+
+        def cnn_step(i):
+            hold["cp"] = ceng.forward_pipelined(cwav)
+
+        for i in range(2):
+            cnn_step_serial(i)
+        c_steps = max(4, min(args.steps, 8))
+        cdt_serial = timed_region(cnn_step_serial, c_steps, world)
+        for i in range(2):
+            cnn_step(i)
+        torch.cuda.synchronize()
+        cdt2 = timed_region(cnn_step, c_steps, world)
+        assert abs(float(hold["co"].norm(dim=1).mean()) - 1.0) < 1e-3
+        assert torch.equal(hold["cp"].result(), hold["co"]), "Cnn14: in-flight and serial embeddings differ"
+        cprof = prof_pass(lib, cnn_step_serial, c_steps, c_steps * 40 + 8)
+        cg_ms, cg_n, cg_flop = cprof[0]
+        cfl = flops_per_clip(480000)
+        extra["clap_cnn14"] = {"value": round(world * cb * c_steps / cdt2, 1), "unit": "clips/s",
+                               "ms_per_step": round(cdt2 / c_steps * 1e3, 3), "steps": c_steps, "batches_in_flight": 2,
+                               "one_batch_at_a_time_clips_per_s": round(world * cb * c_steps / cdt_serial, 1),
+                               "config": {"workload": "MS-CLAP 2022 Cnn14 audio encoder + projection, 10-s clips (480000 "
+                                                      "samples @48 kHz), bs=64 per GPU", "dtype": "bf16",
+                                          "gflop_per_clip": round(cfl / 1e9, 2)},
+                               "tflops": round(cb * c_steps / cdt2 * cfl / 1e12, 2),
+                               "frac_of_bf16_peak": round(cb * c_steps / cdt2 * cfl / 1e12 / PEAK_BF16_TFLOPS, 4),
+                               "roofline": {"kernel": "the eleven 3x3 convolutions as implicit GEMMs + the head's GEMMs, one "
+                                                      "batch at a time (HIP events on the launch stream)",
+                                            "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_BF16_TFLOPS,
+                                            "achieved": round(cg_flop / max(cg_ms, 1e-9) / 1e9, 2),
+                                            "frac": round(cg_flop / max(cg_ms, 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                            "launches_per_forward": int(cg_n // c_steps),
+                                            "ms_per_forward": round(cg_ms / c_steps, 3),
+                                            "share_of_forward": round(cg_ms / c_steps / (cdt_serial / c_steps * 1e3), 3)}}
+        hold.pop("co", None); hold.pop("cp", None)
+        del ceng, cwav, wav
         torch.cuda.empty_cache()
         # cfg-4 (image half): ViT-L/14 at bs=256 per GPU; and ViT-H/14 (head width 80), the image tower of the reference's
         # default feature id (extract-features.py:192)

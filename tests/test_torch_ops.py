@@ -44,6 +44,13 @@ def test_shape_inference_on_meta_tensors():
     w = torch.ops.wise_hip.htsat_forward(torch.empty(5, 480000, device="meta"), torch.empty(8, device="meta"),
                                          torch.empty(8, device="meta"))
     assert w.shape == (5, 1024)
+    w = torch.ops.wise_hip.cnn14_forward(torch.empty(5, 480000, device="meta"), torch.empty(8, device="meta"),
+                                         torch.empty(8, device="meta"))
+    assert w.shape == (5, 1024)
+    y = torch.ops.wise_hip.conv3x3_relu(torch.empty(2, 9, 6, 64, dtype=torch.bfloat16, device="meta"),
+                                        torch.empty(128, 576, dtype=torch.bfloat16, device="meta"),
+                                        torch.empty(128, device="meta"), True)
+    assert y.shape == (2, 4, 3, 128) and y.dtype == torch.bfloat16
     c = torch.ops.wise_hip.clip_preprocess_u8(torch.empty(4, 3, 240, 320, dtype=torch.uint8, device="meta"), 224)
     assert c.shape == (4, 3, 224, 224) and c.dtype == torch.uint8
 
@@ -94,6 +101,14 @@ def test_feature_operators_equal_the_engines(golden_dir):
     heng = HtsatEngine(random_htsat_state_dict(0), max_batch=2, max_samples=192000)
     w = 0.1 * torch.randn(2, 192000, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
     assert torch.equal(torch.ops.wise_hip.htsat_forward(w, heng.wb, heng.pf), heng.forward(w))
+    from wise_amd.feature.cnn14 import Cnn14Engine, conv3x3_relu, random_cnn14_state_dict
+    ceng = Cnn14Engine(random_cnn14_state_dict(0), max_batch=2, max_samples=192000)
+    assert torch.equal(torch.ops.wise_hip.cnn14_forward(w, ceng.wb, ceng.pf), ceng.forward(w))
+    cx = torch.randn(2, 9, 6, 64, device="cuda").to(torch.bfloat16)
+    cw = (0.05 * torch.randn(128, 576, device="cuda")).to(torch.bfloat16)
+    cbias = torch.randn(128, device="cuda")
+    assert torch.equal(torch.ops.wise_hip.conv3x3_relu(cx, cw, cbias, True), conv3x3_relu(cx, cw, cbias, True))
+    assert torch.ops.wise_hip.conv3x3_relu(cx, cw, cbias, False).shape == (2, 9, 6, 128)
     tspec = text_spec_for("ViT-B-32", "openai")
     teng = TextEngine(tspec, random_text_state_dict(tspec, 0), max_batch=4)
     toks = torch.zeros(3, tspec.context, dtype=torch.int32, device="cuda")

@@ -43,6 +43,8 @@ SCHEMAS = {
     "text_forward": "(Tensor tokens, Tensor wb, Tensor pf, int[] config) -> Tensor",
     "xlmr_forward": "(Tensor tokens, Tensor wb, Tensor pf, int[] config) -> Tensor",
     "htsat_forward": "(Tensor wave, Tensor wb, Tensor pf) -> Tensor",
+    "cnn14_forward": "(Tensor wave, Tensor wb, Tensor pf) -> Tensor",
+    "conv3x3_relu": "(Tensor x, Tensor wt, Tensor bias, bool pool) -> Tensor",
     "clip_preprocess_u8": "(Tensor frames, int size) -> Tensor",
 }
 
@@ -246,6 +248,29 @@ def _htsat_forward(wave, wb, pf):
     return out
 
 
+def _cnn14_forward(wave, wb, pf):
+    lib = _lib.lib()
+    _dev(wave, wb, pf)
+    x = _f32c(wave)
+    B, N = x.shape
+    out = torch.empty(B, 1024, dtype=torch.float32, device=x.device)
+    need = lib.wise_cnn14_workspace_bytes(B, N)
+    if need == 0:
+        raise ValueError("wise_hip::cnn14_forward: bad shape (at least 32 STFT frames)")
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    _check(lib.wise_cnn14_forward(wb.data_ptr(), pf.data_ptr(), x.data_ptr(), B, N, out.data_ptr(), ws.data_ptr(),
+                                  ws.numel(), _lib.stream_ptr()), "wise_cnn14_forward")
+    return out
+
+
+def _conv3x3_relu(x, wt, bias, pool):
+    _dev(x, wt, bias)
+    if x.dim() != 4 or x.dtype != torch.bfloat16 or wt.dtype != torch.bfloat16 or wt.shape[1] != 9 * x.shape[3]:
+        raise ValueError("wise_hip::conv3x3_relu: x [B,T,F,Cin] bf16, wt [Cout, 9*Cin] bf16, bias [Cout] fp32")
+    from .feature.cnn14 import conv3x3_relu
+    return conv3x3_relu(x, wt, _f32c(bias), bool(pool))
+
+
 def _clip_preprocess_u8(frames, size):
     from .feature.preprocess import ClipPreprocessor
 
@@ -273,6 +298,9 @@ _IMPLS = {
     "text_forward": (_text_forward, lambda t, wb, pf, cfg: t.new_empty((t.shape[0], cfg[6]), dtype=torch.float32)),
     "xlmr_forward": (_xlmr_forward, lambda t, wb, pf, cfg: t.new_empty((t.shape[0], cfg[8]), dtype=torch.float32)),
     "htsat_forward": (_htsat_forward, lambda w, wb, pf: w.new_empty((w.shape[0], 1024), dtype=torch.float32)),
+    "cnn14_forward": (_cnn14_forward, lambda w, wb, pf: w.new_empty((w.shape[0], 1024), dtype=torch.float32)),
+    "conv3x3_relu": (_conv3x3_relu, lambda x, wt, b, pool: x.new_empty(
+        (x.shape[0], x.shape[1] // 2 if pool else x.shape[1], x.shape[2] // 2 if pool else x.shape[2], wt.shape[0]))),
     "clip_preprocess_u8": (_clip_preprocess_u8, lambda f, s: f.new_empty((f.shape[0], 3, s, s), dtype=torch.uint8)),
 }
 
