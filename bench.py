@@ -552,10 +552,10 @@ def main():
                                                    "ms_per_forward": round(hg_ms / a_steps, 3),
                                                    "share_of_forward": round(hg_ms / a_steps / (step_s * 1e3), 3)}}}
         del heng
-        # MS-CLAP 2022's audio encoder (PANNs Cnn14), same clips, bs=64 per GPU: convolutions as implicit GEMMs
+        # MS-CLAP 2022's audio encoder (PANNs Cnn14), same clips, bs=128 per GPU: convolutions as implicit GEMMs
         from wise_amd.feature.cnn14 import Cnn14Engine, flops_per_clip, random_cnn14_state_dict
 
-        cb = 64
+        cb = 128
         ceng = Cnn14Engine(random_cnn14_state_dict(0), max_batch=cb, max_samples=480000)
         cwav = wav[:cb]
 
@@ -582,7 +582,7 @@ def main():
                                "ms_per_step": round(cdt2 / c_steps * 1e3, 3), "steps": c_steps, "batches_in_flight": 2,
                                "one_batch_at_a_time_clips_per_s": round(world * cb * c_steps / cdt_serial, 1),
                                "config": {"workload": "MS-CLAP 2022 Cnn14 audio encoder + projection, 10-s clips (480000 "
-                                                      "samples @48 kHz), bs=64 per GPU", "dtype": "bf16",
+                                                      "samples @48 kHz), bs=128 per GPU", "dtype": "bf16",
                                           "gflop_per_clip": round(cfl / 1e9, 2)},
                                "tflops": round(cb * c_steps / cdt2 * cfl / 1e12, 2),
                                "frac_of_bf16_peak": round(cb * c_steps / cdt2 * cfl / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -34,7 +34,8 @@ def engine():
     (1, 8, 8, 64, 64, True), (3, 7, 5, 64, 128, True), (2, 21, 2, 128, 128, True), (2, 33, 16, 64, 64, True),
     (1, 2, 2, 128, 256, True),
     (1, 331, 128, 64, 256, False), (1, 331, 128, 64, 256, True),      # >= 160 tiles of 256 x 256: the ping-pong kernels
-    (2, 93, 4, 128, 512, True)])
+    (2, 93, 4, 128, 512, True),
+    (2, 257, 256, 64, 64, False), (2, 257, 256, 64, 64, True)])        # 64 channels, many cells: the 256 x 64 tile
 def test_conv3x3_building_block(B, T, Fq, cin, cout, pool):
     """the implicit-GEMM convolution alone against torch's conv2d on the same bf16-rounded operands: edges (zero
     padding at every border, rows past the last tile), both tile widths (64 and 128 output channels), the ping-pong

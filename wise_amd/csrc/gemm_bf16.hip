@@ -430,35 +430,41 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
 // ReLU, no shuffle, no LDS — and the full-resolution tensor is never written (block 1 of Cnn14 at 64 clips x 10 s:
 // 787 MB not written and not read back).  M counts window members (4 per output cell); out [B, T/2, F/2, Cout].
 // ------------------------------------------------------------------------------------------------
-template <int NTJ, bool POOL>
+// WMW = waves along the rows: 2 -> 128 x (32 NTJ) tile (waves 2 x 2), 4 -> 256 x (16 NTJ) (waves 4 x 1: a 64-channel
+// layer then gives every wave a 64 x 64 sub-tile — 0.5 fragment reads per MFMA instead of 0.75 for the 64 x 32 of the 2 x 2 form).
+template <int NTJ, bool POOL, int WMW = 2>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt,
                                                          const float* __restrict__ bias,
                                                          const bf16_t* __restrict__ zeros, int T, int F, int Cin, int M,
                                                          int Cout, bf16_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BNC = 32 * NTJ;                     // output channels per block
+    constexpr int WNW = 4 / WMW;
+    constexpr int BNC = WNW * 16 * NTJ;               // output channels per block
+    constexpr int BMR = WMW * 64;                     // rows per block
+    constexpr int TAB = BMR * BK * 2;                 // bytes of an A tile
     constexpr int TW = BNC * BK * 2;                  // bytes of a W tile
-    constexpr int SBC = TILE_BYTES + TW;              // bytes of a stage
+    constexpr int SBC = TAB + TW;                     // bytes of a stage
+    constexpr int RA = BMR / 32, RW = BNC / 32;       // 1-KiB staging rounds per wave: A, W
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNW, wn = wave % WNW;
     const int tiles_n = Cout / BNC;
     int tm, tn;
-    tile_coords((M + BM - 1) / BM, tiles_n, 8, &tm, &tn);
-    const int m0 = tm * BM, n0 = tn * BNC;
+    tile_coords((M + BMR - 1) / BMR, tiles_n, 8, &tm, &tn);
+    const int m0 = tm * BMR, n0 = tn * BNC;
     const int K = 9 * Cin, ck = Cin / BK, nk = 9 * ck;
 
-    // the four rows this lane stages: position, coordinates, element offset of its 16-byte chunk at tap (0, 0)
-    int pt[4], pf[4];
-    long long poff[4];
+    // the rows this lane stages: position, coordinates, element offset of its 16-byte chunk at tap (0, 0)
+    int pt[RA], pf[RA];
+    long long poff[RA];
     const int T2 = T >> 1, F2 = F >> 1;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < RA; ++t) {
         const int r = (t * 4 + wave) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (r & 7);
         if constexpr (POOL) {
             const int mem = (r >> 4) & 3;
-            const int q = tm * 32 + (r >> 6) * 16 + (r & 15);          // output cell of this row's window
+            const int q = tm * (BMR / 4) + (r >> 6) * 16 + (r & 15);   // output cell of this row's window
             const int qf = q / F2, f2 = q - qf * F2, b = qf / T2, t2 = qf - b * T2;
             const int tt = 2 * t2 + (mem >> 1), ff = 2 * f2 + (mem & 1);
             pf[t] = ff;
@@ -476,15 +482,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const bf16_t* __restric
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const long long shift = (long long)(dy * F + dx) * Cin + cc * BK;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < RA; ++t) {
             const bool in = (unsigned)(pt[t] + dy) < (unsigned)T && (unsigned)(pf[t] + dx) < (unsigned)F;
             glds16(in ? X + poff[t] + shift : zeros, dst + (t * 4 + wave) * 1024);
         }
 #pragma unroll
-        for (int t = 0; t < NTJ; ++t) {               // W tile: 32*NTJ rows of 128 bytes
+        for (int t = 0; t < RW; ++t) {                // W tile: BNC rows of 128 bytes
             const int r = (t * 4 + wave) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ (r & 7);
-            glds16(Wt + (size_t)(n0 + r) * K + (size_t)(tap * ck + cc) * BK + c * 8, dst + TILE_BYTES + (t * 4 + wave) * 1024);
+            glds16(Wt + (size_t)(n0 + r) * K + (size_t)(tap * ck + cc) * BK + c * 8, dst + TAB + (t * 4 + wave) * 1024);
         }
     };
 
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const bf16_t* __restric
             if (++cc == ck) { cc = 0; ++tap; }
         }
         const unsigned char* At = smem + cur * SBC;
-        const unsigned char* Bt = At + TILE_BYTES;
+        const unsigned char* Bt = At + TAB;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int chunk = s * 4 + (lane >> 4);
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const bf16_t* __restric
         }
     }
     if constexpr (POOL) {
-        const int q = tm * 32 + wm * 16 + (lane & 15);
+        const int q = tm * (BMR / 4) + wm * 16 + (lane & 15);
 #pragma unroll
         for (int j = 0; j < NTJ; ++j) {
             const int n = n0 + wn * (16 * NTJ) + j * 16 + (lane >> 4) * 4;
@@ -2255,6 +2261,11 @@ int conv3x3_bf16(const bf16_t* X, const bf16_t* Wt, const float* bias, const bf1
         const size_t lds = 2 * (TILE_BYTES + 128 * BK * 2);   // 64 KiB
         if (pool) conv_launch(conv3x3_kernel<4, true>, lds, tiles_m * (Cout / 128), 256, X, Wt, bias, zeros, T, F, Cin, (int)M, Cout, out, st);
         else conv_launch(conv3x3_kernel<4, false>, lds, tiles_m * (Cout / 128), 256, X, Wt, bias, zeros, T, F, Cin, (int)M, Cout, out, st);
+    } else if (g_conv_variant != 1 && M >= 256 * 512) {
+        // 64-channel steps (block 1 of Cnn14): 256 x 64 tiles, every wave a 64 x 64 sub-tile (tools/conv_bench.py)
+        const size_t lds = 2 * (2 * TILE_BYTES + 64 * BK * 2);    // 80 KiB: two blocks fill a CU's LDS exactly
+        if (pool) conv_launch(conv3x3_kernel<4, true, 4>, lds, tiles256 * (Cout / 64), 256, X, Wt, bias, zeros, T, F, Cin, (int)M, Cout, out, st);
+        else conv_launch(conv3x3_kernel<4, false, 4>, lds, tiles256 * (Cout / 64), 256, X, Wt, bias, zeros, T, F, Cin, (int)M, Cout, out, st);
     } else {
         const size_t lds = 2 * (TILE_BYTES + 64 * BK * 2);    // 48 KiB
         if (pool) conv_launch(conv3x3_kernel<2, true>, lds, tiles_m * (Cout / 64), 256, X, Wt, bias, zeros, T, F, Cin, (int)M, Cout, out, st);
