@@ -15,6 +15,10 @@ int gemm_bf16_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, 
 // out [B*(T/2)*(F/2), Cout], fused; zeros = 16 bytes of zeros on the device
 int conv3x3_bf16(const bf16_t* X, const bf16_t* Wt, const float* bias, const bf16_t* zeros, int B, int T, int F, int Cin,
                  int Cout, bool pool, bf16_t* out, hipStream_t st);
+// x[M,N] += A @ Wt^T + bias, then h = LN(x) (bf16) and, for post-LN blocks, x = LN(x): the residual GEMM of a block and the
+// LayerNorm behind it; skinny calls fuse the split-K reduction with the LayerNorm (one launch less, same bits)
+int gemm_resid_ln_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int ln_rows, int N, int K,
+                       float* x, const float* ln_w, const float* ln_b, float eps, bool post_ln, bf16_t* h, hipStream_t st);
 // hint for the tile heuristic: the caller is about to enqueue GEMMs on several streams that overlap in time
 // (host-side state; the library is single-threaded by contract)
 void gemm_set_overlapped(bool on);

@@ -744,17 +744,28 @@ int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int a
     const int M = batch * T, Mp = (M + 255) / 256 * 256;
     const int Mv = skinny ? M : Mp;
     int rc;
+    // rows the LayerNorms touch: all M of them (the image towers also feed rows M..Mp of h to the GEMMs, which they never
+    // wrote and whose results nobody reads)
+    if (L > 0 && (rc = layernorm_f32_bf16(x, bw.pf + bw.ln1_w, bw.pf + bw.ln1_b, M, W, eps, h, st))) return rc;
     for (int l = 0; l < L; ++l) {
         const bf16_t* lwb = bw.wb + bw.per_layer_b * l;
         const float* lpf = bw.pf + bw.per_layer_f * l;
-        if ((rc = layernorm_f32_bf16(x, lpf + bw.ln1_w, lpf + bw.ln1_b, M, W, eps, h, st))) return rc;
         if ((rc = gemm_bf16_rows(h, lwb + bw.in_proj, lpf + bw.in_b, Mp, Mv, 3 * W, W, 0, qkv, st))) return rc;
         if ((rc = attention_bf16(qkv, batch, T, H, h, st, causal, W / H))) return rc;
-        if ((rc = gemm_bf16_rows(h, lwb + bw.out_proj, lpf + bw.out_b, Mp, Mv, W, W, 3, x, st))) return rc;
-        if ((rc = layernorm_f32_bf16(x, lpf + bw.ln2_w, lpf + bw.ln2_b, M, W, eps, h, st))) return rc;
+        // x += out_proj(attention); h = ln_2(x)   (one launch behind the split-K kernel for a single text query)
+        if ((rc = gemm_resid_ln_rows(h, lwb + bw.out_proj, lpf + bw.out_b, Mp, Mv, M, W, W, x, lpf + bw.ln2_w, lpf + bw.ln2_b, eps,
+                                     false, h, st)))
+            return rc;
         // act: 0 QuickGELU, 1 erf GELU, 2 gelu_new (tanh) -> epilogue modes 1, 2, 5
         if ((rc = gemm_bf16_rows(h, lwb + bw.c_fc, lpf + bw.fc_b, Mp, Mv, F, W, act == 0 ? 1 : (act == 1 ? 2 : 5), a, st))) return rc;
-        if ((rc = gemm_bf16_rows(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, Mv, W, F, 3, x, st))) return rc;
+        if (l + 1 < L) {   // x += c_proj(...); h = ln_1 of the NEXT block
+            const float* npf = bw.pf + bw.per_layer_f * (l + 1);
+            if ((rc = gemm_resid_ln_rows(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, Mv, M, W, F, x, npf + bw.ln1_w, npf + bw.ln1_b, eps,
+                                         false, h, st)))
+                return rc;
+        } else if ((rc = gemm_bf16_rows(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, Mv, W, F, 3, x, st))) {
+            return rc;
+        }
     }
     return WISE_OK;
 }

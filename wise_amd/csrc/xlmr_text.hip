@@ -194,11 +194,11 @@ extern "C" int wise_xlmr_forward(const wise_xlmr_config* cfg, const uint16_t* wb
         const float* lp = pf + o.layer0_f + o.per_layer_f * l;
         if ((rc = gemm_bf16_rows(h, lw + o.qkv, lp + o.qkv_b, Mp, M, 3 * W, W, 0, qkv, st))) return rc;
         if ((rc = attention_bf16(qkv, batch, d.T, d.H, h, st, false, 64, lens))) return rc;
-        if ((rc = gemm_bf16_rows(h, lw + o.out, lp + o.out_b, Mp, M, W, W, 3, x, st))) return rc;
-        if ((rc = layernorm_f32_dual(x, lp + o.ln1_w, lp + o.ln1_b, M, W, eps, x, h, st))) return rc;
+        // x = LN(x + out(attention)) and x = LN(x + fc2(gelu(fc1 x))): the residual GEMM and the post-LN behind it as one call
+        // (a single query: split-K partials + ONE kernel for reduction, residual and LayerNorm)
+        if ((rc = gemm_resid_ln_rows(h, lw + o.out, lp + o.out_b, Mp, M, M, W, W, x, lp + o.ln1_w, lp + o.ln1_b, eps, true, h, st))) return rc;
         if ((rc = gemm_bf16_rows(h, lw + o.fc1, lp + o.fc1_b, Mp, M, d.F, W, 2, a, st))) return rc;
-        if ((rc = gemm_bf16_rows(a, lw + o.fc2, lp + o.fc2_b, Mp, M, W, d.F, 3, x, st))) return rc;
-        if ((rc = layernorm_f32_dual(x, lp + o.ln2_w, lp + o.ln2_b, M, W, eps, x, h, st))) return rc;
+        if ((rc = gemm_resid_ln_rows(a, lw + o.fc2, lp + o.fc2_b, Mp, M, M, W, d.F, x, lp + o.ln2_w, lp + o.ln2_b, eps, true, h, st))) return rc;
     }
     // mean over the sequence's own tokens -> MLP projection (no biases) -> L2 normalise
     const int Bp = (batch + 255) / 256 * 256;
