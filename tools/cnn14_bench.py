@@ -1,4 +1,4 @@
-"""clips/s of the Cnn14 forward (MS-CLAP 2022 audio encoder): python tools/cnn14_bench.py [batch] [samples]"""
+"""clips/s of the Cnn14 forward (MS-CLAP 2022 audio encoder): python tools/cnn14_bench.py [batch] [samples] [--serial-only]"""
 import sys
 import time
 from pathlib import Path
@@ -8,8 +8,10 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from wise_amd.feature.cnn14 import Cnn14Engine, flops_per_clip, random_cnn14_state_dict  # noqa: E402
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 480000
+SERIAL_ONLY = "--serial-only" in sys.argv        # (profiling: per-kernel durations without a second batch beside them)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(args[0]) if len(args) > 0 else 64
+N = int(args[1]) if len(args) > 1 else 480000
 
 eng = Cnn14Engine(random_cnn14_state_dict(0), max_batch=B, max_samples=N)
 w = 0.1 * torch.randn(B, N, device="cuda")
@@ -26,6 +28,8 @@ for rep in range(2):
     dt = (time.perf_counter() - t0) / n
     print(f"Cnn14 B={B} N={N}: {dt*1e3:.3f} ms/step  {B/dt:.1f} clips/s  {B/dt*fl/1e12:.1f} TFLOP/s ({fl/1e9:.1f} GFLOP per clip)", flush=True)
 ref = o.clone()
+if SERIAL_ONLY:
+    sys.exit(0)
 for rep in range(2):
     hs = [eng.forward_pipelined(w) for _ in range(2)]
     torch.cuda.synchronize()

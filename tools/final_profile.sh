@@ -32,6 +32,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   cp "$(find $OUT/${TAG}_pmc_${L}_htsat -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_pmc_${L}_htsat_counter_collection.csv
 done
 echo "HTSAT PMC passes done"
+# MS-CLAP 2022 Cnn14: per-kernel durations of whole forwards, one batch at a time (bs=128, 10-s clips)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_cnn14stats -o cnn -- python3 tools/cnn14_bench.py 128 480000 --serial-only > $OUT/${TAG}_cnn14.log 2>&1 || exit 1
+python3 tools/prof_top.py $OUT/${TAG}_cnn14stats/cnn_results.db 14 --csv $OUT/${TAG}_cnn14_kernel_stats.csv > $OUT/${TAG}_cnn14_kernel_stats.txt
+echo "Cnn14 stats done"
 # matrix-core utilisation of the GEMM launches: busy cycles of the MFMA pipes over the launch's cycles (own pass)
 timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_mfma -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --roofline-only > $OUT/${TAG}_pmc_mfma.log 2>&1 || exit 1
 cp "$(find $OUT/${TAG}_pmc_mfma -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_pmc_mfma_counter_collection.csv
