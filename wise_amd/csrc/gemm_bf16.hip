@@ -1988,6 +1988,7 @@ static int g_tile320 = 1;  // allow the 320x256 ping-pong tiling (wise_debug_set
 static int g_mlp96_resident = 1;  // (debug knob) 0: the staged mlp96_kernel
 static int g_overlapped = 0;  // the caller is running another stream's kernels beside this one (gemm_set_overlapped)
 static int g_overlap_policy = 0;  // (debug knob) tiles under overlap: 0 = as for a lone stream minus the 320-row tilings (the product), 1 = 128x128 only, 2 = 128x128 except the QKV-shaped launches, 3 = hint ignored
+static int g_splitk_policy = 0;  // (debug knob) skinny GEMMs: 0 = the product rule, 1 = split-K for the residual GEMMs only, 2 = never
 static int g_split_m = 1;  // split M between the ping-pong kernel and the 128x128 kernel (bit 29 of the knob: off)
   // 0: 2-stage BK=64 ; 1: ring BK=32 x4 (2 blocks/CU) ; 2: ring BK=64 x4 (1 block/CU) ; 3: ring BK=64 x3
 
@@ -2204,7 +2205,8 @@ int gemm_bf16_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, 
     WISE_CHECK_ARG(A && Wt && out, "gemm_bf16: null pointer");
     WISE_CHECK_ARG(M > 0 && M % BM == 0 && N > 0 && N % 4 == 0 && K > 0 && K % 32 == 0 && mode >= 0 && mode <= 6,
                    "gemm_bf16: M=%d must be a multiple of %d, N=%d of 4, K=%d of 32", M, BM, N, K);
-    if (g_gemm_variant == 0 && m_valid <= 128 && gemm_splitk(A, Wt, bias, M, m_valid, N, K, mode, out, st)) {
+    if (g_gemm_variant == 0 && m_valid <= 128 && g_splitk_policy != 2 && !(g_splitk_policy == 1 && mode != EPI_RESID) &&
+        gemm_splitk(A, Wt, bias, M, m_valid, N, K, mode, out, st)) {
         WISE_LAUNCH_CHECK("gemm_splitk_kernel");
         return WISE_OK;
     }
@@ -2219,7 +2221,7 @@ int gemm_resid_ln_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int
                        float* x, const float* ln_w, const float* ln_b, float eps, bool post_ln, bf16_t* h, hipStream_t st) {
     WISE_CHECK_ARG(A && Wt && x && ln_w && ln_b && h, "gemm_resid_ln: null pointer");
     // (ln_rows: the rows the LayerNorm covers — the caller's real rows; m_valid may include tile padding)
-    const int S = (g_gemm_variant == 0 && N > 128 && N <= 4096 && ln_rows == m_valid) ? splitk_slices(M, m_valid, N, K) : 0;
+    const int S = (g_gemm_variant == 0 && g_splitk_policy != 2 && N > 128 && N <= 4096 && ln_rows == m_valid) ? splitk_slices(M, m_valid, N, K) : 0;
     float* part = S ? splitk_scratch(st) : nullptr;
     if (part) {
         {
@@ -2429,7 +2431,8 @@ extern "C" int wise_debug_set_gemm_flags(int flags) {
     wise::g_mlp96_resident = (flags >> 7) & 1 ? 0 : 1;   // bit 7: the staged MLP kernel instead of the weight-resident one
     wise::g_overlap_policy = (flags >> 4) & 7;     // bits 4-6: tiles under overlap (0 lone-stream tiles, 1 = 128x128, 2 = mixed, 3 = hint ignored, 4/5/6 = 128x128 for the residual / fc1 / QKV launches only)
     wise::g_ablate = flags & 6;
-    wise::g_conv_variant = (flags >> 8) & 3;       // bits 8-9: convolution tile (0 by shape, 1 = 128-row tile, 2 = ping-pong)
+    wise::g_conv_variant = (flags >> 8) & 3;
+    wise::g_splitk_policy = (flags >> 10) & 3;     // bits 10-11: skinny GEMMs (0 product rule, 1 split-K for residual GEMMs only, 2 never)       // bits 8-9: convolution tile (0 by shape, 1 = 128-row tile, 2 = ping-pong)
     return 0;
 }
 
