@@ -412,6 +412,40 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
     }
 }
 
+// (b, t, f) of cell `base + local` of a [B][Tn][Fn] raster, for a wave-uniform `base` (a tile's first cell) and a small
+// per-lane `local` <= lmax.  The convolution kernels need the coordinates of every row a lane stages — up to 8 rows, two
+// integer divisions each, ~600 VALU instructions per lane in front of a main loop that is nine K-steps long in Cnn14's
+// first block.  Here the divisions are done once per wave on the tile's base; a lane adds its offset with a shift and one
+// conditional wrap (Fn a power of two and no more than one wrap of t within the tile: every Cnn14 layer but the last);
+// other geometries fall back to the per-lane divisions.
+struct CellBase {
+    int b, t, f, fshift;
+    bool fast;
+};
+__device__ __forceinline__ CellBase cell_base(int base, int Tn, int Fn, int lmax) {
+    CellBase cb;
+    const int q = base / Fn;
+    cb.f = base - q * Fn;
+    cb.b = q / Tn;
+    cb.t = q - cb.b * Tn;
+    cb.fshift = 31 - __clz(Fn);
+    cb.fast = (Fn & (Fn - 1)) == 0 && ((cb.f + lmax) >> cb.fshift) < Tn;
+    return cb;
+}
+__device__ __forceinline__ void cell_at(const CellBase& cb, int base, int local, int Tn, int Fn, int* b, int* t, int* f) {
+    if (cb.fast) {
+        const int x = cb.f + local;
+        int y = cb.t + (x >> cb.fshift), bb = cb.b;
+        if (y >= Tn) { y -= Tn; ++bb; }
+        *f = x & (Fn - 1); *t = y; *b = bb;
+    } else {
+        const int q = base + local, qf = q / Fn;
+        *f = q - qf * Fn;
+        *b = qf / Tn;
+        *t = qf - *b * Tn;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 3x3 convolution, stride 1, zero padding 1, over an NHWC bf16 image, as an implicit GEMM on the same 128-row tile:
 //   out[p, n] = relu( sum_{tap, c} X[p + dy(tap)*F + dx(tap), c] * Wt[n, tap*Cin + c] + bias[n] ),   p = (b*T + t)*F + f
@@ -459,24 +493,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const bf16_t* __restric
     int pt[RA], pf[RA];
     long long poff[RA];
     const int T2 = T >> 1, F2 = F >> 1;
+    const int base = POOL ? tm * (BMR / 4) : m0;      // first output cell / first cell of the tile (wave-uniform)
+    const CellBase cb = POOL ? cell_base(base, T2, F2, BMR / 4 - 1) : cell_base(base, T, F, BMR - 1);
 #pragma unroll
     for (int t = 0; t < RA; ++t) {
         const int r = (t * 4 + wave) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (r & 7);
         if constexpr (POOL) {
             const int mem = (r >> 4) & 3;
-            const int q = tm * (BMR / 4) + (r >> 6) * 16 + (r & 15);   // output cell of this row's window
-            const int qf = q / F2, f2 = q - qf * F2, b = qf / T2, t2 = qf - b * T2;
+            const int local = (r >> 6) * 16 + (r & 15);                // output cell of this row's window, within the tile
+            int b, t2, f2;
+            cell_at(cb, base, local, T2, F2, &b, &t2, &f2);
             const int tt = 2 * t2 + (mem >> 1), ff = 2 * f2 + (mem & 1);
             pf[t] = ff;
-            pt[t] = (4 * q < M) ? tt : -4;
+            pt[t] = (4 * (base + local) < M) ? tt : -4;
             poff[t] = ((long long)(b * T + tt) * F + ff) * Cin + c * 8;
         } else {
-            const int p = m0 + r;
-            const int q = p / F;
-            pf[t] = p - q * F;
-            pt[t] = (p < M) ? q % T : -4;             // rows past M: every tap is "outside"
-            poff[t] = (long long)p * Cin + c * 8;
+            int b, tt, ff;
+            cell_at(cb, base, r, T, F, &b, &tt, &ff);
+            pf[t] = ff;
+            pt[t] = (m0 + r < M) ? tt : -4;           // rows past M: every tap is "outside"
+            poff[t] = (long long)(m0 + r) * Cin + c * 8;
         }
     }
     auto stage = [&](int tap, int cc, unsigned char* dst) {
@@ -1715,24 +1752,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const bf16_t* __rest
     int pt[RA], pf[RA];
     long long poff[RA];
     const int T2 = T >> 1, F2 = F >> 1;
+    const int base = POOL ? tm * 64 : m0;
+    const CellBase cb = POOL ? cell_base(base, T2, F2, 63) : cell_base(base, T, F, BMB - 1);
 #pragma unroll
     for (int t = 0; t < RA; ++t) {
         const int r = (t * 8 + wave) * 16 + (lane >> 2);
         const int c = swz_chunk<BKT>(r, lane & 3);
         if constexpr (POOL) {
             const int i = (r >> 4) & 7, mem = i & 3;
-            const int q = tm * 64 + (r >> 7) * 32 + (i >> 2) * 16 + (r & 15);
-            const int qf = q / F2, f2 = q - qf * F2, b = qf / T2, t2 = qf - b * T2;
+            const int local = (r >> 7) * 32 + (i >> 2) * 16 + (r & 15);
+            int b, t2, f2;
+            cell_at(cb, base, local, T2, F2, &b, &t2, &f2);
             const int tt = 2 * t2 + (mem >> 1), ff = 2 * f2 + (mem & 1);
             pf[t] = ff;
-            pt[t] = (4 * q < M) ? tt : -4;
+            pt[t] = (4 * (base + local) < M) ? tt : -4;
             poff[t] = ((long long)(b * T + tt) * F + ff) * Cin + c * 8;
         } else {
-            const int p = m0 + r;
-            const int q = p / F;
-            pf[t] = p - q * F;
-            pt[t] = (p < M) ? q % T : -4;
-            poff[t] = (long long)p * Cin + c * 8;
+            int b, tt, ff;
+            cell_at(cb, base, r, T, F, &b, &tt, &ff);
+            pf[t] = ff;
+            pt[t] = (m0 + r < M) ? tt : -4;
+            poff[t] = (long long)(m0 + r) * Cin + c * 8;
         }
     }
     int tap = 0, cc = 0;                               // of the K-tile staged next
