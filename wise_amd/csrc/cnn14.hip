@@ -6,9 +6,11 @@
 //
 //   front end     htsat_frontend.hip's kernel (STFT power -> sparse mel -> dB -> folded bn0); the 2022 config differs
 //                 from the 2023 one only in the filterbank (fmax 14000), which the packer builds       fp32 [B, T, 64]
-//   conv_first    block 1's first convolution, 1 -> 64 channels: nine taps per output, VALU            bf16 NHWC
-//   conv3x3       the other eleven convolutions as implicit GEMMs on the matrix cores (gemm_bf16.hip:
-//                 no im2col buffer — a K-tile is 64 channels of one tap, gathered by the LDS-DMA);
+//   block 1       conv 1 (1 -> 64) + conv 2 (64 -> 64) + pooling in ONE kernel (conv_block1_kernel below): the 1.57 GB tensor
+//                 between the two convolutions (128 clips x 10 s) exists only as a 33 KiB image in LDS; conv 1 on the matrix
+//                 cores with split-bf16 operands, conv 2's weights resident in registers                  bf16 NHWC, pooled
+//   conv3x3       the other ten convolutions as implicit GEMMs on the matrix cores (gemm_bf16.hip:
+//                 no im2col buffer — a K-tile is 32 or 64 channels of one tap, gathered by the LDS-DMA);
 //                 BatchNorm folded into the weights and a bias by the packer, ReLU in the epilogue     bf16 NHWC
 //   avgpool2      2x2 average pooling (floor) after blocks 1-5: fused into the second convolution of the block (the tile's
 //                 rows are the members of pooling windows; see conv3x3_kernel), the unpooled tensor is never written
@@ -20,6 +22,8 @@
 // alternate; rows are padded to the 256-row tile (padding rows are written, never read as data).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "transformer.h"
 
@@ -30,47 +34,241 @@ constexpr int NBLK = 6, EMB = 2048, OUT = 1024, MIN_FRAMES = 32;
 constexpr int CH[NBLK] = {64, 128, 256, 512, 1024, 2048};
 
 // ------------------------------------------------------------------------------------------------
-// block 1, conv 1: 1 -> 64 channels.  A thread owns ONE group of 8 output channels (lane & 7) for the life of the
-// kernel — its 72 weights (BatchNorm scale folded) and 8 shifts stay in registers — and walks cells with a grid
-// stride; the eight threads of a cell write its 128 bytes together.  Nine input values per cell come from the log-mel
-// (cache hits: neighbouring cells share them).  Bound by the bf16 tensor it writes (787 MB at 64 clips x 10 s).
+// Block 1 as ONE kernel: conv 1 (1 -> 64), BatchNorm, ReLU, conv 2 (64 -> 64), BatchNorm, ReLU, 2x2 average pooling.
+//
+// Why: as separate kernels (a VALU first convolution + conv3x3_kernel<.., POOL> on its output; round-2 history, 0.60 + 1.25 ms at
+// 128 clips x 10 s) block 1 was 22 % of the forward and neither half was bound by arithmetic.  The first convolution was
+// bound by the 1.57 GB it WROTE — 2.5 TB/s sustained whether VALU or matrix cores computed it — and the second by staging that
+// tensor back in: nine taps x 32 KiB of A tile per 256 rows is 13.8 GB of L2 -> LDS traffic per launch, the chip's LDS-DMA
+// ceiling (K = 576 leaves nothing to amortise it over).  Here the tensor between the two convolutions exists only as a
+// 33 KiB image in LDS (1.27 ms for both; what bounds it now is latency per wave — two waves per SIMD, registers full):
+//   tile      one POOLED row g2 = (clip, t2): 32 pooling windows = 128 conv-2 outputs x 64 channels, four waves as 2 x 2
+//             (wm: 16 windows, wn: 32 channels), persistent over g2 with a grid stride;
+//   image     conv 1's output for the four input rows 2 t2 - 1 .. 2 t2 + 2 (conv 2's neighbourhood of the two rows it
+//             pools), 64 cells x 64 channels bf16 each, rows outside the clip zero (conv 2's padding).  Wave w builds row w:
+//             per 16 cells one MFMA per 16 channels with split-bf16 operands, K = 27 of 32: x_hi w_hi + x_lo w_hi + x_hi w_lo
+//             (fp32-grade products: the dropped term is 2^-16), the nine taps gathered from the log-mel by each lane;
+//   conv 2    its 64 x 576 weights live in REGISTERS for the life of the wave (36 fragments of the wave's 32 channels), so
+//             the nine-tap loop has no staging, no barrier and no LDS write: per tap 8 fragment reads of the image at rows
+//             shifted by the tap (a lane whose neighbour column falls outside the image takes a zero fragment) and 16 MFMAs;
+//   pooling   the four members of a window are the four row tiles of one lane (as in conv3x3_kernel<POOL>): three adds.
+// Two images per workgroup: the next tile's image is built while nothing waits on it, one barrier per tile.  A cell is
+// 128 B with its 16-byte chunks XOR-swizzled by (cell >> 1) & 7: conv 2 reads cells 2 l + const (stride two), eight
+// consecutive lanes hit eight different chunk positions.  The 72 fragment addresses of a tile are 8 per-lane bases (column
+// offset -1 .. 2 x k-half) plus compile-time row offsets: no address arithmetic and no masking inside the tap loop.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ mel /*[B,T,64]*/,
-                                                         const float* __restrict__ w /*[64][9]*/,
-                                                         const float* __restrict__ shift /*[64]*/, int T, long long cells,
-                                                         bf16_t* __restrict__ out /*[cells, 64]*/) {
-    const int g = threadIdx.x & 7;
-    float wr[8][9], sh[8];
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return (unsigned short)f32_to_bf16(v); }
+__device__ __forceinline__ float bf16_val(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+// the 8 k-slots of lane group kq (k = 8 kq .. 8 kq + 7) of the 27-deep operand [a(9), b(9), c(9)], zero beyond
+__device__ __forceinline__ bf16x8 slots27(const unsigned short (&a)[9], const unsigned short (&b)[9],
+                                          const unsigned short (&c)[9], int kq) {
+    unsigned short k[8];
+    if (kq == 0) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        sh[c] = shift[g * 8 + c];
+        for (int e = 0; e < 8; ++e) k[e] = a[e];
+    } else if (kq == 1) {
+        k[0] = a[8];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) wr[c][tap] = w[(g * 8 + c) * 9 + tap];
+        for (int e = 1; e < 8; ++e) k[e] = b[e - 1];
+    } else if (kq == 2) {
+        k[0] = b[7]; k[1] = b[8];
+#pragma unroll
+        for (int e = 2; e < 8; ++e) k[e] = c[e - 2];
+    } else {
+        k[0] = c[6]; k[1] = c[7]; k[2] = c[8];
+#pragma unroll
+        for (int e = 3; e < 8; ++e) k[e] = 0;
     }
-    const long long stride = (long long)gridDim.x * 32;
-    for (long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); p < cells; p += stride) {
-        const int f = (int)(p & 63);
-        const int t = (int)((p >> 6) % T);
-        float x[9];
+    uint4 u;
+    u.x = k[0] | ((unsigned)k[1] << 16); u.y = k[2] | ((unsigned)k[3] << 16);
+    u.z = k[4] | ((unsigned)k[5] << 16); u.w = k[6] | ((unsigned)k[7] << 16);
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+// one image: 4 input rows x 66 cells (columns -1 .. 64: the two border cells stay zero, conv 2's padding in f, so the
+// nine-tap loop needs no masking) x 64 channels bf16
+constexpr int B1_ROW = 66 * 128, B1_IMG = 4 * B1_ROW;
+constexpr int B1_MEL = 2 * B1_IMG + 4096;      // behind the images and conv 1's fragments: [2 buffers][4 waves][1 KiB] of log-mel rows
+
+// 16 bytes per lane from global memory straight into LDS (base wave-uniform, lane i lands at base + 16 i)
+__device__ __forceinline__ void b1_glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// byte offset of 16-byte chunk `chunk` of cell c (0 .. 65 = column c - 1) within an image row
+__device__ __forceinline__ int b1_cell(int c, int chunk) { return c * 128 + ((chunk ^ ((c >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256, 2) void conv_block1_kernel(const float* __restrict__ mel /*[B,T,64]*/,
+                                                             const float* __restrict__ w0 /*[64][9]*/,
+                                                             const float* __restrict__ s0 /*[64]*/,
+                                                             const bf16_t* __restrict__ Wt /*[64][9*64]*/,
+                                                             const float* __restrict__ bias2 /*[64]*/, int T, int rows2,
+                                                             bf16_t* __restrict__ out /*[rows2*32, 64]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // two images
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, kq = lane >> 4;
+    const int T2 = T >> 1;
+
+    // conv 2: this wave's 32 channels x 576, as MFMA A-operand fragments, in registers
+    bf16x8 wreg[9][2][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                wreg[tap][sk][j] = *reinterpret_cast<const bf16x8*>(Wt + (size_t)(wn * 32 + j * 16 + l15) * 576 + tap * 64 +
+                                                                    sk * 32 + kq * 8);
+    // conv 1: channel j*16 + l15, operand [w_hi, w_hi, w_lo] (pairs with [x_hi, x_lo, x_hi]); the four fragments are the
+    // same for every wave and are parked in LDS behind the images (registers are full of conv 2's weights)
+    bf16x8* wf0s = reinterpret_cast<bf16x8*>(smem + 2 * B1_IMG);
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned short hi[9], lo[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float v = w0[(j * 16 + l15) * 9 + tap];
+                hi[tap] = bf16_bits(v);
+                lo[tap] = bf16_bits(v - bf16_val(hi[tap]));
+            }
+            wf0s[j * 64 + lane] = slots27(hi, hi, lo, kq);
+        }
+    }
+    __syncthreads();
+
+    // The three log-mel rows image row `wave` of tile g2 needs (t_in - 1 .. t_in + 1, clamped into the clip: rows outside
+    // it are masked where they are used), by LDS-DMA into the wave's own 1 KiB: requested a whole tile ahead, so the
+    // gather below reads LDS instead of waiting ~1.5 us on L2 four times per tile.
+    auto fetch_mel = [&](int g2, int buf) {
+        const int b = g2 / T2, t2 = g2 - b * T2;
+        int t = 2 * t2 - 2 + wave + min(lane >> 4, 2);
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        b1_glds16(mel + ((size_t)b * T + t) * 64 + (lane & 15) * 4, smem + B1_MEL + (buf * 4 + wave) * 1024);
+    };
+    // image row `wave` of tile g2: conv 1 + BatchNorm + ReLU of input row 2 t2 - 1 + wave, 64 cells x 64 channels
+    auto build_image = [&](int g2, unsigned char* img, int buf) {
+        const int b = g2 / T2, t2 = g2 - b * T2;
+        const int t_in = 2 * t2 - 1 + wave;
+        const bool row_in = (unsigned)t_in < (unsigned)T;          // wave-uniform
+        const float* mrow = reinterpret_cast<const float*>(smem + B1_MEL + (buf * 4 + wave) * 1024) + 64;   // row t_in
+        unsigned char* irow = img + wave * B1_ROW;
+        bf16x8 wf0[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf0[j] = wf0s[j * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = u * 16 + l15;
+            bf16x8 af0 = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+            if (row_in) {
+                unsigned short xh[9], xl[9];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                    const bool in = (unsigned)(t_in + dy) < (unsigned)T && (unsigned)(f + dx) < 64u;
+                    const float v = in ? mrow[dy * 64 + f + dx] : 0.f;
+                    xh[tap] = bf16_bits(v);
+                    xl[tap] = bf16_bits(v - bf16_val(xh[tap]));
+                }
+                af0 = slots27(xh, xl, xh, kq);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint2 pk = make_uint2(0u, 0u);
+                if (row_in) {
+                    const float4 sh = *reinterpret_cast<const float4*>(s0 + j * 16 + kq * 4);
+                    const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[j], af0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    pk.x = pack_bf16x2(fmaxf(a[0] + sh.x, 0.f), fmaxf(a[1] + sh.y, 0.f));
+                    pk.y = pack_bf16x2(fmaxf(a[2] + sh.z, 0.f), fmaxf(a[3] + sh.w, 0.f));
+                }
+                // channels j*16 + kq*4 .. +3 of column f (cell f + 1): chunk j*2 + (kq >> 1), second half of it when kq is odd
+                *reinterpret_cast<uint2*>(irow + b1_cell(f + 1, j * 2 + (kq >> 1)) + (kq & 1) * 8) = pk;
+            }
+        }
+    };
+
+    // the border cells of both images: zero once, never written again
+    if (threadIdx.x < 128) {
+        const int im = threadIdx.x >> 6, sl = (threadIdx.x >> 4) & 3, side = (threadIdx.x >> 3) & 1, ch = threadIdx.x & 7;
+        *reinterpret_cast<uint4*>(smem + im * B1_IMG + sl * B1_ROW + (side ? 65 : 0) * 128 + ch * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // fragment addresses of the tap loop: column 2 f2 + e (e = -1 .. 2) -> cell 2 f2 + e + 1, k-half sk
+    // (the second k-half is chunk 4 + kq = kq ^ 4: the same address with bit 6 flipped)
+    int abase[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) abase[e] = b1_cell(2 * (wm * 16 + l15) + e, kq);
+    int g2 = blockIdx.x, cur = 0;
+    if (g2 < rows2) {
+        fetch_mel(g2, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        build_image(g2, smem, 0);
+    }
+    __syncthreads();
+    // A tile's 16 bytes per lane leave for HBM at the top of the NEXT iteration: the wait in front of build_image (vmcnt
+    // counts stores too) then finds them a whole tap loop old instead of stalling on stores it has just issued.  Until
+    // then they sit in the wave's own log-mel buffer of the finished tile (consumed when that tile's image was built, refilled
+    // only by the fetch that follows the flush), each lane in its own 16 bytes — registers are full.
+    auto flush = [&](int g_done, int buf) {
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + B1_MEL + (buf * 4 + wave) * 1024 + lane * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the next fetch's LDS-DMA may land on it
+        bf16_t* o = out + ((size_t)g_done * 32 + wm * 16 + l15) * 64 + wn * 32 + kq * 4;
+        *reinterpret_cast<uint2*>(o) = make_uint2(v.x, v.y);
+        *reinterpret_cast<uint2*>(o + 16) = make_uint2(v.z, v.w);
+    };
+    const int g_first = blockIdx.x;
+    for (; g2 < rows2; g2 += gridDim.x) {
+        const unsigned char* img = smem + cur * B1_IMG;
+        const int nx = g2 + gridDim.x;
+        if (g2 != g_first) flush(g2 - gridDim.x, cur ^ 1);
+        if (nx < rows2) fetch_mel(nx, cur ^ 1);
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const bool in = (unsigned)(t + dy) < (unsigned)T && (unsigned)(f + dx) < 64u;
-            x[tap] = in ? mel[p + dy * 64 + dx] : 0.f;
-        }
-        float v[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float a = 0.f;
+            for (int sk = 0; sk < 2; ++sk) {
+                bf16x8 af[4];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) a = fmaf(x[tap], wr[c][tap], a);
-            v[c] = fmaxf(a + sh[c], 0.f);
+                for (int i = 0; i < 4; ++i)        // member i of window wm*16 + l15: input cell (2 t2 + (i >> 1), 2 f2 + (i & 1))
+                    af[i] = *reinterpret_cast<const bf16x8*>(img + (1 + (i >> 1) + dy) * B1_ROW + (abase[(i & 1) + dx + 1] ^ (sk << 6)));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[tap][sk][j], af[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of later steps where they are: registers are full
+            }
         }
-        uint4 pk;
-        pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
-        pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(out + p * 64 + g * 8) = pk;
+        {
+            uint4 pk;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 bj = *reinterpret_cast<const float4*>(bias2 + wn * 32 + j * 16 + kq * 4);
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v0 += fmaxf(acc[i][j][0] + bj.x, 0.f); v1 += fmaxf(acc[i][j][1] + bj.y, 0.f);
+                    v2 += fmaxf(acc[i][j][2] + bj.z, 0.f); v3 += fmaxf(acc[i][j][3] + bj.w, 0.f);
+                }
+                (j ? pk.z : pk.x) = pack_bf16x2(0.25f * v0, 0.25f * v1);
+                (j ? pk.w : pk.y) = pack_bf16x2(0.25f * v2, 0.25f * v3);
+            }
+            *reinterpret_cast<uint4*>(smem + B1_MEL + (cur * 4 + wave) * 1024 + lane * 16) = pk;   // this lane's own slot
+        }
+        if (nx < rows2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's log-mel rows of the next tile have landed
+            build_image(nx, smem + (cur ^ 1) * B1_IMG, cur ^ 1);
+        }
+        __syncthreads();      // the next image is complete; every wave is done with the current one
+        cur ^= 1;
     }
+    if (g2 != g_first) flush(g2 - gridDim.x, cur ^ 1);   // the last tile of this workgroup
 }
 
 __device__ __forceinline__ void unpack8(const uint4 v, float* f) {
@@ -149,12 +347,14 @@ static Ws workspace(int B, int samples) {
     Ws w{};
     w.T = samples / HOP + 1;
     const size_t Bp = (size_t)(B + 127) / 128 * 128;
-    const size_t rows1 = ((size_t)B * w.T * 64 + 255) / 256 * 256;     // block 1 holds the largest tensors (rows padded to the 256-row tile)
+    // the largest tensor that reaches HBM is block 2's first convolution: B x T/2 x 32 cells x 128 channels (block 1's
+    // unpooled tensors stay on chip); rows padded to the 256-row tile
+    const size_t rows2 = ((size_t)B * (w.T / 2) * 32 + 255) / 256 * 256;
     size_t off = 0;
     w.zeros = off; off += 256;
     w.mel = off; off += up256((size_t)B * w.T * 64 * 4);
-    w.a = off; off += up256(rows1 * 64 * 2);
-    w.b = off; off += up256(rows1 * 64 * 2);
+    w.a = off; off += up256(rows2 * 128 * 2);
+    w.b = off; off += up256(rows2 * 128 * 2);
     w.lat = off; off += up256(Bp * EMB * 2);
     w.h = off; off += up256(Bp * EMB * 2);
     w.e = off; off += up256(Bp * OUT * 4);
@@ -187,18 +387,23 @@ static int forward(const bf16_t* wb, const float* pf, const float* wave, int B, 
     if ((rc = htsat::frontend(wave, B, samples, T, pf + o.hann, pf + o.mel_start, pf + o.mel_len, pf + o.mel_wt,
                               pf + o.bn_scale, pf + o.bn_shift, mel, st)))
         return rc;
-    {
-        const long long cells = (long long)B * T * 64;
-        const long long want = (cells + 31) / 32;
-        hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)(want < 256 * 16 ? want : 256 * 16)), dim3(256), 0, st, mel,
-                           pf + o.c0_w, pf + o.c0_b, T, cells, cur);
-        WISE_LAUNCH_CHECK("cnn14 conv_first_kernel");
+    {   // block 1: both convolutions and the pooling in one kernel (the tensor between them never leaves the CU)
+        const int rows2 = B * (T / 2);
+        const size_t lds = B1_MEL + 8192;        // two images + conv 1's four weight fragments + the log-mel rows in flight
+        static std::once_flag attr_b1;
+        std::call_once(attr_b1, [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block1_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
+        hipLaunchKernelGGL(conv_block1_kernel, dim3(rows2 < 512 ? rows2 : 512), dim3(256), lds, st, mel, pf + o.c0_w, pf + o.c0_b,
+                           wb + o.cw[0][1], pf + o.cb[0][1], T, rows2, cur);
+        WISE_LAUNCH_CHECK("cnn14 conv_block1_kernel");
+        T /= 2; F /= 2;
     }
-    for (int i = 0; i < NBLK; ++i) {
-        const int cin = i ? CH[i - 1] : 1, cout = CH[i];
+    for (int i = 1; i < NBLK; ++i) {
+        const int cin = CH[i - 1], cout = CH[i];
         for (int j = 0; j < 2; ++j) {
-            if (i == 0 && j == 0) continue;
-            // the block's second convolution carries the 2x2 average pooling that follows it (blocks 1-5)
+            // the block's second convolution carries the 2x2 average pooling that follows it (blocks 2-5)
             if ((rc = conv3x3_bf16(cur, wb + o.cw[i][j], pf + o.cb[i][j], zeros, B, T, F, j ? cout : cin, cout,
                                    j == 1 && i < NBLK - 1, nxt, st)))
                 return rc;
