@@ -228,22 +228,26 @@ __global__ __launch_bounds__(256, 2) void conv_block1_kernel(const float* __rest
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        // 18 steps (tap, k-half), the A fragments of step n + 1 requested before the MFMAs of step n
+        auto load_af = [&](int step, bf16x8 (&af)[4]) {
+            const int tap = step >> 1, sk = step & 1;
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
-            for (int sk = 0; sk < 2; ++sk) {
-                bf16x8 af[4];
+            for (int i = 0; i < 4; ++i)            // member i of window wm*16 + l15: input cell (2 t2 + (i >> 1), 2 f2 + (i & 1))
+                af[i] = *reinterpret_cast<const bf16x8*>(img + (1 + (i >> 1) + dy) * B1_ROW + (abase[(i & 1) + dx + 1] ^ (sk << 6)));
+        };
+        bf16x8 afa[4], afb[4];
+        load_af(0, afa);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)        // member i of window wm*16 + l15: input cell (2 t2 + (i >> 1), 2 f2 + (i & 1))
-                    af[i] = *reinterpret_cast<const bf16x8*>(img + (1 + (i >> 1) + dy) * B1_ROW + (abase[(i & 1) + dx + 1] ^ (sk << 6)));
+        for (int step = 0; step < 18; ++step) {
+            const int tap = step >> 1, sk = step & 1;
+            if (step + 1 < 18) { if (step & 1) load_af(step + 1, afa); else load_af(step + 1, afb); }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[tap][sk][j], af[i], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of later steps where they are: registers are full
-            }
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[tap][sk][j], (step & 1) ? afb[i] : afa[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // keep later steps' reads where they are: registers are full
         }
         {
             uint4 pk;
