@@ -8,6 +8,9 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from wise_amd.feature.cnn14 import Cnn14Engine, flops_per_clip, random_cnn14_state_dict  # noqa: E402
 
+import os
+if any(a.startswith("--ablate=") for a in sys.argv):
+    os.environ.setdefault("WISE_AMD_DEBUG_LIB", "1")
 SERIAL_ONLY = "--serial-only" in sys.argv        # (profiling: per-kernel durations without a second batch beside them)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 B = int(args[0]) if len(args) > 0 else 64
@@ -28,6 +31,20 @@ for rep in range(2):
     dt = (time.perf_counter() - t0) / n
     print(f"Cnn14 B={B} N={N}: {dt*1e3:.3f} ms/step  {B/dt:.1f} clips/s  {B/dt*fl/1e12:.1f} TFLOP/s ({fl/1e9:.1f} GFLOP per clip)", flush=True)
 ref = o.clone()
+ABL = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--ablate=")]   # timing-only instantiations of block 1 (debug library)
+for ab in ABL:
+    from wise_amd import _lib
+    _lib.lib().wise_debug_set_cnn14(ab)
+    for _ in range(2):
+        eng.forward(w)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        eng.forward(w)
+    torch.cuda.synchronize()
+    print(f"block-1 ablation {ab}: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms/step", flush=True)
+if ABL:
+    sys.exit(0)
 if SERIAL_ONLY:
     sys.exit(0)
 for rep in range(2):

@@ -89,6 +89,9 @@ __device__ __forceinline__ bf16x8 slots27(const unsigned short (&a)[9], const un
 // one image: 4 input rows x 66 cells (columns -1 .. 64: the two border cells stay zero, conv 2's padding in f, so the
 // nine-tap loop needs no masking) x 64 channels bf16
 constexpr int B1_ROW = 66 * 128, B1_IMG = 4 * B1_ROW;
+#ifdef WISE_DEBUG_KNOBS
+static int g_b1_ablate = 0;   // host-side: which timing-only instantiation of block 1 to launch (wise_debug_set_cnn14)
+#endif
 constexpr int B1_MEL = 2 * B1_IMG + 4096;      // behind the images and conv 1's fragments: [2 buffers][4 waves][1 KiB] of log-mel rows
 
 // 16 bytes per lane from global memory straight into LDS (base wave-uniform, lane i lands at base + 16 i)
@@ -100,6 +103,8 @@ __device__ __forceinline__ void b1_glds16(const void* gsrc, void* lds_dst) {
 // byte offset of 16-byte chunk `chunk` of cell c (0 .. 65 = column c - 1) within an image row
 __device__ __forceinline__ int b1_cell(int c, int chunk) { return c * 128 + ((chunk ^ ((c >> 1) & 7)) << 4); }
 
+// ABL (timing-only instantiations, reachable from the debug library alone): 1 = images built once per workgroup, 2 = no tap loop
+template <int ABL>
 __global__ __launch_bounds__(256, 2) void conv_block1_kernel(const float* __restrict__ mel /*[B,T,64]*/,
                                                              const float* __restrict__ w0 /*[64][9]*/,
                                                              const float* __restrict__ s0 /*[64]*/,
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_block1_kernel(const float* __rest
         bf16x8 afa[4], afb[4];
         load_af(0, afa);
 #pragma unroll
-        for (int step = 0; step < 18; ++step) {
+        for (int step = 0; step < (ABL == 2 ? 0 : 18); ++step) {
             const int tap = step >> 1, sk = step & 1;
             if (step + 1 < 18) { if (step & 1) load_af(step + 1, afa); else load_af(step + 1, afb); }
 #pragma unroll
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_block1_kernel(const float* __rest
             }
             *reinterpret_cast<uint4*>(smem + B1_MEL + (cur * 4 + wave) * 1024 + lane * 16) = pk;   // this lane's own slot
         }
-        if (nx < rows2) {
+        if (nx < rows2 && ABL != 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's log-mel rows of the next tile have landed
             build_image(nx, smem + (cur ^ 1) * B1_IMG, cur ^ 1);
         }
@@ -396,10 +401,19 @@ static int forward(const bf16_t* wb, const float* pf, const float* wave, int B, 
         const size_t lds = B1_MEL + 8192;        // two images + conv 1's four weight fragments + the log-mel rows in flight
         static std::once_flag attr_b1;
         std::call_once(attr_b1, [&] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block1_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block1_kernel<0>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#ifdef WISE_DEBUG_KNOBS
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
         });
-        hipLaunchKernelGGL(conv_block1_kernel, dim3(rows2 < 512 ? rows2 : 512), dim3(256), lds, st, mel, pf + o.c0_w, pf + o.c0_b,
+        auto kern = conv_block1_kernel<0>;
+#ifdef WISE_DEBUG_KNOBS
+        if (g_b1_ablate == 1) kern = conv_block1_kernel<1>;
+        if (g_b1_ablate == 2) kern = conv_block1_kernel<2>;
+#endif
+        hipLaunchKernelGGL(kern, dim3(rows2 < 512 ? rows2 : 512), dim3(256), lds, st, mel, pf + o.c0_w, pf + o.c0_b,
                            wb + o.cw[0][1], pf + o.cb[0][1], T, rows2, cur);
         WISE_LAUNCH_CHECK("cnn14 conv_block1_kernel");
         T /= 2; F /= 2;
@@ -450,6 +464,13 @@ extern "C" int wise_cnn14_forward(const uint16_t* wb, const float* pf, const flo
     return cnn14::forward(wb, pf, wave, batch, samples, out, reinterpret_cast<unsigned char*>(workspace),
                           (hipStream_t)stream);
 }
+
+#ifdef WISE_DEBUG_KNOBS
+extern "C" int wise_debug_set_cnn14(int block1_ablate) {
+    wise::cnn14::g_b1_ablate = block1_ablate;
+    return 0;
+}
+#endif
 
 // parity taps of the last forward in this workspace: 0 = log-mel + bn0 fp32 [B*T*64], 1 = pooled latent bf16 [B*2048],
 // 2 = fc1 output ('embedding') bf16 [B*2048]
