@@ -50,6 +50,16 @@ q1 = X[:1] + 0.01; q32 = X[100:132] + 0.01
 victims["flat top-10, nq=1"] = lambda: torch.cat([t.double().flatten() for t in idx.search_device(q1, 10)])
 victims["flat top-10, nq=32"] = lambda: torch.cat([t.double().flatten() for t in idx.search_device(q32, 10)])
 
+from wise_amd.feature.cnn14 import Cnn14Engine, random_cnn14_state_dict
+cnn = Cnn14Engine(random_cnn14_state_dict(0), max_batch=16, max_samples=480000)
+victims["Cnn14 forward, 16 clips"] = lambda: cnn.forward(wav).clone()
+from wise_amd.feature.clap_bert import CLAP_BERT_SPEC, pack_clap_bert_weights, random_clap_bert_state_dict
+from wise_amd.feature.xlmr_text import XlmrTextEngine
+bert = XlmrTextEngine(CLAP_BERT_SPEC, random_clap_bert_state_dict(CLAP_BERT_SPEC, 0), max_batch=4, pack=pack_clap_bert_weights)
+bert.graph_max_batch = 0          # direct launches on the current stream (the split-K + fused reduce/LayerNorm kernels)
+btok = torch.zeros(1, 100, dtype=torch.int32, device="cuda"); btok[:, 0] = 101; btok[:, 1:12] = 2000; btok[:, 12] = 102
+victims["CLAP 2022 BERT, 1 query"] = lambda: bert.forward(btok).clone()
+
 bad_total = 0
 for vname, vf in victims.items():
     solo = vf(); torch.cuda.synchronize()
