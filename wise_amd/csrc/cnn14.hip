@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 #include "transformer.h"
@@ -41,21 +42,27 @@ constexpr int CH[NBLK] = {64, 128, 256, 512, 1024, 2048};
 // bound by the 1.57 GB it WROTE — 2.5 TB/s sustained whether VALU or matrix cores computed it — and the second by staging that
 // tensor back in: nine taps x 32 KiB of A tile per 256 rows is 13.8 GB of L2 -> LDS traffic per launch, the chip's LDS-DMA
 // ceiling (K = 576 leaves nothing to amortise it over).  Here the tensor between the two convolutions exists only as a
-// 33 KiB image in LDS (1.27 ms for both; what bounds it now is latency per wave — two waves per SIMD, registers full):
+// ring of image rows in LDS (0.94 ms for both; what bounds it now is latency per wave — two waves per SIMD, registers full):
 //   tile      one POOLED row g2 = (clip, t2): 32 pooling windows = 128 conv-2 outputs x 64 channels, four waves as 2 x 2
-//             (wm: 16 windows, wn: 32 channels), persistent over g2 with a grid stride;
+//             (wm: 16 windows, wn: 32 channels); a workgroup owns a contiguous RUN of pooled rows and walks it in order;
 //   image     conv 1's output for the four input rows 2 t2 - 1 .. 2 t2 + 2 (conv 2's neighbourhood of the two rows it
-//             pools), 64 cells x 64 channels bf16 each, rows outside the clip zero (conv 2's padding).  Wave w builds row w:
-//             per 16 cells one MFMA per 16 channels with split-bf16 operands, K = 27 of 32: x_hi w_hi + x_lo w_hi + x_hi w_lo
-//             (fp32-grade products: the dropped term is 2^-16), the nine taps gathered from the log-mel by each lane;
+//             pools), 64 cells x 64 channels bf16 each, rows outside the clip zero (conv 2's padding).  Consecutive tiles of
+//             a clip share two of their four rows, so the rows live in a RING of six slots (slot = (row + 1) mod 6): a tile
+//             reads four and, meanwhile, the two rows the next tile adds are built into the other two (waves 0, 1 one row,
+//             waves 2, 3 the other, half a row each) — every conv-1 row is computed once (a first form with a fresh four-row
+//             image per tile built each row twice: 1.21 -> 0.94 ms).  A run's first tile and every clip's first tile build
+//             all four rows.  Per 16 cells one MFMA per 16 channels with split-bf16 operands, K = 27 of 32 = x_hi w_hi +
+//             x_lo w_hi + x_hi w_lo (fp32-grade products: the dropped term is 2^-16), the nine taps gathered by each lane
+//             from log-mel rows that arrived by LDS-DMA during the tap loop;
 //   conv 2    its 64 x 576 weights live in REGISTERS for the life of the wave (36 fragments of the wave's 32 channels), so
 //             the nine-tap loop has no staging, no barrier and no LDS write: per tap 8 fragment reads of the image at rows
-//             shifted by the tap (a lane whose neighbour column falls outside the image takes a zero fragment) and 16 MFMAs;
+//             shifted by the tap and 16 MFMAs; the ring position t2 mod 3 is a compile-time parameter of the loop (three
+//             copies), so every read is a per-lane base + an immediate;
 //   pooling   the four members of a window are the four row tiles of one lane (as in conv3x3_kernel<POOL>): three adds.
-// Two images per workgroup: the next tile's image is built while nothing waits on it, one barrier per tile.  A cell is
-// 128 B with its 16-byte chunks XOR-swizzled by (cell >> 1) & 7: conv 2 reads cells 2 l + const (stride two), eight
-// consecutive lanes hit eight different chunk positions.  The 72 fragment addresses of a tile are 8 per-lane bases (column
-// offset -1 .. 2 x k-half) plus compile-time row offsets: no address arithmetic and no masking inside the tap loop.
+// One barrier per tile.  A cell is 128 B with its 16-byte chunks XOR-swizzled by (cell >> 1) & 7: conv 2 reads cells
+// 2 l + const (stride two), eight consecutive lanes hit eight different chunk positions.  The image has zero border
+// columns (cells 0 and 65), so the tap loop needs no masking; its 72 fragment addresses are 4 per-lane bases (column
+// offset -1 .. 2) plus compile-time row offsets.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned short bf16_bits(float v) { return (unsigned short)f32_to_bf16(v); }
 __device__ __forceinline__ float bf16_val(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
@@ -88,11 +95,11 @@ __device__ __forceinline__ bf16x8 slots27(const unsigned short (&a)[9], const un
 
 // one image: 4 input rows x 66 cells (columns -1 .. 64: the two border cells stay zero, conv 2's padding in f, so the
 // nine-tap loop needs no masking) x 64 channels bf16
-constexpr int B1_ROW = 66 * 128, B1_IMG = 4 * B1_ROW;
+constexpr int B1_ROW = 66 * 128, B1_IMG = 6 * B1_ROW;   // a ring of six rows (four read by a tile, two being built)
 #ifdef WISE_DEBUG_KNOBS
 static int g_b1_ablate = 0;   // host-side: which timing-only instantiation of block 1 to launch (wise_debug_set_cnn14)
 #endif
-constexpr int B1_MEL = 2 * B1_IMG + 4096;      // behind the images and conv 1's fragments: [2 buffers][4 waves][1 KiB] of log-mel rows
+constexpr int B1_MEL = B1_IMG + 4096;          // behind the ring and conv 1's fragments: [2 buffers][4 waves][1 KiB] of log-mel rows
 
 // 16 bytes per lane from global memory straight into LDS (base wave-uniform, lane i lands at base + 16 i)
 __device__ __forceinline__ void b1_glds16(const void* gsrc, void* lds_dst) {
@@ -110,8 +117,8 @@ __global__ __launch_bounds__(256, 2) void conv_block1_kernel(const float* __rest
                                                              const float* __restrict__ s0 /*[64]*/,
                                                              const bf16_t* __restrict__ Wt /*[64][9*64]*/,
                                                              const float* __restrict__ bias2 /*[64]*/, int T, int rows2,
-                                                             bf16_t* __restrict__ out /*[rows2*32, 64]*/) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // two images
+                                                             int chunk, bf16_t* __restrict__ out /*[rows2*32, 64]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // ring of six image rows | conv 1 fragments | log-mel rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, kq = lane >> 4;
     const int T2 = T >> 1;
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_block1_kernel(const float* __rest
                                                                     sk * 32 + kq * 8);
     // conv 1: channel j*16 + l15, operand [w_hi, w_hi, w_lo] (pairs with [x_hi, x_lo, x_hi]); the four fragments are the
     // same for every wave and are parked in LDS behind the images (registers are full of conv 2's weights)
-    bf16x8* wf0s = reinterpret_cast<bf16x8*>(smem + 2 * B1_IMG);
+    bf16x8* wf0s = reinterpret_cast<bf16x8*>(smem + B1_IMG);
     if (wave == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -144,27 +151,23 @@ __global__ __launch_bounds__(256, 2) void conv_block1_kernel(const float* __rest
     }
     __syncthreads();
 
-    // The three log-mel rows image row `wave` of tile g2 needs (t_in - 1 .. t_in + 1, clamped into the clip: rows outside
-    // it are masked where they are used), by LDS-DMA into the wave's own 1 KiB: requested a whole tile ahead, so the
-    // gather below reads LDS instead of waiting ~1.5 us on L2 four times per tile.
-    auto fetch_mel = [&](int g2, int buf) {
-        const int b = g2 / T2, t2 = g2 - b * T2;
-        int t = 2 * t2 - 2 + wave + min(lane >> 4, 2);
+    // The three log-mel rows one conv-1 row t_in needs (t_in - 1 .. t_in + 1, clamped into the clip: rows outside it are
+    // masked where they are used), by LDS-DMA into the wave's own 1 KiB, requested a tap loop ahead of their use.
+    auto fetch_mel = [&](int b, int t_in, int buf) {
+        int t = t_in - 1 + min(lane >> 4, 2);
         t = t < 0 ? 0 : (t >= T ? T - 1 : t);
         b1_glds16(mel + ((size_t)b * T + t) * 64 + (lane & 15) * 4, smem + B1_MEL + (buf * 4 + wave) * 1024);
     };
-    // image row `wave` of tile g2: conv 1 + BatchNorm + ReLU of input row 2 t2 - 1 + wave, 64 cells x 64 channels
-    auto build_image = [&](int g2, unsigned char* img, int buf) {
-        const int b = g2 / T2, t2 = g2 - b * T2;
-        const int t_in = 2 * t2 - 1 + wave;
+    // conv 1 + BatchNorm + ReLU of input row t_in of clip b, cells u0*16 .. (u0 + NU)*16 - 1, into ring slot `slot`
+    // (t_in outside the clip: zeros — conv 2's padding).  The wave's log-mel rows are in its buffer `buf`.
+    auto build_row = [&](int t_in, int slot, int u0, int nu, int buf) {
         const bool row_in = (unsigned)t_in < (unsigned)T;          // wave-uniform
         const float* mrow = reinterpret_cast<const float*>(smem + B1_MEL + (buf * 4 + wave) * 1024) + 64;   // row t_in
-        unsigned char* irow = img + wave * B1_ROW;
+        unsigned char* irow = smem + slot * B1_ROW;
         bf16x8 wf0[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf0[j] = wf0s[j * 64 + lane];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = u0; u < u0 + nu; ++u) {
             const int f = u * 16 + l15;
             bf16x8 af0 = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
             if (row_in) {
@@ -194,27 +197,19 @@ __global__ __launch_bounds__(256, 2) void conv_block1_kernel(const float* __rest
         }
     };
 
-    // the border cells of both images: zero once, never written again
-    if (threadIdx.x < 128) {
-        const int im = threadIdx.x >> 6, sl = (threadIdx.x >> 4) & 3, side = (threadIdx.x >> 3) & 1, ch = threadIdx.x & 7;
-        *reinterpret_cast<uint4*>(smem + im * B1_IMG + sl * B1_ROW + (side ? 65 : 0) * 128 + ch * 16) = make_uint4(0u, 0u, 0u, 0u);
+    // the border cells of the six ring rows: zero once, never written again
+    if (threadIdx.x < 96) {
+        const int sl = threadIdx.x >> 4, side = (threadIdx.x >> 3) & 1, ch = threadIdx.x & 7;
+        *reinterpret_cast<uint4*>(smem + sl * B1_ROW + (side ? 65 : 0) * 128 + ch * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
     // fragment addresses of the tap loop: column 2 f2 + e (e = -1 .. 2) -> cell 2 f2 + e + 1, k-half sk
     // (the second k-half is chunk 4 + kq = kq ^ 4: the same address with bit 6 flipped)
     int abase[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) abase[e] = b1_cell(2 * (wm * 16 + l15) + e, kq);
-    int g2 = blockIdx.x, cur = 0;
-    if (g2 < rows2) {
-        fetch_mel(g2, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        build_image(g2, smem, 0);
-    }
-    __syncthreads();
-    // A tile's 16 bytes per lane leave for HBM at the top of the NEXT iteration: the wait in front of build_image (vmcnt
+    // A tile's 16 bytes per lane leave for HBM at the top of the NEXT iteration: the wait in front of the row build (vmcnt
     // counts stores too) then finds them a whole tap loop old instead of stalling on stores it has just issued.  Until
-    // then they sit in the wave's own log-mel buffer of the finished tile (consumed when that tile's image was built, refilled
-    // only by the fetch that follows the flush), each lane in its own 16 bytes — registers are full.
+    // then they sit in the wave's other log-mel buffer, each lane in its own 16 bytes — registers are full.
     auto flush = [&](int g_done, int buf) {
         const uint4 v = *reinterpret_cast<const uint4*>(smem + B1_MEL + (buf * 4 + wave) * 1024 + lane * 16);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read before the next fetch's LDS-DMA may land on it
@@ -222,24 +217,18 @@ __global__ __launch_bounds__(256, 2) void conv_block1_kernel(const float* __rest
         *reinterpret_cast<uint2*>(o) = make_uint2(v.x, v.y);
         *reinterpret_cast<uint2*>(o + 16) = make_uint2(v.z, v.w);
     };
-    const int g_first = blockIdx.x;
-    for (; g2 < rows2; g2 += gridDim.x) {
-        const unsigned char* img = smem + cur * B1_IMG;
-        const int nx = g2 + gridDim.x;
-        if (g2 != g_first) flush(g2 - gridDim.x, cur ^ 1);
-        if (nx < rows2) fetch_mel(nx, cur ^ 1);
-        f32x4 acc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the nine-tap loop of one tile; PH = t2 mod 3 fixes the ring slots of its four rows at compile time
+    f32x4 acc[4][2];
+    auto taps = [&](auto ph) {
+        constexpr int PH = decltype(ph)::value;
         // 18 steps (tap, k-half), the A fragments of step n + 1 requested before the MFMAs of step n
         auto load_af = [&](int step, bf16x8 (&af)[4]) {
             const int tap = step >> 1, sk = step & 1;
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
             for (int i = 0; i < 4; ++i)            // member i of window wm*16 + l15: input cell (2 t2 + (i >> 1), 2 f2 + (i & 1))
-                af[i] = *reinterpret_cast<const bf16x8*>(img + (1 + (i >> 1) + dy) * B1_ROW + (abase[(i & 1) + dx + 1] ^ (sk << 6)));
+                af[i] = *reinterpret_cast<const bf16x8*>(smem + ((2 * PH + 1 + (i >> 1) + dy) % 6) * B1_ROW +
+                                                         (abase[(i & 1) + dx + 1] ^ (sk << 6)));
         };
         bf16x8 afa[4], afb[4];
         load_af(0, afa);
@@ -254,6 +243,36 @@ __global__ __launch_bounds__(256, 2) void conv_block1_kernel(const float* __rest
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[tap][sk][j], (step & 1) ? afb[i] : afa[i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);   // keep later steps' reads where they are: registers are full
         }
+    };
+
+    // this workgroup's pooled rows: a contiguous run, walked in order so that consecutive tiles of a clip share image rows
+    const int r0 = blockIdx.x * chunk, r1 = min(rows2, r0 + chunk);
+    int b = r0 / T2, t2 = r0 - b * T2, par = 0;
+    bool cold = true;
+    for (int g2 = r0; g2 < r1; ++g2) {
+        const int ph = t2 % 3;
+        if (g2 != r0) flush(g2 - 1, par);
+        if (cold) {
+            // all four rows of this tile, wave w row 2 t2 - 1 + w (ring slot (2 ph + w) mod 6)
+            fetch_mel(b, 2 * t2 - 1 + wave, par);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                 // the previous tile's readers are done with the ring
+            build_row(2 * t2 - 1 + wave, (2 * ph + wave) % 6, 0, 4, par);
+            __syncthreads();
+            cold = false;
+        }
+        // the next tile of the same clip needs two more rows, 2 t2 + 3 and 2 t2 + 4: waves 0, 1 build halves of the first,
+        // waves 2, 3 of the second, into the two ring slots this tile does not read
+        const bool more = t2 + 1 < T2 && g2 + 1 < r1;
+        const int t_new = 2 * t2 + 3 + (wave >> 1);
+        if (more) fetch_mel(b, t_new, par);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ph == 0) taps(std::integral_constant<int, 0>{});
+        else if (ph == 1) taps(std::integral_constant<int, 1>{});
+        else taps(std::integral_constant<int, 2>{});
         {
             uint4 pk;
 #pragma unroll
@@ -268,16 +287,21 @@ __global__ __launch_bounds__(256, 2) void conv_block1_kernel(const float* __rest
                 (j ? pk.z : pk.x) = pack_bf16x2(0.25f * v0, 0.25f * v1);
                 (j ? pk.w : pk.y) = pack_bf16x2(0.25f * v2, 0.25f * v3);
             }
-            *reinterpret_cast<uint4*>(smem + B1_MEL + (cur * 4 + wave) * 1024 + lane * 16) = pk;   // this lane's own slot
+            *reinterpret_cast<uint4*>(smem + B1_MEL + ((par ^ 1) * 4 + wave) * 1024 + lane * 16) = pk;   // this lane's own slot
         }
-        if (nx < rows2 && ABL != 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's log-mel rows of the next tile have landed
-            build_image(nx, smem + (cur ^ 1) * B1_IMG, cur ^ 1);
+        if (more) {
+            if (ABL != 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's log-mel rows have landed
+                build_row(t_new, (2 * ph + 4 + (wave >> 1)) % 6, (wave & 1) * 2, 2, par);
+            }
+        } else {
+            cold = true;                                     // the next tile starts a clip (or the run ends)
         }
-        __syncthreads();      // the next image is complete; every wave is done with the current one
-        cur ^= 1;
+        __syncthreads();      // the new rows are complete; every wave is done with this tile's rows
+        par ^= 1;
+        if (++t2 == T2) { t2 = 0; ++b; }
     }
-    if (g2 != g_first) flush(g2 - gridDim.x, cur ^ 1);   // the last tile of this workgroup
+    if (r1 > r0) flush(r1 - 1, par);
 }
 
 __device__ __forceinline__ void unpack8(const uint4 v, float* f) {
@@ -398,7 +422,7 @@ static int forward(const bf16_t* wb, const float* pf, const float* wave, int B, 
         return rc;
     {   // block 1: both convolutions and the pooling in one kernel (the tensor between them never leaves the CU)
         const int rows2 = B * (T / 2);
-        const size_t lds = B1_MEL + 8192;        // two images + conv 1's four weight fragments + the log-mel rows in flight
+        const size_t lds = B1_MEL + 8192;        // six image rows + conv 1's four weight fragments + the log-mel rows in flight
         static std::once_flag attr_b1;
         std::call_once(attr_b1, [&] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block1_kernel<0>),
@@ -413,8 +437,10 @@ static int forward(const bf16_t* wb, const float* pf, const float* wave, int B, 
         if (g_b1_ablate == 1) kern = conv_block1_kernel<1>;
         if (g_b1_ablate == 2) kern = conv_block1_kernel<2>;
 #endif
-        hipLaunchKernelGGL(kern, dim3(rows2 < 512 ? rows2 : 512), dim3(256), lds, st, mel, pf + o.c0_w, pf + o.c0_b,
-                           wb + o.cw[0][1], pf + o.cb[0][1], T, rows2, cur);
+        // two persistent workgroups per CU, each a contiguous run of pooled rows (consecutive rows of a clip share image rows)
+        const int nblk = rows2 < 512 ? rows2 : 512, chunk = (rows2 + nblk - 1) / nblk;
+        hipLaunchKernelGGL(kern, dim3((rows2 + chunk - 1) / chunk), dim3(256), lds, st, mel, pf + o.c0_w, pf + o.c0_b,
+                           wb + o.cw[0][1], pf + o.cb[0][1], T, rows2, chunk, cur);
         WISE_LAUNCH_CHECK("cnn14 conv_block1_kernel");
         T /= 2; F /= 2;
     }
