@@ -33,10 +33,7 @@ int mlp96_fused(float* x, const float* lnw, const float* lnb, const bf16_t* W1, 
                 const float* b2, int M, float eps, hipStream_t st);
 
 namespace htsat {
-// htsat_frontend.hip
-int frontend(const float* wave, int B, int samples, int Fc, const float* hann, const float* mel_start,
-             const float* mel_len, const float* mel_wt, const float* bn_scale, const float* bn_shift, float* melbn,
-             hipStream_t st);
+// htsat_frontend.hip: frontend() — declared in transformer.h
 static int g_frontend_only = 0;  // (debug) stop after the front end: concurrency tests tap the log-mel
 static int g_fuse_ln = 7;  // bit 0: LayerNorm-in-GEMM fusion, bit 1: fused MLP (stage 1), bit 2: fused attention half of a stage-1 block; wise_debug_set_htsat flips them off
 constexpr int N_FFT = 1024, HOP = 320, N_MELS = 64, MELW = FRONT_MELW, MAXF = 1024;
@@ -816,7 +813,7 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
     int rc;
 
     if ((rc = frontend(wave, B, samples, Fc, pf + o.hann, pf + o.mel_start, pf + o.mel_len, pf + o.mel_wt, pf + o.bn_scale,
-                       pf + o.bn_shift, mel, st)))
+                       pf + o.bn_shift, mel, st, 16 /* widest band of the 50..8000 Hz filterbank (pack_htsat_weights asserts it) */)))
         return rc;
     if (g_frontend_only) return WISE_OK;
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)(B * 64)), dim3(256), 0, st, mel, B, Fc,

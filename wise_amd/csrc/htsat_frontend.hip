@@ -57,6 +57,10 @@ __device__ __forceinline__ void bfly(float2& a, float2& q, const float2 t) {
 
 constexpr int FFT_LDS = 1088;  // float2 per wave: max(64 * 17, 1024 + 3 * 16)
 
+// MW = mel weights a lane keeps and applies per frame: the widest band of the filterbank in use (16 FFT bins for the 2023
+// config's 50..8000 Hz, 35 for the 2022 config's 50..14000 Hz; the table's row stride is MELW either way).  The kernel is
+// bound by its LDS operations (~108 per frame and lane), so the 20 reads a narrow filterbank does not need are worth leaving out.
+template <int MW>
 __global__ __launch_bounds__(256, 2) void frontend_kernel(const float* __restrict__ wave, int B, int N, int Fc,
                                                           const float* __restrict__ hann,
                                                           const float* __restrict__ mel_start,
@@ -89,9 +93,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const float* __restric
         t10[2 * u + 1] = tw[512 + lane + 64 * u + 256];
     }
     const int mst = (int)mel_start[lane], mln = (int)mel_len[lane];
-    float mw[MELW];
+    float mw[MW];
 #pragma unroll
-    for (int j = 0; j < MELW; ++j) mw[j] = (j < mln) ? mel_wt[j * 64 + lane] : 0.f;
+    for (int j = 0; j < MW; ++j) mw[j] = (j < mln) ? mel_wt[j * 64 + lane] : 0.f;
     const float bsc = bn_scale[lane], bsh = bn_shift[lane];
 
     const long long total = (long long)B * Fc;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const float* __restric
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < MELW; ++j) acc = fmaf(mw[j], pw[min(mst + j, 512)], acc);
+        for (int j = 0; j < MW; ++j) acc = fmaf(mw[j], pw[min(mst + j, 512)], acc);
         const float db = 10.f * log10f(fmaxf(acc, 1e-10f));
         melbn[((size_t)b * Fc + f) * 64 + lane] = db * bsc + bsh;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const float* __restric
 // mel+bn0 of the first Fc frames of every clip: melbn [B, Fc, 64]; params are the packed fp32 front-end tables
 int frontend(const float* wave, int B, int samples, int Fc, const float* hann, const float* mel_start,
              const float* mel_len, const float* mel_wt, const float* bn_scale, const float* bn_shift, float* melbn,
-             hipStream_t st) {
+             hipStream_t st, int max_band) {
     static std::once_flag once;
     static hipError_t init_err = hipSuccess;
     std::call_once(once, [&] {   // the twiddle table lives in a __device__ array; complete before any stream reads it
@@ -199,8 +203,13 @@ int frontend(const float* wave, int B, int samples, int Fc, const float* hann, c
     });
     if (init_err != hipSuccess) { set_error("htsat fft_twiddle_kernel: %s", hipGetErrorString(init_err)); return (int)init_err; }
     const long long fblocks = ((long long)B * Fc + 3) / 4;
-    hipLaunchKernelGGL(frontend_kernel, dim3((unsigned)(fblocks < 512 ? fblocks : 512)), dim3(256), 0, st, wave, B,
-                       samples, Fc, hann, mel_start, mel_len, mel_wt, bn_scale, bn_shift, melbn);
+    const dim3 grid((unsigned)(fblocks < 512 ? fblocks : 512));
+    if (max_band <= 16)
+        hipLaunchKernelGGL(frontend_kernel<16>, grid, dim3(256), 0, st, wave, B, samples, Fc, hann, mel_start, mel_len, mel_wt,
+                           bn_scale, bn_shift, melbn);
+    else
+        hipLaunchKernelGGL(frontend_kernel<MELW>, grid, dim3(256), 0, st, wave, B, samples, Fc, hann, mel_start, mel_len, mel_wt,
+                           bn_scale, bn_shift, melbn);
     WISE_LAUNCH_CHECK("htsat frontend_kernel");
     return WISE_OK;
 }

@@ -57,7 +57,7 @@ namespace htsat {
 // mel + bn0 of the first Fc frames of every clip (htsat_frontend.hip): melbn fp32 [B, Fc, 64]
 int frontend(const float* wave, int B, int samples, int Fc, const float* hann, const float* mel_start,
              const float* mel_len, const float* mel_wt, const float* bn_scale, const float* bn_shift, float* melbn,
-             hipStream_t st);
+             hipStream_t st, int max_band = 36 /* FFT bins of the widest mel band in the table: 16 for fmax 8000, 35 for 14000 */);
 constexpr int FRONT_MELW = 36;   // most FFT bins a mel band may span in the sparse table (2023 config: 16, 2022: 35)
 }  // namespace htsat
 

@@ -189,6 +189,7 @@ def pack_htsat_weights(sd: Dict[str, torch.Tensor]):
     scale = f32(pre + "bn0.weight") / torch.sqrt(f32(pre + "bn0.running_var") + 1e-5)
     shift = f32(pre + "bn0.bias") - f32(pre + "bn0.running_mean") * scale
     start, length, weights = fe.sparse_mel()
+    assert int(length.max()) <= 16, "HTSAT front end: the kernel applies 16 weights per mel band (csrc/htsat.hip)"
     pf += [scale, shift, start.to(torch.float32), length.to(torch.float32), weights.t().contiguous().reshape(-1),
            fe.hann_periodic(),
            f32(pre + "patch_embed.proj.weight").reshape(-1), f32(pre + "patch_embed.proj.bias"),
