@@ -1866,6 +1866,119 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const bf16_t* __rest
 
 #ifdef WISE_DEBUG_KNOBS
 // ------------------------------------------------------------------------------------------------
+// Ping-pong kernel, third form (debug variant 47; MEASURED SLOWER, 20-25 % on every shape — 980 against 1229 TFLOP/s at 8192^3:
+// a W fragment load is sixteen 64-byte row segments per instruction): only the A tile goes through the LDS-DMA ring; the W
+// fragments travel from L2 straight into registers, two K-tiles ahead.  Per K-tile and CU that is 16 KiB of LDS-DMA
+// writes instead of 32 and 64 KiB of fragment reads instead of 96, and the ring holds six A tiles in 96 KiB.
+// 256 x 256 tile, 8 waves as 2 x 4, each 128 rows x 64 columns.  Same two-group schedule and barriers as gemm_pp_kernel.
+//   vmcnt: a wave issues, per K-tile and in this order, 2 LDS-DMA (A tile kt + 5) and 4 loads (W fragments of kt + 2); loads
+//   complete in order, so vmcnt(12) in front of the cluster of tile kt says: W(kt) is here, and so is every A tile <= kt + 3.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_ppb_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+                                                          const float* __restrict__ bias, int M, int N, int K,
+                                                          void* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BKT = 32, NT = 4, MI = 8, WROWS = 128, BMB = 256, BNB = 256, STAGES = 6;
+    constexpr int TA = BMB * BKT * 2;              // 16 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool late = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+    const int tiles_n = N / BNB;
+    int tm, tn;
+    tile_coords(M / BMB, tiles_n, g_group_m ? g_group_m : 4, &tm, &tn);
+    const int m0 = tm * BMB, n0 = tn * BNB;
+    f32x4 acc[MI][NT];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = K / BKT;
+    // this lane's W rows: fragment j of K-tile kt = 16 bytes at wrow[j] + kt * 32
+    const bf16_t* wrow = Wt + (size_t)(n0 + wn * 64 + (lane & 15)) * K + (lane >> 4) * 8;
+    const size_t wj = (size_t)16 * K;
+    bf16x8 wq[3][NT];                              // W fragments of tiles kt, kt + 1, kt + 2 (slot = tile % 3)
+    auto load_w = [&](int kt, bf16x8 (&dst)[NT]) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(wrow + j * wj + (size_t)kt * BKT);
+    };
+    // prologue: A tiles 0..4 and W of tiles 0, 1 — issued tile by tile in the loop's order (A first, then W)
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) stage_rows8_ring<BMB, BKT>(A, K, m0, s * BKT, smem + s * TA, wave, lane);
+    load_w(0, wq[0]);
+    if (nk > 1) load_w(1, wq[1]);
+    if (late) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    }
+    auto step = [&](int kt, int cur, bf16x8 (&wf)[NT], bf16x8 (&wnext)[NT]) {
+        // ---- L part
+        // W(kt) was requested two steps ago; newer than it are only the previous step's requests (2 LDS-DMA + 4 loads,
+        // fewer at the ends).  Everything older — every A tile up to kt + 3 — has landed with it.
+        if (kt == 0) { if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+        else if (kt + 4 < nk) wait_vmcnt<6>();
+        else if (kt + 1 < nk) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + STAGES - 1 < nk) {
+            int ns = cur + STAGES - 1;
+            if (ns >= STAGES) ns -= STAGES;
+            stage_rows8_ring<BMB, BKT>(A, K, m0, (kt + STAGES - 1) * BKT, smem + ns * TA, wave, lane);
+        }
+        if (kt + 2 < nk) load_w(kt + 2, wnext);
+        const unsigned char* At = smem + cur * TA;
+        const int chunk = lane >> 4;
+        bf16x8 af[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = lds_frag_ring<BKT>(At, wm * WROWS + i * 16 + (lane & 15), chunk);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- M part: registers only
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int cur = 0;
+    for (int kt = 0; kt < nk; kt += 3) {
+        step(kt, cur, wq[0], wq[2]);
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+        if (kt + 1 < nk) { step(kt + 1, cur, wq[1], wq[0]); cur = (cur + 1 == STAGES) ? 0 : cur + 1; }
+        if (kt + 2 < nk) { step(kt + 2, cur, wq[2], wq[1]); cur = (cur + 1 == STAGES) ? 0 : cur + 1; }
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+    constexpr bool BF16OUT = bf16_out(MODE);
+    __syncthreads();
+    if (BF16OUT)
+        epilogue_big_lds<MODE, MI>(acc, bias, reinterpret_cast<bf16_t*>(out), N, m0, n0, wm, wn, lane, wave, smem);
+    else
+        epilogue_f32_lds_wave<MODE, MI, NT>(acc, bias, reinterpret_cast<float*>(out), N, m0 + wm * WROWS, n0 + wn * 64, lane,
+                                            smem + wave * 16384);
+}
+
+template <int MODE>
+static void launch_ppb(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out, hipStream_t st) {
+    auto kern = gemm_ppb_kernel<MODE>;
+    const size_t lds = 131072;   // six 16-KiB A tiles; the epilogues use up to 128 KiB of the same space
+    static std::once_flag attr_set;
+    std::call_once(attr_set, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    hipLaunchKernelGGL(kern, dim3((M / 256) * (N / 256)), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
+}
+#endif
+
+#ifdef WISE_DEBUG_KNOBS
+// ------------------------------------------------------------------------------------------------
 // Ping-pong kernel, second form: the fragment reads ride inside the MFMA cluster.  (MEASURED SLOWER — round 2, kept in
 // the debug library only as variant 50: 881 -> 795 TFLOP/s on 12800x2304x768, 1254 -> 1122 on 8192^3.  The reads
 // lengthen the cluster by more than they take off the part between clusters: on this chip work moved between the two
@@ -2051,6 +2164,8 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
         case 45: if (M % 256 == 0 && N % 256 == 0) { launch_pp<MODE, 128, 5>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 46: if (M % 256 == 0 && N % 128 == 0) { launch_pp<MODE, 64, 3>(A, Wt, bias, M, N, K, out, st); break; }   // 72 KiB: two blocks per CU
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 47: if (M % 256 == 0 && N % 256 == 0 && K >= 192) { launch_ppb<MODE>(A, Wt, bias, M, N, K, out, st); break; }   // W fragments straight to registers
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
 #endif
 #ifdef WISE_DEBUG_KNOBS
