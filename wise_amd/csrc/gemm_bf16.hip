@@ -1586,7 +1586,10 @@ __device__ __forceinline__ void epilogue_big_lds(f32x4 (&acc)[MI][4], const floa
 // (waves 2x4, 4 stages of 36 KiB) for shapes that fill the chip in whole rounds only with 320-row tiles
 // (M = 6400, N = 3072: 240 tiles).  A 320-row A tile is 20 KiB per stage = 2.5 rounds of the 8 waves, so waves
 // 0-3 (the early group) issue one LDS-DMA more per K-tile than waves 4-7: the counted vmcnt differs per group.
-template <int MODE, int WROWS, int STG = 0>
+// MF32 (debug library, TIMING ONLY — the result is not a GEMM): the cluster as 16 v_mfma_f32_32x32x16_bf16 on the same operand
+// registers instead of 32 v_mfma_f32_16x16x32_bf16: same LDS / LDS-DMA traffic and barriers, half the matrix instructions per
+// FLOP — what the loop would gain from the larger instruction before its fragment layouts and epilogues are rewritten for it.
+template <int MODE, int WROWS, int STG = 0, bool MF32 = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                          const float* __restrict__ bias, int M, int N, int K,
                                                          void* __restrict__ out) {
@@ -1616,6 +1619,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    using f32x16 = __attribute__((ext_vector_type(16))) float;
+    f32x16 acc32[MF32 ? 8 : 1];
+    if constexpr (MF32) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc32[i][r] = 0.f;
+    }
     const int nk = K / BKT;
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) {
@@ -1669,15 +1680,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
         __builtin_amdgcn_sched_barrier(0);
         WISE_STAMP(6);
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (MF32) {
+            static_assert(!MF32 || (MI == 8 && NT == 4), "timing variant: 128 x 64 per wave");
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i2 = 0; i2 < 4; ++i2)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh)
+                        acc32[i2 * 2 + j2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j2 * 2 + kh], af[i2 * 2 + kh], acc32[i2 * 2 + j2], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         WISE_STAMP(7);
         cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+    }
+    if constexpr (MF32) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r >> 2][r & 3] = acc32[i][r];
     }
     if (!late) __builtin_amdgcn_s_barrier();
     constexpr bool BF16OUT = bf16_out(MODE);
@@ -2119,10 +2147,10 @@ static void launch_pp2(const bf16_t* A, const bf16_t* Wt, const float* bias, int
 
 #endif  // WISE_DEBUG_KNOBS
 
-template <int MODE, int WROWS, int STG = 0>
+template <int MODE, int WROWS, int STG = 0, bool MF32 = false>
 static void launch_pp(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out,
                       hipStream_t st) {
-    auto kern = gemm_pp_kernel<MODE, WROWS, STG>;
+    auto kern = gemm_pp_kernel<MODE, WROWS, STG, MF32>;
     constexpr int BNB = (WROWS == 64 || WROWS == 80) ? 128 : 256;
     constexpr int BMB = (WROWS == 64) ? 256 : (WROWS == 80) ? 320 : 2 * WROWS;
     constexpr int STAGES = STG ? STG : ((WROWS == 64) ? 5 : 4);
@@ -2167,6 +2195,8 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 47: if (M % 256 == 0 && N % 256 == 0 && K >= 192) { launch_ppb<MODE>(A, Wt, bias, M, N, K, out, st); break; }   // W fragments straight to registers
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 48: if (M % 256 == 0 && N % 256 == 0) { launch_pp<MODE, 128, 0, true>(A, Wt, bias, M, N, K, out, st); break; }   // TIMING ONLY: 32x32x16 MFMAs
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
 #endif
 #ifdef WISE_DEBUG_KNOBS
         case 50: if (M % 256 == 0 && N % 256 == 0 && K >= 96) { launch_pp2<MODE>(A, Wt, bias, M, N, K, out, st); break; }
@@ -2186,7 +2216,7 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
 
 static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode,
                        void* out, hipStream_t st) {
-    if (K % 64 != 0 && v != 40 && v != 42 && v != 45 && v != 46 && v != 50) v = 1;
+    if (K % 64 != 0 && v != 40 && v != 42 && v != 45 && v != 46 && v != 48 && v != 50) v = 1;
     else if (N % BN != 0 && v != 1) v = 0;  // N edge is handled by the 128x128 kernels only
     switch (mode) {
         case EPI_BF16: launch_variant<EPI_BF16>(v, A, Wt, bias, M, N, K, out, st); break;
