@@ -1683,11 +1683,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restric
         if constexpr (MF32) {
             static_assert(!MF32 || (MI == 8 && NT == 4), "timing variant: 128 x 64 per wave");
 #pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2)
+            for (int kh = 0; kh < 2; ++kh)         // k-half outermost: eight independent accumulators between two uses of one
 #pragma unroll
-                for (int j2 = 0; j2 < 2; ++j2)
+                for (int i2 = 0; i2 < 4; ++i2)
 #pragma unroll
-                    for (int kh = 0; kh < 2; ++kh)
+                    for (int j2 = 0; j2 < 2; ++j2)
                         acc32[i2 * 2 + j2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j2 * 2 + kh], af[i2 * 2 + kh], acc32[i2 * 2 + j2], 0, 0, 0);
         } else {
 #pragma unroll
