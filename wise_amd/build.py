@@ -86,7 +86,7 @@ def _compile(srcs, objdir: Path, defines, force: bool, verbose: bool, extra_flag
                *defines, "-c", str(s), "-o", str(o), *COMMON_FLAGS, *FILE_FLAGS.get(s.name, ()), *extra_flags]
         stamp = o.with_suffix(".cmd")
         cmdline = " ".join(cmd) + "\n# build.py " + hashlib.sha256(Path(__file__).read_bytes()).hexdigest()[:16] + "\n"
-        stale = force or _newer(o, [s] + headers) or not stamp.exists() or stamp.read_text() != cmdline
+        stale = force or _newer(o, [s, Path(__file__)] + headers) or not stamp.exists() or stamp.read_text() != cmdline
         if stale:
             if verbose:
                 print(" ".join(cmd), flush=True)

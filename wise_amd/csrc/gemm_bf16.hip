@@ -19,11 +19,10 @@
 
 #include "common.h"
 #include "transformer.h"
+#include "gemm_shared.h"
+#include "gemm_w4.h"
 
 namespace wise {
-
-enum : int { EPI_BF16 = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4, EPI_GELU_TANH = 5, EPI_RELU = 6 };
-constexpr bool bf16_out(int mode) { return mode == EPI_BF16 || mode == EPI_QUICKGELU || mode == EPI_GELU || mode == EPI_GELU_TANH || mode == EPI_RELU; }
 
 // Tuning / ablation switches.  They exist only in the debug build (libwise_hip_debug.so, -DWISE_DEBUG_KNOBS: tools/ and
 // wise_debug_set_gemm_variant); in the product library they are compile-time constants and the branches fold away.
@@ -70,37 +69,6 @@ __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* lds_tile, int ro
     return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 
-// x * sigmoid(1.702 x) on the two native transcendentals (v_exp_f32 is 2^x, v_rcp_f32 ~1 ulp): an IEEE divide
-// costs ~10 more instructions per element and the epilogue applies this to 128-160 elements per thread
-__device__ __forceinline__ float act_quickgelu(float x) {
-    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
-}
-// erf GELU, 0.5 x (1 + erf(x / sqrt 2)) = x Phi(x), as x * sigmoid(p(x)) with an odd degree-5 p fitted (minimax on
-// [-8, 8], tools/fit_gelu.py) to the erf form: |error| <= 2.6e-5 everywhere — a hundredth of the bf16 rounding the
-// result gets right after (2^-9 relative), and 20x closer than the tanh form (4.7e-4).  Six plain VALU operations,
-// one v_exp_f32 and one v_rcp_f32: half the issue slots of the Abramowitz-Stegun erf it replaces (|error| 5e-7, a
-// precision the bf16 output could not carry).  It matters: HTSAT applies GELU to 0.96 G values per forward — at 20
-// issue slots each that alone was ~0.6 ms of the 4.8 ms forward.  x^2 is clamped at 64 so that the x^5 term cannot turn
-// p around for |x| > 10; beyond |x| = 8 the sigmoid is saturated either way.  -log2(e) is folded into the coefficients.
-__device__ __forceinline__ float act_gelu(float x) {
-    const float x2 = fminf(x * x, 64.f);
-    const float p = x * fmaf(x2, fmaf(x2, 0.0010142630198970437f, -0.10677572339773178f), -2.301121234893799f);
-    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(p));
-}
-// GPT-2's gelu_new, 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x * sigmoid(2u): one exp2 and one rcp
-__device__ __forceinline__ float act_gelu_tanh(float x) {
-    const float u = 0.7978845608028654f * fmaf(0.044715f * x, x * x, x);
-    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.f * 1.4426950408889634f * u));
-}
-template <int MODE>
-__device__ __forceinline__ float act_apply(float x) {
-    if (MODE == EPI_QUICKGELU) return act_quickgelu(x);
-    if (MODE == EPI_GELU) return act_gelu(x);
-    if (MODE == EPI_GELU_TANH) return act_gelu_tanh(x);
-    if (MODE == EPI_RELU) return fmaxf(x, 0.f);
-    return x;
-}
-
 // acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)][n0 + wn*64 + j*16 + (lane>>4)*4 + r]
 template <int MODE>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const float* __restrict__ bias, void* __restrict__ out,
@@ -136,26 +104,6 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], const float* __rest
     }
 }
 
-
-// Tile order.  Blocks b, b+8, ... share an XCD (round-robin dispatch), so the remap first gives each
-// XCD a contiguous run of virtual ids, then walks them in GROUP_M x tiles_n bands, m fastest inside a
-// band ("grouped ordering"): the ~64 tiles an XCD has resident at once form a ~8x8 patch of the output
-// that shares 8 A panels and 8 W panels, which fits the XCD's 4 MiB L2.  With plain n-fastest order the
-// resident set spans every W panel (3.5 MB at N=2304) and thrashes: PMC showed 139 MB fetched from
-// the memory side for a GEMM whose operands total 23 MB.  Placement only affects speed.
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int group_m, int* tm, int* tn) {
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int per_group = group_m * tiles_n;
-    const int gid = bid / per_group;
-    const int first_m = gid * group_m;
-    const int gsize = min(tiles_m - first_m, group_m);
-    const int in_group = bid - gid * per_group;
-    *tm = first_m + in_group % gsize;
-    *tn = in_group / gsize;
-}
 
 // bf16-output epilogue through LDS: the MFMA layout gives a lane 4 consecutive columns of one row
 // (8-byte pieces, 32-byte row segments: four store instructions per 128-byte line).  Each wave writes its
@@ -635,11 +583,6 @@ __device__ __forceinline__ void stage_tile_ring(const bf16_t* __restrict__ G, in
 template <int BKT>
 __device__ __forceinline__ bf16x8 lds_frag_ring(const unsigned char* lds_tile, int row, int chunk) {
     return *reinterpret_cast<const bf16x8*>(lds_tile + row * (BKT * 2) + (swz_chunk<BKT>(row, chunk) << 4));
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <int MODE, int BKT, int STAGES, int MINB, int ABL = 0>
@@ -2170,6 +2113,7 @@ static int g_mlp96_resident = 1;  // (debug knob) 0: the staged mlp96_kernel
 static int g_overlapped = 0;  // the caller is running another stream's kernels beside this one (gemm_set_overlapped)
 static int g_overlap_policy = 0;  // (debug knob) tiles under overlap: 0 = as for a lone stream minus the 320-row tilings (the product), 1 = 128x128 only, 2 = 128x128 except the QKV-shaped launches, 3 = hint ignored
 static int g_splitk_policy = 0;  // (debug knob) skinny GEMMs: 0 = the product rule, 1 = split-K for the residual GEMMs only, 2 = never
+static int g_w4_enabled = 1;  // (debug knob, bit 28 of wise_debug_set_gemm_variant: off) the one-wave-per-SIMD kernel of gemm_w4.h
 static int g_split_m = 1;  // split M between the ping-pong kernel and the 128x128 kernel (bit 29 of the knob: off)
   // 0: 2-stage BK=64 ; 1: ring BK=32 x4 (2 blocks/CU) ; 2: ring BK=64 x4 (1 block/CU) ; 3: ring BK=64 x3
 
@@ -2208,6 +2152,11 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 42: if (M % 320 == 0 && N % 256 == 0) { launch_pp<MODE, 160>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        // 60 / 61: the one-wave-per-SIMD kernel (gemm_w4.h), 256 x 256 / 160 x 256 tiles
+        case 60: if (w4_shape_ok(M, N, K, 8)) { launch_w4<MODE, 8>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 61: if (w4_shape_ok(M, N, K, 5)) { launch_w4<MODE, 5>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 8: launch_gemm<MODE, 1>(A, Wt, bias, M, N, K, out, st); break;
         case 9: launch_gemm<MODE, 2>(A, Wt, bias, M, N, K, out, st); break;
         default: launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
@@ -2216,7 +2165,8 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
 
 static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode,
                        void* out, hipStream_t st) {
-    if (K % 64 != 0 && v != 40 && v != 42 && v != 45 && v != 46 && v != 48 && v != 50) v = 1;
+    if (v == 60 || v == 61) { /* gemm_w4.h checks its own shape */ }
+    else if (K % 64 != 0 && v != 40 && v != 42 && v != 45 && v != 46 && v != 48 && v != 50) v = 1;
     else if (N % BN != 0 && v != 1) v = 0;  // N edge is handled by the 128x128 kernels only
     switch (mode) {
         case EPI_BF16: launch_variant<EPI_BF16>(v, A, Wt, bias, M, N, K, out, st); break;
@@ -2248,6 +2198,26 @@ static int auto_variant(int M, int N, int K) {
 }
 
 void gemm_set_overlapped(bool on) { g_overlapped = on ? 1 : 0; }
+
+// The one-wave-per-SIMD kernel (gemm_w4.h) takes every problem it can tile into at least ~3/4 of a round of the 256 CUs.
+// Between its two tiles the model is rounds x (prologue + K-steps x cycles per step) with the cycles its in-kernel
+// stamps show on MI355X (tools/gemm_lab.hip: 256 x 256: ~3100 + 2580 per 64-deep step; 160 x 256: ~2800 + 1750); the
+// epilogue is HBM-bound on the C tile either way.  Returns the variant id (60 / 61) or 0.
+static int w4_variant(int M, int N, int K) {
+    if (!g_w4_enabled) return 0;
+    double best = 0.0;
+    int v = 0;
+    for (int c = 0; c < 2; ++c) {
+        const int mi = c == 0 ? 8 : 5;
+        if (!w4_shape_ok(M, N, K, mi)) continue;
+        const long long tiles = (long long)(M / (32 * mi)) * (N / 256);
+        if (tiles < 192) continue;
+        const long long rounds = (tiles + 255) / 256;
+        const double cost = (double)rounds * ((mi == 8 ? 3100.0 : 2800.0) + (K / 64) * (mi == 8 ? 2580.0 : 1750.0));
+        if (v == 0 || cost < best) { best = cost; v = c == 0 ? 60 : 61; }
+    }
+    return v;
+}
 
 // x[M,96] += fc2(gelu(fc1(LN(x)))) in one kernel; M % 128 == 0 (rows readable and writable)
 int mlp96_fused(float* x, const float* lnw, const float* lnb, const bf16_t* W1, const float* b1, const bf16_t* W2,
@@ -2451,6 +2421,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
         g_overlapped = keep;
         return rc3;
     }
+    if (const int vw = w4_variant(M, N, K)) return launch_mode(vw, A, Wt, bias, M, N, K, mode, out, st);
     if (g_overlapped && g_overlap_policy == 1) return launch_mode(auto_variant(M, N, K) == 2 ? 2 : 0, A, Wt, bias, M, N, K, mode, out, st);
     if (g_overlapped && g_overlap_policy == 2 && !(bf16_out(mode) && N >= 3 * K)) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);
     if (g_overlapped && g_overlap_policy == 4 && (mode == EPI_RESID || mode == EPI_F32)) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);
@@ -2625,13 +2596,14 @@ extern "C" int wise_debug_set_gemm_flags(int flags) {
 extern "C" int wise_debug_set_gemm_variant(int v) {
     wise::g_gemm_variant = v & 0xFF;
     wise::g_split_m = ((v >> 29) & 1) ? 0 : 1;
+    wise::g_w4_enabled = ((v >> 28) & 1) ? 0 : 1;
     int skip = (v >> 8) & 1;  // bit 8: skip epilogue stores (timing-only ablation)
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_skip_epilogue), &skip, sizeof(int));
     int nt = (v >> 9) & 1 ? 0 : 1;   // bit 9: plain (temporal) epilogue stores
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_store_nt), &nt, sizeof(int));
     int el = ((v >> 30) & 1) ? 0 : 1;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_epi_lds), &el, sizeof(int));
-    int dp = (v >> 24) & 0x3F;
+    int dp = (v >> 24) & 0xF;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_dephase), &dp, sizeof(int));
     int gm = (v >> 16) & 0xFF;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(wise::g_group_m), &gm, sizeof(int));
