@@ -56,15 +56,15 @@ static float host_act(float x, int mode) {
     return x;
 }
 
-template <int MI>
+template <int MI, int NJ, int SA, int SW>
 static void launch_new(int mode, const bf16_t* A, const bf16_t* W, const float* b, int M, int N, int K, void* out, hipStream_t st) {
     using namespace wise;
     switch (mode) {
-        case 0: launch_w4<EPI_BF16, MI>(A, W, b, M, N, K, out, st); break;
-        case 1: launch_w4<EPI_QUICKGELU, MI>(A, W, b, M, N, K, out, st); break;
-        case 2: launch_w4<EPI_GELU, MI>(A, W, b, M, N, K, out, st); break;
-        case 3: launch_w4<EPI_RESID, MI>(A, W, b, M, N, K, out, st); break;
-        case 4: launch_w4<EPI_F32, MI>(A, W, b, M, N, K, out, st); break;
+        case 0: launch_w4<EPI_BF16, MI, NJ, SA, SW>(A, W, b, M, N, K, out, st); break;
+        case 1: launch_w4<EPI_QUICKGELU, MI, NJ, SA, SW>(A, W, b, M, N, K, out, st); break;
+        case 2: launch_w4<EPI_GELU, MI, NJ, SA, SW>(A, W, b, M, N, K, out, st); break;
+        case 3: launch_w4<EPI_RESID, MI, NJ, SA, SW>(A, W, b, M, N, K, out, st); break;
+        case 4: launch_w4<EPI_F32, MI, NJ, SA, SW>(A, W, b, M, N, K, out, st); break;
     }
 }
 
@@ -118,20 +118,22 @@ int main(int argc, char** argv) {
         std::vector<Var> vars;
         if (old_gemm) {
             vars.push_back({"lib auto", 0, -1});
-            if (s.M % 256 == 0 && s.N % 256 == 0) vars.push_back({"lib pp256 (40)", 0, 40});
-            if (s.M % 320 == 0 && s.N % 256 == 0) vars.push_back({"lib pp320 (42)", 0, 42});
-            if (s.M % 320 == 0 && s.N % 128 == 0) vars.push_back({"lib pp320x128 (44)", 0, 44});
         }
         if (wise::w4_shape_ok(s.M, s.N, s.K, 8)) vars.push_back({"w4 256x256", 1, 8});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 5)) vars.push_back({"w4 160x256", 1, 5});
+        if (wise::w4_shape_ok(s.M, s.N, s.K, 10)) vars.push_back({"w4 320x256", 1, 10});
+        if (wise::w4_shape_ok(s.M, s.N, s.K, 10, 6)) vars.push_back({"w4 320x192", 1, 106});
+        if (wise::w4_shape_ok(s.M, s.N, s.K, 8, 6)) vars.push_back({"w4 256x192", 1, 86});
 
         auto run = [&](const Var& v) {
             if (v.kind == 0) {
-                set_variant(v.arg < 0 ? 0 : v.arg);   // 0 = the library's own shape heuristic
                 int rc = old_gemm(A, W, bias, s.M, s.N, s.K, s.mode, out, st);
                 if (rc) { printf("old gemm rc %d\n", rc); exit(1); }
-            } else if (v.arg == 8) launch_new<8>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
-            else launch_new<5>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            } else if (v.arg == 8) launch_new<8, 8, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            else if (v.arg == 5) launch_new<5, 8, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            else if (v.arg == 10) launch_new<10, 8, 2, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            else if (v.arg == 106) launch_new<10, 6, 2, 3>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            else launch_new<8, 6, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
         };
 
         // correctness: rows [0,256) and the last 256 rows against the reference

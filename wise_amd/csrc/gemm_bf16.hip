@@ -2152,10 +2152,18 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 42: if (M % 320 == 0 && N % 256 == 0) { launch_pp<MODE, 160>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        // 60 / 61: the one-wave-per-SIMD kernel (gemm_w4.h), 256 x 256 / 160 x 256 tiles
-        case 60: if (w4_shape_ok(M, N, K, 8)) { launch_w4<MODE, 8>(A, Wt, bias, M, N, K, out, st); break; }
+        // 60 .. 63: the one-wave-per-SIMD kernel (gemm_w4.h), 256 x 256 / 160 x 256 / 320 x 256 / 320 x 192 tiles
+        case 60: if (w4_shape_ok(M, N, K, 8)) { launch_w4<MODE, 8, 8, 3, 2>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
-        case 61: if (w4_shape_ok(M, N, K, 5)) { launch_w4<MODE, 5>(A, Wt, bias, M, N, K, out, st); break; }
+        case 61: if (w4_shape_ok(M, N, K, 5)) { launch_w4<MODE, 5, 8, 3, 2>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 62: if constexpr (bf16_out(MODE)) {   // (the fp32 epilogues of a 320-row tile spill: bf16 outputs only)
+                     if (w4_shape_ok(M, N, K, 10)) { launch_w4<MODE, 10, 8, 2, 2>(A, Wt, bias, M, N, K, out, st); break; }
+                 }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 63: if constexpr (bf16_out(MODE)) {
+                     if (w4_shape_ok(M, N, K, 10, 6)) { launch_w4<MODE, 10, 6, 2, 3>(A, Wt, bias, M, N, K, out, st); break; }
+                 }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 8: launch_gemm<MODE, 1>(A, Wt, bias, M, N, K, out, st); break;
         case 9: launch_gemm<MODE, 2>(A, Wt, bias, M, N, K, out, st); break;
@@ -2165,7 +2173,7 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
 
 static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode,
                        void* out, hipStream_t st) {
-    if (v == 60 || v == 61) { /* gemm_w4.h checks its own shape */ }
+    if (v >= 60 && v <= 63) { /* gemm_w4.h checks its own shape */ }
     else if (K % 64 != 0 && v != 40 && v != 42 && v != 45 && v != 46 && v != 48 && v != 50) v = 1;
     else if (N % BN != 0 && v != 1) v = 0;  // N edge is handled by the 128x128 kernels only
     switch (mode) {
@@ -2200,21 +2208,29 @@ static int auto_variant(int M, int N, int K) {
 void gemm_set_overlapped(bool on) { g_overlapped = on ? 1 : 0; }
 
 // The one-wave-per-SIMD kernel (gemm_w4.h) takes every problem it can tile into at least ~3/4 of a round of the 256 CUs.
-// Between its two tiles the model is rounds x (prologue + K-steps x cycles per step) with the cycles its in-kernel
-// stamps show on MI355X (tools/gemm_lab.hip: 256 x 256: ~3100 + 2580 per 64-deep step; 160 x 256: ~2800 + 1750); the
-// epilogue is HBM-bound on the C tile either way.  Returns the variant id (60 / 61) or 0.
-static int w4_variant(int M, int N, int K) {
-    if (!g_w4_enabled) return 0;
+// Among its tiles the model is rounds x (prologue + K-steps x cycles per step + epilogue) with the cycles its in-kernel
+// stamps show on MI355X (tools/gemm_lab.hip; the loops run at 76-79 % of the MFMA rate: 160 x 256 ~1700 cycles per
+// 64-deep step, 256 x 256 ~2560, 320 x 192 ~2430, 320 x 256 ~3250; prologue ~3200); the epilogue is bound by the HBM
+// traffic of the C tile, i.e. proportional to the tile's area whatever its shape, so it only enters through the
+// rounds.  Returns the variant id (60 .. 63) or 0.
+static int w4_variant(int M, int N, int K, int mode) {
+    // (K < 512: a tile is a handful of K-steps between a prologue and an epilogue that nothing overlaps at one workgroup
+    // per CU; the two-blocks-per-CU kernels keep those shapes)
+    if (!g_w4_enabled || K < 512) return 0;
+    struct Cand { int id, mi, nj; double step; bool bf16_only; };
+    static const Cand cands[] = {{60, 8, 8, 2560.0, false}, {61, 5, 8, 1700.0, false}, {62, 10, 8, 3250.0, true},
+                                 {63, 10, 6, 2430.0, true}};
     double best = 0.0;
     int v = 0;
-    for (int c = 0; c < 2; ++c) {
-        const int mi = c == 0 ? 8 : 5;
-        if (!w4_shape_ok(M, N, K, mi)) continue;
-        const long long tiles = (long long)(M / (32 * mi)) * (N / 256);
+    for (const Cand& c : cands) {
+        if (c.bf16_only && !bf16_out(mode)) continue;
+        if (!w4_shape_ok(M, N, K, c.mi, c.nj)) continue;
+        const long long tiles = (long long)(M / (32 * c.mi)) * (N / (32 * c.nj));
         if (tiles < 192) continue;
         const long long rounds = (tiles + 255) / 256;
-        const double cost = (double)rounds * ((mi == 8 ? 3100.0 : 2800.0) + (K / 64) * (mi == 8 ? 2580.0 : 1750.0));
-        if (v == 0 || cost < best) { best = cost; v = c == 0 ? 60 : 61; }
+        const double epilogue = 10500.0 * (c.mi * c.nj / 64.0) * (bf16_out(mode) ? 1.0 : 2.0);
+        const double cost = (double)rounds * (3200.0 + (K / 64) * c.step + epilogue);
+        if (v == 0 || cost < best) { best = cost; v = c.id; }
     }
     return v;
 }
@@ -2421,7 +2437,7 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
         g_overlapped = keep;
         return rc3;
     }
-    if (const int vw = w4_variant(M, N, K)) return launch_mode(vw, A, Wt, bias, M, N, K, mode, out, st);
+    if (const int vw = w4_variant(M, N, K, mode)) return launch_mode(vw, A, Wt, bias, M, N, K, mode, out, st);
     if (g_overlapped && g_overlap_policy == 1) return launch_mode(auto_variant(M, N, K) == 2 ? 2 : 0, A, Wt, bias, M, N, K, mode, out, st);
     if (g_overlapped && g_overlap_policy == 2 && !(bf16_out(mode) && N >= 3 * K)) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);
     if (g_overlapped && g_overlap_policy == 4 && (mode == EPI_RESID || mode == EPI_F32)) return launch_mode(0, A, Wt, bias, M, N, K, mode, out, st);
