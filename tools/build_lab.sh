@@ -4,4 +4,4 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/bin
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops \
-    tools/gemm_lab.hip -o tools/bin/gemm_lab -ldl -save-temps=obj 2>&1 | grep -v "not a recognized feature\|ignoring feature" || true
+    $LAB_DEFS tools/gemm_lab.hip -o tools/bin/${LAB_OUT:-gemm_lab} -ldl -save-temps=obj 2>&1 | grep -v "not a recognized feature\|ignoring feature" || true

@@ -71,6 +71,7 @@ static void launch_new(int mode, const bf16_t* A, const bf16_t* W, const float* 
 int main(int argc, char** argv) {
     std::string which = argc > 1 ? argv[1] : "vit";
     const int rounds = argc > 2 ? atoi(argv[2]) : 5;
+    const int NB = argc > 3 ? atoi(argv[3]) : 1;   // buffer sets rotated between launches (working set beyond the 256 MB Infinity Cache)
     std::vector<Shape> shapes;
     if (which == "vit" || which == "all") {
         shapes.push_back({"qkv  12800x2304x768", 12800, 2304, 768, 0});
@@ -104,12 +105,16 @@ int main(int argc, char** argv) {
     for (const Shape& s : shapes) {
         const size_t nA = (size_t)s.M * s.K, nW = (size_t)s.N * s.K, nC = (size_t)s.M * s.N;
         bf16_t *A, *W; float* bias; void* out; float* ref;
-        CK(hipMalloc(&A, nA * 2)); CK(hipMalloc(&W, nW * 2)); CK(hipMalloc(&bias, s.N * 4));
         const bool f32o = s.mode == 3 || s.mode == 4;
-        CK(hipMalloc(&out, nC * (f32o ? 4 : 2)));
+        bf16_t* Abase; unsigned char* outbase;
+        const size_t outB = nC * (f32o ? 4 : 2);
+        CK(hipMalloc(&Abase, nA * 2 * NB)); CK(hipMalloc(&W, nW * 2)); CK(hipMalloc(&bias, s.N * 4));
+        CK(hipMalloc(&outbase, outB * NB));
+        A = Abase; out = outbase;
+        int rot = 0;
         const int RR = 512;   // reference rows: 2 x 256 rows spread over the matrix
         CK(hipMalloc(&ref, (size_t)RR * s.N * 4));
-        fill_bf16<<<(nA + 255) / 256, 256, 0, st>>>(A, nA, 0x1234u, 1.0f);
+        for (int b = 0; b < NB; ++b) fill_bf16<<<(nA + 255) / 256, 256, 0, st>>>(Abase + b * nA, nA, 0x1234u, 1.0f);
         fill_bf16<<<(nW + 255) / 256, 256, 0, st>>>(W, nW, 0x9e37u, 2.0f / sqrtf((float)s.K));
         fill_f32<<<(s.N + 255) / 256, 256, 0, st>>>(bias, s.N, 0x77u, 0.5f);
         CK(hipStreamSynchronize(st));
@@ -123,9 +128,11 @@ int main(int argc, char** argv) {
         if (wise::w4_shape_ok(s.M, s.N, s.K, 5)) vars.push_back({"w4 160x256", 1, 5});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 10)) vars.push_back({"w4 320x256", 1, 10});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 10, 6)) vars.push_back({"w4 320x192", 1, 106});
-        if (wise::w4_shape_ok(s.M, s.N, s.K, 8, 6)) vars.push_back({"w4 256x192", 1, 86});
+        if (wise::w4p_shape_ok(s.M, s.N, s.K) && !f32o) vars.push_back({"w4p persistent 160x256", 1, 500});
 
         auto run = [&](const Var& v) {
+            rot = (rot + 1) % NB;
+            A = Abase + (size_t)rot * nA; out = outbase + (size_t)rot * outB;
             if (v.kind == 0) {
                 int rc = old_gemm(A, W, bias, s.M, s.N, s.K, s.mode, out, st);
                 if (rc) { printf("old gemm rc %d\n", rc); exit(1); }
@@ -133,14 +140,19 @@ int main(int argc, char** argv) {
             else if (v.arg == 5) launch_new<5, 8, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 10) launch_new<10, 8, 2, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 106) launch_new<10, 6, 2, 3>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
-            else launch_new<8, 6, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            else if (v.arg == 500) {
+                using namespace wise;
+                if (s.mode == 0) launch_w4p<EPI_BF16>(A, W, bias, s.M, s.N, s.K, out, 256, st);
+                else if (s.mode == 1) launch_w4p<EPI_QUICKGELU>(A, W, bias, s.M, s.N, s.K, out, 256, st);
+                else launch_w4p<EPI_GELU>(A, W, bias, s.M, s.N, s.K, out, 256, st);
+            }
         };
 
         // correctness: rows [0,256) and the last 256 rows against the reference
         std::vector<float> href((size_t)RR * s.N), hout_f;
         std::vector<uint16_t> hout_b;
         for (const Var& v : vars) {
-            CK(hipMemsetAsync(out, 0, nC * (f32o ? 4 : 2), st));
+            CK(hipMemsetAsync(outbase, 0, outB * NB, st));
             run(v);
             CK(hipStreamSynchronize(st));
             CK(hipGetLastError());
@@ -191,6 +203,16 @@ int main(int argc, char** argv) {
                    flop / med * 1e-6, mn, flop / mn * 1e-6);
         }
         for (size_t vi = 0; vi < vars.size(); ++vi) {
+            if (vars[vi].kind == 1 && vars[vi].arg == 500) {
+                run(vars[vi]); run(vars[vi]);
+                CK(hipStreamSynchronize(st));
+                unsigned long long hp[4][4];
+                CK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(wise::w4::g_w4p_stamps), sizeof(hp)));
+                for (int t = 0; t < 3; ++t)
+                    printf("  stamps w4p tile %d: steps 0-4 %6llu  rest of loop %6llu  pack %6llu  (to next tile start %6llu)\n", t,
+                           hp[t][1] - hp[t][0], hp[t][2] - hp[t][1], hp[t][3] - hp[t][2], t < 2 ? hp[t + 1][0] - hp[t][3] : 0ull);
+                continue;
+            }
             if (vars[vi].kind != 1) continue;
             run(vars[vi]); run(vars[vi]);
             CK(hipStreamSynchronize(st));
@@ -201,7 +223,7 @@ int main(int argc, char** argv) {
                        vars[vi].name.c_str(), b ? "last " : "first", hs[b][1] - hs[b][0], hs[b][2] - hs[b][1], hs[b][3] - hs[b][2]);
         }
         fflush(stdout);
-        CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(out)); CK(hipFree(ref));
+        CK(hipFree(Abase)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(outbase)); CK(hipFree(ref));
     }
     return 0;
 }

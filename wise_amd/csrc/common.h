@@ -53,8 +53,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(unsigned short, b);
 }
+// two values in ONE v_cvt_pk_bf16_f32 (the scalar form above costs a conversion per value plus a shift and an or per pair)
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t v = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, v);
 }
 
 using short8 = __attribute__((ext_vector_type(8))) short;

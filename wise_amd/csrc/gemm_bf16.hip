@@ -2117,6 +2117,20 @@ static int g_w4_enabled = 1;  // (debug knob, bit 28 of wise_debug_set_gemm_vari
 static int g_split_m = 1;  // split M between the ping-pong kernel and the 128x128 kernel (bit 29 of the knob: off)
   // 0: 2-stage BK=64 ; 1: ring BK=32 x4 (2 blocks/CU) ; 2: ring BK=64 x4 (1 block/CU) ; 3: ring BK=64 x3
 
+// compute units of the current device (the persistent kernel's grid), asked once per device
+static int device_cus() {
+    static int cus[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 template <int MODE>
 static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K,
                            void* out, hipStream_t st) {
@@ -2165,6 +2179,11 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
                      if (w4_shape_ok(M, N, K, 10, 6)) { launch_w4<MODE, 10, 6, 2, 3>(A, Wt, bias, M, N, K, out, st); break; }
                  }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        // 64: its persistent form (160 x 256 tiles, the C tile leaves during the next tile's loop), bf16 outputs
+        case 64: if constexpr (bf16_out(MODE)) {
+                     if (w4p_shape_ok(M, N, K)) { launch_w4p<MODE>(A, Wt, bias, M, N, K, out, device_cus(), st); break; }
+                 }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 8: launch_gemm<MODE, 1>(A, Wt, bias, M, N, K, out, st); break;
         case 9: launch_gemm<MODE, 2>(A, Wt, bias, M, N, K, out, st); break;
         default: launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
@@ -2173,7 +2192,7 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
 
 static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode,
                        void* out, hipStream_t st) {
-    if (v >= 60 && v <= 63) { /* gemm_w4.h checks its own shape */ }
+    if (v >= 60 && v <= 64) { /* gemm_w4.h checks its own shape */ }
     else if (K % 64 != 0 && v != 40 && v != 42 && v != 45 && v != 46 && v != 48 && v != 50) v = 1;
     else if (N % BN != 0 && v != 1) v = 0;  // N edge is handled by the 128x128 kernels only
     switch (mode) {
@@ -2229,8 +2248,21 @@ static int w4_variant(int M, int N, int K, int mode) {
         if (tiles < 192) continue;
         const long long rounds = (tiles + 255) / 256;
         const double epilogue = 10500.0 * (c.mi * c.nj / 64.0) * (bf16_out(mode) ? 1.0 : 2.0);
-        const double cost = (double)rounds * (3200.0 + (K / 64) * c.step + epilogue);
+        const double act = (mode == EPI_QUICKGELU || mode == EPI_GELU || mode == EPI_GELU_TANH) ? 5000.0 * (c.mi * c.nj / 40.0) : 0.0;
+        const double cost = (double)rounds * (3200.0 + (K / 64) * c.step + epilogue + act);
         if (v == 0 || cost < best) { best = cost; v = c.id; }
+    }
+    // the persistent form: no prologue between tiles, the C tile leaves under the next tile's loop; what stays exposed per
+    // tile is the packing of the accumulators (~1.9k cycles, ~6.2k with a sigmoid-shaped activation) and ~1.7k of drain
+    if (bf16_out(mode) && w4p_shape_ok(M, N, K)) {
+        const long long tiles = (long long)(M / 160) * (N / 256);
+        const int cus = device_cus();
+        if (tiles >= cus) {
+            const long long rounds = (tiles + cus - 1) / cus;
+            const double pack = (mode == EPI_QUICKGELU || mode == EPI_GELU || mode == EPI_GELU_TANH) ? 6200.0 : 1900.0;
+            const double cost = 3200.0 + (double)rounds * ((K / 64) * 1660.0 + 1700.0 + pack) + 5000.0;
+            if (v == 0 || cost < best) { best = cost; v = 64; }
+        }
     }
     return v;
 }

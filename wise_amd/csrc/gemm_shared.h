@@ -30,6 +30,46 @@ __device__ __forceinline__ float act_gelu_tanh(float x) {
     const float u = 0.7978845608028654f * fmaf(0.044715f * x, x * x, x);
     return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.f * 1.4426950408889634f * u));
 }
+// The three sigmoid-shaped activations are x * rcp(1 + exp2(p(x))): act_arg gives p.  act_apply_n evaluates N values stage
+// by stage (all arguments, all exp2, all +1, all rcp, all products), pinned with scheduling barriers: written value by
+// value the compiler emits each chain serially — five dependent instructions with a wait state behind each of the two
+// transcendentals — and a wave that is alone on its SIMD (gemm_w4.h) pays that latency in full: 7.4k cycles for the
+// 160 values a lane holds of a 160 x 256 tile against ~5k staged.
+template <int MODE>
+__device__ __forceinline__ float act_arg(float x) {
+    if (MODE == EPI_QUICKGELU) return -1.702f * 1.4426950408889634f * x;
+    if (MODE == EPI_GELU) {
+        const float x2 = fminf(x * x, 64.f);
+        return x * fmaf(x2, fmaf(x2, 0.0010142630198970437f, -0.10677572339773178f), -2.301121234893799f);
+    }
+    if (MODE == EPI_GELU_TANH) return -2.f * 1.4426950408889634f * (0.7978845608028654f * fmaf(0.044715f * x, x * x, x));
+    return x;
+}
+template <int MODE, int N>
+__device__ __forceinline__ void act_apply_n(float (&x)[N]) {
+    if (MODE == EPI_RELU) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) x[k] = fmaxf(x[k], 0.f);
+    } else if (MODE == EPI_QUICKGELU || MODE == EPI_GELU || MODE == EPI_GELU_TANH) {
+        float t[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) t[k] = act_arg<MODE>(x[k]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < N; ++k) t[k] = __builtin_amdgcn_exp2f(t[k]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < N; ++k) t[k] = 1.f + t[k];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < N; ++k) t[k] = __builtin_amdgcn_rcpf(t[k]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < N; ++k) x[k] *= t[k];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ float act_apply(float x) {
     if (MODE == EPI_QUICKGELU) return act_quickgelu(x);

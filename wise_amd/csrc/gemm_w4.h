@@ -39,6 +39,8 @@ namespace w4 {
 // In-kernel s_memtime stamps of block 0 and of the last block (tools/gemm_lab.hip builds with -DW4_STAMPS): slot 0 kernel
 // entry, 1 first operands landed, 2 main loop done, 3 epilogue done.  Compiled out of the product.
 #ifdef W4_STAMPS
+__device__ unsigned long long g_w4p_stamps[4][4];
+#define W4P_STAMP(t, k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && (t) < 4) g_w4p_stamps[t][k] = __builtin_amdgcn_s_memtime(); } while (0)
 __device__ unsigned long long g_w4_stamps[2][4];
 #define W4_STAMP(k)                                                                                              \
     do {                                                                                                         \
@@ -47,6 +49,7 @@ __device__ unsigned long long g_w4_stamps[2][4];
     } while (0)
 #else
 #define W4_STAMP(k) do {} while (0)
+#define W4P_STAMP(t, k) do {} while (0)
 #endif
 
 
@@ -85,6 +88,13 @@ __device__ __forceinline__ void mfma16a(f32x4& acc, const bf16x8& a, const bf16x
 __device__ __forceinline__ void mfma16v(f32x4& acc, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
+// The compiler does not know these statements are MFMAs, so it pads no wait states between one and a read of its result,
+// and it may move such a read (a plain register copy) up to right behind the statement.  After the loop: idle long enough
+// for the last MFMA to retire, then pass every accumulator through a volatile statement — volatile statements keep their
+// order, so every later read of the accumulators stays behind the idle slots.
+__device__ __forceinline__ void mfma_retire() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+__device__ __forceinline__ void pin_a(f32x4& acc) { asm volatile("" : "+a"(acc)); }
+__device__ __forceinline__ void pin_v(f32x4& acc) { asm volatile("" : "+v"(acc)); }
 
 // bf16 epilogue of RI row tiles (RI <= 4) x NJ*16 columns: wave-private image of 16*RI rows, then a row-major walk in
 // which every global store instruction writes whole row segments (16 bytes per lane, consecutive lanes consecutive)
@@ -95,13 +105,15 @@ __device__ __forceinline__ void epi_bf16_pass(const f32x4 (&acc)[MI][NJ], int i0
     static_assert((RI * 16 * CPR) % 64 == 0, "walk covers the piece in whole wave instructions");
     const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ; j += 2)
 #pragma unroll
-        for (int ii = 0; ii < RI; ++ii) {
-            const f32x4 a = acc[i0 + ii][j];
-            const float v0 = act_apply<MODE>(a[0] + bv[j].x), v1 = act_apply<MODE>(a[1] + bv[j].y),
-                        v2 = act_apply<MODE>(a[2] + bv[j].z), v3 = act_apply<MODE>(a[3] + bv[j].w);
-            W4_LDS(u32x2_t, my + (ii * 16 + l15) * RS + (j * 16 + g * 4) * 2) = u32x2_t{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+        for (int ii = 0; ii < RI; ++ii) {          // eight values at a time, stage by stage (act_apply_n)
+            const f32x4 a = acc[i0 + ii][j], b = acc[i0 + ii][j + 1];
+            float x[8] = {a[0] + bv[j].x,     a[1] + bv[j].y,     a[2] + bv[j].z,     a[3] + bv[j].w,
+                          b[0] + bv[j + 1].x, b[1] + bv[j + 1].y, b[2] + bv[j + 1].z, b[3] + bv[j + 1].w};
+            act_apply_n<MODE, 8>(x);
+            W4_LDS(u32x2_t, my + (ii * 16 + l15) * RS + (j * 16 + g * 4) * 2) = u32x2_t{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
+            W4_LDS(u32x2_t, my + (ii * 16 + l15) * RS + ((j + 1) * 16 + g * 4) * 2) = u32x2_t{pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -110,7 +122,11 @@ __device__ __forceinline__ void epi_bf16_pass(const f32x4 (&acc)[MI][NJ], int i0
     for (int t = 0; t < RI * 16 * CPR / 64; ++t) {
         const int idx = t * 64 + lane, row = idx / CPR, c = idx % CPR;
         const u32x4_t v = W4_LDS(const u32x4_t, my + row * RS + c * 16);
+#ifdef W4_PLAIN_STORES
+        *reinterpret_cast<u32x4_t*>(out + (size_t)(row0 + i0 * 16 + row) * N + col0 + c * 8) = v;
+#else
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(out + (size_t)(row0 + i0 * 16 + row) * N + col0 + c * 8));
+#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -284,7 +300,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const bf16_t* __restric
     for (int s = 0; s < nk - 2; ++s) step(T{}, T{}, F{});
     step(F{}, T{}, T{});     // s = nk-2: nothing left to request; step nk-1 must have landed
     step(F{}, F{}, T{});     // s = nk-1
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs retire before the epilogue reads the accumulators
+    mfma_retire();
+#pragma unroll
+    for (int m = 0; m < MI * NJ; ++m) { if (m < 64) pin_a(acc[m / NJ][m % NJ]); else pin_v(acc[m / NJ][m % NJ]); }
 
     W4_STAMP(2);
     // ---- epilogue: the slots are dead once every wave is past its last fragment read
@@ -339,6 +357,250 @@ static void launch_w4(const bf16_t* A, const bf16_t* Wt, const float* bias, int 
     const int grid = (M / (32 * MI)) * (N / (32 * NJ));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, A, Wt, bias, M, N, K, out);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent form for bf16 outputs, 160 x 256 tiles (MI = 5, NJ = 8; 3 + 2 slots): a workgroup per CU walks tiles
+// b, b + G, b + 2G, ... and runs their K-steps as ONE stream.  The stamps of the plain kernel (tools/gemm_lab.hip) show a
+// tile's life as ~3.5k cycles waiting for its first operands, ~20k in the loop and 9-25k in an epilogue that is one
+// HBM-bound store burst (every CU stores its C tile at the same moment) plus, with an activation, VALU work at half rate
+// (one wave per SIMD).  Here
+//   * the last two steps of a tile request steps 0 and 1 of the workgroup's NEXT tile (same slots, same counts), and the
+//     last phase reads their first fragments: no prologue between tiles;
+//   * after the last MFMA the accumulators are biased, activated and packed to bf16 into 80 VGPRs (the only exposed part
+//     of the epilogue: VALU work without memory traffic), and the first MFMA phase of the next tile starts from C = 0;
+//   * the packed tile then leaves DURING the next tile's first five K-steps: per step one 16-row tile goes through a
+//     4-KiB wave-private LDS image — eight ds_write_b64 between the MFMAs of phase A, four ds_read_b128 + global_store
+//     pairs between those of phase B — so the C traffic is spread over the loop instead of bursting behind it.
+// Stores sit in phase B only, so the counted vmcnt in front of a barrier (the DMAs of phase A) is the plain kernel's.
+// K % 64 == 0, K >= 512 (five drain steps + the two that request the next tile); M % 160 == 0, N % 256 == 0.
+// ------------------------------------------------------------------------------------------------------------------
+namespace w4 {
+
+// a tile's first MFMA per accumulator: C = 0, no accumulator initialisation pass.  (Starting from the bias instead would
+// save the epilogue's adds but round differently from every other kernel of the library, which add the bias to the
+// finished sum: the same row must give the same bits whatever kernel its batch size selects.)
+__device__ __forceinline__ void mfma16a_init(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+}
+
+__device__ __forceinline__ void tile_coords_v(int vb, int nwg, int tiles_m, int tiles_n, int group_m, int* tm, int* tn) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per_group = group_m * tiles_n;
+    const int gid = bid / per_group;
+    const int first_m = gid * group_m;
+    const int gsize = min(tiles_m - first_m, group_m);
+    const int in_group = bid - gid * per_group;
+    *tm = first_m + in_group % gsize;
+    *tn = in_group / gsize;
+}
+
+}  // namespace w4
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void gemm_w4p_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+                                                          const float* __restrict__ bias, int M, int N, int K,
+                                                          bf16_t* __restrict__ out) {
+    using namespace w4;
+    static_assert(bf16_out(MODE), "packed drain: bf16 outputs");
+    constexpr int MI = 5, NJ = 8, BMB = 160, BNB = 256;
+    constexpr int ASZ = BMB * 128, WSZ = BNB * 128, WBASE = 3 * ASZ, SCR = WBASE + 2 * WSZ, SCRW = 16 * 272;
+    constexpr int PA = BMB / 32, PW = BNB / 32;
+    constexpr int NDRAIN = MI;          // K-steps over which a packed tile leaves (one row tile each)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tiles_m = M / BMB, tiles_n = N / BNB, ntiles = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int T = (ntiles - (int)blockIdx.x + G - 1) / G;     // this workgroup's tiles: blockIdx.x + r * G
+
+    const int ldb = K * 2;
+    const int voff = (lane >> 3) * ldb + (((lane & 7) ^ (lane >> 3)) << 4);
+    const unsigned fa0 = (wm * MI * 16 + l15) * 128 + ((g ^ (l15 & 7)) << 4), fa1 = fa0 ^ 64;
+    const unsigned fw0 = WBASE + (wn * NJ * 16 + l15) * 128 + ((g ^ (l15 & 7)) << 4), fw1 = fw0 ^ 64;
+    const unsigned scr = SCR + wave * SCRW;
+    const int nk = K / 64;
+
+    int tm, tn;
+    tile_coords_v(blockIdx.x, ntiles, tiles_m, tiles_n, 4, &tm, &tn);
+    int m0 = tm * BMB, n0 = tn * BNB;
+    auto rsrc_of = [&](const bf16_t* base, int row) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)row * K), 0, 0x7fffffff, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t rA = rsrc_of(A, m0), rW = rsrc_of(Wt, n0);
+
+    // prologue of the FIRST tile: steps 0 and 1
+    stage_operand<BMB>(rA, 0, voff, ldb, 0, wave);
+    stage_operand<BNB>(rW, WBASE, voff, ldb, 0, wave);
+    stage_operand<BMB>(rA, ASZ, voff, ldb, 128, wave);
+    stage_operand<BNB>(rW, WBASE + WSZ, voff, ldb, 128, wave);
+    wait_vmcnt<PA + PW>();
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[MI][NJ];
+    bf16x8 af0[MI], wf0[NJ], af1[MI], wf1[NJ];
+    {
+        lds_cptr pw = (lds_cptr)(uintptr_t)fw0, pa = (lds_cptr)(uintptr_t)fa0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wf0[j] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(pw + j * 2048);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af0[i] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(pa + i * 2048);
+    }
+    unsigned oA0 = 0, oA1 = ASZ, oA2 = 2 * ASZ;       // slots of A(g), A(g+1), A(g+2) over the stream of steps g
+    unsigned oW0 = 0, oW1 = WSZ, oW2 = 0;
+
+    u32x2_t packed[MI][NJ];          // the previous tile, activated / rounded: lane holds (row i*16+l15, cols j*16+g*4..+3)
+    // the packed tile's way out: buffer stores, a lane's voffset fixed (row g of a 4-row piece, its 16 bytes of the row),
+    // piece and tile position in the scalar offset
+    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 0x7fffffff, 0x00020000);
+    const int vst = (g * N + l15 * 8) * 2;
+    int sst = 0;                                                    // ((pm0 + wm*80) * N + pn0 + wn*128) * 2
+    typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
+    const lds_ptr scw = (lds_ptr)(uintptr_t)(scr + l15 * 272 + g * 8);   // image writes: + j*32
+    const lds_cptr scrd = (lds_cptr)(uintptr_t)(scr + g * 272 + l15 * 16); // image reads: + t*4*272
+    auto load_bias = [&](int ncol, f32x4 (&b)[NJ]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float4 v = bias ? *reinterpret_cast<const float4*>(bias + ncol + wn * 128 + j * 16 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[j] = f32x4{v.x, v.y, v.z, v.w};
+        }
+    };
+    f32x4 bv[NJ];                    // the bias of the tile in flight (loaded in front of its last two steps)
+
+    // One phase: 40 MFMAs (INIT: the tile's first, C = 0) with the fragment reads of the next phase, the DMAs of the
+    // phase, and DW / DR = the drain's LDS writes / read + store pairs of row tile DI of the packed tile between them.
+    auto phase = [&](const bf16x8 (&af)[MI], const bf16x8 (&wf)[NJ], bf16x8 (&afn)[MI], bf16x8 (&wfn)[NJ], lds_cptr pw,
+                     lds_cptr pa, auto init_c, auto nd_c, __amdgpu_buffer_rsrc_t rq, unsigned dslot, int dkb,
+                     auto di_c, auto dw_c, auto dr_c) {
+        constexpr bool INIT = decltype(init_c)::value, DW = decltype(dw_c)::value, DR = decltype(dr_c)::value;
+        constexpr int ND = decltype(nd_c)::value, DI = decltype(di_c)::value;
+        constexpr int NM = MI * NJ, NR = MI + NJ;
+        constexpr int MPR = (NM * 3 / 4) / NR;                 // reads in front of MFMAs 0, 2, 4, ...
+        constexpr int MPD = (NM * 3 / 4) / ND;
+        u32x4_t piece[4];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            if (m % MPR == 0 && m / MPR < NR) {
+                const int r = m / MPR;
+                if (r < NJ) wfn[r] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(pw + r * 2048);
+                else afn[r - NJ] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(pa + (r - NJ) * 2048);
+            }
+            if (m >= 1 && (m - 1) % MPD == 0 && (m - 1) / MPD < ND) {
+                const int u = ((m - 1) / MPD) * 4 + wave;
+                dma16(rq, dslot + u * 1024, voff, u * 8 * ldb + dkb);
+            }
+            if (DW && m % 4 == 3 && m / 4 < NJ)                 // eight 8-byte writes: the row tile's image, 272-byte rows
+                *reinterpret_cast<__attribute__((address_space(3))) u32x2_t*>(scw + (m / 4) * 32) = packed[DI][m / 4];
+            if (DR && m % 8 == 3 && m / 8 < 4)                  // four 16-byte reads ...
+                piece[m / 8] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(scrd + (m / 8) * 4 * 272);
+            if (DR && m % 8 == 1 && m >= 9)                     // ... each stored six MFMAs later (m = 9: piece 0, ..., 33: piece 3)
+                __builtin_amdgcn_raw_buffer_store_b128(piece[m / 8 - 1], rO, vst, sst + (DI * 16 + (m / 8 - 1) * 4) * N * 2, 2);
+            if (INIT) mfma16a_init(acc[m / NJ][m % NJ], wf[m % NJ], af[m / NJ]);
+            else mfma16a(acc[m / NJ][m % NJ], wf[m % NJ], af[m / NJ]);
+        }
+    };
+
+    // K-step of the current tile; rqA / rqW, kq: where the request two steps down the stream goes (this tile, or the first
+    // steps of the next one).  DI >= 0: row tile DI of the packed tile leaves in this step.
+    auto step = [&](auto init_c, auto di_c, __amdgpu_buffer_rsrc_t rqA, __amdgpu_buffer_rsrc_t rqW, int kq) {
+        constexpr int DI = decltype(di_c)::value;
+        using DIc = std::integral_constant<int, DI < 0 ? 0 : DI>;
+        using DOc = std::integral_constant<bool, (DI >= 0)>;
+        phase(af0, wf0, af1, wf1, (lds_cptr)(uintptr_t)(oW0 + fw1), (lds_cptr)(uintptr_t)(oA0 + fa1), init_c,
+              std::integral_constant<int, PA>{}, rqA, oA2, kq, DIc{}, DOc{}, std::false_type{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt<PA>();
+        __builtin_amdgcn_s_barrier();
+        phase(af1, wf1, af0, wf0, (lds_cptr)(uintptr_t)(oW1 + fw0), (lds_cptr)(uintptr_t)(oA1 + fa0), std::false_type{},
+              std::integral_constant<int, PW>{}, rqW, WBASE + oW2, kq, DIc{}, std::false_type{}, DOc{});
+        const unsigned a0 = oA0;
+        oA0 = oA1; oA1 = oA2; oA2 = a0;
+        oW0 = oW1; oW1 = oW2; oW2 = oW0;
+    };
+    // (two W slots: W(g+2) shares the slot of W(g))
+    oW2 = oW0;
+
+    for (int t = 0; t < T; ++t) {
+        // the next tile of this workgroup (the last tile requests its own first steps again: valid addresses, dead slots)
+        int m0n = m0, n0n = n0;
+        if (t + 1 < T) {
+            tile_coords_v((int)blockIdx.x + (t + 1) * G, ntiles, tiles_m, tiles_n, 4, &tm, &tn);
+            m0n = tm * BMB; n0n = tn * BNB;
+        }
+        const __amdgpu_buffer_rsrc_t rAn = rsrc_of(A, m0n), rWn = rsrc_of(Wt, n0n);
+        using F = std::false_type; using Tt = std::true_type;
+        using NoDrain = std::integral_constant<int, -1>;
+        W4P_STAMP(t, 0);
+        if (t > 0) {
+            step(Tt{}, std::integral_constant<int, 0>{}, rA, rW, 2 * 128);
+            step(F{}, std::integral_constant<int, 1>{}, rA, rW, 3 * 128);
+            step(F{}, std::integral_constant<int, 2>{}, rA, rW, 4 * 128);
+            step(F{}, std::integral_constant<int, 3>{}, rA, rW, 5 * 128);
+            step(F{}, std::integral_constant<int, 4>{}, rA, rW, 6 * 128);
+        } else {
+            step(Tt{}, NoDrain{}, rA, rW, 2 * 128);
+            for (int s = 1; s < NDRAIN; ++s) step(F{}, NoDrain{}, rA, rW, (s + 2) * 128);
+        }
+        W4P_STAMP(t, 1);
+        for (int s = NDRAIN; s < nk - 2; ++s) step(F{}, NoDrain{}, rA, rW, (s + 2) * 128);
+        // the tile's bias: requested in front of the last two steps, so that the wait in front of its first use leaves the
+        // DMAs of those steps — the next tile's first operands — in flight
+        load_bias(n0, bv);
+        step(F{}, NoDrain{}, rAn, rWn, 0);          // s = nk-2: step 0 of the next tile
+        step(F{}, NoDrain{}, rAn, rWn, 128);        // s = nk-1: step 1 of the next tile
+        W4P_STAMP(t, 2);
+        mfma_retire();
+#pragma unroll
+        for (int m = 0; m < MI * NJ; ++m) pin_a(acc[m / NJ][m % NJ]);
+
+        // bias, activation, round: the tile becomes 80 packed registers
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; j += 2) {       // eight values at a time, stage by stage (act_apply_n)
+                float x[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { x[r] = acc[i][j][r] + bv[j][r]; x[4 + r] = acc[i][j + 1][r] + bv[j + 1][r]; }
+                act_apply_n<MODE, 8>(x);
+                packed[i][j] = u32x2_t{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
+                packed[i][j + 1] = u32x2_t{pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
+            }
+        sst = ((m0 + wm * 80) * N + n0 + wn * 128) * 2;
+        m0 = m0n; n0 = n0n; rA = rAn; rW = rWn;
+        W4P_STAMP(t, 3);
+    }
+    // the last tile leaves without a loop to hide behind
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) *reinterpret_cast<__attribute__((address_space(3))) u32x2_t*>(scw + j * 32) = packed[i][j];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const u32x4_t v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(scrd + t4 * 4 * 272);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rO, vst, sst + (i * 16 + t4 * 4) * N * 2, 2);
+        }
+    }
+}
+
+template <int MODE>
+static void launch_w4p(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out, int num_cus,
+                       hipStream_t st) {
+    if constexpr (bf16_out(MODE)) {
+        auto kern = gemm_w4p_kernel<MODE>;
+        constexpr int LDS = 3 * 160 * 128 + 2 * 256 * 128 + 4 * 16 * 272;
+        static std::once_flag attr_set;
+        std::call_once(attr_set, [&] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        });
+        const int ntiles = (M / 160) * (N / 256);
+        const int grid = ntiles < num_cus ? ntiles : num_cus;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, A, Wt, bias, M, N, K, reinterpret_cast<bf16_t*>(out));
+    }
+}
+
+constexpr bool w4p_shape_ok(int M, int N, int K) { return M % 160 == 0 && N % 256 == 0 && K % 64 == 0 && K >= 512; }
 
 constexpr bool w4_shape_ok(int M, int N, int K, int MI, int NJ = 8) {
     return M % (32 * MI) == 0 && N % (32 * NJ) == 0 && K % 64 == 0 && K >= 192;
