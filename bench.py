@@ -97,6 +97,13 @@ def load_pmc_traffic(kernel_key):
         return None
 
 
+def traffic_fields(kernel_key):
+    """`traffic` of a roofline object + where it comes from: the committed PMC summary, NOT counters of this run."""
+    return {"traffic": load_pmc_traffic(kernel_key),
+            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the profile "
+                              "sequence committed with this round, corrected per MI355X_MICROARCH.md; not measured in this run)"}
+
+
 def cpu_baseline_vit(spec, sd, seconds):
     """SURVEY 8(d) cfg-1 stand-in, image half: the reference's CPU extraction path on synthetic decoded frames —
     uint8 [n,3,240,320] frames, 8 at a time exactly as extract-features.py:294,324-341 feeds them: per-frame PIL
@@ -136,7 +143,7 @@ def cpu_baseline_search(d, k, seconds, n_queries=20):
     The one-core C heap loop (oracle/ip_topk_ref.c: faiss's small-nq code path without its SIMD) is timed beside it."""
     import psutil
 
-    from wise_amd.build import build_oracle
+    from oracle.build import build_oracle
 
     threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
@@ -279,14 +286,15 @@ def main():
     g_ms, g_n, g_flop = prof[0]
     gemm_tflops = (g_flop / g_n) / (g_ms / g_n * 1e-3) / 1e12 if g_n else 0.0
     roofline = {
-        "kernel": "bf16 MFMA GEMM family (gemm_pp_kernel 256x256 ping-pong / gemm_bf16_kernel 128x128 / "
-                  "gemm_big_kernel 256x192, MFMA 16x16x32): every GEMM launch of the forward, HIP events on the "
-                  "launch stream, single-stream pass",
+        "kernel": "bf16 MFMA GEMM family (gemm_w4p_kernel persistent 160x256 for QKV / fc1, gemm_w4_kernel 160x256 for the "
+                  "two residual GEMMs and 224x192 for the patch embedding: one wave per SIMD, MFMA 16x16x32; "
+                  "gemm_ring_kernel for the projection): every GEMM launch of the forward, HIP events on the launch "
+                  "stream, single-stream pass",
         "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
         "avg_launch_us": round(g_ms / max(g_n, 1) * 1e3, 2), "launches": int(g_n),
         "flop_per_launch_avg": g_flop / max(g_n, 1),
-        "traffic": load_pmc_traffic("gemm_bf16_kernel"),
+        **traffic_fields("gemm_bf16_kernel"),
         "end_to_end_tflops": round(frames_per_s / world * spec.flops_per_frame() / 1e12, 2),
         "end_to_end_frac": round(frames_per_s / world * spec.flops_per_frame() / 1e12 / PEAK_BF16_TFLOPS, 4),
     }
@@ -411,7 +419,7 @@ def main():
                          "note": "bytes the kernel has to move: the bf16 shadow rows, N*d*2 per query; the fp32 rows "
                                  "(N*d*4, SURVEY 8(d)) are touched only for the collected candidates and by the fallback scan",
                          "fp32_rows_equivalent_gbs": round(n_loc * d * 4 / (s_ms / max(s_n, 1) * 1e-3) / 1e9, 1),
-                         "traffic": load_pmc_traffic("ip_collect_bf16_kernel")},
+                         **traffic_fields("ip_collect_bf16_kernel")},
             "two_stage": {"answered_from_the_shadow": int(shadow_stats[0]), "handed_to_fp32_scan": int(shadow_stats[1]),
                           "fp32_scan_only_queries_per_s": round(qps_f32, 2)},
             "batched_nq4_queries_per_s": round(4 * s_steps / sdt4, 2),
@@ -427,14 +435,14 @@ def main():
                                                "bf16 piece, its rounding carried in the error bound); whole call / 2 passes "
                                                "(sample, thresholds, collect, per-query refine + fp32 re-scoring + select, "
                                                "gated fallback launches), per GPU",
-                                       "traffic": load_pmc_traffic("ip_scan_shadow64_kernel")},
+                                       **traffic_fields("ip_scan_shadow64_kernel")},
             "batched_nq32_roofline": {"kernel": "ip_scan_shadow64_kernel<4,64,false> (one pass, half its 64 query slots used)",
                                       "bound": "hbm",
                                       "achieved": round(N * d * 2 / world / (sdt32 / s_steps) / 1e9, 1),
                                       "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": round(N * d * 2 / world / (sdt32 / s_steps) / 1e9 / PEAK_HBM_GBS, 4),
                                       "note": "bf16 shadow rows (N*d*2 bytes) per call; whole call, per GPU",
-                                      "traffic": load_pmc_traffic("ip_scan_shadow64_kernel")},
+                                      **traffic_fields("ip_scan_shadow64_kernel")},
         }
         # the regime the reference really indexes (2-fps frames of the same videos, extract-features.py:292-297,353): runs
         # of 20 near-duplicate rows (cosine >= 0.999).  Same N, same kernels; queries are noisy copies of indexed rows
@@ -544,7 +552,7 @@ def main():
                                    "frac": round(hbm_bytes / step_s / 1e9 / PEAK_HBM_GBS, 4),
                                    "bytes_per_forward_at_kernel_boundaries": hbm_bytes,
                                    "bytes_per_forward_if_each_block_were_one_kernel": fused_ideal + front,
-                                   "traffic": load_pmc_traffic("htsat_forward"),
+                                   **traffic_fields("htsat_forward"),
                                    "gemm_family": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_BF16_TFLOPS,
                                                    "achieved": round(hg_flop / max(hg_ms, 1e-9) / 1e9, 2),
                                                    "frac": round(hg_flop / max(hg_ms, 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4),
@@ -690,7 +698,7 @@ def main():
                                   "bytes_per_launch": pre_bytes,
                                   "achieved": round(pre_bytes / pre_us / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                   "frac": round(pre_bytes / pre_us / 1e3 / PEAK_HBM_GBS, 4),
-                                  "traffic": load_pmc_traffic("clip_resize_kernel"),
+                                  **traffic_fields("clip_resize_kernel"),
                                   "frames_per_s": round(args.batch / pre_us * 1e6, 0)}}
         del raw, crop, crops
         # f4: the query side — CLIP text tower (ViT-B/32 text), one query at a time and in batches of 256

@@ -32,9 +32,10 @@ const char* wise_last_error(void);
  * towers — and the wise_xlmr_* entry points; 4: wise_xlmr_config.pos_mode / pool / head / eps_e12 — MS-CLAP 2022's BERT
  * caption encoder — and the wise_cnn14_* entry points). */
 int wise_abi_version(void);
-/* Host-side hint for the GEMM tile heuristic (no device work): on != 0 while the caller enqueues batches that will run
- * beside another stream's (two batches in flight); one-block-per-CU tilings are then avoided where they measured slower.
- * wise_vit_forward sets it itself for its half batches; the engines' forward_pipelined bracket their calls with it. */
+/* Host-side hint for the GEMM tile heuristic (no device work), local to the CALLING THREAD: on != 0 while this thread
+ * enqueues batches that will run beside another stream's (two batches in flight); tilings that measured slower there
+ * are then avoided for the shapes the one-wave-per-SIMD kernels do not take.  wise_vit_forward sets it itself for its
+ * half batches; the engines' forward_pipelined bracket their calls with it.  Results never depend on it. */
 void wise_overlap_hint(int on);
 /* The compiler flags the device code of this library was built with (wise_amd/build.py).  The product kernels must
  * be built without packed f32 VALU math ("-fno-slp-vectorize ... -packed-fp32-ops": DESIGN.md section 4, a gfx950

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import ip_topk_ref, vit_ref
-from wise_amd.build import build_oracle
+from oracle.build import build_oracle
 from wise_amd.feature.vit import VitSpec, random_state_dict
 
 

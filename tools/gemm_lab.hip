@@ -81,6 +81,7 @@ int main(int argc, char** argv) {
         shapes.push_back({"fc1-noact 12800x3072x768", 12800, 3072, 768, 0});
         shapes.push_back({"fc2-f32store 12800x768x3072", 12800, 768, 3072, 4});
     }
+    if (which == "patch" || which == "all") shapes.push_back({"patch 12544x768x3072", 12544, 768, 3072, 4});
     if (which == "sq" || which == "all") {
         shapes.push_back({"sq4096", 4096, 4096, 4096, 0});
         shapes.push_back({"sq8192", 8192, 8192, 8192, 0});
@@ -128,6 +129,7 @@ int main(int argc, char** argv) {
         if (wise::w4_shape_ok(s.M, s.N, s.K, 5)) vars.push_back({"w4 160x256", 1, 5});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 10)) vars.push_back({"w4 320x256", 1, 10});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 10, 6)) vars.push_back({"w4 320x192", 1, 106});
+        if (wise::w4_shape_ok(s.M, s.N, s.K, 7, 6)) vars.push_back({"w4 224x192", 1, 76});
         if (wise::w4p_shape_ok(s.M, s.N, s.K) && !f32o) vars.push_back({"w4p persistent 160x256", 1, 500});
 
         auto run = [&](const Var& v) {
@@ -140,6 +142,7 @@ int main(int argc, char** argv) {
             else if (v.arg == 5) launch_new<5, 8, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 10) launch_new<10, 8, 2, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 106) launch_new<10, 6, 2, 3>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            else if (v.arg == 76) launch_new<7, 6, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 500) {
                 using namespace wise;
                 if (s.mode == 0) launch_w4p<EPI_BF16>(A, W, bias, s.M, s.N, s.K, out, 256, st);

@@ -1,4 +1,4 @@
-"""In-tree build of libwise_hip.so (hipcc, gfx950 only), of its debug twin and of the C oracle.
+"""In-tree build of libwise_hip.so (hipcc, gfx950 only) and of its debug twin.
 
 `python -m wise_amd.build` or `wise_amd.build.build_all()`.  The .so files are git-ignored but
 travel to the GPU box with the working tree, so nothing is compiled there unless a source is newer.
@@ -144,30 +144,57 @@ def build_debug(force: bool = False, verbose: bool = False) -> Path:
     return LIB_DEBUG
 
 
-def build_oracle(force: bool = False) -> Path | None:
-    """gcc build of oracle/ C restatement (test infrastructure, never loaded by the product path)."""
-    odir = ROOT / "oracle"
-    src = odir / "ip_topk_ref.c"
-    if not src.exists():
-        return None
-    out = odir / "_build" / "libwise_oracle.so"
-    if not force and not _newer(out, [src]):
-        return out
-    out.parent.mkdir(parents=True, exist_ok=True)
-    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-o", str(out), str(src), "-lm"]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"oracle build failed:\n{r.stdout}")
-    return out
+LIB_ASAN = LIBDIR / "libwise_hip_asan.so"
+
+
+def asan_runtime() -> Path | None:
+    """clang's shared AddressSanitizer runtime (must be LD_PRELOADed into the python that loads LIB_ASAN)."""
+    hits = sorted(Path(hipcc_path()).resolve().parent.parent.glob("lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    hits += sorted(Path("/opt/rocm/lib/llvm/lib/clang").glob("*/lib/linux/libclang_rt.asan-x86_64.so"))
+    return hits[0] if hits else None
+
+
+def build_asan(force: bool = False, verbose: bool = False) -> Path:
+    """HOST side of the library under AddressSanitizer + UndefinedBehaviorSanitizer (sanitizers on the
+    CPU build only): argument validation, layout / workspace planners, tap builders, the error buffer — everything
+    that runs before a launch.  Host pass only (--cuda-host-only: no device code, nothing can be launched); loaded by
+    tests/test_host_asan.py through WISE_AMD_LIB_PATH with the sanitizer runtime preloaded.  Never used by wise_amd."""
+    srcs = [CSRC / s for s in HIP_SOURCES]
+    flags = ["--cuda-host-only", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+             "-fno-sanitize-recover=undefined"]
+    objs, rebuilt = _compile(srcs, LIBDIR / "obj_asan", _api_define(), force, verbose, flags)
+    if rebuilt or not LIB_ASAN.exists():
+        # a host-only object still registers its (absent) device code when the library is loaded: give it empty fat
+        # binaries and registration entry points of its own (-Bsymbolic: bound here, not to the HIP runtime)
+        und = subprocess.run(["nm", "-u", *map(str, objs)], stdout=subprocess.PIPE, text=True).stdout
+        fat = sorted(set(re.findall(r"\b(__hip_fatbin_[0-9a-f]+)\b", und)))
+        stub = LIBDIR / "obj_asan" / "hip_registration_stub.c"
+        stub.write_text("".join(f"const char {n}[16] = {{0}};\n" for n in fat) +
+                        "static void* handle_;\n"
+                        "void** __hipRegisterFatBinary(const void* d) { (void)d; return &handle_; }\n"
+                        "void __hipUnregisterFatBinary(void** h) { (void)h; }\n"
+                        "void __hipRegisterFunction(void** h, const char* f, char* df, const char* dn, unsigned tl, void* a, "
+                        "void* b, void* c, void* d, int* w) { (void)h; (void)f; (void)df; (void)dn; (void)tl; (void)a; (void)b; "
+                        "(void)c; (void)d; (void)w; }\n"
+                        "void __hipRegisterVar(void** h, char* v, char* da, const char* dn, int e, unsigned long s, int c, int g) "
+                        "{ (void)h; (void)v; (void)da; (void)dn; (void)e; (void)s; (void)c; (void)g; }\n")
+        stub_o = stub.with_suffix(".o")
+        subprocess.run(["gcc", "-O1", "-fPIC", "-c", str(stub), "-o", str(stub_o)], check=True)
+        cmd = [hipcc_path(), "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan", "-Wl,-Bsymbolic", "-o",
+               str(LIB_ASAN), *map(str, objs), str(stub_o)]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB_ASAN
 
 
 def build_all(force: bool = False, verbose: bool = False):
+    """Both libraries.  (The oracle's C restatement has its own recipe, oracle/build.py: test infrastructure.)"""
     lib = build_hip(force=force, verbose=verbose)
     build_debug(force=force, verbose=verbose)
-    orc = build_oracle(force=force)
-    return lib, orc
+    return lib
 
 
 if __name__ == "__main__":
-    lib, orc = build_all(force="--force" in sys.argv, verbose=True)
-    print("built", lib, LIB_DEBUG, orc)
+    lib = build_all(force="--force" in sys.argv, verbose=True)
+    print("built", lib, LIB_DEBUG)

@@ -2110,7 +2110,7 @@ static void launch_pp(const bf16_t* A, const bf16_t* Wt, const float* bias, int 
 static int g_gemm_variant = 0;
 static int g_tile320 = 1;  // allow the 320x256 ping-pong tiling (wise_debug_set_gemm_flags bit 0 turns it off)
 static int g_mlp96_resident = 1;  // (debug knob) 0: the staged mlp96_kernel
-static int g_overlapped = 0;  // the caller is running another stream's kernels beside this one (gemm_set_overlapped)
+static thread_local int g_overlapped = 0;  // the calling thread is running another stream's kernels beside this one (gemm_set_overlapped)
 static int g_overlap_policy = 0;  // (debug knob) tiles under overlap: 0 = as for a lone stream minus the 320-row tilings (the product), 1 = 128x128 only, 2 = 128x128 except the QKV-shaped launches, 3 = hint ignored
 static int g_splitk_policy = 0;  // (debug knob) skinny GEMMs: 0 = the product rule, 1 = split-K for the residual GEMMs only, 2 = never
 static int g_w4_enabled = 1;  // (debug knob, bit 28 of wise_debug_set_gemm_variant: off) the one-wave-per-SIMD kernel of gemm_w4.h
@@ -2179,6 +2179,9 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
                      if (w4_shape_ok(M, N, K, 10, 6)) { launch_w4<MODE, 10, 6, 2, 3>(A, Wt, bias, M, N, K, out, st); break; }
                  }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        // 65: 224 x 192 tiles (M = 12544 = 49 x 256 rows of a ViT-B/32 patch matrix: 56 x 4 = 224 tiles, one round)
+        case 65: if (w4_shape_ok(M, N, K, 7, 6)) { launch_w4<MODE, 7, 6, 3, 2>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         // 64: its persistent form (160 x 256 tiles, the C tile leaves during the next tile's loop), bf16 outputs
         case 64: if constexpr (bf16_out(MODE)) {
                      if (w4p_shape_ok(M, N, K)) { launch_w4p<MODE>(A, Wt, bias, M, N, K, out, device_cus(), st); break; }
@@ -2192,7 +2195,7 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
 
 static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode,
                        void* out, hipStream_t st) {
-    if (v >= 60 && v <= 64) { /* gemm_w4.h checks its own shape */ }
+    if (v >= 60 && v <= 65) { /* gemm_w4.h checks its own shape */ }
     else if (K % 64 != 0 && v != 40 && v != 42 && v != 45 && v != 46 && v != 48 && v != 50) v = 1;
     else if (N % BN != 0 && v != 1) v = 0;  // N edge is handled by the 128x128 kernels only
     switch (mode) {
@@ -2238,7 +2241,7 @@ static int w4_variant(int M, int N, int K, int mode) {
     if (!g_w4_enabled || K < 512) return 0;
     struct Cand { int id, mi, nj; double step; bool bf16_only; };
     static const Cand cands[] = {{60, 8, 8, 2560.0, false}, {61, 5, 8, 1700.0, false}, {62, 10, 8, 3250.0, true},
-                                 {63, 10, 6, 2430.0, true}};
+                                 {63, 10, 6, 2430.0, true}, {65, 7, 6, 1720.0, false}};
     double best = 0.0;
     int v = 0;
     for (const Cand& c : cands) {
@@ -2322,33 +2325,7 @@ int gemm_ln_bf16(const float* x, const float* lnw, const float* lnb, const bf16_
 // fp32 scratch of the split-K path: a pool of eight buffers allocated together on the first skinny launch of the process
 // (outside any graph capture: the engines warm up before they capture); a stream is bound to one of them the first time it
 // takes the path — no allocation then, so a capture stream may be new — and a ninth stream gets the ordinary kernels.
-constexpr size_t SPLITK_SCRATCH_BYTES = (size_t)24 << 20;
-constexpr int SPLITK_POOL = 8;
-static std::mutex g_splitk_mu;
-static float* g_splitk_pool[SPLITK_POOL] = {};
-static hipStream_t g_splitk_owner[SPLITK_POOL] = {};
-static int g_splitk_bound = 0, g_splitk_state = 0;   // state: 0 = not yet allocated, 1 = pool ready, -1 = allocation failed
-static float* splitk_scratch(hipStream_t st) {
-    std::lock_guard<std::mutex> lk(g_splitk_mu);
-    if (g_splitk_state == 0) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
-        unsigned char* base = nullptr;
-        if (hipMalloc(reinterpret_cast<void**>(&base), SPLITK_SCRATCH_BYTES * SPLITK_POOL) != hipSuccess) {
-            (void)hipGetLastError();
-            g_splitk_state = -1;
-            return nullptr;
-        }
-        for (int i = 0; i < SPLITK_POOL; ++i) g_splitk_pool[i] = reinterpret_cast<float*>(base + SPLITK_SCRATCH_BYTES * i);
-        g_splitk_state = 1;
-    }
-    if (g_splitk_state != 1) return nullptr;
-    for (int i = 0; i < g_splitk_bound; ++i)
-        if (g_splitk_owner[i] == st) return g_splitk_pool[i];
-    if (g_splitk_bound == SPLITK_POOL) return nullptr;
-    g_splitk_owner[g_splitk_bound] = st;
-    return g_splitk_pool[g_splitk_bound++];
-}
+constexpr size_t SPLITK_SCRATCH_CAP = (size_t)24 << 20;   // a GEMM whose partials would not fit is not split
 
 template <int MODE>
 static void launch_reduce(const float* part, int S, int rows, int N, const float* bias, void* out, hipStream_t st) {
@@ -2367,8 +2344,11 @@ static int splitk_slices(int M, int m_valid, int N, int K) {
         S = c;
         if (slabs * c >= 160) break;
     }
-    if (S < 2 || (size_t)S * 128 * N * sizeof(float) > SPLITK_SCRATCH_BYTES) return 0;
+    if (S < 2 || (size_t)S * 128 * N * sizeof(float) > SPLITK_SCRATCH_CAP) return 0;
     return S;
+}
+size_t gemm_splitk_bytes(int M, int m_valid, int N, int K) {
+    return (size_t)splitk_slices(M, m_valid, N, K) * 128 * (size_t)N * sizeof(float);
 }
 static void splitk_partials(const bf16_t* A, const bf16_t* Wt, int N, int K, int S, float* part, hipStream_t st) {
     constexpr int STAGES = 4;
@@ -2382,11 +2362,9 @@ static void splitk_partials(const bf16_t* A, const bf16_t* Wt, int N, int K, int
 }
 
 static bool gemm_splitk(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int N, int K, int mode,
-                        void* out, hipStream_t st) {
+                        void* out, hipStream_t st, float* part, size_t part_bytes) {
     const int S = splitk_slices(M, m_valid, N, K);
-    if (S == 0) return false;
-    float* part = splitk_scratch(st);
-    if (!part) return false;
+    if (S == 0 || !part || part_bytes < (size_t)S * 128 * N * sizeof(float)) return false;
     ProfScope prof(PROF_GEMM, 2.0 * (double)m_valid * (double)N * (double)K, st);
     splitk_partials(A, Wt, N, K, S, part, st);
     switch (mode) {
@@ -2404,12 +2382,12 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
 
 // m_valid: the rows of A that carry data (the rest of the M rows are padding whose results nobody reads)
 int gemm_bf16_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int N, int K, int mode,
-                   void* out, hipStream_t st) {
+                   void* out, hipStream_t st, float* sk, size_t sk_bytes) {
     WISE_CHECK_ARG(A && Wt && out, "gemm_bf16: null pointer");
     WISE_CHECK_ARG(M > 0 && M % BM == 0 && N > 0 && N % 4 == 0 && K > 0 && K % 32 == 0 && mode >= 0 && mode <= 6,
                    "gemm_bf16: M=%d must be a multiple of %d, N=%d of 4, K=%d of 32", M, BM, N, K);
     if (g_gemm_variant == 0 && m_valid <= 128 && g_splitk_policy != 2 && !(g_splitk_policy == 1 && mode != EPI_RESID) &&
-        gemm_splitk(A, Wt, bias, M, m_valid, N, K, mode, out, st)) {
+        gemm_splitk(A, Wt, bias, M, m_valid, N, K, mode, out, st, sk, sk_bytes)) {
         WISE_LAUNCH_CHECK("gemm_splitk_kernel");
         return WISE_OK;
     }
@@ -2421,11 +2399,12 @@ int gemm_bf16_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, 
 // kernel and ONE kernel for reduction + residual + LayerNorm; everything else is the two launches it stands for.  The same
 // bits either way.
 int gemm_resid_ln_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int ln_rows, int N, int K,
-                       float* x, const float* ln_w, const float* ln_b, float eps, bool post_ln, bf16_t* h, hipStream_t st) {
+                       float* x, const float* ln_w, const float* ln_b, float eps, bool post_ln, bf16_t* h, hipStream_t st,
+                       float* sk, size_t sk_bytes) {
     WISE_CHECK_ARG(A && Wt && x && ln_w && ln_b && h, "gemm_resid_ln: null pointer");
     // (ln_rows: the rows the LayerNorm covers — the caller's real rows; m_valid may include tile padding)
     const int S = (g_gemm_variant == 0 && g_splitk_policy != 2 && N > 128 && N <= 4096 && ln_rows == m_valid) ? splitk_slices(M, m_valid, N, K) : 0;
-    float* part = S ? splitk_scratch(st) : nullptr;
+    float* part = (S && sk && sk_bytes >= (size_t)S * 128 * N * sizeof(float)) ? sk : nullptr;
     if (part) {
         {
             ProfScope prof(PROF_GEMM, 2.0 * (double)m_valid * (double)N * (double)K, st);
@@ -2444,7 +2423,7 @@ int gemm_resid_ln_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int
         return WISE_OK;
     }
     int rc;
-    if ((rc = gemm_bf16_rows(A, Wt, bias, M, m_valid, N, K, EPI_RESID, x, st))) return rc;
+    if ((rc = gemm_bf16_rows(A, Wt, bias, M, m_valid, N, K, EPI_RESID, x, st, sk, sk_bytes))) return rc;
     return post_ln ? layernorm_f32_dual(x, ln_w, ln_b, ln_rows, N, eps, x, h, st) : layernorm_f32_bf16(x, ln_w, ln_b, ln_rows, N, eps, h, st);
 }
 

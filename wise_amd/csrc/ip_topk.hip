@@ -1436,23 +1436,25 @@ struct PassWs {
 static PassWs pass_workspace(unsigned char* wsb, long long N, int d, int k) {
     PassWs w;
     size_t off = 0;
+    // (sizing calls pass no buffer: offsets are applied to a real base only)
+    auto at = [&](size_t o) -> unsigned char* { return wsb ? wsb + o : nullptr; };
     const ScanPlan p2 = plan_scan(N, d, 2, k);
     size_t lists = (size_t)2 * split64_lists(N) * MFMA_QB2 * MFMA_KL * sizeof(u64);
     const size_t valu = (size_t)p2.grid * 4 * k * sizeof(u64);
     if (valu > lists) lists = valu;
-    w.mpart = reinterpret_cast<u64*>(wsb + off); off += align_up(lists, 256);
-    w.mq = reinterpret_cast<float*>(wsb + off); off += align_up((size_t)PASS_QMAX * d * sizeof(float), 256);
-    w.cand_rows = reinterpret_cast<long long*>(wsb + off);
-    w.cand_scores = reinterpret_cast<float*>(wsb + off + (size_t)MFMA_QB2 * MFMA_KL * 8);
+    w.mpart = reinterpret_cast<u64*>(at(off)); off += align_up(lists, 256);
+    w.mq = reinterpret_cast<float*>(at(off)); off += align_up((size_t)PASS_QMAX * d * sizeof(float), 256);
+    w.cand_rows = reinterpret_cast<long long*>(at(off));
+    w.cand_scores = reinterpret_cast<float*>(at(off + (size_t)MFMA_QB2 * MFMA_KL * 8));
     off += align_up((size_t)MFMA_QB2 * MFMA_KL * 12, 256);
-    w.tau0 = reinterpret_cast<u64*>(wsb + off); off += 512;
-    w.ctl = reinterpret_cast<int*>(wsb + off); off += PASS_QMAX * 4 * sizeof(int);
-    w.gate = reinterpret_cast<int*>(wsb + off); off += 256;
-    w.thr = reinterpret_cast<float*>(wsb + off); off += align_up(PASS_QMAX * sizeof(float), 256);
-    w.dump = reinterpret_cast<float*>(wsb + off); off += align_up((size_t)PASS_QMAX * SAMPLE_CHUNKS * 512 * sizeof(float), 256);
-    w.cand = reinterpret_cast<u64*>(wsb + off); off += align_up((size_t)PASS_QMAX * BATCH_CAP * sizeof(u64), 256);
-    w.cand2 = reinterpret_cast<u64*>(wsb + off); off += align_up((size_t)PASS_QMAX * RESCORE_CAP * sizeof(u64), 256);
-    w.ekeys = reinterpret_cast<u64*>(wsb + off); off += align_up((size_t)PASS_QMAX * RESCORE_CAP * sizeof(u64), 256);
+    w.tau0 = reinterpret_cast<u64*>(at(off)); off += 512;
+    w.ctl = reinterpret_cast<int*>(at(off)); off += PASS_QMAX * 4 * sizeof(int);
+    w.gate = reinterpret_cast<int*>(at(off)); off += 256;
+    w.thr = reinterpret_cast<float*>(at(off)); off += align_up(PASS_QMAX * sizeof(float), 256);
+    w.dump = reinterpret_cast<float*>(at(off)); off += align_up((size_t)PASS_QMAX * SAMPLE_CHUNKS * 512 * sizeof(float), 256);
+    w.cand = reinterpret_cast<u64*>(at(off)); off += align_up((size_t)PASS_QMAX * BATCH_CAP * sizeof(u64), 256);
+    w.cand2 = reinterpret_cast<u64*>(at(off)); off += align_up((size_t)PASS_QMAX * RESCORE_CAP * sizeof(u64), 256);
+    w.ekeys = reinterpret_cast<u64*>(at(off)); off += align_up((size_t)PASS_QMAX * RESCORE_CAP * sizeof(u64), 256);
     w.total = off;
     return w;
 }

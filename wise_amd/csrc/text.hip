@@ -109,7 +109,7 @@ static TextOffsets text_offsets(const TextDims& d) {
 }
 
 struct TextWs {
-    size_t x, h, qkv, a, eot, total;
+    size_t x, h, qkv, a, eot, sk, sk_bytes, total;
     int M, Mp;
 };
 static TextWs text_ws(const TextDims& d, int B) {
@@ -123,6 +123,9 @@ static TextWs text_ws(const TextDims& d, int B) {
     w.qkv = off; off += align_up(std::max((size_t)w.Mp * 3 * d.W * 2, Bp * d.D * 4), 256);
     w.a = off; off += align_up(std::max((size_t)w.Mp * d.F * 2, Bp * d.D * 2), 256);   // also the head's bf16 scratch
     w.eot = off; off += align_up((size_t)B * 4, 256);
+    // split-K partials of a skinny call (one query: 77 rows), private to this workspace: graph- and stream-safe
+    w.sk_bytes = transformer_splitk_bytes(d.W, d.F, B, d.T);
+    w.sk = off; off += align_up(w.sk_bytes, 256);
     w.total = off;
     return w;
 }
@@ -176,7 +179,8 @@ extern "C" int wise_text_forward(const wise_text_config* cfg, const uint16_t* wb
     const BlockWeights bw = {wb + o.layer0_b, o.per_layer_b, o.in_proj, o.out_proj, o.c_fc, o.c_proj,
                              pf + o.layer0_f, o.per_layer_f, o.ln1_w, o.ln1_b, o.in_b, o.out_b, o.ln2_w, o.ln2_b,
                              o.fc_b, o.proj_b};
-    if ((rc = transformer_blocks(bw, d.L, d.W, d.H, d.F, d.act, batch, d.T, d.no_causal == 0, x, h, qkv, a, st, d.eps, true))) return rc;
+    if ((rc = transformer_blocks(bw, d.L, d.W, d.H, d.F, d.act, batch, d.T, d.no_causal == 0, x, h, qkv, a, st, d.eps, true,
+                                 reinterpret_cast<float*>(wsb + ws.sk), ws.sk_bytes))) return rc;
     if (d.head == 0 || d.head == 2)
         return pooled_head(x, pf + o.lnf_w, pf + o.lnf_b, wb + o.projT, batch, d.T, d.W, d.D, eot, h,
                            reinterpret_cast<float*>(qkv), out, st, d.eps, d.head == 2 ? pf + o.pj_lw : nullptr);

@@ -8,8 +8,12 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
               hipStream_t st);
 // the same when only the first m_valid of the M rows carry data (a single text query: 77 of 256): skinny problems go
 // through a split-K pair of kernels instead of leaving most of the chip idle
+// Split-K partials live in the CALLER's workspace: `sk` points at sk_bytes of device scratch private to the calling
+// engine (and stream); nullptr / too small = the ordinary kernels.  gemm_splitk_bytes says what a call would use (0: it
+// would not split), so that a tower sizes its workspace from its own GEMM shapes and the choice depends on the shape alone.
+size_t gemm_splitk_bytes(int M, int m_valid, int N, int K);
 int gemm_bf16_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int N, int K, int mode,
-                   void* out, hipStream_t st);
+                   void* out, hipStream_t st, float* sk = nullptr, size_t sk_bytes = 0);
 // relu(conv3x3(X [B, T, F, Cin] bf16 NHWC, zero padding 1) + bias) as an implicit GEMM (Wt [Cout, 9*Cin] with
 // k = (kh*3 + kw)*Cin + c): out [ceil256(B*T*F), Cout] bf16, or with pool its 2x2 average pooling (floor),
 // out [B*(T/2)*(F/2), Cout], fused; zeros = 16 bytes of zeros on the device
@@ -18,9 +22,10 @@ int conv3x3_bf16(const bf16_t* X, const bf16_t* Wt, const float* bias, const bf1
 // x[M,N] += A @ Wt^T + bias, then h = LN(x) (bf16) and, for post-LN blocks, x = LN(x): the residual GEMM of a block and the
 // LayerNorm behind it; skinny calls fuse the split-K reduction with the LayerNorm (one launch less, same bits)
 int gemm_resid_ln_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int ln_rows, int N, int K,
-                       float* x, const float* ln_w, const float* ln_b, float eps, bool post_ln, bf16_t* h, hipStream_t st);
-// hint for the tile heuristic: the caller is about to enqueue GEMMs on several streams that overlap in time
-// (host-side state; the library is single-threaded by contract)
+                       float* x, const float* ln_w, const float* ln_b, float eps, bool post_ln, bf16_t* h, hipStream_t st,
+                       float* sk = nullptr, size_t sk_bytes = 0);
+// hint for the tile heuristic: the calling THREAD is about to enqueue GEMMs on several streams that overlap in time
+// (thread-local: two host threads driving two engines do not see each other's hint)
 void gemm_set_overlapped(bool on);
 int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows, int W, float eps, bf16_t* y,
                        hipStream_t st);
@@ -40,7 +45,10 @@ struct BlockWeights {
 };
 int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int act, int batch, int T, bool causal,
                        float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st, float eps = 1e-5f,
-                       bool skinny = false /*text towers: calls of <= 128 rows may take the split-K kernels*/);
+                       bool skinny = false /*text towers: calls of <= 128 rows may take the split-K kernels*/,
+                       float* sk = nullptr, size_t sk_bytes = 0 /*their partials: transformer_splitk_bytes() of workspace*/);
+// split-K scratch a skinny transformer_blocks call of these dimensions uses (0 when it would not split)
+size_t transformer_splitk_bytes(int W, int F, int batch, int T);
 int l2norm_rows(const float* e, int rows, int D, float* out, hipStream_t st);
 // LayerNorm of row pos[b] (or 0) of every sequence -> hb bf16 [batch, W]
 int pooled_ln(const float* x, const float* ln_w, const float* ln_b, int batch, int T, int W, const int* pos,

@@ -735,9 +735,18 @@ int l2norm_rows(const float* e, int rows, int D, float* out, hipStream_t st) {
     return WISE_OK;
 }
 
+size_t transformer_splitk_bytes(int W, int F, int batch, int T) {
+    const int M = batch * T, Mp = (M + 255) / 256 * 256;
+    size_t b = gemm_splitk_bytes(Mp, M, 3 * W, W);
+    b = std::max(b, gemm_splitk_bytes(Mp, M, W, W));
+    b = std::max(b, gemm_splitk_bytes(Mp, M, F, W));
+    return std::max(b, gemm_splitk_bytes(Mp, M, W, F));
+}
+
 // L pre-LN residual blocks over x fp32 [B*T (padded to 256), W]; h / qkv / a are the bf16 scratch operands
 int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int act, int batch, int T, bool causal,
-                       float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st, float eps, bool skinny) {
+                       float* x, bf16_t* h, bf16_t* qkv, bf16_t* a, hipStream_t st, float eps, bool skinny, float* sk,
+                       size_t sk_bytes) {
     // skinny (the text towers): a call of <= 128 rows may take the split-K kernels.  The image towers do not: their
     // one-stream, two-half-batch and two-batches-in-flight forms must return the same bits, and a half batch could fall
     // under 128 rows where the whole batch does not.
@@ -750,20 +759,20 @@ int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int a
     for (int l = 0; l < L; ++l) {
         const bf16_t* lwb = bw.wb + bw.per_layer_b * l;
         const float* lpf = bw.pf + bw.per_layer_f * l;
-        if ((rc = gemm_bf16_rows(h, lwb + bw.in_proj, lpf + bw.in_b, Mp, Mv, 3 * W, W, 0, qkv, st))) return rc;
+        if ((rc = gemm_bf16_rows(h, lwb + bw.in_proj, lpf + bw.in_b, Mp, Mv, 3 * W, W, 0, qkv, st, sk, sk_bytes))) return rc;
         if ((rc = attention_bf16(qkv, batch, T, H, h, st, causal, W / H))) return rc;
         // x += out_proj(attention); h = ln_2(x)   (one launch behind the split-K kernel for a single text query)
         if ((rc = gemm_resid_ln_rows(h, lwb + bw.out_proj, lpf + bw.out_b, Mp, Mv, M, W, W, x, lpf + bw.ln2_w, lpf + bw.ln2_b, eps,
-                                     false, h, st)))
+                                     false, h, st, sk, sk_bytes)))
             return rc;
         // act: 0 QuickGELU, 1 erf GELU, 2 gelu_new (tanh) -> epilogue modes 1, 2, 5
-        if ((rc = gemm_bf16_rows(h, lwb + bw.c_fc, lpf + bw.fc_b, Mp, Mv, F, W, act == 0 ? 1 : (act == 1 ? 2 : 5), a, st))) return rc;
+        if ((rc = gemm_bf16_rows(h, lwb + bw.c_fc, lpf + bw.fc_b, Mp, Mv, F, W, act == 0 ? 1 : (act == 1 ? 2 : 5), a, st, sk, sk_bytes))) return rc;
         if (l + 1 < L) {   // x += c_proj(...); h = ln_1 of the NEXT block
             const float* npf = bw.pf + bw.per_layer_f * (l + 1);
             if ((rc = gemm_resid_ln_rows(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, Mv, M, W, F, x, npf + bw.ln1_w, npf + bw.ln1_b, eps,
-                                         false, h, st)))
+                                         false, h, st, sk, sk_bytes)))
                 return rc;
-        } else if ((rc = gemm_bf16_rows(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, Mv, W, F, 3, x, st))) {
+        } else if ((rc = gemm_bf16_rows(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, Mv, W, F, 3, x, st, sk, sk_bytes))) {
             return rc;
         }
     }

@@ -123,7 +123,7 @@ static XlmrOffsets xlmr_offsets(const XlmrDims& d) {
 }
 
 struct XlmrWs {
-    size_t x, h, qkv, a, lens, total;
+    size_t x, h, qkv, a, lens, sk, sk_bytes, total;
     int M, Mp;
 };
 static XlmrWs xlmr_ws(const XlmrDims& d, int B) {
@@ -136,6 +136,11 @@ static XlmrWs xlmr_ws(const XlmrDims& d, int B) {
     w.qkv = off; off += align_up(std::max((size_t)w.Mp * 3 * d.W * 2, Bp * d.D * 4), 256); // also the projected rows fp32
     w.a = off; off += align_up(std::max((size_t)w.Mp * d.F * 2, Bp * d.Hd * 2), 256);       // also the projection's hidden rows
     w.lens = off; off += align_up((size_t)B * 4, 256);
+    // split-K partials of a skinny call (one query) and of the head's two GEMMs, private to this workspace
+    w.sk_bytes = transformer_splitk_bytes(d.W, d.F, B, d.T);
+    w.sk_bytes = std::max(w.sk_bytes, gemm_splitk_bytes((int)Bp, B, d.Hd, d.W));
+    w.sk_bytes = std::max(w.sk_bytes, gemm_splitk_bytes((int)Bp, B, d.D, d.Hd));
+    w.sk = off; off += align_up(w.sk_bytes, 256);
     w.total = off;
     return w;
 }
@@ -182,6 +187,8 @@ extern "C" int wise_xlmr_forward(const wise_xlmr_config* cfg, const uint16_t* wb
     bf16_t* qkv = reinterpret_cast<bf16_t*>(wsb + ws.qkv);
     bf16_t* a = reinterpret_cast<bf16_t*>(wsb + ws.a);
     int* lens = reinterpret_cast<int*>(wsb + ws.lens);
+    float* sk = reinterpret_cast<float*>(wsb + ws.sk);
+    const size_t skb = ws.sk_bytes;
     const int M = ws.M, Mp = ws.Mp, W = d.W;
     const float eps = d.eps;                                  // layer_norm_eps: 1e-5 XLM-RoBERTa, 1e-12 BERT
 
@@ -192,13 +199,13 @@ extern "C" int wise_xlmr_forward(const wise_xlmr_config* cfg, const uint16_t* wb
     for (int l = 0; l < d.L; ++l) {
         const bf16_t* lw = wb + o.per_layer_b * l;
         const float* lp = pf + o.layer0_f + o.per_layer_f * l;
-        if ((rc = gemm_bf16_rows(h, lw + o.qkv, lp + o.qkv_b, Mp, M, 3 * W, W, 0, qkv, st))) return rc;
+        if ((rc = gemm_bf16_rows(h, lw + o.qkv, lp + o.qkv_b, Mp, M, 3 * W, W, 0, qkv, st, sk, skb))) return rc;
         if ((rc = attention_bf16(qkv, batch, d.T, d.H, h, st, false, 64, lens))) return rc;
         // x = LN(x + out(attention)) and x = LN(x + fc2(gelu(fc1 x))): the residual GEMM and the post-LN behind it as one call
         // (a single query: split-K partials + ONE kernel for reduction, residual and LayerNorm)
-        if ((rc = gemm_resid_ln_rows(h, lw + o.out, lp + o.out_b, Mp, M, M, W, W, x, lp + o.ln1_w, lp + o.ln1_b, eps, true, h, st))) return rc;
-        if ((rc = gemm_bf16_rows(h, lw + o.fc1, lp + o.fc1_b, Mp, M, d.F, W, 2, a, st))) return rc;
-        if ((rc = gemm_resid_ln_rows(a, lw + o.fc2, lp + o.fc2_b, Mp, M, M, W, d.F, x, lp + o.ln2_w, lp + o.ln2_b, eps, true, h, st))) return rc;
+        if ((rc = gemm_resid_ln_rows(h, lw + o.out, lp + o.out_b, Mp, M, M, W, W, x, lp + o.ln1_w, lp + o.ln1_b, eps, true, h, st, sk, skb))) return rc;
+        if ((rc = gemm_bf16_rows(h, lw + o.fc1, lp + o.fc1_b, Mp, M, d.F, W, 2, a, st, sk, skb))) return rc;
+        if ((rc = gemm_resid_ln_rows(a, lw + o.fc2, lp + o.fc2_b, Mp, M, M, W, d.F, x, lp + o.ln2_w, lp + o.ln2_b, eps, true, h, st, sk, skb))) return rc;
     }
     // mean over the sequence's own tokens -> MLP projection (no biases) -> L2 normalise
     const int Bp = (batch + 255) / 256 * 256;
@@ -211,8 +218,8 @@ extern "C" int wise_xlmr_forward(const wise_xlmr_config* cfg, const uint16_t* wb
     float* e = reinterpret_cast<float*>(qkv);
     if (d.head == 1)
         return clap_projection(h, wb + o.proj1, wb + o.proj2, pf + o.head_ln, pf + o.head_ln + d.D, batch, W, e, a, out, st);
-    if ((rc = gemm_bf16_rows(h, wb + o.proj1, nullptr, Bp, batch, d.Hd, W, 2, a, st))) return rc;
-    if ((rc = gemm_bf16_rows(a, wb + o.proj2, nullptr, Bp, batch, d.D, d.Hd, 4, e, st))) return rc;
+    if ((rc = gemm_bf16_rows(h, wb + o.proj1, nullptr, Bp, batch, d.Hd, W, 2, a, st, sk, skb))) return rc;
+    if ((rc = gemm_bf16_rows(a, wb + o.proj2, nullptr, Bp, batch, d.D, d.Hd, 4, e, st, sk, skb))) return rc;
     return l2norm_rows(e, batch, d.D, out, st);
 }
 
