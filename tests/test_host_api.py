@@ -218,6 +218,53 @@ def test_numpy_save_store_roundtrip(tmp_path):
         st2.add(0, np.zeros((2, 4), np.float32))
 
 
+def test_numpy_save_store_against_shards_written_by_the_reference(tmp_path):
+    """f1 pinned to the reference itself: tests/golden/store_ref holds shard files written, and a read-back summary
+    produced, by the reference's own NumpySaveStore (oracle/make_golden_store.py; cases: its own test of 7 adds in shards
+    of 3, a roll-over case, a case whose last shard is full).  (i) this repo's reader on the reference's shards returns
+    what the reference's reader returned; (ii) this repo's writer, fed the same adds, produces array-identical files."""
+    import json
+    import shutil
+
+    from wise_amd.feature.store.numpy_save_store import NumpySaveStore
+
+    ref_dir = ROOT / "tests" / "golden" / "store_ref"
+    summary = json.loads((ref_dir / "summary.json").read_text())
+    assert set(summary) == {"t7", "r10", "x8"}
+    for name, info in summary.items():
+        # (i) reader
+        rdir = tmp_path / f"read_{name}"
+        rdir.mkdir()
+        for f in info["files"]:
+            shutil.copy(ref_dir / f, rdir / f)
+        rd = NumpySaveStore(name, rdir)
+        rd.enable_read()
+        assert rd.feature_count == info["feature_count"] and rd.feature_dim == info["feature_dim"]
+        got = [(int(i), v) for i, v in rd]
+        assert [i for i, _ in got] == info["read_ids"]
+        assert [list(v.shape) for _, v in got] == info["read_shapes"]
+        by_id = {a["id"]: np.asarray(a["row"], dtype=np.float32) for a in info["adds"]}
+        assert all(v.dtype == np.float32 and np.array_equal(v[0], by_id[i]) for i, v in got)
+        batches = list(rd.iter_batch(3))
+        assert [i for ids, _ in batches for i in ids] == info["read_ids"]
+        assert np.array_equal(np.concatenate([v for _, v in batches]), np.stack([by_id[i] for i in info["read_ids"]]))
+        # (ii) writer: same adds (same input dtypes) -> same file names, same arrays, same dtypes and shapes
+        wdir = tmp_path / f"write_{name}"
+        wdir.mkdir()
+        wr = NumpySaveStore(name, wdir)
+        wr.enable_write(info["shard_maxcount"], -1)
+        for a in info["adds"]:
+            wr.add(a["id"], np.asarray([a["row"]], dtype=np.dtype(a["dtype"])))
+        wr.close()
+        assert sorted(p.name for p in wdir.glob("*.npz")) == info["files"]
+        for f in info["files"]:
+            ours, ref = np.load(wdir / f), np.load(ref_dir / f)
+            assert sorted(ours.files) == sorted(ref.files) == ["feature_id", "features"]
+            for key in ("feature_id", "features"):
+                assert ours[key].dtype == ref[key].dtype and ours[key].shape == ref[key].shape
+                assert np.array_equal(ours[key], ref[key])
+
+
 def test_webdataset_store_format_and_order(tmp_path):
     """tar shards with '%010d.features.pyd' members holding pickled [1,D] arrays; read back in key order."""
     import tarfile

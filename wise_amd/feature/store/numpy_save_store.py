@@ -1,10 +1,19 @@
-"""NumpySaveStore — reads and writes the reference's npz shard format
-(src/feature/store/numpy_save_store.py:9-116): `{dir}/{name}-%06d.npz` holding
-`feature_id int32[n]` and `features float32[n,D]`; one [1,D] row per add(); shard roll-over at
-shard_maxcount.  Unlike the reference it also offers iter_batch(), so an npz store can be indexed
-(the reference's create_index calls iter_batch on whatever load_store returns: SURVEY App. B.9).
+"""NumpySaveStore — reader and writer of the reference's npz shard format.
+
+The CONTRACT (src/feature/store/numpy_save_store.py:9-116, and what other WISE code relies on): shard files
+`{dir}/{name}-%06d.npz` with two arrays, `feature_id int32[n]` and `features float32[n, D]`; the method names
+`enable_write / enable_read / add / save_current_shard / close`, one `[1, D]` row per `add()`, at most `shard_maxcount`
+rows per shard, iteration yielding `(feature_id, vector[1, D])` in file-name order.  The format is pinned against shards
+written by the reference class itself (tests/golden/store_ref, made by oracle/make_golden_store.py): this reader must
+return what the reference's reader returned, this writer must produce array-identical files.
+
+The implementation is this repo's own: rows are appended to per-shard Python lists and a shard is stacked and written
+when it is full or the store is closed (the reference keeps a preallocated `[shard_maxcount, D]` buffer and trims the last
+one).  Beyond the reference: `iter_batch()` (the reference's `create_index` calls it on whatever store it loads, which its
+own npz store lacks: SURVEY App. B.9) and `first_shard` (several ranks writing disjoint shard ranges of one store).
 """
-import glob
+from __future__ import annotations
+
 import random
 from pathlib import Path
 
@@ -12,101 +21,108 @@ import numpy as np
 
 from .feature_store import FeatureStore
 
+_ID_DTYPE = np.int32          # the reference's shard_feature_id buffer
+_VEC_DTYPE = np.float32       # ... and its shard_features buffer
+
 
 class NumpySaveStore(FeatureStore):
     def __init__(self, store_name, store_data_dir):
         self.store_name = store_name
         self.store_data_dir = Path(store_data_dir)
+        self._ids: list = []
+        self._rows: list = []
 
+    # ------------------------------------------------------------------ writing
     def enable_write(self, shard_maxcount, shard_maxsize, verbose=0, first_shard=0):
-        """first_shard (not in the reference; default = its behaviour): number of the first shard file this writer
-        creates, so that several processes can write disjoint shard ranges of one store."""
-        self.shard_maxcount = shard_maxcount
+        """`shard_maxsize` is accepted and, as in the reference, not used by this store."""
+        if int(shard_maxcount) < 1:
+            raise ValueError(f'shard_maxcount must be positive, not {shard_maxcount}')
+        self.shard_maxcount = int(shard_maxcount)
         self.shard_maxsize = shard_maxsize
         self.verbose = verbose
-        self.current_shard_index = -1
-        self.first_shard_index = int(first_shard)
+        self.current_shard_index = int(first_shard)
+        self.feature_dim = None
+        self._ids, self._rows = [], []
 
+    @property
+    def shard_feature_index(self):
+        """rows waiting for the next shard file (the reference exposes its buffer cursor under this name)"""
+        return len(self._ids)
+
+    def add(self, id, features):
+        features = np.asarray(features)
+        if features.ndim != 2:
+            raise ValueError(f'features must be [1, D], not {features.shape}')
+        if features.shape[0] != 1:
+            raise ValueError(f'cannot add {features.shape[0]} features, only one feature can be added at a time')
+        if self.feature_dim is None:
+            self.feature_dim = features.shape[1]
+        elif features.shape[1] != self.feature_dim:
+            raise ValueError(f'feature dimension cannot change and must be {self.feature_dim}')
+        self._ids.append(id)
+        self._rows.append(features[0].astype(_VEC_DTYPE))
+        if len(self._ids) == self.shard_maxcount:
+            self.save_current_shard()
+
+    def save_current_shard(self):
+        """Write the pending rows as the next shard file (nothing pending: nothing written)."""
+        if not self._ids:
+            return
+        target = self.store_data_dir / ('%s-%06d' % (self.store_name, self.current_shard_index))
+        np.savez(target, feature_id=np.asarray(self._ids, dtype=_ID_DTYPE), features=np.stack(self._rows))
+        if self.verbose:
+            print(f'saved {len(self._ids)} features to shard {target}')
+        self.current_shard_index += 1
+        self._ids, self._rows = [], []
+
+    def close(self):
+        self.save_current_shard()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reading
     def enable_read(self, shard_shuffle=False, shuffle_values=False, shuffle_bufsize=10000):
         self.shard_shuffle = shard_shuffle
         self.shuffle_values = shuffle_values
         self.shuffle_bufsize = shuffle_bufsize
-        pattern = self.store_data_dir / (self.store_name + '-*.npz')
-        self.npz_filename_list = list(glob.iglob(pathname=pattern.as_posix(), recursive=False))
-        if self.shard_shuffle:
-            random.shuffle(self.npz_filename_list)
+        shards = [p.as_posix() for p in self.store_data_dir.glob(self.store_name + '-*.npz')]
+        if shard_shuffle:
+            random.shuffle(shards)
         else:
-            self.npz_filename_list.sort()
+            shards.sort()
+        self.npz_filename_list = shards
         self.feature_count = 0
         self.feature_dim = -1
-        for fn in self.npz_filename_list:
-            payload = np.load(fn)
-            self.feature_count += payload['feature_id'].shape[0]
-            if self.feature_dim < 0:
-                first = payload['features'][0]
-                if first.ndim == 1:
-                    self.feature_dim = first.shape[0]
-                elif first.ndim == 2:
-                    self.feature_dim = first.shape[1]
-                else:
-                    raise ValueError(f'unrecognized feature shape {first.shape}')
+        for fn in shards:
+            with np.load(fn) as payload:
+                self.feature_count += int(payload['feature_id'].shape[0])
+                if self.feature_dim < 0:
+                    shape = payload['features'].shape      # [n, D], or [n, 1, D] from writers that kept the row axis
+                    if len(shape) not in (2, 3):
+                        raise ValueError(f'unrecognized feature shape {shape[1:]}')
+                    self.feature_dim = int(shape[-1])
 
-    def add(self, id, features):
-        if self.current_shard_index == -1:
-            self.feature_dim = features.shape[1]
-            self.shard_features = np.ndarray((self.shard_maxcount, self.feature_dim), dtype=np.float32)
-            self.shard_feature_id = np.ndarray((self.shard_maxcount), dtype=np.int32)
-            self.shard_feature_index = 0
-            self.current_shard_index = getattr(self, 'first_shard_index', 0)
-        if self.feature_dim != features.shape[1]:
-            raise ValueError(f'feature dimension cannot change and must be {self.feature_dim}')
-        if features.shape[0] != 1:
-            raise ValueError(f'cannot add {features.shape[0]} features, only one feature can be added at a time')
-        if self.shard_feature_index == self.shard_maxcount:
-            self.save_current_shard()
-            self.add(id, features)
-        else:
-            self.shard_features[self.shard_feature_index] = features
-            self.shard_feature_id[self.shard_feature_index] = id
-            self.shard_feature_index += 1
-
-    def save_current_shard(self):
-        shard_id = '%s-%06d' % (self.store_name, self.current_shard_index)
-        np.savez(self.store_data_dir / shard_id, feature_id=self.shard_feature_id, features=self.shard_features)
-        if self.verbose:
-            print(f'saved {self.shard_feature_index} features to shard {self.store_data_dir / shard_id}')
-        self.current_shard_index += 1
-        self.shard_feature_index = 0
+    def _shard_arrays(self, fn):
+        with np.load(fn) as payload:
+            return payload['feature_id'], payload['features'].reshape(-1, self.feature_dim)
 
     def __iter__(self):
         for fn in self.npz_filename_list:
-            payload = np.load(fn)
-            ids, feats = payload['feature_id'], payload['features']
-            n = ids.shape[0]
-            order = random.sample(range(0, n), n) if self.shuffle_values else range(0, n)
+            ids, feats = self._shard_arrays(fn)
+            order = list(range(ids.shape[0]))
+            if self.shuffle_values:
+                random.shuffle(order)
             for i in order:
-                yield ids[i], np.take(feats, [i], 0)  # (1,D), not (D,)
+                yield ids[i], feats[i:i + 1]          # (1, D), as the reference yields
 
     def iter_batch(self, batch_size=512):
         """(ids list[<=batch], vectors [<=batch, D]) like WebdatasetStore.iter_batch."""
         for fn in self.npz_filename_list:
-            payload = np.load(fn)
-            ids, feats = payload['feature_id'], payload['features'].reshape(-1, self.feature_dim)
+            ids, feats = self._shard_arrays(fn)
             for s in range(0, ids.shape[0], batch_size):
-                yield [int(v) for v in ids[s:s + batch_size]], np.ascontiguousarray(feats[s:s + batch_size],
-                                                                                   dtype=np.float32)
-
-    def close(self):
-        if getattr(self, 'shard_feature_index', 0) != 0:
-            n = self.shard_feature_index
-            self.shard_feature_id = self.shard_feature_id[:n].copy()
-            self.shard_features = self.shard_features[:n].copy()
-            self.save_current_shard()
-            self.shard_feature_index = 0
-
-    def __del__(self):
-        try:
-            if getattr(self, 'shard_feature_index', 0) != 0:
-                self.close()
-        except Exception:
-            pass
+                yield ([int(v) for v in ids[s:s + batch_size]],
+                       np.ascontiguousarray(feats[s:s + batch_size], dtype=np.float32))
