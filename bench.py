@@ -390,6 +390,48 @@ def main():
             search256(i)
         s256 = max(4, s_steps // 5)
         sdt256 = timed_region(search256, s256, world)
+        # the k the reference's server and evaluations send (REST `end` = 20: api/routes.py:1171,1407; k = 100:
+        # docs/Search-Index-Evaluation.md:109; --topk 1000: docs/Retrieval-Evaluation.md:39), nq = 1, same index
+        by_k = {}
+        for kk in (20, 100, 1000):
+            def search_k(i, kk=kk):
+                j = i % 1000
+                res["DIk"] = index.search_device(Q[j:j + 1], kk)
+            for i in range(3):
+                search_k(i)
+            c0k = flat.shadow_counts()
+            dtk = timed_region(search_k, s_steps, world)
+            c1k = flat.shadow_counts()
+            by_k[f"k{kk}_queries_per_s"] = round(s_steps / dtk, 2)
+            by_k[f"k{kk}_ms_per_query"] = round(dtk / s_steps * 1e3, 4)
+            by_k[f"k{kk}_from_shadow_of_{s_steps}"] = int(c1k[0] - c0k[0])
+        # ONE rank's share of this index at 8 GPUs (N / 8 rows, nq = 1, k = 10): the strong-scaling number one GPU can
+        # measure — the scan shrinks 8-fold, the per-query fixed cost (sample, threshold, finish, gated launches) does not
+        shard = None
+        if world == 1 and n_loc >= 8 * (1 << 18):
+            n8 = n_loc // 8
+            sh = FlatIPIndex(d).adopt(X[:n8], None, id_base=1)
+
+            def search_shard(i):
+                j = i % 1000
+                res["DIs"] = sh.search_device(Q[j:j + 1], k)
+
+            for i in range(5):
+                search_shard(i)
+            s8 = max(s_steps, 50)
+            dts = timed_region(search_shard, s8, world)
+            sprof8 = prof_pass(lib, search_shard, s8, s8 + 8)
+            s8_ms, s8_n, _ = sprof8[1]
+            Ds, Is = res["DIs"]
+            sh.shadow = False
+            Df, If = sh.search_device(Q[(s8 - 1) % 1000:(s8 - 1) % 1000 + 1], k)
+            assert torch.equal(Is, If) and torch.equal(Ds, Df), "shard: two-stage != f32 scan"
+            shard = {"rows": int(n8), "queries_per_s": round(s8 / dts, 1), "ms_per_query": round(dts / s8 * 1e3, 4),
+                     "collect_kernel_us": round(s8_ms / max(s8_n, 1) * 1e3, 2),
+                     "everything_else_us": round((dts / s8 - s8_ms / max(s8_n, 1) * 1e-3) * 1e6, 1),
+                     "note": "one rank's rows of the 10M x 512 index at 8 GPUs, nq=1, k=10, ids and scores bit-equal to the "
+                             "f32 scan of the same rows; the all-gather and merge of the 8-rank exchange are not in it"}
+            del sh
         D32, I32 = index.search_device(Q[:32], k)
         D1, I1 = index.search_device(Q[:1], k)
         # the two kernels sum the d products in different orders: same ids, scores to the tested 2e-5
@@ -407,7 +449,7 @@ def main():
                                    f"({N * d * 4 / 1e9:.2f} GB) with a bf16 shadow copy ({N * d * 2 / 1e9:.2f} GB), k={k}, "
                                    "nq=1; two-stage exact search: sample -> threshold -> every row that could belong to "
                                    "the top-k collected from the bf16 rows -> fp32 re-scoring (fp32 scan only if more "
-                                   "than 16384 rows qualify)", "rows_per_gpu": rows_per_rank,
+                                   "than 16384 rows qualify); any k <= 1024", "rows_per_gpu": rows_per_rank,
                        "parallelism": f"row-shard x{world} + ONE RCCL all-gather of the packed per-shard (score,id)[nq,k] lists",
                        "allgather_payload_bytes_per_rank_nq1": int(getattr(index, "last_exchange_bytes", 0)) if world > 1
                        else 0, "collectives_per_query": 1 if world > 1 else 0},
@@ -422,6 +464,8 @@ def main():
                          **traffic_fields("ip_collect_bf16_kernel")},
             "two_stage": {"answered_from_the_shadow": int(shadow_stats[0]), "handed_to_fp32_scan": int(shadow_stats[1]),
                           "fp32_scan_only_queries_per_s": round(qps_f32, 2)},
+            **by_k,
+            "one_rank_of_8_shard": shard,
             "batched_nq4_queries_per_s": round(4 * s_steps / sdt4, 2),
             "batched_nq32_queries_per_s": round(32 * s_steps / sdt32, 2),
             "batched_nq32_ms_per_pass": round(sdt32 / s_steps * 1e3, 4),

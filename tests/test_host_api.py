@@ -83,9 +83,10 @@ def test_argument_validation_without_gpu():
     # the two-stage search: shapes it does not serve are refused before anything is launched
     assert lib.wise_ip_topk_shadow_workspace_bytes(1000, 512, 1, 10) > 0
     assert lib.wise_ip_topk_shadow_workspace_bytes(1000, 516, 1, 10) == 0        # d % 8
-    assert lib.wise_ip_topk_shadow_workspace_bytes(1000, 512, 1, 17) == 0        # k > 16
-    rc = lib.wise_ip_topk_shadow_f32(0, 0, 0, 1000, 512, 0, 1, 17, 0, 0, 0, 0, 0, 0, 0, 0)
-    assert rc == -1 and b"k=17" in lib.wise_last_error()
+    assert lib.wise_ip_topk_shadow_workspace_bytes(1000, 512, 1, 1000) > 0       # any k <= 1024 (REST end = 20, --topk 1000)
+    assert lib.wise_ip_topk_shadow_workspace_bytes(1000, 512, 1, 1025) == 0      # k > 1024
+    rc = lib.wise_ip_topk_shadow_f32(0, 0, 0, 1000, 512, 0, 1, 1025, 0, 0, 0, 0, 0, 0, 0, 0)
+    assert rc == -1 and b"k=1025" in lib.wise_last_error()
     rc = lib.wise_ip_topk_shadow_f32(0, 0, 0, 1000, 512, 0, 1, 10, 0, 0, 0, 0, 0, 0, 0, 0)
     assert rc == -1 and b"null pointer" in lib.wise_last_error()
     rc = lib.wise_ip_shadow_bf16(0, 10, 12, 0, 0, 0)

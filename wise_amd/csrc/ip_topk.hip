@@ -549,10 +549,13 @@ struct ShadowGroup {
 // The SAMPLE pass of the single-query search: evenly spaced chunks of 2^chunk_shift groups of R rows (chunk_stride groups
 // apart); every wave scores its share of the sampled groups and writes the best score it saw (wave_best[global wave]).
 // The k-th largest of those per-wave maxima is reached by k different sampled rows (sample_threshold_kernel).
+// dump != null: the score of sampled row j (j = sampled group * R + row within the group) goes to dump[j] as well — the
+// general-k threshold takes the exact k-th largest of ALL sampled scores (sample_threshold_kth_kernel).
 template <int NV8, int R>
 __global__ __launch_bounds__(256) void ip_sample_bf16_kernel(const uint4* __restrict__ Xb, long long n_groups, int d8,
                                                              const float* __restrict__ Q, int chunk_shift,
-                                                             long long chunk_stride, float* __restrict__ wave_best) {
+                                                             long long chunk_stride, float* __restrict__ wave_best,
+                                                             float* __restrict__ dump = nullptr) {
     const int lane = threadIdx.x & 63;
     const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
     ShadowGroup<NV8, R> grp;
@@ -562,6 +565,7 @@ __global__ __launch_bounds__(256) void ip_sample_bf16_kernel(const uint4* __rest
         const long long row0 = ((g >> chunk_shift) * chunk_stride + (g & ((1ll << chunk_shift) - 1))) * R;
         const float sc = grp.score(Xb, row0, row0 + R, d8, lane);     // whole groups only: no ragged edge in a sample
         best = (grp.owner && sc > best) ? sc : best;
+        if (dump && grp.owner) dump[g * R + grp.myr] = sc;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
@@ -646,7 +650,8 @@ constexpr int SAMPLE_GRID = 512;            // blocks of the sample scan: 2048 w
 template <int NV8, int R>
 __global__ __launch_bounds__(256) void ip_collect_bf16_kernel(const uint4* __restrict__ Xb, long long N, int d8,
                                                               const float* __restrict__ Q, const float* __restrict__ thr_p,
-                                                              int* __restrict__ counter, u64* __restrict__ cand, int cap) {
+                                                              int* __restrict__ counter, u64* __restrict__ cand, int cap,
+                                                              long long row_base = 0 /*index row of Xb's first row*/) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     ShadowGroup<NV8, R> grp;
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(256) void ip_collect_bf16_kernel(const uint4* __res
             if (lane == first) base = atomicAdd(counter, __popcll(mask));
             base = __shfl(base, first, 64);
             const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-            if (pass && pos < cap) cand[pos] = make_key(sc, (unsigned)row);
+            if (pass && pos < cap) cand[pos] = make_key(sc, (unsigned)(row_base + row));
         }
     }
 }
@@ -762,7 +767,7 @@ __global__ __launch_bounds__(256) void collect_rescore_kernel(const float* __res
     cand += (size_t)blockIdx.y * RESCORE_CAP;
     ekeys += (size_t)blockIdx.y * RESCORE_CAP;
     Q += (size_t)blockIdx.y * d;
-    if (ctl[1] != 0) return;                    // a list overflowed: the f32 scan answers
+    if (ctl[1] != 0 || ctl[3] != 0) return;     // a list overflowed (the f32 scan answers), or the one-block finish answered
     const int n = ctl[2];
     const int lane = threadIdx.x & 63;
     const int d4 = d >> 2;
@@ -867,6 +872,415 @@ __global__ __launch_bounds__(1024) void collect_select_kernel(const int* __restr
 #pragma unroll
         for (int j = 0; j < PER; ++j) mine[j] = (mine[j] == g) ? 0 : mine[j];   // keys are unique (the row is part of them)
         __syncthreads();
+    }
+    if (tid == 0 && stats) atomicAdd(stats, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// General k (the k the reference's server and evaluations send: REST `end` = 20, api/routes.py:1171,1407; k = 100,
+// docs/Search-Index-Evaluation.md:109; --topk 1000, docs/Retrieval-Evaluation.md:39).  The threshold form itself does not
+// care about k; what did were the selections (k rounds of a block-wide maximum).  They are radix selections here.
+// ------------------------------------------------------------------------------------------------
+// k-th largest of the 64-bit keys a 1024-thread block holds (PER per thread, 0 = empty slot; keys are unique because the
+// row is part of them): eight byte-wise histogram passes from the top byte down.  Returns the key (0 if fewer than k
+// non-empty keys).  hist: 256 words, sh: 2 u64 + 1 int of shared memory.  All threads must call it.
+template <int PER>
+__device__ u64 block_kth_largest_key(const u64 (&mine)[PER], int k, unsigned* hist, u64* sh_prefix, int* sh_rem) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { *sh_prefix = 0; *sh_rem = k; }
+    u64 mask = 0;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const u64 prefix = *sh_prefix;
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (mine[j] != 0 && (mine[j] & mask) == prefix) atomicAdd(&hist[(unsigned)(mine[j] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (tid < 64) {
+            // suffix sums over the 256 buckets, four per lane (lane 63 holds buckets 252..255)
+            unsigned h[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) h[b] = hist[tid * 4 + b];
+            const unsigned own = h[0] + h[1] + h[2] + h[3];
+            unsigned above = own;                      // inclusive suffix over lanes >= tid
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_down(above, o, 64);
+                if (tid + o < 64) above += t;
+            }
+            above -= own;                              // buckets of higher lanes only
+            const unsigned rem = (unsigned)*sh_rem;
+            // the bucket where the count from the top reaches rem: exactly one lane finds it (if rem <= total)
+            unsigned cum = above;
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                if (cum < rem && cum + h[b] >= rem) {
+                    *sh_rem = (int)(rem - cum);
+                    *sh_prefix = prefix | ((u64)(tid * 4 + b) << shift);
+                }
+                cum += h[b];
+            }
+            if (tid == 0 && cum < rem) *sh_rem = -1;   // fewer than k keys in all
+        }
+        mask |= (u64)255 << shift;
+        __syncthreads();
+        if (*sh_rem < 0) return 0;
+    }
+    return *sh_prefix;
+}
+
+// the same over 32-bit keys (ordered scores, duplicates counted): four passes
+template <int PER>
+__device__ unsigned block_kth_largest_u32(const unsigned (&mine)[PER], const bool (&live)[PER], int k, unsigned* hist,
+                                          unsigned* sh_prefix, int* sh_rem) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { *sh_prefix = 0; *sh_rem = k; }
+    unsigned mask = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = *sh_prefix;
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (live[j] && (mine[j] & mask) == prefix) atomicAdd(&hist[(mine[j] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (tid < 64) {
+            unsigned h[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) h[b] = hist[tid * 4 + b];
+            const unsigned own = h[0] + h[1] + h[2] + h[3];
+            unsigned above = own;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_down(above, o, 64);
+                if (tid + o < 64) above += t;
+            }
+            above -= own;
+            const unsigned rem = (unsigned)*sh_rem;
+            unsigned cum = above;
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                if (cum < rem && cum + h[b] >= rem) {
+                    *sh_rem = (int)(rem - cum);
+                    *sh_prefix = prefix | ((unsigned)(tid * 4 + b) << shift);
+                }
+                cum += h[b];
+            }
+            if (tid == 0 && cum < rem) *sh_rem = -1;
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+        if (*sh_rem < 0) return 0;
+    }
+    return *sh_prefix;
+}
+
+// thr = (k-th largest of the n dumped sample scores) - 2 eps(q); zeroes the control words of the query (ctl[0..3]) on
+// the way: one block, 64 scores per thread at n = 65536.
+__global__ __launch_bounds__(1024) void sample_threshold_kth_kernel(const float* __restrict__ dump, int n, int k,
+                                                                    const float* __restrict__ Q, int d,
+                                                                    const float* __restrict__ norms, float* __restrict__ thr,
+                                                                    int* __restrict__ ctl) {
+    // 8192 disjoint segments of the sampled scores (8 per thread, n / 8192 scores each: segment s = elements
+    // s, s + 8192, ...), their maxima, and the k-th largest of those: k DIFFERENT sampled rows reach it.  Against the
+    // exact k-th largest sampled score this loses only the top scores that share a segment (k^2 / 16384 of them on
+    // average: 61 at k = 1000, none to speak of at k = 20) and selects among 8 keys per thread instead of 64.
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh_prefix;
+    __shared__ int sh_rem;
+    __shared__ float wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = 8, SEGS = 8192;
+    unsigned mine[PER];
+    bool live[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int seg = j * 1024 + tid;
+        float m = -3.4028234663852886e38f;
+        for (int i = seg; i < n; i += SEGS) m = fmaxf(m, dump[i]);
+        live[j] = seg < n;
+        mine[j] = f32_order(m);
+    }
+    float qq = 0.f;
+    for (int j = tid; j < d; j += 1024) qq = fmaf(Q[j], Q[j], qq);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    if (lane == 0) wsum[wave] = qq;
+    if (tid < 4) ctl[tid] = 0;
+    const unsigned L = block_kth_largest_u32<PER>(mine, live, k, hist, &sh_prefix, &sh_rem);
+    if (tid == 0) {
+        qq = 0.f;
+        for (int w = 0; w < 16; ++w) qq += wsum[w];
+        // (fewer than k segments: no threshold — everything is collected, the lists overflow, the f32 scan answers)
+        thr[0] = sh_rem >= 0 ? f32_unorder(L) - 2.f * shadow_eps(norms, d, qq) : -3.4028234663852886e38f;
+    }
+}
+
+// score part (upper 32 bits of the key, lower half zero) of the k-th largest of the n keys of a list in global memory
+// (L2-resident), 0 if the list is shorter than k: four byte passes over the list by a 1024-thread block; the bucket scan
+// of a pass is wave 0's (four buckets per lane).  hist[256], sh_prefix, sh_rem: shared.  All threads must call it.
+__device__ u64 list_kth_score(const u64* __restrict__ cand, int n, int k, unsigned* hist, u64* sh_prefix, int* sh_rem) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { *sh_prefix = 0; *sh_rem = k; }
+    u64 mask = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 56 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const u64 prefix = *sh_prefix;
+        for (int i = tid; i < n; i += 1024) {
+            const u64 key = cand[i];
+            if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            unsigned h[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) h[b] = hist[tid * 4 + b];
+            const unsigned own = h[0] + h[1] + h[2] + h[3];
+            unsigned above = own;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_down(above, o, 64);
+                if (tid + o < 64) above += t;
+            }
+            above -= own;
+            const unsigned rem = (unsigned)*sh_rem;
+            unsigned cum = above;
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                if (cum < rem && cum + h[b] >= rem) {
+                    *sh_rem = (int)(rem - cum);
+                    *sh_prefix = prefix | ((u64)(tid * 4 + b) << shift);
+                }
+                cum += h[b];
+            }
+            if (tid == 0 && cum < rem) *sh_rem = -1;
+        }
+        mask |= (u64)255 << shift;
+        __syncthreads();
+        if (*sh_rem < 0) return 0;
+    }
+    return *sh_prefix;
+}
+
+// Between the two ranges of a large-k collect pass: thr = max(thr, (k-th largest score collected from the first range)
+// - 2 eps).  The first range is a sample sixteen times the sample pass's, so the second range collects a few k rows
+// instead of N / 65536 * k (150,000 at k = 1000 over 10M rows, which also slowed the scan by its appends).
+__global__ __launch_bounds__(1024) void collect_tighten_kernel(const int* __restrict__ ctl, const u64* __restrict__ cand, int cap,
+                                                               int k, const float* __restrict__ Q, int d,
+                                                               const float* __restrict__ norms, float* __restrict__ thr) {
+    __shared__ unsigned hist[256];
+    __shared__ u64 sh_prefix;
+    __shared__ int sh_rem;
+    __shared__ float wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = ctl[0];
+    if (n > cap) return;                       // overflow already: the finish kernel raises the gate
+    float qq = 0.f;
+    for (int j = tid; j < d; j += 1024) qq = fmaf(Q[j], Q[j], qq);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    if (lane == 0) wsum[wave] = qq;
+    const u64 L = list_kth_score(cand, n, k, hist, &sh_prefix, &sh_rem);
+    if (tid == 0 && L != 0) {
+        qq = 0.f;
+        for (int w = 0; w < 16; ++w) qq += wsum[w];
+        const float t2 = f32_unorder((unsigned)(L >> 32)) - 2.f * shadow_eps(norms, d, qq);
+        if (t2 > thr[0]) thr[0] = t2;
+    }
+}
+
+constexpr int FINISH_LDS_ROWS = 2048;       // survivors the one-block finish can hold (16 KiB of keys)
+constexpr int FINISH_OWN_ROWS = 512;        // ... and re-scores itself (1 MiB of f32 rows through one CU); more: the multi-block kernels
+
+// Everything behind the collect pass of ONE query in one block (refine -> exact scores -> the k best), k <= 1024:
+//   refine   T2 = (k-th largest collected approximate score) - 2 eps by radix selection over the collected list (read
+//            from L2 once per byte pass), survivors (approximate score >= T2) compacted;
+//   rescore  <= FINISH_LDS_ROWS survivors: their exact f32 scores here, a wave per row, two rows in flight — the same
+//            per-lane fmaf chain and butterfly as collect_rescore_kernel, i.e. the f32 scan's bits;
+//   select   radix selection of the k-th exact key, the winners ranked by counting, written as (score, id).
+// More survivors (near-duplicate runs: up to RESCORE_CAP) go to cand2 with ctl[2] = their number and ctl[3] = 0: the
+// multi-block collect_rescore_kernel and collect_select_kernel queued behind take over (they return at once when
+// ctl[3] != 0 = answered here).  Overflow of either list raises the gate (ctl[1]) for the f32 scan behind them.
+__global__ __launch_bounds__(1024) void collect_finish_kernel(int* __restrict__ ctl, const u64* __restrict__ cand, int cap,
+                                                              int k, const float* __restrict__ Q, int d,
+                                                              const float* __restrict__ X, const float* __restrict__ norms,
+                                                              u64* __restrict__ cand2, const long long* __restrict__ ids,
+                                                              long long id_base, float* __restrict__ outD,
+                                                              long long* __restrict__ outI, int* __restrict__ stats) {
+    __shared__ unsigned hist[256];
+    __shared__ u64 sh_prefix;
+    __shared__ int sh_rem;
+    __shared__ float wsum[16];
+    __shared__ int kept;
+    __shared__ u64 keys[FINISH_LDS_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = ctl[0];
+    if (n > cap) {
+        if (tid == 0) { atomicOr(ctl + 1, 1); ctl[3] = 1; if (stats) atomicAdd(stats + 1, 1); }
+        return;
+    }
+    if (tid == 0) kept = 0;
+    float qq = 0.f;
+    for (int j = tid; j < d; j += 1024) qq = fmaf(Q[j], Q[j], qq);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    if (lane == 0) wsum[wave] = qq;
+    // ---- refine: the k-th largest collected score by byte passes over the list (n up to cap keys, L2-resident)
+    const u64 L = list_kth_score(cand, n, k, hist, &sh_prefix, &sh_rem);
+    qq = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) qq += wsum[w];
+    const float t2 = L != 0 ? f32_unorder((unsigned)(L >> 32)) - 2.f * shadow_eps(norms, d, qq) : -3.4028234663852886e38f;
+    // ---- survivors: into LDS while they fit, into cand2 always (the multi-block path reads them there)
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const u64 key = i < n ? cand[i] : 0;
+        const bool pass = key != 0 && f32_unorder((unsigned)(key >> 32)) >= t2;
+        const u64 bal = __ballot(pass);
+        if (bal != 0) {
+            const int first = __ffsll((long long)bal) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd(&kept, __popcll(bal));
+            base = __shfl(base, first, 64);
+            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pass && pos < FINISH_LDS_ROWS) keys[pos] = key;
+            if (pass && pos < RESCORE_CAP) cand2[pos] = key;
+        }
+    }
+    __syncthreads();
+    const int nk = kept;
+    if (nk > FINISH_OWN_ROWS) {
+        if (tid == 0) {
+            ctl[2] = nk;
+            if (nk > RESCORE_CAP) { atomicOr(ctl + 1, 1); ctl[3] = 1; if (stats) atomicAdd(stats + 1, 1); }
+            else ctl[3] = 0;                            // the multi-block kernels behind answer
+        }
+        return;
+    }
+    // ---- exact scores of the survivors: wave per row, two in flight (collect_rescore_kernel's arithmetic)
+    {
+        const int d4 = d >> 2;
+        const float4* qv = reinterpret_cast<const float4*>(Q);
+        for (int i0 = wave * 2; i0 < nk; i0 += 32) {
+            long long rows[2];
+            float p[2] = {0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                rows[u] = i0 + u < nk ? (long long)(0xFFFFFFFFu - (unsigned)(keys[i0 + u] & 0xFFFFFFFFull)) : -1;
+            for (int j = lane; j < d4; j += 64) {
+                const float4 b = qv[j];
+                float4 a[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    a[u] = rows[u] >= 0 ? reinterpret_cast<const float4*>(X + (size_t)rows[u] * d)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    p[u] = fmaf(a[u].x, b.x, p[u]); p[u] = fmaf(a[u].y, b.y, p[u]);
+                    p[u] = fmaf(a[u].z, b.z, p[u]); p[u] = fmaf(a[u].w, b.w, p[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) p[u] += __shfl_xor(p[u], o, 64);
+                if (lane == 0 && rows[u] >= 0) keys[i0 + u] = make_key(p[u], (unsigned)rows[u]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the k best exact keys: selection, then rank by counting among the winners
+    u64 mine[2];
+    mine[0] = tid < nk ? keys[tid] : 0;
+    mine[1] = tid + 1024 < nk ? keys[tid + 1024] : 0;
+    const int kk = k < nk ? k : nk;
+    const u64 kth = kk > 0 ? block_kth_largest_key<2>(mine, kk, hist, &sh_prefix, &sh_rem) : ~0ull;
+    __syncthreads();
+    if (tid == 0) kept = 0;
+    __syncthreads();
+    // winners (exactly kk of them: keys are unique) compacted to the front of `keys`
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const bool win = mine[j] != 0 && mine[j] >= kth;
+        const u64 bal = __ballot(win);
+        int base = 0;
+        if (bal != 0) {
+            const int first = __ffsll((long long)bal) - 1;
+            if (lane == first) base = atomicAdd(&kept, __popcll(bal));
+            base = __shfl(base, first, 64);
+        }
+        __syncthreads();                                // every key is in a register before its slot may be rewritten
+        if (win) keys[base + __popcll(bal & ((1ull << lane) - 1ull))] = mine[j];
+        __syncthreads();
+    }
+    if (tid < kk) {
+        const u64 mykey = keys[tid];
+        int rank = 0;
+        for (int j = 0; j < kk; ++j) rank += keys[j] > mykey;
+        const long long row = (long long)(0xFFFFFFFFu - (unsigned)(mykey & 0xFFFFFFFFull));
+        outD[rank] = f32_unorder((unsigned)(mykey >> 32));
+        outI[rank] = ids ? ids[row] : id_base + row;
+    }
+    for (int j = kk + tid; j < k; j += 1024) {          // fewer rows than k: padding
+        outD[j] = -3.4028234663852886e38f;
+        outI[j] = -1;
+    }
+    if (tid == 0) { ctl[2] = nk; ctl[3] = 1; if (stats) atomicAdd(stats, 1); }
+}
+
+// the k best (k <= 1024) of n <= RESCORE_CAP exact keys by radix selection + ranking of the winners: the multi-block
+// path's last kernel for any k (collect_select_kernel's k rounds of a block-wide maximum are its k <= 16 form)
+__global__ __launch_bounds__(1024) void collect_select_kth_kernel(const int* __restrict__ ctl, const u64* __restrict__ ekeys,
+                                                                  int k, const long long* __restrict__ ids, long long id_base,
+                                                                  float* __restrict__ outD, long long* __restrict__ outI,
+                                                                  int* __restrict__ stats) {
+    __shared__ unsigned hist[256];
+    __shared__ u64 sh_prefix;
+    __shared__ int sh_rem;
+    __shared__ int cnt;
+    __shared__ u64 win[1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (ctl[1] != 0 || ctl[3] != 0) return;             // overflow (the f32 scan answers) or answered by the finish kernel
+    const int n = ctl[2];
+    constexpr int PER = RESCORE_CAP / 1024;
+    u64 mine[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int idx = j * 1024 + tid;
+        mine[j] = idx < n ? ekeys[idx] : 0;
+    }
+    const int kk = k < n ? k : n;
+    if (tid == 0) cnt = 0;
+    const u64 kth = kk > 0 ? block_kth_largest_key<PER>(mine, kk, hist, &sh_prefix, &sh_rem) : ~0ull;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const bool w = mine[j] != 0 && mine[j] >= kth;
+        const u64 bal = __ballot(w);
+        if (bal != 0) {
+            const int first = __ffsll((long long)bal) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd(&cnt, __popcll(bal));
+            base = __shfl(base, first, 64);
+            if (w) win[base + __popcll(bal & ((1ull << lane) - 1ull))] = mine[j];
+        }
+    }
+    __syncthreads();
+    if (tid < kk) {
+        const u64 mykey = win[tid];
+        int rank = 0;
+        for (int j = 0; j < kk; ++j) rank += win[j] > mykey;
+        const long long row = (long long)(0xFFFFFFFFu - (unsigned)(mykey & 0xFFFFFFFFull));
+        outD[rank] = f32_unorder((unsigned)(mykey >> 32));
+        outI[rank] = ids ? ids[row] : id_base + row;
+    }
+    for (int j = kk + tid; j < k; j += 1024) {
+        outD[j] = -3.4028234663852886e38f;
+        outI[j] = -1;
     }
     if (tid == 0 && stats) atomicAdd(stats, 1);
 }
@@ -1202,7 +1616,10 @@ static int shadow_grid(long long N) {
     const long long cap = g_scan_blocks_per_cu > 0 ? 256ll * g_scan_blocks_per_cu : 512;
     return need < cap ? (int)need : (int)cap;
 }
-static bool shadow_supported(int d, int k) { return d % 8 == 0 && d >= 8 && d <= 1024 && k >= 1 && k <= 16; }
+// k <= 1024: the one-query threshold form serves any such k (radix selections); batches of queries go through the
+// matrix-core passes for k <= SHADOW_BATCH_K, else one query at a time
+constexpr int SHADOW_KMAX = 1024, SHADOW_BATCH_K = 16;
+static bool shadow_supported(int d, int k) { return d % 8 == 0 && d >= 8 && d <= 1024 && k >= 1 && k <= SHADOW_KMAX; }
 }  // namespace wise
 
 extern "C" int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* Xb, float* norms, void* stream) {
@@ -1229,9 +1646,10 @@ extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, 
         const ScanPlan pm = plan_scan(N, d, m, k);
         if (pm.grid > p.grid) p.grid = pm.grid;
     }
-    // one query: per-wave sample maxima | threshold | control words | collected keys | kept keys | exact keys | lists of the gated f32 scan
+    // one query: per-wave sample maxima | threshold | control words | collected keys | kept keys | exact keys | sampled scores | lists of the gated f32 scan
     size_t one = align_up((size_t)SAMPLE_GRID * 4 * sizeof(float), 256) + 256 + 256 +
                  align_up((size_t)COLLECT_CAP * sizeof(u64), 256) + 2 * align_up((size_t)RESCORE_CAP * sizeof(u64), 256) +
+                 align_up((size_t)SAMPLE_CHUNKS * 512 * sizeof(float), 256) +              // every sampled row's score
                  align_up((size_t)p.grid * 4 * k * sizeof(u64), 256);
     // batches: see pass_workspace()
     const size_t many = pass_workspace_bytes(N, d, k);
@@ -1363,47 +1781,70 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norm
     off += align_up((size_t)RESCORE_CAP * sizeof(u64), 256);
     u64* ekeys = reinterpret_cast<u64*>(wsb + off);
     off += align_up((size_t)RESCORE_CAP * sizeof(u64), 256);
+    float* dump = reinterpret_cast<float*>(wsb + off);
+    off += align_up((size_t)SAMPLE_CHUNKS * 512 * sizeof(float), 256);
     u64* epart = reinterpret_cast<u64*>(wsb + off);
     const int d8 = d / 8, nv8 = (d8 + 63) / 64;
     if (nv8 > 2) { set_error("ip_topk_shadow: no kernel for d=%d", d); return WISE_E_INVALID; }
     const uint4* xb = reinterpret_cast<const uint4*>(Xb);
-    hipError_t e = hipMemsetAsync(counter, 0, 4 * sizeof(int), st);
-    if (e != hipSuccess) { set_error("ip_topk_shadow: %s", hipGetErrorString(e)); return (int)e; }
-    // ---- sample: SAMPLE_CHUNKS evenly spaced chunks of 2^SAMPLE_CHUNK_SHIFT groups of 8 rows
+    // ---- sample: SAMPLE_CHUNKS evenly spaced chunks of 2^shift groups of 8 rows, every sampled score dumped.  About
+    // N / 64 rows, between 16384 and 65536 (a shard of an index sharded over eight GPUs pays a quarter of the sample a
+    // whole index does); the threshold is the exact k-th largest sampled score (k <= 1024 of >= 16384 samples) and it
+    // also zeroes the control words: no memset in front.
     {
+        int shift = SAMPLE_CHUNK_SHIFT;                  // 512 rows per chunk
+        while (shift > 4 && (long long)SAMPLE_CHUNKS * (8ll << shift) * 64 > N) --shift;
         const long long groups = N / 8;                  // whole groups only: a sampled group is never ragged
-        const long long chunk_groups = 1ll << SAMPLE_CHUNK_SHIFT;
+        const long long chunk_groups = 1ll << shift;
         const long long stride = (groups - chunk_groups) / (SAMPLE_CHUNKS - 1);      // last chunk ends inside the index
         const long long sgroups = (long long)SAMPLE_CHUNKS * chunk_groups;
+        const int sgrid = (int)((sgroups + 15) / 16 < SAMPLE_GRID ? (sgroups + 15) / 16 : SAMPLE_GRID);
         if (nv8 == 1)
-            hipLaunchKernelGGL((ip_sample_bf16_kernel<1, 8>), dim3(SAMPLE_GRID), dim3(256), 0, st, xb, sgroups, d8, q,
-                               SAMPLE_CHUNK_SHIFT, stride, wave_best);
+            hipLaunchKernelGGL((ip_sample_bf16_kernel<1, 8>), dim3(sgrid), dim3(256), 0, st, xb, sgroups, d8, q, shift, stride,
+                               wave_best, dump);
         else
-            hipLaunchKernelGGL((ip_sample_bf16_kernel<2, 8>), dim3(SAMPLE_GRID), dim3(256), 0, st, xb, sgroups, d8, q,
-                               SAMPLE_CHUNK_SHIFT, stride, wave_best);
+            hipLaunchKernelGGL((ip_sample_bf16_kernel<2, 8>), dim3(sgrid), dim3(256), 0, st, xb, sgroups, d8, q, shift, stride,
+                               wave_best, dump);
         WISE_LAUNCH_CHECK("ip_sample_bf16_kernel");
-        hipLaunchKernelGGL(sample_threshold_kernel1, dim3(1), dim3(1024), 0, st, wave_best, SAMPLE_GRID * 4, k, q, d, norms, thr);
-        WISE_LAUNCH_CHECK("sample_threshold_kernel1");
+        hipLaunchKernelGGL(sample_threshold_kth_kernel, dim3(1), dim3(1024), 0, st, dump, (int)(sgroups * 8), k, q, d, norms, thr,
+                           counter);
+        WISE_LAUNCH_CHECK("sample_threshold_kth_kernel");
     }
-    // ---- collect over all rows
+    // ---- collect over all rows; for large k in two ranges, the threshold tightened in between by what the first
+    // range (2^20 rows: a sample sixteen times the sample pass's) collected
     {
         ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
-        const int grid = shadow_grid(N);
-        if (nv8 == 1)
-            hipLaunchKernelGGL((ip_collect_bf16_kernel<1, 8>), dim3(grid), dim3(256), 0, st, xb, N, d8, q, thr, counter, cand,
-                               COLLECT_CAP);
-        else
-            hipLaunchKernelGGL((ip_collect_bf16_kernel<2, 8>), dim3(grid), dim3(256), 0, st, xb, N, d8, q, thr, counter, cand,
-                               COLLECT_CAP);
+        auto collect = [&](long long r0, long long rows) {
+            const int grid = shadow_grid(rows);
+            const uint4* base = xb + (size_t)r0 * d8;
+            if (nv8 == 1)
+                hipLaunchKernelGGL((ip_collect_bf16_kernel<1, 8>), dim3(grid), dim3(256), 0, st, base, rows, d8, q, thr, counter,
+                                   cand, COLLECT_CAP, r0);
+            else
+                hipLaunchKernelGGL((ip_collect_bf16_kernel<2, 8>), dim3(grid), dim3(256), 0, st, base, rows, d8, q, thr, counter,
+                                   cand, COLLECT_CAP, r0);
+        };
+        const long long R1 = 1ll << 20;
+        if (k > 64 && N >= 4 * R1) {
+            collect(0, R1);
+            WISE_LAUNCH_CHECK("ip_collect_bf16_kernel");
+            hipLaunchKernelGGL(collect_tighten_kernel, dim3(1), dim3(1024), 0, st, counter, cand, COLLECT_CAP, k, q, d, norms, thr);
+            WISE_LAUNCH_CHECK("collect_tighten_kernel");
+            collect(R1, N - R1);
+        } else {
+            collect(0, N);
+        }
         WISE_LAUNCH_CHECK("ip_collect_bf16_kernel");
     }
-    hipLaunchKernelGGL(collect_refine_kernel, dim3(1), dim3(1024), 0, st, counter, cand, COLLECT_CAP, k, q, d, norms, cand2,
-                       stats, (int*)nullptr, (int)QMODE_F32);
-    WISE_LAUNCH_CHECK("collect_refine_kernel");
+    // ---- refine, exact scores, the k best: one block; the two kernels behind it only run when more than
+    // FINISH_LDS_ROWS rows survive the refinement (runs of near-duplicates)
+    hipLaunchKernelGGL(collect_finish_kernel, dim3(1), dim3(1024), 0, st, counter, cand, COLLECT_CAP, k, q, d, X, norms, cand2, ids,
+                       id_base, outD, outI, stats);
+    WISE_LAUNCH_CHECK("collect_finish_kernel");
     hipLaunchKernelGGL(collect_rescore_kernel, dim3(64), dim3(256), 0, st, X, d, q, counter, cand2, ekeys);
     WISE_LAUNCH_CHECK("collect_rescore_kernel");
-    hipLaunchKernelGGL(collect_select_kernel, dim3(1), dim3(1024), 0, st, counter, ekeys, k, ids, id_base, outD, outI, stats);
-    WISE_LAUNCH_CHECK("collect_select_kernel");
+    hipLaunchKernelGGL(collect_select_kth_kernel, dim3(1), dim3(1024), 0, st, counter, ekeys, k, ids, id_base, outD, outI, stats);
+    WISE_LAUNCH_CHECK("collect_select_kth_kernel");
     // ---- the f32 scan of the same query, which returns at once unless the list overflowed
     ScanPlan p = plan_scan(N, d, 1, k);
     if (p.nq_per_pass != 1) { set_error("ip_topk_shadow: f32 plan serves %d queries per pass", p.nq_per_pass); return WISE_E_INVALID; }
@@ -1582,7 +2023,7 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
                                        const float* Q, int nq, int k, const int64_t* ids, int64_t id_base, float* outD,
                                        int64_t* outI, int32_t* counters, void* workspace, size_t workspace_bytes,
                                        void* stream) {
-    WISE_CHECK_ARG(shadow_supported(d, k), "ip_topk_shadow: d=%d must be a multiple of 8 in [8,1024], k=%d in [1,16]", d, k);
+    WISE_CHECK_ARG(shadow_supported(d, k), "ip_topk_shadow: d=%d must be a multiple of 8 in [8,1024], k=%d in [1,1024]", d, k);
     WISE_CHECK_ARG(N > 0 && N < 0xFFFFFFFFll, "ip_topk_shadow: N=%lld out of range", (long long)N);
     WISE_CHECK_ARG(nq >= 1 && nq <= 1024, "ip_topk_shadow: nq=%d out of [1,1024]", nq);
     WISE_CHECK_ARG(X && Xb && norms && Q && outD && outI, "ip_topk_shadow: null pointer");
