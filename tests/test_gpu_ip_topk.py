@@ -400,6 +400,29 @@ def test_general_k_on_clustered_rows_and_on_overflow(k):
     check_against_oracle(X2, q[None], k, ids2, D, I)
 
 
+@pytest.mark.parametrize("N,d,k,nq", [(300000, 512, 20, 40), (300000, 512, 100, 130), (262144, 256, 128, 9),
+                                      (270001, 768, 100, 70), (300000, 512, 17, 3)])
+def test_batched_two_stage_search_up_to_k128(N, d, k, nq):
+    """Batches of queries at the evaluation's k (100: docs/Search-Index-Evaluation.md:109) and the REST default (20):
+    the matrix-core passes over the bf16 shadow with the selections of the general-k path; ids and scores are the f32
+    scan's and the oracle's, everything answered from the shadow (the gated fallback for k > 12 is the f32 VALU scan)."""
+    X = unit_rows(N, d, 800 + k + nq)
+    ids = np.arange(N, dtype=np.int64) + 7
+    idx = FlatIPIndex(d, shadow=True)
+    idx.add_with_ids(X, ids)
+    ref = FlatIPIndex(d, shadow=False)
+    ref.add_with_ids(X, ids)
+    Q = unit_rows(nq, d, 990 + k)
+    Q[0] = X[N // 7] + 0.03 * Q[0]
+    Q[0] /= np.linalg.norm(Q[0])
+    before = idx.shadow_counts()
+    D, I = idx.search(Q, k)
+    assert counts_since(idx, before) == (nq, 0)
+    check_against_oracle(X, Q, k, ids, D, I, tol=2e-5)
+    Dr, Ir = ref.search(Q, k)
+    assert np.array_equal(I, Ir) and np.allclose(D, Dr, atol=2e-5)
+
+
 def test_small_index_with_near_ties_in_one_block():
     """N ~ 100 with more than 16 rows within 1e-3 of the query.  (The old two-stage path kept 16 rows per
     scan block and could report such a query exact; small indexes now never enter the two-stage path.)"""

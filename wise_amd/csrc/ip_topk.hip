@@ -676,7 +676,10 @@ __global__ __launch_bounds__(256) void ip_collect_bf16_kernel(const uint4* __res
     }
 }
 
-// Refinement of the collected list (one block): L = k-th largest of the 1024 threads' slice maxima, keep what reaches
+__device__ u64 list_kth_score(const u64* __restrict__ cand, int n, int k, unsigned* hist, u64* sh_prefix, int* sh_rem);
+
+// Refinement of the collected list (one block): L = k-th largest of the 1024 threads' slice maxima (k <= 16; for larger k
+// the exact k-th largest collected score, list_kth_score), keep what reaches
 // L - 2 eps, compacted into cand2 (order irrelevant: the final selection orders by exact score and row).
 // ctl: [0] collected (written by the collect pass), [1] gate, [2] kept (written here).
 // One query per blockIdx.y (the batched search runs a whole pass of queries through the same three kernels): query q
@@ -716,6 +719,12 @@ __global__ __launch_bounds__(1024) void collect_refine_kernel(int* __restrict__ 
     for (int o = 32; o >= 1; o >>= 1) { qq += __shfl_xor(qq, o, 64); qr += __shfl_xor(qr, o, 64); }
     if (lane == 0) { wsum[wave] = qq; wres[wave] = qr; }
     u64 L = 0;
+    if (k > 16) {
+        __shared__ unsigned hist[256];
+        __shared__ u64 sh_prefix;
+        __shared__ int sh_rem;
+        L = list_kth_score(cand, n, k, hist, &sh_prefix, &sh_rem);
+    } else
     for (int r = 0; r < k; ++r) {
         u64 m = mine;
 #pragma unroll
@@ -1244,6 +1253,10 @@ __global__ __launch_bounds__(1024) void collect_select_kth_kernel(const int* __r
     __shared__ int cnt;
     __shared__ u64 win[1024];
     const int tid = threadIdx.x, lane = tid & 63;
+    ctl += 4 * blockIdx.y;                               // one query per blockIdx.y (the batched passes)
+    ekeys += (size_t)blockIdx.y * RESCORE_CAP;
+    outD += (size_t)blockIdx.y * k;
+    outI += (size_t)blockIdx.y * k;
     if (ctl[1] != 0 || ctl[3] != 0) return;             // overflow (the f32 scan answers) or answered by the finish kernel
     const int n = ctl[2];
     constexpr int PER = RESCORE_CAP / 1024;
@@ -1618,7 +1631,7 @@ static int shadow_grid(long long N) {
 }
 // k <= 1024: the one-query threshold form serves any such k (radix selections); batches of queries go through the
 // matrix-core passes for k <= SHADOW_BATCH_K, else one query at a time
-constexpr int SHADOW_KMAX = 1024, SHADOW_BATCH_K = 16;
+constexpr int SHADOW_KMAX = 1024, SHADOW_BATCH_K = 128;
 static bool shadow_supported(int d, int k) { return d % 8 == 0 && d >= 8 && d <= 1024 && k >= 1 && k <= SHADOW_KMAX; }
 }  // namespace wise
 
@@ -1739,6 +1752,13 @@ __global__ __launch_bounds__(1024) void batch_tighten_kernel(const int* __restri
     for (int o = 32; o >= 1; o >>= 1) { qq += __shfl_xor(qq, o, 64); qr += __shfl_xor(qr, o, 64); }
     if (lane == 0) { wsum[wave] = qq; wres[wave] = qr; }
     u64 L = 0;
+    if (k > 16) {
+        __shared__ unsigned hist[256];
+        __shared__ u64 sh_prefix;
+        __shared__ int sh_rem;
+        L = list_kth_score(cand, n, k, hist, &sh_prefix, &sh_rem);
+        __syncthreads();
+    } else
     for (int r = 0; r < k; ++r) {
         u64 m = mine;
 #pragma unroll
@@ -1879,7 +1899,7 @@ static PassWs pass_workspace(unsigned char* wsb, long long N, int d, int k) {
     size_t off = 0;
     // (sizing calls pass no buffer: offsets are applied to a real base only)
     auto at = [&](size_t o) -> unsigned char* { return wsb ? wsb + o : nullptr; };
-    const ScanPlan p2 = plan_scan(N, d, 2, k);
+    const ScanPlan p2 = plan_scan(N, d, 4, k);     // (the VALU fallback plans up to four queries per launch)
     size_t lists = (size_t)2 * split64_lists(N) * MFMA_QB2 * MFMA_KL * sizeof(u64);
     const size_t valu = (size_t)p2.grid * 4 * k * sizeof(u64);
     if (valu > lists) lists = valu;
@@ -1955,14 +1975,19 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* nor
         WISE_LAUNCH_CHECK("collect_refine_kernel");
         hipLaunchKernelGGL(collect_rescore_kernel, dim3(8, nqa), dim3(256), 0, st, X, d, mq, w.ctl, w.cand2, w.ekeys);
         WISE_LAUNCH_CHECK("collect_rescore_kernel");
-        hipLaunchKernelGGL(collect_select_kernel, dim3(1, nqa), dim3(1024), 0, st, w.ctl, w.ekeys, k, ids, id_base, outD, outI,
-                           stats);
+        if (k > 16)
+            hipLaunchKernelGGL(collect_select_kth_kernel, dim3(1, nqa), dim3(1024), 0, st, w.ctl, w.ekeys, k, ids, id_base, outD,
+                               outI, stats);
+        else
+            hipLaunchKernelGGL(collect_select_kernel, dim3(1, nqa), dim3(1024), 0, st, w.ctl, w.ekeys, k, ids, id_base, outD, outI,
+                               stats);
         WISE_LAUNCH_CHECK("collect_select_kernel");
     }
     // ---- gated fallback over the f32 rows: every launch returns at once while *gate == 0
-    if (d > 512) {
-        // d > 512: the split-bf16 kernels do not reach; the f32 VALU scan redoes the pass, two queries per launch
-        const ScanPlan p = plan_scan(N, d, 2, k);
+    if (d > 512 || k > MFMA_KC) {
+        // d > 512 or k > 12: the split-bf16 kernels do not reach (they keep 16 candidates); the f32 VALU scan redoes the
+        // pass, up to four queries per launch
+        const ScanPlan p = plan_scan(N, d, 4, k);
         const int nv = (d / 4 + 63) / 64;
         u64* epart = mpart;          // the stage-1 lists are dead by now
         int emw = 8192 / p.cap;
@@ -1972,10 +1997,17 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* nor
             const int nqp = nqa - q0 < p.nq_per_pass ? nqa - q0 : p.nq_per_pass;   // mq is zero-padded to QB rows
             const float* qq = mq + (size_t)q0 * d;
             bool ok = false;
-            if (p.nq_per_pass == 2) {
+            if (p.nq_per_pass == 4) {
+                if (nv == 1) { launch_scan<1, 4>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
+                if (nv == 2) { launch_scan<2, 4>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
+            } else if (p.nq_per_pass == 2) {
+                if (nv == 1) { launch_scan<1, 2>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
+                if (nv == 2) { launch_scan<2, 2>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
                 if (nv == 3) { launch_scan<3, 2>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
                 if (nv == 4) { launch_scan<4, 2>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
             } else if (p.nq_per_pass == 1) {
+                if (nv == 1) { launch_scan<1, 1>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
+                if (nv == 2) { launch_scan<2, 1>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
                 if (nv == 3) { launch_scan<3, 1>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
                 if (nv == 4) { launch_scan<4, 1>(p, X, N, d, qq, k, epart, st, gate); ok = true; }
             }
@@ -2048,12 +2080,14 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
         if (fneed == 0 || fneed > workspace_bytes) { set_error("ip_topk_shadow: workspace %zu < %zu bytes", workspace_bytes, fneed); return WISE_E_WORKSPACE; }
         return wise_ip_topk_f32(X, N, d, Q, nq, k, ids, id_base, outD, outI, workspace, workspace_bytes, stream);
     }
-    const bool batched = d <= 512 && nq >= 2 && k <= MFMA_KC && shadow64_supported(d) && mfma_split_supported(d, 8, k) &&
-                         split64_supported(d) && split_direct_enabled();
+    // (k <= 12: the split-bf16 scan of the f32 rows as the gated fallback; 12 < k <= 128: the f32 VALU scan)
+    const bool batched = d <= 512 && nq >= 2 && shadow64_supported(d) &&
+                         ((k <= MFMA_KC && mfma_split_supported(d, 8, k) && split64_supported(d) && split_direct_enabled()) ||
+                          (k > MFMA_KC && k <= SHADOW_BATCH_K && nq >= 3));
     // 512 < d <= 1024 (768: the ViT-L/14 dimension): the f32 VALU scan as the gated fallback; 64 queries per pass with
     // one-piece queries (their images fit LDS), 32 with two pieces; worth it from 3 queries on (a pass moves the bf16
     // rows once: 2.7 ms at 10M x 768, a single query 2.4 ms)
-    const bool batched32 = !batched && nq >= 3 && k <= 16 && d > 512 && (shadow64_supported(d) || shadow32_supported(d));
+    const bool batched32 = !batched && nq >= 3 && k <= SHADOW_BATCH_K && d > 512 && (shadow64_supported(d) || shadow32_supported(d));
     if (batched || batched32) {
         const int qmax = shadow_pass_queries(d);    // 128 (one-piece queries, d <= 512), 64 or 32
         for (int q0 = 0, qb = qmax; q0 < nq; q0 += qb) {

@@ -131,13 +131,13 @@ class FlatIPIndex:
         if nq == 0:
             return D, I
         # one query (the reference's shape) at any k <= 1024 — REST `end` = 20, evaluation k = 100 / 1000 —, or two and
-        # more where the 64-query matrix-core kernels apply (k <= 12, d = 256 / 512; 32-query passes for d = 768 / 1024,
-        # k <= 16); a few queries outside those limits go one at a time when that beats the f32 batch kernels.  Small
+        # more where the matrix-core passes apply (d = 256 / 512 / 768 / 1024: k <= 12 from two queries on, k <= 128 —
+        # the evaluation's k = 100 — from three); a few queries outside those limits go one at a time when that beats the f32 batch kernels.  Small
         # indexes (under 2^18 rows the library answers with the f32 scan anyway) never build a shadow.
         two_stage = self.shadow and self._n >= (1 << 18) and self.d % 8 == 0 and self.d <= 1024 and (
             (nq == 1 and 1 <= k <= 1024) or
             (nq >= 2 and 1 <= k <= 12 and self.d in (256, 512)) or
-            (nq >= 3 and 1 <= k <= 16 and self.d in (768, 1024)) or
+            (nq >= 3 and 1 <= k <= 128 and self.d in (256, 512, 768, 1024)) or      # batched passes, k up to 128
             (2 <= nq <= 3 and 1 <= k <= 1024))
         if two_stage and lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k) == 0:
             two_stage = False
