@@ -20,7 +20,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 from oracle import ip_topk_ref, vit_ref  # noqa: E402
-from wise_amd.feature.vit import VitSpec, random_state_dict, spec_for  # noqa: E402
+from wise_amd.feature.vit import VitSpec, checkpoint_like_state_dict, random_state_dict, spec_for  # noqa: E402
 
 GOLD = ROOT / "tests" / "golden"
 
@@ -90,13 +90,15 @@ def pin_against_hf(spec: VitSpec, sd, x: torch.Tensor, tol: float):
         if spec.layers else 0.0
     scale = ours.abs().max().item()
     print(f"  pin {spec.name}: |oracle - HF| out {d_out:.3e} (scale {scale:.2f}), hidden {d_hid:.3e}")
-    assert d_out <= tol * max(scale, 1.0) and d_hid <= tol * 50, "oracle does not match transformers CLIP"
+    hid_scale = max(t.abs().max().item() for t in taps) if taps else 1.0
+    assert d_out <= tol * max(scale, 1.0) and d_hid <= tol * max(50.0, hid_scale), "oracle does not match transformers CLIP"
     return d_out, d_hid
 
 
-def golden_vit(spec: VitSpec, seed: int, n_frames: int, frame_seed: int, fname: str, full_taps: bool, pin: bool):
-    print(f"[vit] {spec.name}")
-    sd = random_state_dict(spec, seed)
+def golden_vit(spec: VitSpec, seed: int, n_frames: int, frame_seed: int, fname: str, full_taps: bool, pin: bool,
+               checkpoint_like: bool = False):
+    print(f"[vit] {spec.name}" + (" (checkpoint-like weights)" if checkpoint_like else ""))
+    sd = checkpoint_like_state_dict(spec, seed) if checkpoint_like else random_state_dict(spec, seed)
     frames = seeded_frames(n_frames, spec.image_size, frame_seed)
     x = vit_ref.normalize_u8(torch.from_numpy(frames))
     torch.set_num_threads(8)
@@ -140,6 +142,11 @@ def golden_ip():
 
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
+    if "--stress-only" in sys.argv:
+        golden_vit(TINY, 21, 3, 31, "vit_tiny_stress.npz", full_taps=True, pin=True, checkpoint_like=True)
+        golden_vit(spec_for("ViT-B-32"), 3, 4, 32, "vit_b32_stress.npz", full_taps=False, pin=True, checkpoint_like=True)
+        golden_vit(spec_for("ViT-L-14"), 4, 2, 33, "vit_l14_stress.npz", full_taps=False, pin=True, checkpoint_like=True)
+        return
     golden_vit(TINY, 7, 3, 11, "vit_tiny.npz", full_taps=True, pin=True)
     golden_vit(TINY_GELU, 8, 2, 12, "vit_tiny_gelu.npz", full_taps=True, pin=True)
     golden_vit(TINY_H80, 9, 2, 13, "vit_tiny_h80.npz", full_taps=True, pin=True)
@@ -147,6 +154,11 @@ def main():
     golden_vit(spec_for("ViT-L-14"), 0, 2, 5, "vit_l14.npz", full_taps=False, pin=True)
     golden_vit(spec_for("ViT-B-16", "laion2b_s34b_b88k"), 0, 2, 14, "vit_b16.npz", full_taps=False, pin=True)   # 197 tokens, erf GELU
     golden_vit(spec_for("ViT-H-14", "laion2b_s32b_b79k"), 0, 2, 6, "vit_h14.npz", full_taps=False, pin=True)
+    # checkpoint-like statistics (massive activation channels, heavy-tailed LN gains, peaky attention): see
+    # wise_amd/feature/vit.py::checkpoint_like_state_dict
+    golden_vit(TINY, 21, 3, 31, "vit_tiny_stress.npz", full_taps=True, pin=True, checkpoint_like=True)
+    golden_vit(spec_for("ViT-B-32"), 3, 4, 32, "vit_b32_stress.npz", full_taps=False, pin=True, checkpoint_like=True)
+    golden_vit(spec_for("ViT-L-14"), 4, 2, 33, "vit_l14_stress.npz", full_taps=False, pin=True, checkpoint_like=True)
     golden_ip()
 
 

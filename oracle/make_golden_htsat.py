@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 from oracle import htsat_ref  # noqa: E402
-from wise_amd.feature.htsat import DEPTHS, EMBED, HEADS, random_htsat_state_dict  # noqa: E402
+from wise_amd.feature.htsat import DEPTHS, EMBED, HEADS, checkpoint_like_htsat_state_dict, random_htsat_state_dict  # noqa: E402
 
 GOLD = ROOT / "tests" / "golden"
 
@@ -71,9 +71,36 @@ def hf_audio_model(sd):
     return m
 
 
+def stress():
+    """checkpoint-like statistics (wise_amd/feature/htsat.py::checkpoint_like_htsat_state_dict): pin the oracle's body to
+    transformers' ClapAudioModel on these weights again, then write tests/golden/htsat_stress.npz"""
+    sd = checkpoint_like_htsat_state_dict(5)
+    rng = np.random.default_rng(14)
+    wave = torch.from_numpy((0.1 * rng.standard_normal((2, 192000))).astype(np.float32))
+    mel = htsat_ref.logmel(wave)
+    m = hf_audio_model(sd)
+    taps = []
+    with torch.no_grad():
+        hf = m(input_features=mel.unsqueeze(1), output_hidden_states=True)
+        latent = htsat_ref.body_forward(sd, mel, taps=taps)
+        out = htsat_ref.htsat_forward(sd, wave)
+    d_lat = (hf.pooler_output - latent).abs().max().item()
+    big = max(t.abs().max().item() for t in taps)
+    print(f"  pin body (checkpoint-like): |oracle - HF| pooled latent {d_lat:.3e} (scale {latent.abs().max():.2f}); "
+          f"largest residual value {big:.1f}")
+    assert d_lat < 5e-4 * max(1.0, latent.abs().max().item())
+    np.savez_compressed(GOLD / "htsat_stress.npz", out=out.numpy(), latent=latent.numpy(), weight_seed=5, wave_seed=14,
+                        pin_latent=d_lat, largest_residual=big, tap4=taps[-1][:, :4, :].numpy())
+    print(f"  wrote htsat_stress.npz: out {tuple(out.shape)}")
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
+    if "--stress-only" in sys.argv:
+        stress()
+        return
+    stress()
     sd = random_htsat_state_dict(0)
     rng = np.random.default_rng(4)
     wave = torch.from_numpy((0.1 * rng.standard_normal((2, 192000))).astype(np.float32))  # 4 s @ 48 kHz (reference)

@@ -132,6 +132,47 @@ def random_state_dict(spec: VitSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
     return sd
 
 
+def checkpoint_like_state_dict(spec: VitSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded weights with the statistics that make real CLIP checkpoints hard for a bf16 path (no checkpoint exists
+    offline; the benign Gaussians of `random_state_dict` do not show these):
+      * massive activations — four residual channels carry values 40-100x the typical magnitude from the embeddings on
+        (class / positional embedding entries of +-60..100) and a fifth is switched on by the c_proj bias of block 1;
+      * heavy-tailed LayerNorm gains — log-normal (sigma 0.6, clamped to [0.05, 12]); on the massive channels the gains
+        alternate between tiny (0.05: the channel is squashed, as trained models do) and large (3.0: the massive value
+        reaches the next GEMM's bf16 operand at full size);
+      * large embeddings — class and positional embeddings at 3x the benign scale;
+      * peaky attention — the q and k projections of the first third of the heads are scaled so that their logits are
+        ~9x the benign ones (near one-hot softmax rows).
+    Same key order and generator discipline as `random_state_dict` (the GPU box regenerates the weights from the seed).
+    Parity on these weights is what tests/test_gpu_vit.py::test_vit_checkpoint_like_golden holds the HIP path to."""
+    sd = random_state_dict(spec, seed)
+    g = torch.Generator().manual_seed(seed + 7919)
+    W, H = spec.width, spec.heads
+    dh = W // H
+    chans = torch.randperm(W, generator=g)[:5].tolist()
+    big = [80.0, -60.0, 100.0, -70.0]
+    sd["visual.class_embedding"] = sd["visual.class_embedding"] * 3.0
+    sd["visual.positional_embedding"] = sd["visual.positional_embedding"] * 3.0
+    for c, v in zip(chans[:4], big):
+        sd["visual.class_embedding"][c] = v
+        sd["visual.positional_embedding"][:, c] = 0.5 * v
+    ln_keys = [k for k in sd if (".ln_" in k or "ln_pre" in k or "ln_post" in k) and k.endswith(".weight")]
+    for n, key in enumerate(ln_keys):
+        w = torch.exp(0.6 * torch.randn(sd[key].shape, generator=g)).clamp_(0.05, 12.0)
+        for c in chans:
+            w[c] = 0.05 if n % 2 == 0 else 3.0
+        sd[key] = w.contiguous()
+    if spec.layers >= 2:
+        sd["visual.transformer.resblocks.1.mlp.c_proj.bias"][chans[4]] = 90.0
+    hot = max(1, H // 3)
+    for l in range(spec.layers):
+        key = f"visual.transformer.resblocks.{l}.attn.in_proj_weight"
+        w = sd[key]
+        w[: hot * dh] *= 3.0                 # q rows of the hot heads
+        w[W: W + hot * dh] *= 3.0            # k rows of the hot heads
+    return sd
+
+
 def pack_weights(spec: VitSpec, sd: Dict[str, torch.Tensor]):
     """state dict -> (bf16 blob, fp32 blob) in the layout include/wise_hip.h documents (CPU tensors)."""
     W, F = spec.width, spec.mlp
