@@ -92,6 +92,13 @@ __device__ __forceinline__ void mfma16v(f32x4& acc, const bf16x8& a, const bf16x
 // and it may move such a read (a plain register copy) up to right behind the statement.  After the loop: idle long enough
 // for the last MFMA to retire, then pass every accumulator through a volatile statement — volatile statements keep their
 // order, so every later read of the accumulators stays behind the idle slots.
+// a 16-byte buffer load whose destination is an AGPR tuple (gfx90a+: vector memory instructions may target AGPRs): the
+// residual prefetch parks values in the accumulator file's spare registers.  The compiler does not count it in vmcnt: the
+// kernel's own counted waits include it, and s_waitcnt vmcnt(0) stands in front of the first use.
+typedef unsigned rsrc_words_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load16_to_agpr(f32x4& dst, rsrc_words_t rsrc, int voff, int soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
 __device__ __forceinline__ void mfma_retire() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 __device__ __forceinline__ void pin_a(f32x4& acc) { asm volatile("" : "+a"(acc)); }
 __device__ __forceinline__ void pin_v(f32x4& acc) { asm volatile("" : "+v"(acc)); }
@@ -244,13 +251,31 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const bf16_t* __restric
     unsigned oW0 = 0, oW1 = WSZ, oW2 = (SW == 3) ? 2 * WSZ : 0;
     int kb = 0;                          // byte offset of K-step s inside a row
 
+    // Residual prefetch (EPI_RESID, 160 x 256 tiles): the fp32 values this tile will be added to are requested during the
+    // last three K-steps — four 16-byte loads at the end of each of their six phases — into the 96 accumulator-file
+    // registers the 40 accumulator tiles leave free: the epilogue's passes 0 (rows 0-31 of the wave) and 2 (rows 64-79).
+    // The stamps of the plain epilogue show it as one HBM-bound burst of 8 bytes per output element (4 read + 4 written)
+    // that nothing overlaps; with the reads under the loop it is the 4 written, plus pass 1's reads.
+    constexpr bool RESPRE = MODE == EPI_RESID && MI == 5 && NJ == 8;
+    constexpr int NPRE = RESPRE ? 24 : 1;
+    f32x4 rpre[NPRE];
+    rsrc_words_t rO = {0u, 0u, 0u, 0u};
+    int rvoff = 0, rsoff = 0;
+    if constexpr (RESPRE) {
+        const unsigned long long ob = (unsigned long long)(uintptr_t)out;
+        rO = rsrc_words_t{(unsigned)ob, (unsigned)(ob >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+        rvoff = ((lane >> 5) * N + (lane & 31) * 4) * 4;                       // walk order of epi_f32_pass / resid_load
+        rsoff = ((m0 + wm * MI * 16) * N + n0 + wn * NJ * 16) * 4;
+    }
+
     // One phase: NM = MI*NJ MFMAs on (af, wf) in i-major order, with the phase's fragment reads (first the NJ weight
     // fragments, then the MI activation fragments: the order the next phase needs them) and DMAs placed between them:
     // read r in front of MFMA r*MPR, DMA d in front of MFMA 1 + d*MPD (DMAs 0..NDA-1 fetch the activation tile into
     // slot dA, the rest the weight tile into slot dW).
     auto phase = [&](const bf16x8 (&af)[MI], const bf16x8 (&wf)[NJ], bf16x8 (&afn)[MI], bf16x8 (&wfn)[NJ], auto read_c,
-                     lds_cptr pw, lds_cptr pa, auto nda_c, auto ndw_c, unsigned dA, unsigned dW, int dkb) {
+                     lds_cptr pw, lds_cptr pa, auto nda_c, auto ndw_c, unsigned dA, unsigned dW, int dkb, auto rb_c) {
         constexpr bool READ = decltype(read_c)::value;
+        constexpr int RB = decltype(rb_c)::value;                // >= 0: residual loads RB .. RB+3 behind this phase's DMAs
         constexpr int NDA = decltype(nda_c)::value, NDW = decltype(ndw_c)::value, ND = NDA + NDW;
         constexpr int NM = MI * NJ, NR = MI + NJ;
         constexpr int MPR = (NM * 3 / 4) / NR;                 // reads spread over the first three quarters of the phase
@@ -267,27 +292,34 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const bf16_t* __restric
                 if (d < NDA) { const int u = d * 4 + wave; dma16(rA, dA + u * 1024, voff, u * 8 * ldb + dkb); }
                 else { const int u = (d - NDA) * 4 + wave; dma16(rW, WBASE + dW + u * 1024, voff, u * 8 * ldb + dkb); }
             }
+            if constexpr (RESPRE && RB >= 0) {
+                if (m >= NM - 8 && (m - (NM - 8)) % 2 == 0) {
+                    const int t = RB + (m - (NM - 8)) / 2;           // 0..15: pass 0 (rows 2t, 2t+1); 16..23: pass 2 (rows 64 + ...)
+                    const int row = t < 16 ? t * 2 : 64 + (t - 16) * 2;
+                    load16_to_agpr(rpre[t], rO, rvoff, rsoff + row * N * 4);
+                }
+            }
             if (m < 64) mfma16a(acc[m / NJ][m % NJ], wf[m % NJ], af[m / NJ]);
             else mfma16v(acc[m / NJ][m % NJ], wf[m % NJ], af[m / NJ]);
         }
     };
 
-    // one K-step; DMA: request step s+2; NEXT: read k-half 0 of step s+1; DRAIN: the barrier waits for every DMA
-    auto step = [&](auto dma_c, auto next_c, auto drain_c) {
-        constexpr bool DMA = decltype(dma_c)::value, DRAIN = decltype(drain_c)::value;
-        using Z = std::integral_constant<int, 0>;
+    // one K-step; DMA: request step s+2; NEXT: read k-half 0 of step s+1; VM: the counted wait in front of the barrier
+    // (-1: none); RA / RB: first residual load of phase A / B (-1: none)
+    auto step = [&](auto dma_c, auto next_c, auto vm_c, auto ra_c, auto rb_c) {
+        constexpr bool DMA = decltype(dma_c)::value;
+        constexpr int VM = decltype(vm_c)::value;
         // ---- phase A: k-half 0 of step s; read k-half 1 of step s; request the three-slot operand of step s+2
         phase(af0, wf0, af1, wf1, std::true_type{}, (lds_cptr)(uintptr_t)(oW0 + fw1), (lds_cptr)(uintptr_t)(oA0 + fa1),
               std::integral_constant<int, (DMA && A_EARLY) ? PA : 0>{}, std::integral_constant<int, (DMA && W_EARLY) ? PW : 0>{},
-              oA2, oW2, kb + 256);
+              oA2, oW2, kb + 256, ra_c);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (DRAIN) wait_vmcnt<0>(); else wait_vmcnt<NDMA_A>();
+        if constexpr (VM >= 0) wait_vmcnt<VM>();
         __builtin_amdgcn_s_barrier();
         // ---- phase B: k-half 1 of step s; read k-half 0 of step s+1; request the two-slot operand(s) of step s+2
         phase(af1, wf1, af0, wf0, next_c, (lds_cptr)(uintptr_t)(oW1 + fw0), (lds_cptr)(uintptr_t)(oA1 + fa0),
               std::integral_constant<int, (DMA && !A_EARLY) ? PA : 0>{}, std::integral_constant<int, (DMA && !W_EARLY) ? PW : 0>{},
-              oA2, oW2, kb + 256);
-        (void)Z{};
+              oA2, oW2, kb + 256, rb_c);
         const unsigned a0 = oA0, w0 = oW0;
         oA0 = oA1; oA1 = oA2; oA2 = (SA == 3) ? a0 : oA0;     // two slots: step s+3 goes where step s+1 sits
         oW0 = oW1; oW1 = oW2; oW2 = (SW == 3) ? w0 : oW0;
@@ -297,9 +329,22 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const bf16_t* __restric
     if (SA == 2) oA2 = oA0;
     if (SW == 2) oW2 = oW0;
     using T = std::true_type; using F = std::false_type;
-    for (int s = 0; s < nk - 2; ++s) step(T{}, T{}, F{});
-    step(F{}, T{}, T{});     // s = nk-2: nothing left to request; step nk-1 must have landed
-    step(F{}, F{}, T{});     // s = nk-1
+    using N1 = std::integral_constant<int, -1>;
+    using VMS = std::integral_constant<int, NDMA_A>;      // steady state: the DMAs of phase A may still be in flight
+    using VM0 = std::integral_constant<int, 0>;
+    if constexpr (RESPRE) {
+        // the last three steps carry the residual loads (4 behind the DMAs of every phase).  Counted waits: step nk-3 its
+        // phase-A DMAs + 4 loads; step nk-2 needs W(nk-1), requested in phase B of step nk-3 — the 4 loads issued behind
+        // those DMAs and the 4 of its own phase A may still fly; step nk-1 needs nothing new.
+        for (int s = 0; s < nk - 3; ++s) step(T{}, T{}, VMS{}, N1{}, N1{});
+        step(T{}, T{}, std::integral_constant<int, NDMA_A + 4>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        step(F{}, T{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 12>{});
+        step(F{}, F{}, N1{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 20>{});
+    } else {
+        for (int s = 0; s < nk - 2; ++s) step(T{}, T{}, VMS{}, N1{}, N1{});
+        step(F{}, T{}, VM0{}, N1{}, N1{});     // s = nk-2: nothing left to request; step nk-1 must have landed
+        step(F{}, F{}, VM0{}, N1{}, N1{});     // s = nk-1
+    }
     mfma_retire();
 #pragma unroll
     for (int m = 0; m < MI * NJ; ++m) { if (m < 64) pin_a(acc[m / NJ][m % NJ]); else pin_v(acc[m / NJ][m % NJ]); }
@@ -333,14 +378,31 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const bf16_t* __restric
                 resid_load<NJ, 1>(o, N, row0 + p * RP * 16, col0, lane, h);
             }
         };
-        if (MODE == EPI_RESID) load(0, res[0]);
+        if constexpr (RESPRE) {
+            // passes 0 and 2 come out of the prefetch registers (everything requested has landed behind this wait);
+            // pass 1 is loaded here, under pass 0's transposition
+            load(1, res[1]);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");       // all but pass 1's NRES loads
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            if (MODE == EPI_RESID && p + 1 < NP) load(p + 1, res[(p + 1) & 1]);
-            if (p * RP + RP <= MI) epi_f32_pass<MODE, MI, NJ, RP>(acc, p * RP, bv, o, N, row0, col0, lane, my, res[p & 1]);
-            else if constexpr (RP == 2)
-                epi_f32_pass<MODE, MI, NJ, 1>(acc, p * RP, bv, o, N, row0, col0, lane, my,
-                                              reinterpret_cast<const float4 (&)[NRES / 2]>(res[p & 1]));
+            for (int t = 0; t < NPRE; ++t) pin_a(rpre[t]);     // no copy of a prefetch register may move above the wait
+#pragma unroll
+            for (int t = 0; t < 16; ++t) res[0][t] = make_float4(rpre[t][0], rpre[t][1], rpre[t][2], rpre[t][3]);
+            epi_f32_pass<MODE, MI, NJ, 2>(acc, 0, bv, o, N, row0, col0, lane, my, res[0]);
+            epi_f32_pass<MODE, MI, NJ, 2>(acc, 2, bv, o, N, row0, col0, lane, my, res[1]);
+            float4 last[NRES / 2];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) last[t] = make_float4(rpre[16 + t][0], rpre[16 + t][1], rpre[16 + t][2], rpre[16 + t][3]);
+            epi_f32_pass<MODE, MI, NJ, 1>(acc, 4, bv, o, N, row0, col0, lane, my, last);
+        } else {
+            if (MODE == EPI_RESID) load(0, res[0]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (MODE == EPI_RESID && p + 1 < NP) load(p + 1, res[(p + 1) & 1]);
+                if (p * RP + RP <= MI) epi_f32_pass<MODE, MI, NJ, RP>(acc, p * RP, bv, o, N, row0, col0, lane, my, res[p & 1]);
+                else if constexpr (RP == 2)
+                    epi_f32_pass<MODE, MI, NJ, 1>(acc, p * RP, bv, o, N, row0, col0, lane, my,
+                                                  reinterpret_cast<const float4 (&)[NRES / 2]>(res[p & 1]));
+            }
         }
     }
     W4_STAMP(3);

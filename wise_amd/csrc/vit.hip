@@ -736,7 +736,10 @@ int l2norm_rows(const float* e, int rows, int D, float* out, hipStream_t st) {
 }
 
 size_t transformer_splitk_bytes(int W, int F, int batch, int T) {
-    const int M = batch * T, Mp = (M + 255) / 256 * 256;
+    // (a workspace sized for `batch` sequences serves every smaller batch: the skinny case is ONE sequence whatever
+    // `batch` is, and the number of K slices depends on N and K alone)
+    (void)batch;
+    const int M = T, Mp = (M + 255) / 256 * 256;
     size_t b = gemm_splitk_bytes(Mp, M, 3 * W, W);
     b = std::max(b, gemm_splitk_bytes(Mp, M, W, W));
     b = std::max(b, gemm_splitk_bytes(Mp, M, F, W));

@@ -138,8 +138,8 @@ static XlmrWs xlmr_ws(const XlmrDims& d, int B) {
     w.lens = off; off += align_up((size_t)B * 4, 256);
     // split-K partials of a skinny call (one query) and of the head's two GEMMs, private to this workspace
     w.sk_bytes = transformer_splitk_bytes(d.W, d.F, B, d.T);
-    w.sk_bytes = std::max(w.sk_bytes, gemm_splitk_bytes((int)Bp, B, d.Hd, d.W));
-    w.sk_bytes = std::max(w.sk_bytes, gemm_splitk_bytes((int)Bp, B, d.D, d.Hd));
+    w.sk_bytes = std::max(w.sk_bytes, gemm_splitk_bytes(256, 1, d.Hd, d.W));     // (any batch <= 128 splits alike)
+    w.sk_bytes = std::max(w.sk_bytes, gemm_splitk_bytes(256, 1, d.D, d.Hd));
     w.sk = off; off += align_up(w.sk_bytes, 256);
     w.total = off;
     return w;
