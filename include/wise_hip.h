@@ -90,14 +90,17 @@ int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q, int nq, i
  *           only make the lists longer).  (5) If a list overflows, the fp32 scan queued behind answers instead (it
  *           returns at once otherwise).
  *       All on the stream, no host round trip.
- * Two or more queries (k <= 12, d = 256 or 512; three or more with k <= 16 for d = 768 or 1024, 32 at a time with the
- * fp32 VALU scan as the gated fallback) run 64 queries at a time on the matrix cores: the bf16 rows are MFMA operands as
- * loaded, the 48 best candidates per query are re-scored in fp32, and a per-query certificate (k-th exact score above
- * the 48th approximate score + eps) decides whether the split-bf16 scan of the fp32 rows (wise_ip_topk_f32's batched
- * path), queued behind and gated, redoes the pass.  Otherwise: one query at a time.
+ * Any k <= 1024 for one query (the k WISE sends: REST `end` = 20, api/routes.py:1171,1407; evaluation k = 100 and
+ * --topk 1000, docs/Search-Index-Evaluation.md:109, docs/Retrieval-Evaluation.md:39): the selections are radix selections,
+ * and for k > 64 the collect pass runs in two ranges with the threshold tightened in between.
+ * Two or more queries (k <= 12, d = 256 or 512; three or more with k <= 128 for d = 256 ... 1024, the fp32 VALU scan as the
+ * gated fallback) run 128 / 64 / 32 queries at a time on the matrix cores in the same threshold form: the bf16 rows are MFMA
+ * operands as loaded, every (query, row) that could matter is collected, re-scored in fp32 and the k best selected per
+ * query; if any query's list overflows, the scan of the fp32 rows queued behind and gated redoes the pass.  Otherwise: one
+ * query at a time.
  * counters (device, two int32, may be NULL): [0] += queries answered from the shadow, [1] += queries handed to the fp32
  * scan.  They belong to the caller (one pair per index); the library keeps no process-wide state for this.
- * Same outputs, ties and padding as wise_ip_topk_f32.  Limits: d % 8 == 0, 8 <= d <= 1024, k <= 16, N >= 1, nq <= 1024. */
+ * Same outputs, ties and padding as wise_ip_topk_f32.  Limits: d % 8 == 0, 8 <= d <= 1024, k <= 1024, N >= 1, nq <= 1024. */
 int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* Xb, float* norms /*[2]*/, void* stream);
 size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, int k);
 int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* norms /*[2]*/, int64_t N, int d, const float* Q,
