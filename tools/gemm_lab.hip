@@ -13,6 +13,7 @@
 
 #define W4_STAMPS 1
 #include "../wise_amd/csrc/gemm_w4.h"
+#include "gemm_w4q_lab.h"
 
 namespace wise { void set_error(const char*, ...) {} }
 
@@ -127,9 +128,11 @@ int main(int argc, char** argv) {
         }
         if (wise::w4_shape_ok(s.M, s.N, s.K, 8)) vars.push_back({"w4 256x256", 1, 8});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 5)) vars.push_back({"w4 160x256", 1, 5});
+        if (wise::w4_shape_ok(s.M, s.N, s.K, 4)) vars.push_back({"w4 128x256", 1, 4});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 10)) vars.push_back({"w4 320x256", 1, 10});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 10, 6)) vars.push_back({"w4 320x192", 1, 106});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 7, 6)) vars.push_back({"w4 224x192", 1, 76});
+        if (wise::w4q_shape_ok(s.M, s.N, s.K, s.mode) && !f32o) vars.push_back({"w4q two-set 128x256", 1, 600});
         if (wise::w4p_shape_ok(s.M, s.N, s.K) && !f32o) vars.push_back({"w4p persistent 160x256", 1, 500});
 
         auto run = [&](const Var& v) {
@@ -140,9 +143,16 @@ int main(int argc, char** argv) {
                 if (rc) { printf("old gemm rc %d\n", rc); exit(1); }
             } else if (v.arg == 8) launch_new<8, 8, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 5) launch_new<5, 8, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            else if (v.arg == 4) launch_new<4, 8, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 10) launch_new<10, 8, 2, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 106) launch_new<10, 6, 2, 3>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 76) launch_new<7, 6, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            else if (v.arg == 600) {
+                using namespace wise;
+                if (s.mode == 0) launch_w4q<EPI_BF16>(A, W, bias, s.M, s.N, s.K, out, 256, st);
+                else if (s.mode == 1) launch_w4q<EPI_QUICKGELU>(A, W, bias, s.M, s.N, s.K, out, 256, st);
+                else launch_w4q<EPI_GELU>(A, W, bias, s.M, s.N, s.K, out, 256, st);
+            }
             else if (v.arg == 500) {
                 using namespace wise;
                 if (s.mode == 0) launch_w4p<EPI_BF16>(A, W, bias, s.M, s.N, s.K, out, 256, st);
@@ -206,6 +216,16 @@ int main(int argc, char** argv) {
                    flop / med * 1e-6, mn, flop / mn * 1e-6);
         }
         for (size_t vi = 0; vi < vars.size(); ++vi) {
+            if (vars[vi].kind == 1 && vars[vi].arg == 600) {
+                run(vars[vi]); run(vars[vi]);
+                CK(hipStreamSynchronize(st));
+                unsigned long long hp[4][4];
+                CK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(wise::w4::g_w4p_stamps), sizeof(hp)));
+                for (int t = 0; t < 3; ++t)
+                    printf("  stamps w4q tile %d: drain steps %6llu  rest of loop %6llu  tile end %6llu\n", t,
+                           hp[t][1] - hp[t][0], hp[t][2] - hp[t][1], hp[t][3] - hp[t][2]);
+                continue;
+            }
             if (vars[vi].kind == 1 && vars[vi].arg == 500) {
                 run(vars[vi]); run(vars[vi]);
                 CK(hipStreamSynchronize(st));

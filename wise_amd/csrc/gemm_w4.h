@@ -246,6 +246,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const bf16_t* __restric
         for (int i = 0; i < MI; ++i) af0[i] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(pa + i * 2048);
     }
 
+#ifdef W4_NOREAD
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) wf1[j] = wf0[j];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af1[i] = af0[i];
+#endif
     // slot byte offsets of A(s), A(s+1), A(s+2) and W(s), W(s+1), W(s+2) (relative to the operand's first slot)
     unsigned oA0 = 0, oA1 = ASZ, oA2 = (SA == 3) ? 2 * ASZ : 0;
     unsigned oW0 = 0, oW1 = WSZ, oW2 = (SW == 3) ? 2 * WSZ : 0;
@@ -274,9 +280,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const bf16_t* __restric
     // slot dA, the rest the weight tile into slot dW).
     auto phase = [&](const bf16x8 (&af)[MI], const bf16x8 (&wf)[NJ], bf16x8 (&afn)[MI], bf16x8 (&wfn)[NJ], auto read_c,
                      lds_cptr pw, lds_cptr pa, auto nda_c, auto ndw_c, unsigned dA, unsigned dW, int dkb, auto rb_c) {
+#ifdef W4_NOREAD      // (lab timing knobs: W4_NOREAD / W4_NODMA / W4_NOBAR take one ingredient out of the loop; results are wrong)
+        constexpr bool READ = false;
+#else
         constexpr bool READ = decltype(read_c)::value;
+#endif
         constexpr int RB = decltype(rb_c)::value;                // >= 0: residual loads RB .. RB+3 behind this phase's DMAs
+#ifdef W4_NODMA
+        constexpr int NDA = 0, NDW = 0, ND = 0;
+#else
         constexpr int NDA = decltype(nda_c)::value, NDW = decltype(ndw_c)::value, ND = NDA + NDW;
+#endif
         constexpr int NM = MI * NJ, NR = MI + NJ;
         constexpr int MPR = (NM * 3 / 4) / NR;                 // reads spread over the first three quarters of the phase
         constexpr int MPD = ND > 0 ? ((NM * 3 / 4) / (ND > 0 ? ND : 1) > 0 ? (NM * 3 / 4) / (ND > 0 ? ND : 1) : 1) : 1;
@@ -313,9 +327,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const bf16_t* __restric
         phase(af0, wf0, af1, wf1, std::true_type{}, (lds_cptr)(uintptr_t)(oW0 + fw1), (lds_cptr)(uintptr_t)(oA0 + fa1),
               std::integral_constant<int, (DMA && A_EARLY) ? PA : 0>{}, std::integral_constant<int, (DMA && W_EARLY) ? PW : 0>{},
               oA2, oW2, kb + 256, ra_c);
+#ifndef W4_NOBAR
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (VM >= 0) wait_vmcnt<VM>();
         __builtin_amdgcn_s_barrier();
+#endif
         // ---- phase B: k-half 1 of step s; read k-half 0 of step s+1; request the two-slot operand(s) of step s+2
         phase(af1, wf1, af0, wf0, next_c, (lds_cptr)(uintptr_t)(oW1 + fw0), (lds_cptr)(uintptr_t)(oA1 + fa0),
               std::integral_constant<int, (DMA && !A_EARLY) ? PA : 0>{}, std::integral_constant<int, (DMA && !W_EARLY) ? PW : 0>{},
