@@ -82,6 +82,20 @@ int main(int argc, char** argv) {
         shapes.push_back({"fc1-noact 12800x3072x768", 12800, 3072, 768, 0});
         shapes.push_back({"fc2-f32store 12800x768x3072", 12800, 768, 3072, 4});
     }
+    if (which == "htsat" || which == "all") {   // MS-CLAP HTSAT at 128 clips: stages 2 (C=192), 3 (C=384), 4 (C=768)
+        shapes.push_back({"s2-qkv 131072x576x192", 131072, 576, 192, 0});
+        shapes.push_back({"s2-proj 131072x192x192", 131072, 192, 192, 3});
+        shapes.push_back({"s2-fc1 131072x768x192", 131072, 768, 192, 2});
+        shapes.push_back({"s2-fc2 131072x192x768", 131072, 192, 768, 3});
+        shapes.push_back({"s3-qkv 32768x1152x384", 32768, 1152, 384, 0});
+        shapes.push_back({"s3-proj 32768x384x384", 32768, 384, 384, 3});
+        shapes.push_back({"s3-fc1 32768x1536x384", 32768, 1536, 384, 2});
+        shapes.push_back({"s3-fc2 32768x384x1536", 32768, 384, 1536, 3});
+        shapes.push_back({"s4-qkv 8192x2304x768", 8192, 2304, 768, 0});
+        shapes.push_back({"s4-proj 8192x768x768", 8192, 768, 768, 3});
+        shapes.push_back({"s4-fc1 8192x3072x768", 8192, 3072, 768, 2});
+        shapes.push_back({"s4-fc2 8192x768x3072", 8192, 768, 3072, 3});
+    }
     if (which == "patch" || which == "all") shapes.push_back({"patch 12544x768x3072", 12544, 768, 3072, 4});
     if (which == "sq" || which == "all") {
         shapes.push_back({"sq4096", 4096, 4096, 4096, 0});
@@ -132,6 +146,8 @@ int main(int argc, char** argv) {
         if (wise::w4_shape_ok(s.M, s.N, s.K, 10)) vars.push_back({"w4 320x256", 1, 10});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 10, 6)) vars.push_back({"w4 320x192", 1, 106});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 7, 6)) vars.push_back({"w4 224x192", 1, 76});
+        if (wise::w4_shape_ok(s.M, s.N, s.K, 8, 6)) vars.push_back({"w4 256x192", 1, 86});
+        if (wise::w4_shape_ok(s.M, s.N, s.K, 4, 6)) vars.push_back({"w4 128x192", 1, 46});
         if (wise::w4q_shape_ok(s.M, s.N, s.K, s.mode) && !f32o) vars.push_back({"w4q two-set 128x256", 1, 600});
         if (wise::w4p_shape_ok(s.M, s.N, s.K) && !f32o) vars.push_back({"w4p persistent 160x256", 1, 500});
 
@@ -147,6 +163,8 @@ int main(int argc, char** argv) {
             else if (v.arg == 10) launch_new<10, 8, 2, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 106) launch_new<10, 6, 2, 3>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 76) launch_new<7, 6, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            else if (v.arg == 86) launch_new<8, 6, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            else if (v.arg == 46) launch_new<4, 6, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 600) {
                 using namespace wise;
                 if (s.mode == 0) launch_w4q<EPI_BF16>(A, W, bias, s.M, s.N, s.K, out, 256, st);

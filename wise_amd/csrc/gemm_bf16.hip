@@ -2182,6 +2182,14 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
         // 65: 224 x 192 tiles (M = 12544 = 49 x 256 rows of a ViT-B/32 patch matrix: 56 x 4 = 224 tiles, one round)
         case 65: if (w4_shape_ok(M, N, K, 7, 6)) { launch_w4<MODE, 7, 6, 3, 2>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        // 66 .. 68: 256 x 192, 128 x 192, 128 x 256 tiles — row counts that are powers of two (MS-CLAP HTSAT: 131072 / 32768 /
+        // 8192 tokens at 128 clips) and widths of 192 k (its C = 192, 384, 768 and their multiples)
+        case 66: if (w4_shape_ok(M, N, K, 8, 6)) { launch_w4<MODE, 8, 6, 3, 2>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 67: if (w4_shape_ok(M, N, K, 4, 6)) { launch_w4<MODE, 4, 6, 3, 2>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 68: if (w4_shape_ok(M, N, K, 4, 8)) { launch_w4<MODE, 4, 8, 3, 2>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         // 64: its persistent form (160 x 256 tiles, the C tile leaves during the next tile's loop), bf16 outputs
         case 64: if constexpr (bf16_out(MODE)) {
                      if (w4p_shape_ok(M, N, K)) { launch_w4p<MODE>(A, Wt, bias, M, N, K, out, device_cus(), st); break; }
@@ -2195,7 +2203,7 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
 
 static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode,
                        void* out, hipStream_t st) {
-    if (v >= 60 && v <= 65) { /* gemm_w4.h checks its own shape */ }
+    if (v >= 60 && v <= 68) { /* gemm_w4.h checks its own shape */ }
     else if (K % 64 != 0 && v != 40 && v != 42 && v != 45 && v != 46 && v != 48 && v != 50) v = 1;
     else if (N % BN != 0 && v != 1) v = 0;  // N edge is handled by the 128x128 kernels only
     switch (mode) {
@@ -2236,12 +2244,13 @@ void gemm_set_overlapped(bool on) { g_overlapped = on ? 1 : 0; }
 // traffic of the C tile, i.e. proportional to the tile's area whatever its shape, so it only enters through the
 // rounds.  Returns the variant id (60 .. 63) or 0.
 static int w4_variant(int M, int N, int K, int mode) {
-    // (K < 512: a tile is a handful of K-steps between a prologue and an epilogue that nothing overlaps at one workgroup
-    // per CU; the two-blocks-per-CU kernels keep those shapes)
-    if (!g_w4_enabled || K < 512) return 0;
+    // (K >= 192: three 64-deep K-steps.  Short K used to stay with the two-blocks-per-CU kernels; on the HTSAT shapes —
+    // K = 192 / 384 at 131072 / 32768 rows — these tiles measured 5-25 % faster than those: tools/gemm_lab.hip htsat)
+    if (!g_w4_enabled || K < 192) return 0;
     struct Cand { int id, mi, nj; double step; bool bf16_only; };
     static const Cand cands[] = {{60, 8, 8, 2560.0, false}, {61, 5, 8, 1700.0, false}, {62, 10, 8, 3250.0, true},
-                                 {63, 10, 6, 2430.0, true}, {65, 7, 6, 1720.0, false}};
+                                 {63, 10, 6, 2430.0, true}, {65, 7, 6, 1720.0, false}, {66, 8, 6, 1950.0, false},
+                                 {67, 4, 6, 1100.0, false}, {68, 4, 8, 1360.0, false}};
     double best = 0.0;
     int v = 0;
     for (const Cand& c : cands) {
