@@ -107,6 +107,21 @@ int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const float* nor
                             int nq, int k, const int64_t* ids, int64_t id_base, float* outD, int64_t* outI,
                             int32_t* counters, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same two-stage search over an INT8 shadow: a quarter of the bytes of X per query (N (d + 4) instead of 4 N d).
+ *   wise_ip_shadow_i8   Xq [N,d] int8 = round(X[r,:] / scales[r]), scales[r] = max|X[r,:]| / 127, and four device floats:
+ *       norms[0] = max_r |scales[r] Xq[r,:]|, norms[1] = the score error bound per unit |q| (the largest quantisation
+ *       residual max_r |X[r,:] - scales[r] Xq[r,:]|, in norms[2], plus sqrt(d) 1.6e-5 norms[0] for the query, which the
+ *       scans take as two int8 pieces); no assumption on the data: Cauchy-Schwarz, as for the bf16 shadow.
+ *   wise_ip_topk_shadow8_f32   one query at a time in the threshold form of wise_ip_topk_shadow_f32 — sample, threshold,
+ *       collect, refine, exact re-scoring from the fp32 rows, gated fp32 scan — with the two scans on v_dot4_i32_i8
+ *       (integer sums: exact).  The bound is ~4x the bf16 shadow's, so a few hundred rows are re-scored instead of a
+ *       few dozen; the results are the same bits as wise_ip_topk_f32's.  Workspace: wise_ip_topk_shadow_workspace_bytes.
+ * Limits: d % 16 == 0, 16 <= d <= 1024, k <= 1024, nq <= 1024 (answered one by one). */
+int wise_ip_shadow_i8(const float* X, int64_t N, int d, int8_t* Xq, float* scales /*[N]*/, float* norms /*[4]*/, void* stream);
+int wise_ip_topk_shadow8_f32(const float* X, const int8_t* Xq, const float* scales, const float* norms /*[4]*/, int64_t N, int d,
+                             const float* Q, int nq, int k, const int64_t* ids, int64_t id_base, float* outD, int64_t* outI,
+                             int32_t* counters, void* workspace, size_t workspace_bytes, void* stream);
+
 /* IndexIVFFlat search, second stage (the first stage — the `nprobe` nearest centroids of each query — is
  * wise_ip_topk_f32 over the centroid table): scan the probed inverted lists and keep the k best.
  * Replaces faiss IndexIVFFlat::search as reached through self.index.search at

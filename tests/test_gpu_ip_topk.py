@@ -222,14 +222,16 @@ def counts_since(idx, before):
 
 
 @pytest.mark.parametrize("N,d,k", [(300000, 512, 10), (262144, 256, 1), (270001, 768, 16), (400003, 1024, 5),
-                                   (50000, 512, 10), (4097, 512, 1), (40, 512, 10), (64, 64, 16), (65, 128, 3)])
-def test_single_query_two_stage_search_is_exact(N, d, k):
+                                   (50000, 512, 10), (4097, 512, 1), (40, 512, 10), (64, 64, 16), (65, 128, 3),
+                                   (300017, 128, 10), (262151, 272, 7), (270011, 528, 3)])
+@pytest.mark.parametrize("kind", ["int8", "bf16"])
+def test_single_query_two_stage_search_is_exact(N, d, k, kind):
     """nq = 1, k <= 16 on an index with a bf16 shadow — the reference's call shape (feature_search_index.py:113).
     From 2^18 rows on: sample -> threshold -> every row that could belong to the top-k collected from the bf16 rows ->
     exact fp32 scores; smaller indexes: the fp32 scan itself.  Either way the result is the oracle's and the f32 path's."""
     X = unit_rows(N, d, 500 + N % 97)
     ids = np.arange(N, dtype=np.int64) * 3 + 11
-    idx = FlatIPIndex(d, shadow=True)
+    idx = FlatIPIndex(d, shadow=kind)      # int8: 16 / 32 / 64 lanes per row (d <= 256 / 512 / 1024), ragged last groups
     idx.add_with_ids(X, ids)
     ref = FlatIPIndex(d, shadow=False)
     ref.add_with_ids(X, ids)
@@ -243,6 +245,37 @@ def test_single_query_two_stage_search_is_exact(N, d, k):
         Dr, Ir = ref.search(Q, k)
         assert np.array_equal(I, Ir) and np.allclose(D, Dr, atol=2e-6)
     assert counts_since(idx, before) == ((4, 0) if N >= THRESHOLD_FORM_MIN_ROWS else (0, 0))
+
+
+@pytest.mark.parametrize("d", [64, 512, 768])
+def test_int8_shadow_rows_obey_their_definition(d):
+    """wise_ip_shadow_i8: |c| <= 127, scale_r = max|x_r| / 127, every component within half a step of scale_r c, the error
+    norms the search's bound is computed from are upper bounds of what they stand for (tests/test_shadow_bound_cpu.py has
+    the bound itself)."""
+    from wise_amd import _lib
+    lib = _lib.lib()
+    N = 5003
+    rng = np.random.default_rng(5 + d)
+    X = rng.standard_normal((N, d)).astype(np.float32) * np.exp(rng.uniform(-3, 3, size=(N, 1))).astype(np.float32)
+    X[17] = 0.0                                                     # an all-zero row: scale 0, codes 0
+    X[18, 3] = 1000.0
+    Xd = torch.from_numpy(X).cuda()
+    Xq = torch.empty(N, d, dtype=torch.int8, device="cuda")
+    sc = torch.empty(N, device="cuda")
+    norms = torch.zeros(4, device="cuda")
+    _lib.check(lib.wise_ip_shadow_i8(Xd.data_ptr(), N, d, Xq.data_ptr(), sc.data_ptr(), norms.data_ptr(), _lib.stream_ptr()), "i8")
+    torch.cuda.synchronize()
+    c, s, nm = Xq.cpu().numpy().astype(np.float64), sc.cpu().numpy().astype(np.float64), norms.cpu().numpy().astype(np.float64)
+    assert np.abs(c).max() <= 127 and np.all(c[17] == 0) and s[17] == 0
+    mx = np.abs(X).max(axis=1).astype(np.float64)
+    assert np.allclose(s, mx / 127, rtol=1e-6, atol=0)
+    assert np.all(np.abs(c).max(axis=1)[mx > 0] == 127)             # the largest component sits on the last code
+    back = s[:, None] * c
+    assert np.all(np.abs(X - back) <= s[:, None] * 0.5 * (1 + 1e-4) + 1e-30)      # (x * (127 / max) rounds in fp32: ties move by 3e-5 of a step)
+    assert nm[0] >= np.linalg.norm(back, axis=1).max() and nm[0] <= np.linalg.norm(back, axis=1).max() * 1.0001
+    rho = np.linalg.norm(X - back, axis=1).max()
+    assert rho <= nm[2] <= rho * 1.0001
+    assert np.isclose(nm[1], nm[2] + np.sqrt(d) * 1.6e-5 * nm[0], rtol=1e-5)
 
 
 def clustered_rows(n_items, per_item, d, seed, spread=0.03):
@@ -328,14 +361,15 @@ def test_single_query_search_hands_over_when_the_candidate_list_overflows():
 
 @pytest.mark.parametrize("N,d,k", [(300000, 512, 17), (300000, 512, 20), (400003, 512, 100), (300000, 256, 1000),
                                    (270001, 768, 100), (600000, 512, 1000), (262144, 1024, 128)])
-def test_single_query_two_stage_search_at_the_k_the_reference_sends(N, d, k):
+@pytest.mark.parametrize("kind", ["int8", "bf16"])
+def test_single_query_two_stage_search_at_the_k_the_reference_sends(N, d, k, kind):
     """nq = 1 at the k WISE's server and evaluations actually use: REST `end` defaults to 20 (api/routes.py:1171,1407),
     the index evaluation runs k = 100 (docs/Search-Index-Evaluation.md:109), the retrieval evaluation --topk 1000
     (docs/Retrieval-Evaluation.md:39).  Same threshold form, radix selections instead of k rounds of a maximum: the
     oracle's ids, the f32 scan's ids and scores, everything answered from the shadow."""
     X = unit_rows(N, d, 700 + N % 89 + k)
     ids = np.arange(N, dtype=np.int64) * 2 + 5
-    idx = FlatIPIndex(d, shadow=True)
+    idx = FlatIPIndex(d, shadow=kind)
     idx.add_with_ids(X, ids)
     ref = FlatIPIndex(d, shadow=False)
     ref.add_with_ids(X, ids)
@@ -353,7 +387,8 @@ def test_single_query_two_stage_search_at_the_k_the_reference_sends(N, d, k):
 
 
 @pytest.mark.parametrize("k", [20, 100, 1000])
-def test_general_k_on_clustered_rows_and_on_overflow(k):
+@pytest.mark.parametrize("kind", ["int8", "bf16"])
+def test_general_k_on_clustered_rows_and_on_overflow(k, kind):
     """The same k on the data the reference indexes (runs of 20 near-duplicates, cosine >= 0.999): the threshold form
     keeps every row that could matter — for k = 1000 several thousand survive the refinement, more than the one-block
     finish re-scores itself, so the multi-block kernels behind it answer — and on an adversarial index (20,000 rows
@@ -362,7 +397,7 @@ def test_general_k_on_clustered_rows_and_on_overflow(k):
     X = clustered_rows(20000, 20, d, 141)
     N = X.shape[0]
     ids = np.arange(N, dtype=np.int64) + 1
-    idx = FlatIPIndex(d, shadow=True)
+    idx = FlatIPIndex(d, shadow=kind)
     idx.add_with_ids(X, ids)
     ref = FlatIPIndex(d, shadow=False)
     ref.add_with_ids(X, ids)
@@ -388,7 +423,7 @@ def test_general_k_on_clustered_rows_and_on_overflow(k):
         sc = 0.9999 - 2.5e-5 * n if n < k + 2 else rng.uniform(kth - 1.5e-3, kth - 3e-4)
         X2[c] = sc * q + np.sqrt(1 - sc * sc) * v
     ids2 = np.arange(N2, dtype=np.int64) + 1
-    idx2 = FlatIPIndex(d, shadow=True)
+    idx2 = FlatIPIndex(d, shadow=kind)
     idx2.add_with_ids(X2, ids2)
     ref2 = FlatIPIndex(d, shadow=False)
     ref2.add_with_ids(X2, ids2)

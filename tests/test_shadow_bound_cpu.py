@@ -117,3 +117,64 @@ def test_one_piece_query_bound_of_the_batched_scan(kind, d):
         # and it is not vacuous: within a factor of a few of the two-piece bound on unit data
         if kind == "unit" and qkind == "random":
             assert eps < 4 * (n1 + d * 2.0 ** -23 * n0) * qn
+
+
+def quantize_rows_i8(X: np.ndarray):
+    """wise_ip_shadow_i8 restated: scale_r = max|x_r| / 127, c = clamp(rint(x * (127 / max)), +-127) (fp32 arithmetic)."""
+    mx = np.abs(X).max(axis=1).astype(np.float32)
+    scale = (mx / np.float32(127.0)).astype(np.float32)
+    inv = np.where(mx > 0, np.float32(127.0) / np.where(mx > 0, mx, 1), 0).astype(np.float32)
+    c = np.clip(np.rint(X * inv[:, None]), -127, 127).astype(np.int32)
+    return c, scale
+
+
+def quantize_query_i8(q: np.ndarray):
+    """ShadowGroupI8::load_query restated: q^ = sq h + (sq / 254) l, two int8 pieces."""
+    mq = np.float32(np.abs(q).max())
+    sq = np.float32(mq / np.float32(127.0))
+    sl = np.float32(sq / np.float32(254.0))
+    inv = np.float32(127.0) / mq if mq > 0 else np.float32(0)
+    invl = np.float32(254.0 * 127.0) / mq if mq > 0 else np.float32(0)
+    h = np.clip(np.rint(q * inv), -127, 127).astype(np.float32)
+    r = (q - sq * h).astype(np.float32)
+    l = np.clip(np.rint(r * invl), -127, 127).astype(np.float32)
+    return h.astype(np.int64), l.astype(np.int64), sq, sl
+
+
+@pytest.mark.parametrize("kind", ["unit", "mixed_norms", "one_large_component", "peaky_query"])
+@pytest.mark.parametrize("d", [64, 512, 1024])
+def test_int8_shadow_score_error_is_within_the_bound_its_norms_carry(kind, d):
+    """|q.x - s^| <= |q| (rho_max + sqrt(d) 1.6e-5 X^max) (+ the d 2^-23 X^max |q| slack shadow_eps adds): the residual of the
+    rows by Cauchy-Schwarz, the residual of the two-piece int8 query by its worst case sqrt(d) sq / 508 with
+    sq <= |q| / 127, integer sums exact."""
+    rng = np.random.default_rng(70 + d)
+    n = 4096
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    if kind == "unit":
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+    elif kind == "mixed_norms":
+        X *= np.exp(rng.uniform(-6, 6, size=(n, 1))).astype(np.float32)
+    elif kind == "one_large_component":
+        X[np.arange(n), rng.integers(0, d, n)] = 40.0      # the scale follows the outlier: everything else is coarse
+    q = rng.standard_normal(d).astype(np.float32)
+    if kind == "peaky_query":
+        q[rng.integers(0, d, 3)] = 25.0
+    c, scale = quantize_rows_i8(X)
+    h, l, sq, sl = quantize_query_i8(q)
+    assert np.abs(c).max() <= 127 and np.abs(h).max() <= 127 and np.abs(l).max() <= 127
+    Xhat = scale[:, None].astype(np.float64) * c
+    rho = np.linalg.norm(X.astype(np.float64) - Xhat, axis=1)
+    assert np.all(rho <= scale.astype(np.float64) * np.sqrt(d) / 2 * (1 + 1e-5))          # half a step per component
+    qhat = float(sq) * h + float(sl) * l
+    qn = float(np.linalg.norm(q.astype(np.float64)))
+    assert np.linalg.norm(q.astype(np.float64) - qhat) <= np.sqrt(d) * 1.6e-5 * qn
+    H, L = c @ h, c @ l                                                                    # exact integers
+    assert np.abs(H).max() < 2 ** 24 and np.abs(L).max() < 2 ** 24                         # exact as fp32, too
+    approx = scale.astype(np.float64) * (float(sq) * H + float(sl) * L)
+    truth = X.astype(np.float64) @ q.astype(np.float64)
+    xmax, rmax = float(np.linalg.norm(Xhat, axis=1).max()), float(rho.max())
+    norms1 = rmax + np.sqrt(d) * 1.6e-5 * xmax
+    eps = (norms1 + d * 2.0 ** -23 * xmax) * 1.0001 * qn
+    assert np.abs(approx - truth).max() <= eps
+    if kind == "unit":
+        assert rmax < 0.03                      # ~1-2 % of |x| for Gaussian rows (bf16: 0.2 %)

@@ -52,6 +52,8 @@ SIGNATURES = {
     "wise_ip_shadow_bf16": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     "wise_ip_topk_shadow_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
     "wise_ip_topk_shadow_f32": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "wise_ip_shadow_i8": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "wise_ip_topk_shadow8_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "wise_ivf_scan_workspace_bytes": (_sz, [_i, _i, _i]),
     "wise_ivf_scan_f32": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "wise_ip_scores_f32": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp]),

@@ -546,6 +546,208 @@ struct ShadowGroup {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// The int8 shadow (wise_ip_shadow_i8): a quarter of the bytes of X per query.  Row r is kept as signed bytes c_r with a
+// scale s_r = max|x_r| / 127 (round to nearest): x^_r = s_r c_r.  The query enters as two int8 pieces,
+// q^ = sq h + (sq/254) l with sq = max|q| / 127, so a score is two v_dot4_i32_i8 chains — exact integer sums — and
+// three fp32 operations per lane:  s^ = s_r (sq H + (sq/254) L).  What a score can be off by:
+//   |q.x - s^| <= |q| |x_r - x^_r|  +  |q - q^| |x^_r|  +  fp32 rounding of the per-lane combination and the lane sums
+//              <= |q| (rho_max + sqrt(d) 1.6e-5 X^max + 8 2^-24 X^max)
+// (|q - q^| <= sqrt(d) sq / 508 and sq <= |q| / 127).  shadow_i8_kernel measures rho_max = max_r |x_r - x^_r| and
+// X^max = max_r |x^_r| and stores norms[0] = X^max, norms[1] = rho_max + sqrt(d) 1.6e-5 X^max: shadow_eps(), written for
+// the bf16 shadow, then bounds the int8 scores as it stands, and every kernel behind the two scans is shared.
+// For Gaussian or CLIP-like rows rho is ~0.9 % of |x| (bf16: 0.2 %): the collect pass hands on a few hundred rows
+// instead of a few dozen, all re-scored from the f32 rows as before.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shadow_i8_kernel(const float* __restrict__ X, long long N, int d,
+                                                        signed char* __restrict__ Xq, float* __restrict__ scales,
+                                                        float* __restrict__ norms /*[0] max |x^|, [2] max |x - x^|*/) {
+    const int lane = threadIdx.x & 63;
+    const long long w0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    float best = 0.f, best_err = 0.f;
+    for (long long row = w0; row < N; row += nw) {
+        const float4* xr = reinterpret_cast<const float4*>(X + row * d);
+        unsigned* qr = reinterpret_cast<unsigned*>(Xq + row * d);
+        float mx = 0.f;
+        for (int c = lane; c < (d >> 2); c += 64) {
+            const float4 v = xr[c];
+            mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float scale = mx / 127.f, inv = mx > 0.f ? 127.f / mx : 0.f;
+        float hh = 0.f, ee = 0.f;
+        for (int c = lane; c < (d >> 2); c += 64) {
+            const float4 v = xr[c];
+            const float xs[4] = {v.x, v.y, v.z, v.w};
+            unsigned pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float qf = fminf(fmaxf(rintf(xs[e] * inv), -127.f), 127.f);
+                const float back = scale * qf, err = xs[e] - back;
+                hh = fmaf(back, back, hh);
+                ee = fmaf(err, err, ee);
+                pk |= ((unsigned)(int)qf & 0xFFu) << (8 * e);
+            }
+            qr[c] = pk;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { hh += __shfl_xor(hh, o, 64); ee += __shfl_xor(ee, o, 64); }
+        if (lane == 0) scales[row] = scale;
+        best = hh > best ? hh : best;
+        best_err = ee > best_err ? ee : best_err;
+    }
+    if (lane == 0) {
+        atomicMax(reinterpret_cast<unsigned*>(norms), __float_as_uint(sqrtf(best) * 1.00001f));
+        atomicMax(reinterpret_cast<unsigned*>(norms) + 2, __float_as_uint(sqrtf(best_err) * 1.00001f));
+    }
+}
+__global__ void shadow_i8_finish_kernel(float* __restrict__ norms, int d) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) norms[1] = norms[2] + sqrtf((float)d) * 1.6e-5f * norms[0];
+}
+
+// One group of R = 8 * (64 / LPR) rows of the int8 shadow against the query: LPR lanes cover a row (16 bytes each,
+// LPR = 16 / 32 / 64 for d <= 256 / 512 / 1024), so one wave instruction loads 64 / LPR whole rows; eight such
+// instructions are in flight per group.  Every lane ends up with the score of row `row0 + myr` (valid where `owner`).
+template <int LPR>
+struct ShadowGroupI8 {
+    static constexpr int RPI = 64 / LPR, T = 8, R = T * RPI;
+    static constexpr int LOGL = (LPR == 64) ? 6 : (LPR == 32) ? 5 : 4;
+    int qh[4], ql[4];
+    float sq, sl;
+    int myr, chunk, sub;
+    bool owner, active;
+    __device__ void load_query(const float* __restrict__ Q, int d16, int lane) {
+        chunk = lane & (LPR - 1);
+        sub = lane >> LOGL;
+        active = chunk < d16;
+        float qv[16];
+        float mq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            qv[e] = active ? Q[chunk * 16 + e] : 0.f;
+            mq = fmaxf(mq, fabsf(qv[e]));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mq = fmaxf(mq, __shfl_xor(mq, o, 64));
+        sq = mq / 127.f;
+        sl = sq / 254.f;
+        const float inv = mq > 0.f ? 127.f / mq : 0.f, invl = mq > 0.f ? 254.f * 127.f / mq : 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned ph = 0, pl = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float v = qv[w * 4 + b];
+                const float h = fminf(fmaxf(rintf(v * inv), -127.f), 127.f);
+                const float r = fmaf(-sq, h, v);
+                const float l = fminf(fmaxf(rintf(r * invl), -127.f), 127.f);
+                ph |= ((unsigned)(int)h & 0xFFu) << (8 * b);
+                pl |= ((unsigned)(int)l & 0xFFu) << (8 * b);
+            }
+            qh[w] = (int)ph;
+            ql[w] = (int)pl;
+        }
+        // transposition over the three lane bits under the row-select bits, then plain sums over the rest
+        myr = 0;
+        int bit = LOGL - 1;
+#pragma unroll
+        for (int h = T / 2; h >= 1; h >>= 1, --bit) myr += ((lane >> bit) & 1) * h;
+        myr = myr * RPI + sub;
+        owner = (lane & ((LPR >> 3) - 1)) == 0;
+    }
+    __device__ float score(const signed char* __restrict__ Xq, const float* __restrict__ scales, long long row0,
+                           long long row_end, int d, int lane) const {
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        i32x4_t x[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            long long row = row0 + t * RPI + sub;
+            if (row >= row_end) row = row_end - 1;
+            if (active)
+                x[t] = __builtin_nontemporal_load(reinterpret_cast<const i32x4_t*>(Xq + row * d) + chunk);
+            else
+                x[t] = i32x4_t{0, 0, 0, 0};
+        }
+        long long mrow = row0 + myr;
+        if (mrow >= row_end) mrow = row_end - 1;
+        const float rs = scales[mrow];
+        float a[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            int H = 0, L = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                H = __builtin_amdgcn_sdot4(x[t][w], qh[w], H, false);
+                L = __builtin_amdgcn_sdot4(x[t][w], ql[w], L, false);
+            }
+            a[t] = fmaf(sl, (float)L, sq * (float)H);
+        }
+        int bit = LOGL - 1;
+#pragma unroll
+        for (int h = T / 2; h >= 1; h >>= 1, --bit) {
+            const int m = 1 << bit;
+            const bool up = (lane >> bit) & 1;
+#pragma unroll
+            for (int i = 0; i < h; ++i) {
+                float send = up ? a[i] : a[i + h];
+                float keep = up ? a[i + h] : a[i];
+                a[i] = keep + __shfl_xor(send, m, 64);
+            }
+        }
+        float sc = a[0];
+#pragma unroll
+        for (int m = (LPR >> 4); m >= 1; m >>= 1) sc += __shfl_xor(sc, m, 64);
+        return sc * rs;
+    }
+};
+
+template <int LPR>
+__global__ __launch_bounds__(256) void ip_sample_i8_kernel(const signed char* __restrict__ Xq, const float* __restrict__ scales,
+                                                           long long n_groups, int d, const float* __restrict__ Q,
+                                                           int chunk_shift, long long chunk_stride, float* __restrict__ dump) {
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    ShadowGroupI8<LPR> grp;
+    constexpr int R = ShadowGroupI8<LPR>::R;
+    grp.load_query(Q, d >> 4, lane);
+    for (long long g = gw; g < n_groups; g += nw) {
+        const long long row0 = ((g >> chunk_shift) * chunk_stride + (g & ((1ll << chunk_shift) - 1))) * R;
+        const float sc = grp.score(Xq, scales, row0, row0 + R, d, lane);     // whole groups only
+        if (grp.owner) dump[g * R + grp.myr] = sc;
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void ip_collect_i8_kernel(const signed char* __restrict__ Xq, const float* __restrict__ scales,
+                                                            long long N, int d, const float* __restrict__ Q,
+                                                            const float* __restrict__ thr_p, int* __restrict__ counter,
+                                                            u64* __restrict__ cand, int cap, long long row_base) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    ShadowGroupI8<LPR> grp;
+    constexpr int R = ShadowGroupI8<LPR>::R;
+    grp.load_query(Q, d >> 4, lane);
+    const float thr = thr_p[0];
+    const long long ngroups = (N + R - 1) / R;
+    const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+    for (long long g = gw; g < ngroups; g += nw) {
+        const long long row0 = g * R;
+        const float sc = grp.score(Xq, scales, row0, N, d, lane);
+        const long long row = row0 + grp.myr;
+        const bool pass = grp.owner && (row < N) && (sc >= thr);
+        const u64 mask = __ballot(pass);
+        if (mask != 0) {
+            const int first = __ffsll((long long)mask) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd(counter, __popcll(mask));
+            base = __shfl(base, first, 64);
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pass && pos < cap) cand[pos] = make_key(sc, (unsigned)(row_base + row));
+        }
+    }
+}
+
 // The SAMPLE pass of the single-query search: evenly spaced chunks of 2^chunk_shift groups of R rows (chunk_stride groups
 // apart); every wave scores its share of the sampled groups and writes the best score it saw (wave_best[global wave]).
 // The k-th largest of those per-wave maxima is reached by k different sampled rows (sample_threshold_kernel).
@@ -1651,6 +1853,24 @@ extern "C" int wise_ip_shadow_bf16(const float* X, int64_t N, int d, uint16_t* X
     return WISE_OK;
 }
 
+extern "C" int wise_ip_shadow_i8(const float* X, int64_t N, int d, int8_t* Xq, float* scales, float* norms, void* stream) {
+    WISE_CHECK_ARG(d >= 16 && d % 16 == 0 && d <= 1024 && N >= 0 && ((X && Xq && scales) || N == 0) && norms,
+                   "ip_shadow_i8: bad argument (d=%d must be a multiple of 16 up to 1024)", d);
+    WISE_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Xq & 15) == 0, "ip_shadow_i8: X and Xq must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(norms, 0, 4 * sizeof(float), st);
+    if (e != hipSuccess) { set_error("ip_shadow_i8: %s", hipGetErrorString(e)); return (int)e; }
+    if (N > 0) {
+        const long long want = (N + 3) / 4;
+        hipLaunchKernelGGL(shadow_i8_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, st, X, (long long)N, d,
+                           reinterpret_cast<signed char*>(Xq), scales, norms);
+        WISE_LAUNCH_CHECK("shadow_i8_kernel");
+    }
+    hipLaunchKernelGGL(shadow_i8_finish_kernel, dim3(1), dim3(64), 0, st, norms, d);
+    WISE_LAUNCH_CHECK("shadow_i8_finish_kernel");
+    return WISE_OK;
+}
+
 namespace wise { struct PassWsSize { size_t total; }; static size_t pass_workspace_bytes(long long N, int d, int k); }
 extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, int k) {
     if (N < 0 || nq < 1 || !shadow_supported(d, k)) return 0;
@@ -1787,7 +2007,8 @@ __global__ __launch_bounds__(1024) void batch_tighten_kernel(const int* __restri
 // could belong to the top-k -> exact scores -> the k best; the f32 scan queued behind runs only if the list overflowed.
 static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norms, long long N, int d, const float* q,
                              int k, const long long* ids, long long id_base, float* outD, long long* outI, int* stats,
-                             unsigned char* wsb, hipStream_t st) {
+                             unsigned char* wsb, hipStream_t st, const signed char* Xq = nullptr /*int8 shadow + scales*/,
+                             const float* scales = nullptr) {
     float* wave_best = reinterpret_cast<float*>(wsb);
     size_t off = align_up((size_t)SAMPLE_GRID * 4 * sizeof(float), 256);
     float* thr = reinterpret_cast<float*>(wsb + off);
@@ -1807,6 +2028,10 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norm
     const int d8 = d / 8, nv8 = (d8 + 63) / 64;
     if (nv8 > 2) { set_error("ip_topk_shadow: no kernel for d=%d", d); return WISE_E_INVALID; }
     const uint4* xb = reinterpret_cast<const uint4*>(Xb);
+    // int8 rows: 16 / 32 / 64 lanes per row, groups of 32 / 16 / 8 rows
+    const int lpr = Xq ? (d <= 256 ? 16 : d <= 512 ? 32 : 64) : 0;
+    const int grows = Xq ? 8 * (64 / lpr) : 8;           // rows per group of the two scans
+    if (Xq && (d % 16 != 0 || d > 1024 || !scales)) { set_error("ip_topk_shadow8: d=%d must be a multiple of 16 up to 1024", d); return WISE_E_INVALID; }
     // ---- sample: SAMPLE_CHUNKS evenly spaced chunks of 2^shift groups of 8 rows, every sampled score dumped.  About
     // N / 64 rows, between 16384 and 65536 (a shard of an index sharded over eight GPUs pays a quarter of the sample a
     // whole index does); the threshold is the exact k-th largest sampled score (k <= 1024 of >= 16384 samples) and it
@@ -1814,28 +2039,47 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norm
     {
         int shift = SAMPLE_CHUNK_SHIFT;                  // 512 rows per chunk
         while (shift > 4 && (long long)SAMPLE_CHUNKS * (8ll << shift) * 64 > N) --shift;
-        const long long groups = N / 8;                  // whole groups only: a sampled group is never ragged
+        shift -= (grows == 16) ? 1 : (grows == 32) ? 2 : 0;            // the same rows per chunk in larger groups
+        const long long groups = N / grows;              // whole groups only: a sampled group is never ragged
         const long long chunk_groups = 1ll << shift;
         const long long stride = (groups - chunk_groups) / (SAMPLE_CHUNKS - 1);      // last chunk ends inside the index
         const long long sgroups = (long long)SAMPLE_CHUNKS * chunk_groups;
         const int sgrid = (int)((sgroups + 15) / 16 < SAMPLE_GRID ? (sgroups + 15) / 16 : SAMPLE_GRID);
-        if (nv8 == 1)
+        if (Xq) {
+            if (lpr == 16)
+                hipLaunchKernelGGL((ip_sample_i8_kernel<16>), dim3(sgrid), dim3(256), 0, st, Xq, scales, sgroups, d, q, shift, stride, dump);
+            else if (lpr == 32)
+                hipLaunchKernelGGL((ip_sample_i8_kernel<32>), dim3(sgrid), dim3(256), 0, st, Xq, scales, sgroups, d, q, shift, stride, dump);
+            else
+                hipLaunchKernelGGL((ip_sample_i8_kernel<64>), dim3(sgrid), dim3(256), 0, st, Xq, scales, sgroups, d, q, shift, stride, dump);
+        } else if (nv8 == 1)
             hipLaunchKernelGGL((ip_sample_bf16_kernel<1, 8>), dim3(sgrid), dim3(256), 0, st, xb, sgroups, d8, q, shift, stride,
                                wave_best, dump);
         else
             hipLaunchKernelGGL((ip_sample_bf16_kernel<2, 8>), dim3(sgrid), dim3(256), 0, st, xb, sgroups, d8, q, shift, stride,
                                wave_best, dump);
         WISE_LAUNCH_CHECK("ip_sample_bf16_kernel");
-        hipLaunchKernelGGL(sample_threshold_kth_kernel, dim3(1), dim3(1024), 0, st, dump, (int)(sgroups * 8), k, q, d, norms, thr,
+        hipLaunchKernelGGL(sample_threshold_kth_kernel, dim3(1), dim3(1024), 0, st, dump, (int)(sgroups * grows), k, q, d, norms, thr,
                            counter);
         WISE_LAUNCH_CHECK("sample_threshold_kth_kernel");
     }
     // ---- collect over all rows; for large k in two ranges, the threshold tightened in between by what the first
     // range (2^20 rows: a sample sixteen times the sample pass's) collected
     {
-        ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
+        ProfScope prof(PROF_SCAN, Xq ? (double)N * (d + 4.0) : (double)N * d * 2.0, st);
         auto collect = [&](long long r0, long long rows) {
             const int grid = shadow_grid(rows);
+            if (Xq) {
+                const signed char* base8 = Xq + (size_t)r0 * d;
+                const float* sc8 = scales + r0;
+                if (lpr == 16)
+                    hipLaunchKernelGGL((ip_collect_i8_kernel<16>), dim3(grid), dim3(256), 0, st, base8, sc8, rows, d, q, thr, counter, cand, COLLECT_CAP, r0);
+                else if (lpr == 32)
+                    hipLaunchKernelGGL((ip_collect_i8_kernel<32>), dim3(grid), dim3(256), 0, st, base8, sc8, rows, d, q, thr, counter, cand, COLLECT_CAP, r0);
+                else
+                    hipLaunchKernelGGL((ip_collect_i8_kernel<64>), dim3(grid), dim3(256), 0, st, base8, sc8, rows, d, q, thr, counter, cand, COLLECT_CAP, r0);
+                return;
+            }
             const uint4* base = xb + (size_t)r0 * d8;
             if (nv8 == 1)
                 hipLaunchKernelGGL((ip_collect_bf16_kernel<1, 8>), dim3(grid), dim3(256), 0, st, base, rows, d8, q, thr, counter,
@@ -2103,6 +2347,37 @@ extern "C" int wise_ip_topk_shadow_f32(const float* X, const uint16_t* Xb, const
     for (int q = 0; q < nq; ++q) {
         int rc = shadow_search_one(X, Xb, norms, N, d, Q + (size_t)q * d, k, lids, (long long)id_base,
                                    outD + (size_t)q * k, lI + (size_t)q * k, counters, wsb, st);
+        if (rc) return rc;
+    }
+    return WISE_OK;
+}
+
+// The same search over the int8 shadow (wise_ip_shadow_i8), one query at a time in the threshold form: the two scans read
+// N (d + 4) bytes instead of 2 N d; thresholds, refinement, exact re-scoring from X and the gated f32 scan are the bf16
+// form's kernels (norms carries the int8 error bound).  Same workspace as wise_ip_topk_shadow_f32.
+extern "C" int wise_ip_topk_shadow8_f32(const float* X, const int8_t* Xq, const float* scales, const float* norms, int64_t N,
+                                        int d, const float* Q, int nq, int k, const int64_t* ids, int64_t id_base, float* outD,
+                                        int64_t* outI, int32_t* counters, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+    WISE_CHECK_ARG(shadow_supported(d, k) && d % 16 == 0, "ip_topk_shadow8: d=%d must be a multiple of 16 in [16,1024], k=%d in [1,1024]", d, k);
+    WISE_CHECK_ARG(N > 0 && N < 0xFFFFFFFFll, "ip_topk_shadow8: N=%lld out of range", (long long)N);
+    WISE_CHECK_ARG(nq >= 1 && nq <= 1024, "ip_topk_shadow8: nq=%d out of [1,1024]", nq);
+    WISE_CHECK_ARG(X && Xq && scales && norms && Q && outD && outI, "ip_topk_shadow8: null pointer");
+    WISE_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Xq & 15) == 0 && ((uintptr_t)Q & 15) == 0,
+                   "ip_topk_shadow8: X, Xq and Q must be 16-byte aligned");
+    const size_t need = wise_ip_topk_shadow_workspace_bytes(N, d, nq, k);
+    if (!workspace || workspace_bytes < need) {
+        set_error("ip_topk_shadow8: workspace %zu < %zu bytes", workspace_bytes, need);
+        return WISE_E_WORKSPACE;
+    }
+    if (N < COLLECT_MIN_ROWS)
+        return wise_ip_topk_f32(X, N, d, Q, nq, k, ids, id_base, outD, outI, workspace, workspace_bytes, stream);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+    for (int q = 0; q < nq; ++q) {
+        int rc = shadow_search_one(X, nullptr, norms, N, d, Q + (size_t)q * d, k, reinterpret_cast<const long long*>(ids),
+                                   (long long)id_base, outD + (size_t)q * k, reinterpret_cast<long long*>(outI) + (size_t)q * k,
+                                   counters, wsb, st, reinterpret_cast<const signed char*>(Xq), scales);
         if (rc) return rc;
     }
     return WISE_OK;

@@ -18,17 +18,24 @@ from .. import _lib
 
 
 class FlatIPIndex:
-    def __init__(self, d: int, device: str = "cuda", shadow: Optional[bool] = None):
-        """shadow: keep a bf16 copy of the rows (+50 % memory) so that single-query searches with k <= 16 scan half the
-        bytes and verify in fp32 (wise_ip_topk_shadow_f32: same results, certified or recomputed).  None = on unless
-        WISE_FLAT_SHADOW=0."""
+    def __init__(self, d: int, device: str = "cuda", shadow=None):
+        """shadow: keep a reduced-precision copy of the rows for the first stage of the exact two-stage search (same
+        results as the fp32 scan, by construction): True / "int8" = one query at a time scans an int8 copy (+25 % memory, a
+        quarter of the bytes per query: wise_ip_topk_shadow8_f32), batches of queries a bf16 copy on the matrix cores
+        (+50 %, built on the first batched search: wise_ip_topk_shadow_f32); "bf16" = the bf16 copy for both; False = the
+        fp32 scan only.  None = WISE_FLAT_SHADOW (0 / bf16 / int8; default int8)."""
         if d < 4 or d % 4 != 0 or d > 2048:
             raise ValueError(f"FlatIPIndex: d={d} must be a multiple of 4 in [4, 2048]")
         self.d = int(d)
         self.device = torch.device(device)
         if shadow is None:
-            shadow = os.environ.get("WISE_FLAT_SHADOW", "1") != "0"
+            env = os.environ.get("WISE_FLAT_SHADOW", "1")
+            shadow = False if env == "0" else ("bf16" if env == "bf16" else True)
         self.shadow = bool(shadow) and d % 8 == 0 and d <= 1024
+        self.shadow8 = self.shadow and shadow != "bf16" and d % 16 == 0     # single queries over the int8 copy
+        self._Xq: Optional[torch.Tensor] = None      # [N,d] int8 on device, its row scales [N] and error norms [4]
+        self._scales8: Optional[torch.Tensor] = None
+        self._norms8: Optional[torch.Tensor] = None
         self._Xb: Optional[torch.Tensor] = None      # [N,d] bf16 bits (int16) on device
         self._norms: Optional[torch.Tensor] = None   # device [2]: largest row norm, largest bf16 rounding-residual norm
         self._sws: Optional[torch.Tensor] = None
@@ -81,7 +88,7 @@ class FlatIPIndex:
             self._rids[a:b].copy_(ids)
             self._rfill = b
             self._X, self._ids = rX[:b], self._rids[:b]
-            self._Xb = None
+            self._Xb = self._Xq = None
             self._n = b
             return
         if rX is not None:                          # more rows than reserved: fall back to chunks from here on
@@ -98,7 +105,7 @@ class FlatIPIndex:
             raise ValueError("adopt: ids must be int64 [N]")
         self._chunks, self._id_chunks = [], []
         self._X, self._ids, self.id_base, self._n = X, ids, int(id_base), X.shape[0]
-        self._Xb = None
+        self._Xb = self._Xq = None
         return self
 
     def _finalize(self):
@@ -111,7 +118,7 @@ class FlatIPIndex:
             self._X = torch.cat(parts, dim=0).contiguous()
             self._ids = torch.cat(idp, dim=0).contiguous()
             self._chunks, self._id_chunks = [], []
-            self._Xb = None
+            self._Xb = self._Xq = None
             self._rX = None
         if self._X is None:
             self._X = torch.empty(0, self.d, dtype=torch.float32, device=self.device)
@@ -141,6 +148,19 @@ class FlatIPIndex:
             (2 <= nq <= 3 and 1 <= k <= 1024))
         if two_stage and lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k) == 0:
             two_stage = False
+        if two_stage and nq == 1 and self.shadow8 and self._ensure_shadow8(lib):
+            need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k)
+            if self._sws is None or self._sws.numel() < need:
+                self._sws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            rc = lib.wise_ip_topk_shadow8_f32(self._X.data_ptr(), self._Xq.data_ptr(), self._scales8.data_ptr(),
+                                              self._norms8.data_ptr(), self._n, self.d, q.data_ptr(), nq, k,
+                                              _lib.ptr(self._ids), self.id_base, D.data_ptr(), I.data_ptr(),
+                                              self._counters.data_ptr(), self._sws.data_ptr(), self._sws.numel(),
+                                              _lib.stream_ptr())
+            _lib.check(rc, "wise_ip_topk_shadow8_f32")
+            self._shadow_calls += 1
+            self._review_shadow()
+            return D, I
         if two_stage and self._ensure_shadow(lib):
             need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k)
             if self._sws is None or self._sws.numel() < need:
@@ -182,6 +202,25 @@ class FlatIPIndex:
         _lib.check(rc, "wise_ip_shadow_bf16")
         return True
 
+    def _ensure_shadow8(self, lib) -> bool:
+        """Build the int8 copy (rows, scales, error norms) if it is not there; False when HBM has no room for it."""
+        if self._Xq is not None and self._Xq.shape[0] == self._n:
+            return True
+        need = self._n * (self.d + 4)
+        free, _ = torch.cuda.mem_get_info(self.device)
+        if free < need + (2 << 30):
+            self.shadow8 = False
+            return False
+        self._Xq = torch.empty(self._n, self.d, dtype=torch.int8, device=self.device)
+        self._scales8 = torch.empty(self._n, dtype=torch.float32, device=self.device)
+        self._norms8 = torch.zeros(4, dtype=torch.float32, device=self.device)
+        if self._counters is None:
+            self._counters = torch.zeros(2, dtype=torch.int32, device=self.device)
+        rc = lib.wise_ip_shadow_i8(self._X.data_ptr(), self._n, self.d, self._Xq.data_ptr(), self._scales8.data_ptr(),
+                                   self._norms8.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "wise_ip_shadow_i8")
+        return True
+
     def _review_shadow(self) -> None:
         """Never blocks: every 64 two-stage searches a snapshot of this index's counters is copied to pinned memory
         behind an event; a later call that finds the event complete reads it.  If the fp32 scan had to answer most
@@ -193,8 +232,8 @@ class FlatIPIndex:
             d_done, d_handed = done - self.shadow_certified, handed - self.shadow_fallback
             self.shadow_certified, self.shadow_fallback = done, handed
             if d_handed > d_done:
-                self.shadow = False
-                self._Xb = self._sws = None
+                self.shadow = self.shadow8 = False
+                self._Xb = self._Xq = self._scales8 = self._sws = None
                 return
         if self._snap_event is None and self._shadow_calls % 64 == 0 and self._counters is not None:
             if self._snap is None:
