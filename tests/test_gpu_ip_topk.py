@@ -437,13 +437,14 @@ def test_general_k_on_clustered_rows_and_on_overflow(k, kind):
 
 @pytest.mark.parametrize("N,d,k,nq", [(300000, 512, 20, 40), (300000, 512, 100, 130), (262144, 256, 128, 9),
                                       (270001, 768, 100, 70), (300000, 512, 17, 3)])
-def test_batched_two_stage_search_up_to_k128(N, d, k, nq):
+@pytest.mark.parametrize("kind", ["int8", "bf16"])
+def test_batched_two_stage_search_up_to_k128(N, d, k, nq, kind):
     """Batches of queries at the evaluation's k (100: docs/Search-Index-Evaluation.md:109) and the REST default (20):
     the matrix-core passes over the bf16 shadow with the selections of the general-k path; ids and scores are the f32
     scan's and the oracle's, everything answered from the shadow (the gated fallback for k > 12 is the f32 VALU scan)."""
     X = unit_rows(N, d, 800 + k + nq)
     ids = np.arange(N, dtype=np.int64) + 7
-    idx = FlatIPIndex(d, shadow=True)
+    idx = FlatIPIndex(d, shadow=kind)
     idx.add_with_ids(X, ids)
     ref = FlatIPIndex(d, shadow=False)
     ref.add_with_ids(X, ids)
@@ -476,7 +477,8 @@ def test_small_index_with_near_ties_in_one_block():
     assert np.array_equal(I, Ir) and np.allclose(D, Dr, atol=2e-6)
 
 
-def test_batched_two_stage_search_on_ordinary_and_on_overflowing_queries():
+@pytest.mark.parametrize("kind", ["int8", "bf16"])
+def test_batched_two_stage_search_on_ordinary_and_on_overflowing_queries(kind):
     """A batch of 40 queries on an index with a bf16 shadow (threshold form on the matrix cores): ordinary queries are
     answered from the bf16 pass; one query with 70,000 rows inside the bf16 error band of its best scores overflows its
     list, and the pass is redone from the f32 rows.  Either way: the oracle's."""
@@ -484,7 +486,7 @@ def test_batched_two_stage_search_on_ordinary_and_on_overflowing_queries():
     X = unit_rows(N, d, 71)
     Q = unit_rows(40, d, 72)
     ids = np.arange(N, dtype=np.int64) + 5
-    idx = FlatIPIndex(d, shadow=True)
+    idx = FlatIPIndex(d, shadow=kind)
     idx.add_with_ids(X, ids)
     before = idx.shadow_counts()
     D, I = idx.search(Q, k)
@@ -497,7 +499,7 @@ def test_batched_two_stage_search_on_ordinary_and_on_overflowing_queries():
         v /= np.linalg.norm(v)
         sc = 1.0 - 4e-5 * n if n < 12 else rng.uniform(0.9975, 0.9990)
         X[c] = sc * Q[7] + np.sqrt(1 - sc * sc) * v
-    idx2 = FlatIPIndex(d, shadow=True)
+    idx2 = FlatIPIndex(d, shadow=kind)
     idx2.add_with_ids(X, ids)
     D2, I2 = idx2.search(Q, k)
     answered, handed = idx2.shadow_counts()
@@ -506,7 +508,8 @@ def test_batched_two_stage_search_on_ordinary_and_on_overflowing_queries():
     check_against_oracle(X, Q, k, ids, D2, I2)
 
 
-def test_batched_search_on_clustered_rows_needs_no_fallback():
+@pytest.mark.parametrize("kind", ["int8", "bf16"])
+def test_batched_search_on_clustered_rows_needs_no_fallback(kind):
     """Runs of 20 near-duplicates (cosine >= 0.999): the batched threshold form answers every query from the shadow and
     returns what the f32 path returns."""
     d, k = 512, 10
@@ -516,7 +519,7 @@ def test_batched_search_on_clustered_rows_needs_no_fallback():
     Q = unit_rows(70, d, 48)
     Q[::2] = X[np.random.default_rng(49).integers(0, N, 35)] + 0.02 * Q[::2]
     Q /= np.linalg.norm(Q, axis=1, keepdims=True)
-    idx = FlatIPIndex(d, shadow=True)
+    idx = FlatIPIndex(d, shadow=kind)
     idx.add_with_ids(X, ids)
     ref = FlatIPIndex(d, shadow=False)
     ref.add_with_ids(X, ids)
@@ -543,7 +546,8 @@ def test_batched_two_stage_search_with_threshold_passes():
 
 
 @pytest.mark.parametrize("d,nq", [(512, 65), (512, 128), (512, 129), (512, 200), (512, 257), (768, 65), (768, 130), (256, 300)])
-def test_batched_pass_sizes_and_remainders(d, nq):
+@pytest.mark.parametrize("kind", ["int8", "bf16"])
+def test_batched_pass_sizes_and_remainders(d, nq, kind):
     """passes of 128 queries at d <= 512 (64 at d = 768), a remainder of <= 64 through the 64-query kernel, single-query
     remainders; two collect ranges (N >= 4M rows) — ids and scores equal the f32 scan's for every query"""
     N, k = 4_300_000, 10
@@ -556,7 +560,7 @@ def test_batched_pass_sizes_and_remainders(d, nq):
     ref = FlatIPIndex(d, shadow=False).adopt(X)
     D0, I0 = ref.search_device(Q, k)
     del ref
-    idx = FlatIPIndex(d, shadow=True).adopt(X)
+    idx = FlatIPIndex(d, shadow=kind).adopt(X)
     before = idx.shadow_counts()
     D, I = idx.search_device(Q, k)
     certified, fallback = counts_since(idx, before)
@@ -661,13 +665,14 @@ def test_few_queries_through_the_two_stage_search(N, d, nq, k):
 
 
 @pytest.mark.parametrize("N,d,nq,k", [(280000, 768, 40, 10), (30000, 1024, 5, 16), (600000, 768, 33, 10), (300000, 1024, 5, 16)])
-def test_batched_two_stage_search_for_wide_rows(N, d, nq, k):
+@pytest.mark.parametrize("kind", ["int8", "bf16"])
+def test_batched_two_stage_search_for_wide_rows(N, d, nq, k, kind):
     """512 < d <= 1024 (768 is the ViT-L/14 dimension): 32 queries per pass over the bf16 rows on the matrix cores, the
     f32 VALU scan as the gated fallback."""
     X = unit_rows(N, d, 700 + N % 31)
     Q = unit_rows(nq, d, 33)
     ids = np.arange(N, dtype=np.int64) + 9
-    idx = FlatIPIndex(d, shadow=True)
+    idx = FlatIPIndex(d, shadow=kind)
     idx.add_with_ids(X, ids)
     D, I = idx.search(Q, k)
     certified, fallback = idx.shadow_counts()

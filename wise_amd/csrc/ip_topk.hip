@@ -2175,6 +2175,11 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* nor
                               int* stats, unsigned char* wsb, hipStream_t st, int QB /*64, or 32 for 512 < d <= 1024*/) {
     const PassWs w = pass_workspace(wsb, N, d, k);
     const int q_mode = shadow_one_piece() ? QMODE_ONE_PIECE : QMODE_TWO_PIECE;
+    // one pass of the first stage over rows [r0, r0 + n)
+    auto stage1 = [&](long long r0, long long n, int nq_, const float* thr_, int* ctl_, u64* cand_, int cap_, float* dump_,
+                      int shift_, long long stride_) {
+        return shadow64_scan_launch(Xb + (size_t)r0 * d, n, d, w.mq, nq_, thr_, ctl_, cand_, cap_, st, dump_, QB, shift_, stride_, r0);
+    };
     u64* mpart = w.mpart;
     float* mq = w.mq;
     long long* cand_rows = w.cand_rows;
@@ -2193,9 +2198,7 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* nor
         const long long groups = N / 32, chunk_groups = 1ll << BATCH_SAMPLE_SHIFT;
         const long long stride = (groups - chunk_groups) / (SAMPLE_CHUNKS - 1);
         const long long nsample = (long long)SAMPLE_CHUNKS * chunk_groups * 32;
-        if ((rc = shadow64_scan_launch(Xb, nsample, d, mq, QB, nullptr, nullptr, nullptr, 0, st, w.dump, QB, BATCH_SAMPLE_SHIFT,
-                                       stride)))
-            return rc;
+        if ((rc = stage1(0, nsample, QB, nullptr, nullptr, nullptr, 0, w.dump, BATCH_SAMPLE_SHIFT, stride))) return rc;
         hipLaunchKernelGGL(batch_threshold_kernel, dim3(nqa), dim3(1024), 0, st, w.dump, nsample, k, mq, d, norms,
                            q_mode, w.thr);
         WISE_LAUNCH_CHECK("batch_threshold_kernel");
@@ -2204,14 +2207,12 @@ static int shadow_search_pass(const float* X, const bf16_t* Xb, const float* nor
         {
             ProfScope prof(PROF_SCAN, (double)N * d * 2.0, st);
             const long long R1 = N >= 4 * BATCH_FIRST_RANGE ? BATCH_FIRST_RANGE : N;
-            if ((rc = shadow64_scan_launch(Xb, R1, d, mq, nqa, w.thr, w.ctl, w.cand, BATCH_CAP, st, nullptr, QB))) return rc;
+            if ((rc = stage1(0, R1, nqa, w.thr, w.ctl, w.cand, BATCH_CAP, nullptr, -1, 0))) return rc;
             if (R1 < N) {
                 hipLaunchKernelGGL(batch_tighten_kernel, dim3(nqa), dim3(1024), 0, st, w.ctl, w.cand, BATCH_CAP, k, mq, d, norms,
                                    q_mode, w.thr);
                 WISE_LAUNCH_CHECK("batch_tighten_kernel");
-                if ((rc = shadow64_scan_launch(Xb + (size_t)R1 * d, N - R1, d, mq, nqa, w.thr, w.ctl, w.cand, BATCH_CAP, st,
-                                               nullptr, QB, -1, 0, R1)))
-                    return rc;
+                if ((rc = stage1(R1, N - R1, nqa, w.thr, w.ctl, w.cand, BATCH_CAP, nullptr, -1, 0))) return rc;
             }
         }
         hipLaunchKernelGGL(collect_refine_kernel, dim3(1, nqa), dim3(1024), 0, st, w.ctl, w.cand, BATCH_CAP, k, mq, d, norms,

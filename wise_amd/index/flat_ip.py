@@ -20,10 +20,10 @@ from .. import _lib
 class FlatIPIndex:
     def __init__(self, d: int, device: str = "cuda", shadow=None):
         """shadow: keep a reduced-precision copy of the rows for the first stage of the exact two-stage search (same
-        results as the fp32 scan, by construction): True / "int8" = one query at a time scans an int8 copy (+25 % memory, a
-        quarter of the bytes per query: wise_ip_topk_shadow8_f32), batches of queries a bf16 copy on the matrix cores
-        (+50 %, built on the first batched search: wise_ip_topk_shadow_f32); "bf16" = the bf16 copy for both; False = the
-        fp32 scan only.  None = WISE_FLAT_SHADOW (0 / bf16 / int8; default int8)."""
+        results as the fp32 scan, by construction): True / "int8" = an int8 copy with a scale per row (+25 % memory, a
+        quarter of the bytes per query or per pass of 128 queries: wise_ip_topk_shadow8_f32; d % 16 == 0, else bf16);
+        "bf16" = a bf16 copy (+50 %: wise_ip_topk_shadow_f32); False = the fp32 scan only.
+        None = WISE_FLAT_SHADOW (0 / bf16 / int8; default int8)."""
         if d < 4 or d % 4 != 0 or d > 2048:
             raise ValueError(f"FlatIPIndex: d={d} must be a multiple of 4 in [4, 2048]")
         self.d = int(d)
@@ -148,7 +148,17 @@ class FlatIPIndex:
             (2 <= nq <= 3 and 1 <= k <= 1024))
         if two_stage and lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k) == 0:
             two_stage = False
-        if two_stage and nq == 1 and self.shadow8 and self._ensure_shadow8(lib):
+        # the int8 copy answers one query at a time (0.9 ms each at 10M x 512): alone, in small groups — up to five queries
+        # cost less that way than one bf16 matrix-core pass (1.85 ms whatever it carries) —, and wherever no batched
+        # shape applies (k > 128, or k > 12 with two queries).  A batch proper goes through the bf16 passes: with 128
+        # queries in flight the int8 error band (~0.7 sigma of the score distribution at 10M rows against bf16's 0.25)
+        # puts a candidate in most 32-row groups, and the hit path, not the bytes, then sets the pace (measured: 50 k
+        # queries/s against 65 k at nq = 256, and k = 100 overflows its lists).
+        batched_shape = ((nq >= 2 and 1 <= k <= 12 and self.d in (256, 512)) or
+                         (nq >= 3 and 1 <= k <= 128 and self.d in (256, 512, 768, 1024)))
+        use8 = (self.shadow8 and self._n >= (1 << 18) and 1 <= k <= 1024 and
+                (nq <= 5 or (not batched_shape and nq <= 64)))
+        if use8 and self._ensure_shadow8(lib):
             need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k)
             if self._sws is None or self._sws.numel() < need:
                 self._sws = torch.empty(need, dtype=torch.uint8, device=self.device)
