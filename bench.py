@@ -454,22 +454,25 @@ def main():
             "value": round(qps, 2), "unit": "queries/s", "ms_per_step": round(sdt / s_steps * 1e3, 4),
             "steps": s_steps, "scaling": "strong", "dtype": "f32",
             "config": {"workload": f"IndexFlatIP search, N={N} rows x d={d} fp32 unit rows resident in HBM "
-                                   f"({N * d * 4 / 1e9:.2f} GB) with a bf16 shadow copy ({N * d * 2 / 1e9:.2f} GB), k={k}, "
-                                   "nq=1; two-stage exact search: sample -> threshold -> every row that could belong to "
-                                   "the top-k collected from the bf16 rows -> fp32 re-scoring (fp32 scan only if more "
-                                   "than 16384 rows qualify); any k <= 1024", "rows_per_gpu": rows_per_rank,
+                                   f"({N * d * 4 / 1e9:.2f} GB) with an int8 shadow copy, a scale per row "
+                                   f"({N * (d + 4) / 1e9:.2f} GB), k={k}, nq=1; two-stage exact search: sample -> threshold "
+                                   "-> every row that could belong to the top-k collected from the int8 rows (two int8 "
+                                   "query pieces, v_dot4_i32_i8: exact integer sums) -> fp32 re-scoring (fp32 scan only "
+                                   "if more than 16384 rows qualify); any k <= 1024; batches of queries use a bf16 "
+                                   "shadow on the matrix cores (built on the first batched search)", "rows_per_gpu": rows_per_rank,
                        "parallelism": f"row-shard x{world} + ONE RCCL all-gather of the packed per-shard (score,id)[nq,k] lists",
                        "allgather_payload_bytes_per_rank_nq1": int(getattr(index, "last_exchange_bytes", 0)) if world > 1
                        else 0, "collectives_per_query": 1 if world > 1 else 0},
-            "roofline": {"kernel": "ip_collect_bf16_kernel<1,8> (the pass over the bf16 rows of the two-stage exact search)", "bound": "hbm",
+            "roofline": {"kernel": "ip_collect_i8_kernel<32> (the pass over the int8 rows of the two-stage exact search)", "bound": "hbm",
                          "achieved": round(scan_gbs, 1),
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(scan_gbs / PEAK_HBM_GBS, 4),
                          "avg_launch_us": round(s_ms / max(s_n, 1) * 1e3, 2), "launches": int(s_n),
                          "bytes_per_launch": s_bytes / max(s_n, 1),
-                         "note": "bytes the kernel has to move: the bf16 shadow rows, N*d*2 per query; the fp32 rows "
-                                 "(N*d*4, SURVEY 8(d)) are touched only for the collected candidates and by the fallback scan",
+                         "note": "bytes the kernel has to move: the int8 shadow rows and their scales, N*(d+4) per query; the "
+                                 "fp32 rows (N*d*4, SURVEY 8(d)) are touched only for the collected candidates and by the "
+                                 "fallback scan (fp32_scan_only_queries_per_s: 0.83 of HBM on those bytes)",
                          "fp32_rows_equivalent_gbs": round(n_loc * d * 4 / (s_ms / max(s_n, 1) * 1e-3) / 1e9, 1),
-                         **traffic_fields("ip_collect_bf16_kernel")},
+                         **traffic_fields("ip_collect_i8_kernel")},
             "two_stage": {"answered_from_the_shadow": int(shadow_stats[0]), "handed_to_fp32_scan": int(shadow_stats[1]),
                           "fp32_scan_only_queries_per_s": round(qps_f32, 2)},
             **by_k,

@@ -62,6 +62,7 @@ def main():
     for key, prefix, per in (("gemm_bf16_kernel", "gemm_", 1), ("ip_scan_kernel", "ip_scan_kernel", 1),
                              ("ip_scan_mfma_kernel", "ip_scan_mfma_kernel", 1),
                              ("ip_collect_bf16_kernel", "ip_collect_bf16_kernel", 1),
+                             ("ip_collect_i8_kernel", "ip_collect_i8_kernel", 1),
                              ("ip_scan_split_direct_kernel", "ip_scan_split_direct_kernel", 2),
                              ("ip_scan_split64_kernel", "ip_scan_split64_kernel", 2),
                              ("ip_scan_shadow64_kernel", "ip_scan_shadow64_kernel", 2),
@@ -83,7 +84,7 @@ def main():
         print("htsat_forward", res["htsat_forward"]["hbm_bytes_per_launch"] / 1e9, "GB per forward")
     dst = Path(__file__).resolve().parent.parent / "profiles" / "pmc_traffic.json"
     dst.write_text(json.dumps(res, indent=1))
-    for k in ("gemm_bf16_kernel", "ip_scan_kernel", "ip_collect_bf16_kernel", "ip_scan_shadow64_kernel", "ip_scan_split_direct_kernel", "ip_scan_split64_kernel", "clip_resize_kernel"):
+    for k in ("gemm_bf16_kernel", "ip_scan_kernel", "ip_collect_bf16_kernel", "ip_collect_i8_kernel", "ip_scan_shadow64_kernel", "ip_scan_split_direct_kernel", "ip_scan_split64_kernel", "clip_resize_kernel"):
         if k in res:
             print(k, res[k]["hbm_bytes_per_launch"] / 1e6, "MB/launch over", res[k]["launches"], "launches")
     for k, v in out.items():

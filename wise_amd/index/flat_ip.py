@@ -156,7 +156,7 @@ class FlatIPIndex:
         # queries/s against 65 k at nq = 256, and k = 100 overflows its lists).
         batched_shape = ((nq >= 2 and 1 <= k <= 12 and self.d in (256, 512)) or
                          (nq >= 3 and 1 <= k <= 128 and self.d in (256, 512, 768, 1024)))
-        use8 = (self.shadow8 and self._n >= (1 << 18) and 1 <= k <= 1024 and
+        use8 = (self.shadow and self.shadow8 and self._n >= (1 << 18) and 1 <= k <= 1024 and
                 (nq <= 5 or (not batched_shape and nq <= 64)))
         if use8 and self._ensure_shadow8(lib):
             need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k)
