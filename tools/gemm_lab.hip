@@ -107,6 +107,12 @@ int main(int argc, char** argv) {
         shapes.push_back({"L14fc1 65792x4096x1024", 65792, 4096, 1024, 1});
         shapes.push_back({"L14fc2 65792x1024x4096", 65792, 1024, 4096, 3});
     }
+    if (which == "h14" || which == "all") {
+        shapes.push_back({"H14qkv 65792x3840x1280", 65792, 3840, 1280, 0});
+        shapes.push_back({"H14out 65792x1280x1280", 65792, 1280, 1280, 3});
+        shapes.push_back({"H14fc1 65792x5120x1280", 65792, 5120, 1280, 2});
+        shapes.push_back({"H14fc2 65792x1280x5120", 65792, 1280, 5120, 3});
+    }
     void* h = dlopen("wise_amd/lib/libwise_hip_debug.so", RTLD_NOW | RTLD_LOCAL);
     gemm_fn old_gemm = h ? (gemm_fn)dlsym(h, "wise_gemm_bf16") : nullptr;
     variant_fn set_variant = h ? (variant_fn)dlsym(h, "wise_debug_set_gemm_variant") : nullptr;

@@ -2253,7 +2253,15 @@ static int w4_variant(int M, int N, int K, int mode) {
                                  {67, 4, 6, 1100.0, false}, {68, 4, 8, 1360.0, false}};
     double best = 0.0;
     int v = 0;
+    // The model ranks w4 tiles against each other; it knows nothing of the two-blocks-per-CU kernels.  So the tiles added
+    // for HTSAT (66 .. 68) compete only where the choice is inside the family already — one of the older tiles divides the
+    // shape — or K < 512, where they were measured against those kernels.  (ViT-L/14 and H/14, M = 129 x 128 and 65 x 128
+    // rows with K >= 1024, fit only the new tiles and lose 5 % on them: they stay where they were.)
+    bool family = K < 512;
+    for (const Cand& c : cands)
+        if (c.id <= 65 && !(c.bf16_only && !bf16_out(mode)) && w4_shape_ok(M, N, K, c.mi, c.nj)) family = true;
     for (const Cand& c : cands) {
+        if (c.id > 65 && !family) continue;
         if (c.bf16_only && !bf16_out(mode)) continue;
         if (!w4_shape_ok(M, N, K, c.mi, c.nj)) continue;
         const long long tiles = (long long)(M / (32 * c.mi)) * (N / (32 * c.nj));
@@ -2261,7 +2269,13 @@ static int w4_variant(int M, int N, int K, int mode) {
         const long long rounds = (tiles + 255) / 256;
         const double epilogue = 10500.0 * (c.mi * c.nj / 64.0) * (bf16_out(mode) ? 1.0 : 2.0);
         const double act = (mode == EPI_QUICKGELU || mode == EPI_GELU || mode == EPI_GELU_TANH) ? 5000.0 * (c.mi * c.nj / 40.0) : 0.0;
-        const double cost = (double)rounds * (3200.0 + (K / 64) * c.step + epilogue + act);
+        // operands beyond what the caches hold (> 64 MB): every CU streams its K-steps from the memory side, and a step
+        // cannot be shorter than its bytes at ~28 B per clock and CU (measured: 128 x 256 tiles 1360 -> 1640 cycles per
+        // step on ViT-L/14's fc2, 160 x 256 1700 -> 1950 on ViT-B/32's; 256 x 256, fewer bytes per flop, unchanged)
+        const bool streams = ((double)M + (double)N) * (double)K * 2.0 > 64.0e6;
+        const double step_bytes = (32.0 * c.mi + 32.0 * c.nj) * 128.0;
+        const double step = streams && step_bytes / 28.0 > c.step ? step_bytes / 28.0 : c.step;
+        const double cost = (double)rounds * (3200.0 + (K / 64) * step + epilogue + act);
         if (v == 0 || cost < best) { best = cost; v = c.id; }
     }
     // the persistent form: no prologue between tiles, the C tile leaves under the next tile's loop; what stays exposed per
@@ -2272,7 +2286,8 @@ static int w4_variant(int M, int N, int K, int mode) {
         if (tiles >= cus) {
             const long long rounds = (tiles + cus - 1) / cus;
             const double pack = (mode == EPI_QUICKGELU || mode == EPI_GELU || mode == EPI_GELU_TANH) ? 6200.0 : 1900.0;
-            const double cost = 3200.0 + (double)rounds * ((K / 64) * 1660.0 + 1700.0 + pack) + 5000.0;
+            const bool streams = ((double)M + (double)N) * (double)K * 2.0 > 64.0e6;
+            const double cost = 3200.0 + (double)rounds * ((K / 64) * (streams ? 1902.0 : 1660.0) + 1700.0 + pack) + 5000.0;
             if (v == 0 || cost < best) { best = cost; v = 64; }
         }
     }
