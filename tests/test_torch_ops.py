@@ -73,6 +73,11 @@ def test_search_operators_equal_the_index_classes():
         D1, I1 = torch.ops.wise_hip.ip_topk_shadow(X, Xb, norms, Q[q:q + 1], k, ids, 0, counters)
         assert torch.equal(I1, Ir[q:q + 1]) and torch.allclose(D1, Dr[q:q + 1], atol=2e-6)
     assert counters.tolist() == [2, 0]
+    Xq, scales, norms8 = torch.ops.wise_hip.ip_shadow_i8(X)
+    for q in range(2):       # ... and over the int8 shadow
+        D1, I1 = torch.ops.wise_hip.ip_topk_shadow8(X, Xq, scales, norms8, Q[q:q + 1], k, ids, 0, counters)
+        assert torch.equal(I1, Ir[q:q + 1]) and torch.allclose(D1, Dr[q:q + 1], atol=2e-6)
+    assert counters.tolist() == [4, 0]
     # two half shards merged == the whole
     h = N // 2
     Da, Ia = torch.ops.wise_hip.ip_topk(X[:h], Q, k, ids[:h], 0)

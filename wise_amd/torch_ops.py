@@ -32,6 +32,9 @@ SCHEMAS = {
     "ip_shadow_bf16": "(Tensor X) -> (Tensor, Tensor)",
     "ip_topk_shadow": "(Tensor X, Tensor Xb, Tensor norms, Tensor Q, int k, Tensor? ids, int id_base, "
                       "Tensor(a!) counters) -> (Tensor, Tensor)",
+    "ip_shadow_i8": "(Tensor X) -> (Tensor, Tensor, Tensor)",
+    "ip_topk_shadow8": "(Tensor X, Tensor Xq, Tensor scales, Tensor norms, Tensor Q, int k, Tensor? ids, int id_base, "
+                       "Tensor(a!) counters) -> (Tensor, Tensor)",
     "topk_merge": "(Tensor Ds, Tensor Is, int k) -> (Tensor, Tensor)",
     "reconstruct_batch": "(Tensor X, Tensor? ids, int id_base, Tensor query_ids) -> Tensor",
     # IndexIVFFlat (src/index/feature_search_index.py:53-76, api/routes.py:899-902)
@@ -113,6 +116,43 @@ def _ip_topk_shadow(X, Xb, norms, Q, k, ids, id_base, counters):
     _check(lib.wise_ip_topk_shadow_f32(X.data_ptr(), Xb.data_ptr(), norms.data_ptr(), N, d, Q.data_ptr(), nq, k,
                                        _lib.ptr(ids), id_base, D.data_ptr(), I.data_ptr(), counters.data_ptr(),
                                        ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "wise_ip_topk_shadow_f32")
+    return D, I
+
+
+def _ip_shadow_i8(X):
+    lib = _lib.lib()
+    _dev(X)
+    X = _f32c(X)
+    Xq = torch.empty(X.shape, dtype=torch.int8, device=X.device)
+    scales = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
+    norms = torch.zeros(4, dtype=torch.float32, device=X.device)
+    _check(lib.wise_ip_shadow_i8(X.data_ptr(), X.shape[0], X.shape[1], Xq.data_ptr(), scales.data_ptr(), norms.data_ptr(),
+                                 _lib.stream_ptr()), "wise_ip_shadow_i8")
+    return Xq, scales, norms
+
+
+def _ip_topk_shadow8(X, Xq, scales, norms, Q, k, ids, id_base, counters):
+    lib = _lib.lib()
+    _dev(X, Xq, scales, norms, Q, ids, counters)
+    X, Q = _f32c(X), _f32c(Q)
+    N, d = X.shape
+    nq = Q.shape[0]
+    D = torch.empty(nq, k, dtype=torch.float32, device=X.device)
+    I = torch.empty(nq, k, dtype=torch.int64, device=X.device)
+    if nq == 0:
+        return D, I
+    if counters.dtype != torch.int32 or counters.numel() < 2:
+        raise ValueError("wise_hip::ip_topk_shadow8: counters must be an int32 tensor of two elements")
+    if Xq.dtype != torch.int8 or scales.dtype != torch.float32 or norms.numel() < 4:
+        raise ValueError("wise_hip::ip_topk_shadow8: Xq int8 [N,d], scales fp32 [N], norms fp32 [4] (ip_shadow_i8's outputs)")
+    need = max(lib.wise_ip_topk_shadow_workspace_bytes(N, d, nq, k), lib.wise_ip_topk_workspace_bytes(N, d, nq, k))
+    if need == 0 or d % 16 != 0:
+        raise ValueError(f"wise_hip::ip_topk_shadow8: unsupported shape N={N} d={d} nq={nq} k={k}")
+    ws = torch.empty(need, dtype=torch.uint8, device=X.device)
+    _check(lib.wise_ip_topk_shadow8_f32(X.data_ptr(), Xq.contiguous().data_ptr(), scales.contiguous().data_ptr(),
+                                        norms.data_ptr(), N, d, Q.data_ptr(), nq, k, _lib.ptr(ids), id_base, D.data_ptr(),
+                                        I.data_ptr(), counters.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+           "wise_ip_topk_shadow8_f32")
     return D, I
 
 
@@ -288,6 +328,10 @@ _IMPLS = {
     "ip_shadow_bf16": (_ip_shadow_bf16, lambda X: (X.new_empty(X.shape, dtype=torch.int16),
                                                    X.new_empty((2,), dtype=torch.float32))),
     "ip_topk_shadow": (_ip_topk_shadow, lambda X, Xb, norms, Q, k, ids, id_base, counters: _fake_pair(Q.shape[0], k, X)),
+    "ip_shadow_i8": (_ip_shadow_i8, lambda X: (X.new_empty(X.shape, dtype=torch.int8), X.new_empty((X.shape[0],), dtype=torch.float32),
+                                               X.new_empty((4,), dtype=torch.float32))),
+    "ip_topk_shadow8": (_ip_topk_shadow8,
+                        lambda X, Xq, scales, norms, Q, k, ids, id_base, counters: _fake_pair(Q.shape[0], k, X)),
     "topk_merge": (_topk_merge, lambda Ds, Is, k: _fake_pair(Ds.shape[1], k, Ds)),
     "reconstruct_batch": (_reconstruct_batch, lambda X, ids, id_base, q: X.new_empty((q.numel(), X.shape[1]),
                                                                                    dtype=torch.float32)),
