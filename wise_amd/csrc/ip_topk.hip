@@ -606,12 +606,13 @@ __global__ void shadow_i8_finish_kernel(float* __restrict__ norms, int d) {
     if (threadIdx.x == 0 && blockIdx.x == 0) norms[1] = norms[2] + sqrtf((float)d) * 1.6e-5f * norms[0];
 }
 
-// One group of R = 8 * (64 / LPR) rows of the int8 shadow against the query: LPR lanes cover a row (16 bytes each,
+// One group of R = I8_T * (64 / LPR) rows of the int8 shadow against the query: LPR lanes cover a row (16 bytes each,
 // LPR = 16 / 32 / 64 for d <= 256 / 512 / 1024), so one wave instruction loads 64 / LPR whole rows; eight such
 // instructions are in flight per group.  Every lane ends up with the score of row `row0 + myr` (valid where `owner`).
+constexpr int I8_T = 8, I8_TB = 3;       // wave-loads in flight per group of the int8 scans (and its log2)
 template <int LPR>
 struct ShadowGroupI8 {
-    static constexpr int RPI = 64 / LPR, T = 8, R = T * RPI;
+    static constexpr int RPI = 64 / LPR, T = I8_T, R = T * RPI;
     static constexpr int LOGL = (LPR == 64) ? 6 : (LPR == 32) ? 5 : 4;
     int qh[4], ql[4];
     float sq, sl;
@@ -648,13 +649,14 @@ struct ShadowGroupI8 {
             qh[w] = (int)ph;
             ql[w] = (int)pl;
         }
-        // transposition over the three lane bits under the row-select bits, then plain sums over the rest
+        // transposition over the I8_TB lane bits under the row-select bits, then plain sums over the rest (16 loads in flight
+        // instead of 8 measured 6 % slower at k = 10 and 15 % faster at k = 1000: fewer, larger hit groups)
         myr = 0;
         int bit = LOGL - 1;
 #pragma unroll
         for (int h = T / 2; h >= 1; h >>= 1, --bit) myr += ((lane >> bit) & 1) * h;
         myr = myr * RPI + sub;
-        owner = (lane & ((LPR >> 3) - 1)) == 0;
+        owner = (lane & ((LPR >> I8_TB) - 1)) == 0;
     }
     __device__ float score(const signed char* __restrict__ Xq, const float* __restrict__ scales, long long row0,
                            long long row_end, int d, int lane) const {
@@ -697,7 +699,7 @@ struct ShadowGroupI8 {
         }
         float sc = a[0];
 #pragma unroll
-        for (int m = (LPR >> 4); m >= 1; m >>= 1) sc += __shfl_xor(sc, m, 64);
+        for (int m = (LPR >> (I8_TB + 1)); m >= 1; m >>= 1) sc += __shfl_xor(sc, m, 64);
         return sc * rs;
     }
 };
@@ -1211,7 +1213,14 @@ __global__ __launch_bounds__(1024) void sample_threshold_kth_kernel(const float*
     for (int j = 0; j < PER; ++j) {
         const int seg = j * 1024 + tid;
         float m = -3.4028234663852886e38f;
-        for (int i = seg; i < n; i += SEGS) m = fmaxf(m, dump[i]);
+        // (n <= 65536 = SAMPLE_CHUNKS x 512: at most eight scores per segment, all eight loads of all eight segments in
+        // flight at once — as a counted loop this was 64 dependent round trips to L2, 20 of the kernel's 29 us)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int i = seg + t * SEGS;
+            m = fmaxf(m, i < n ? dump[i] : -3.4028234663852886e38f);
+        }
+        for (int i = seg + 8 * SEGS; i < n; i += SEGS) m = fmaxf(m, dump[i]);
         live[j] = seg < n;
         mine[j] = f32_order(m);
     }
@@ -1242,9 +1251,35 @@ __device__ u64 list_kth_score(const u64* __restrict__ cand, int n, int k, unsign
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const u64 prefix = *sh_prefix;
-        for (int i = tid; i < n; i += 1024) {
-            const u64 key = cand[i];
-            if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+        for (int i0 = 0; i0 < n; i0 += 8 * 1024) {
+            // Eight keys per thread are loaded before any is counted: one key per trip made a pass a chain of n / 1024
+            // dependent round trips to L2 (35 of them with the int8 shadow's lists: 14 us per byte pass).
+            u64 keys8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 1024 + tid;
+                keys8[u] = i < n ? cand[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                // The collected scores sit in a narrow band, so in the upper byte passes nearly every key falls into one
+                // or two buckets: a wave first counts the bucket of its first live lane — and then of the next — with a
+                // ballot and adds the count once; what is left goes one by one.
+                const u64 key = keys8[u];
+                bool todo = i0 + u * 1024 + tid < n && (key & mask) == prefix;
+                const unsigned b = (unsigned)(key >> shift) & 255u;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const u64 act = __ballot(todo);
+                    if (act == 0) break;
+                    const int leader = __ffsll((long long)act) - 1;
+                    const unsigned lb = (unsigned)__shfl((int)b, leader, 64);
+                    const u64 same = __ballot(todo && b == lb);
+                    if ((tid & 63) == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
+                    todo = todo && b != lb;
+                }
+                if (todo) atomicAdd(&hist[b], 1u);
+            }
         }
         __syncthreads();
         if (tid < 64) {
@@ -1348,19 +1383,27 @@ __global__ __launch_bounds__(1024) void collect_finish_kernel(int* __restrict__ 
     for (int w = 0; w < 16; ++w) qq += wsum[w];
     const float t2 = L != 0 ? f32_unorder((unsigned)(L >> 32)) - 2.f * shadow_eps(norms, d, qq) : -3.4028234663852886e38f;
     // ---- survivors: into LDS while they fit, into cand2 always (the multi-block path reads them there)
-    for (int i0 = 0; i0 < n; i0 += 1024) {
-        const int i = i0 + tid;
-        const u64 key = i < n ? cand[i] : 0;
-        const bool pass = key != 0 && f32_unorder((unsigned)(key >> 32)) >= t2;
-        const u64 bal = __ballot(pass);
-        if (bal != 0) {
-            const int first = __ffsll((long long)bal) - 1;
-            int base = 0;
-            if (lane == first) base = atomicAdd(&kept, __popcll(bal));
-            base = __shfl(base, first, 64);
-            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pass && pos < FINISH_LDS_ROWS) keys[pos] = key;
-            if (pass && pos < RESCORE_CAP) cand2[pos] = key;
+    for (int i0 = 0; i0 < n; i0 += 8 * 1024) {
+        u64 keys8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 1024 + tid;
+            keys8[u] = i < n ? cand[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const u64 key = keys8[u];
+            const bool pass = key != 0 && f32_unorder((unsigned)(key >> 32)) >= t2;
+            const u64 bal = __ballot(pass);
+            if (bal != 0) {
+                const int first = __ffsll((long long)bal) - 1;
+                int base = 0;
+                if (lane == first) base = atomicAdd(&kept, __popcll(bal));
+                base = __shfl(base, first, 64);
+                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (pass && pos < FINISH_LDS_ROWS) keys[pos] = key;
+                if (pass && pos < RESCORE_CAP) cand2[pos] = key;
+            }
         }
     }
     __syncthreads();
@@ -1373,30 +1416,35 @@ __global__ __launch_bounds__(1024) void collect_finish_kernel(int* __restrict__ 
         }
         return;
     }
-    // ---- exact scores of the survivors: wave per row, two in flight (collect_rescore_kernel's arithmetic)
+    // ---- exact scores of the survivors: wave per row, EIGHT in flight (collect_rescore_kernel's arithmetic: a row's
+    // per-lane fmaf chain and butterfly do not depend on how many rows travel together; with two in flight a few hundred
+    // survivors were a dozen dependent round trips to HBM)
     {
         const int d4 = d >> 2;
         const float4* qv = reinterpret_cast<const float4*>(Q);
-        for (int i0 = wave * 2; i0 < nk; i0 += 32) {
-            long long rows[2];
-            float p[2] = {0.f, 0.f};
+        constexpr int RF = 8;
+        for (int i0 = wave * RF; i0 < nk; i0 += 16 * RF) {
+            long long rows[RF];
+            float p[RF];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < RF; ++u) {
                 rows[u] = i0 + u < nk ? (long long)(0xFFFFFFFFu - (unsigned)(keys[i0 + u] & 0xFFFFFFFFull)) : -1;
+                p[u] = 0.f;
+            }
             for (int j = lane; j < d4; j += 64) {
                 const float4 b = qv[j];
-                float4 a[2];
+                float4 a[RF];
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < RF; ++u)
                     a[u] = rows[u] >= 0 ? reinterpret_cast<const float4*>(X + (size_t)rows[u] * d)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < RF; ++u) {
                     p[u] = fmaf(a[u].x, b.x, p[u]); p[u] = fmaf(a[u].y, b.y, p[u]);
                     p[u] = fmaf(a[u].z, b.z, p[u]); p[u] = fmaf(a[u].w, b.w, p[u]);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < RF; ++u) {
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) p[u] += __shfl_xor(p[u], o, 64);
                 if (lane == 0 && rows[u] >= 0) keys[i0 + u] = make_key(p[u], (unsigned)rows[u]);
@@ -2030,7 +2078,7 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norm
     const uint4* xb = reinterpret_cast<const uint4*>(Xb);
     // int8 rows: 16 / 32 / 64 lanes per row, groups of 32 / 16 / 8 rows
     const int lpr = Xq ? (d <= 256 ? 16 : d <= 512 ? 32 : 64) : 0;
-    const int grows = Xq ? 8 * (64 / lpr) : 8;           // rows per group of the two scans
+    const int grows = Xq ? I8_T * (64 / lpr) : 8;        // rows per group of the two scans
     if (Xq && (d % 16 != 0 || d > 1024 || !scales)) { set_error("ip_topk_shadow8: d=%d must be a multiple of 16 up to 1024", d); return WISE_E_INVALID; }
     // ---- sample: SAMPLE_CHUNKS evenly spaced chunks of 2^shift groups of 8 rows, every sampled score dumped.  About
     // N / 64 rows, between 16384 and 65536 (a shard of an index sharded over eight GPUs pays a quarter of the sample a
@@ -2039,7 +2087,7 @@ static int shadow_search_one(const float* X, const bf16_t* Xb, const float* norm
     {
         int shift = SAMPLE_CHUNK_SHIFT;                  // 512 rows per chunk
         while (shift > 4 && (long long)SAMPLE_CHUNKS * (8ll << shift) * 64 > N) --shift;
-        shift -= (grows == 16) ? 1 : (grows == 32) ? 2 : 0;            // the same rows per chunk in larger groups
+        for (int gr = grows; gr > 8; gr >>= 1) --shift;                // the same rows per chunk in larger groups
         const long long groups = N / grows;              // whole groups only: a sampled group is never ragged
         const long long chunk_groups = 1ll << shift;
         const long long stride = (groups - chunk_groups) / (SAMPLE_CHUNKS - 1);      // last chunk ends inside the index
