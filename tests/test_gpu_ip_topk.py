@@ -278,6 +278,22 @@ def test_int8_shadow_rows_obey_their_definition(d):
     assert np.isclose(nm[1], nm[2] + np.sqrt(d) * 1.6e-5 * nm[0], rtol=1e-5)
 
 
+@pytest.mark.parametrize("N,d,k", [(300000, 256, 1000), (600000, 512, 1000), (262144, 1024, 300)])
+def test_int8_entry_point_beyond_the_k_the_index_class_sends_it(N, d, k):
+    """FlatIPIndex keeps k > 256 on the bf16 copy (the int8 band fills most of the re-scoring list at k = 1000 on 10M rows); the
+    entry point itself serves any k <= 1024: same ids and scores as the fp32 scan."""
+    import wise_amd.torch_ops  # noqa: F401  (registers torch.ops.wise_hip)
+    X = torch.from_numpy(unit_rows(N, d, 1700 + k)).cuda()
+    Q = torch.from_numpy(unit_rows(2, d, 1701)).cuda()
+    Xq, scales, norms = torch.ops.wise_hip.ip_shadow_i8(X)
+    counters = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for q in range(2):
+        D8, I8 = torch.ops.wise_hip.ip_topk_shadow8(X, Xq, scales, norms, Q[q:q + 1], k, None, 3, counters)
+        Df, If = torch.ops.wise_hip.ip_topk(X, Q[q:q + 1], k, None, 3)
+        assert torch.equal(I8, If) and torch.allclose(D8, Df, atol=2e-6)
+    assert counters.tolist() == [2, 0]
+
+
 def clustered_rows(n_items, per_item, d, seed, spread=0.03):
     """`per_item` near-duplicates of each of `n_items` directions, stored back to back — 2-fps frames of the same
     shot (extract-features.py:292-297,353); cosine between duplicates >= 1 - spread^2 (0.9991 at 0.03)."""

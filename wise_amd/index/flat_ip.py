@@ -156,7 +156,10 @@ class FlatIPIndex:
         # queries/s against 65 k at nq = 256, and k = 100 overflows its lists).
         batched_shape = ((nq >= 2 and 1 <= k <= 12 and self.d in (256, 512)) or
                          (nq >= 3 and 1 <= k <= 128 and self.d in (256, 512, 768, 1024)))
-        use8 = (self.shadow and self.shadow8 and self._n >= (1 << 18) and 1 <= k <= 1024 and
+        # k > 256 (the retrieval evaluation's --topk 1000) goes over the bf16 copy: at k = 1000 on 10M iid rows the int8
+        # band already keeps 13 k of the 16 k rows the re-scoring list holds — any clustering would overflow it into the
+        # fp32 scan — and the two are equally fast there (the lists, not the bytes, set the time)
+        use8 = (self.shadow and self.shadow8 and self._n >= (1 << 18) and 1 <= k <= 256 and
                 (nq <= 5 or (not batched_shape and nq <= 64)))
         if use8 and self._ensure_shadow8(lib):
             need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k)
