@@ -72,10 +72,18 @@ class IVFFlatIPIndex:
 
     # -- training -------------------------------------------------------------------------------
     @staticmethod
-    def _assign(x: torch.Tensor, centroids: torch.Tensor, chunk: int = 1 << 16) -> torch.Tensor:
+    def _assign(x: torch.Tensor, centroids: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
+        """nearest centroid of every row by inner product: this library's exact-f32 score kernel (wise_ip_scores_f32,
+        the coarse stage's own) + an argmax — no vendor GEMM in training or assignment either"""
+        lib = _lib.lib()
+        c = centroids.contiguous()
         out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+        scores = torch.empty(min(chunk, max(x.shape[0], 1)), c.shape[0], dtype=torch.float32, device=x.device)
         for s in range(0, x.shape[0], chunk):
-            out[s:s + chunk] = (x[s:s + chunk] @ centroids.t()).argmax(dim=1)
+            q = x[s:s + chunk].contiguous()
+            _lib.check(lib.wise_ip_scores_f32(c.data_ptr(), c.shape[0], c.shape[1], q.data_ptr(), q.shape[0],
+                                              scores.data_ptr(), _lib.stream_ptr()), "wise_ip_scores_f32")
+            out[s:s + chunk] = scores[: q.shape[0]].argmax(dim=1)
         return out
 
     def train(self, x) -> None:
