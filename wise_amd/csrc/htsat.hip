@@ -35,7 +35,7 @@ int mlp96_fused(float* x, const float* lnw, const float* lnb, const bf16_t* W1, 
 namespace htsat {
 // htsat_frontend.hip: frontend() — declared in transformer.h
 static int g_frontend_only = 0;  // (debug) stop after the front end: concurrency tests tap the log-mel
-static int g_fuse_ln = 7;  // bit 0: LayerNorm-in-GEMM fusion, bit 1: fused MLP (stage 1), bit 2: fused attention half of a stage-1 block; wise_debug_set_htsat flips them off
+static int g_fuse_ln = 15;  // bit 0: LayerNorm-in-GEMM fusion, bit 1: fused MLP (stage 1), bit 2: fused attention half of a stage-1 block, bit 3: token-per-lane embedding; wise_debug_set_htsat flips them off
 constexpr int N_FFT = 1024, HOP = 320, N_MELS = 64, MELW = FRONT_MELW, MAXF = 1024;
 constexpr int EMBED = 96, LATENT = 768, OUT = 1024;
 constexpr int DEPTHS[4] = {2, 2, 6, 2};
@@ -117,6 +117,112 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ me
         float* xr = x + ((size_t)blockIdx.x * 64 + j) * EMBED;
         xr[c0] = d0 * rstd * g0 + h0;
         if (has1) xr[c1] = d1 * rstd * g1 + h1;
+    }
+}
+
+// The same embedding with lane = token (the form that runs): a block = four rows i of one clip's 64 x 64 token grid, a wave
+// = the 64 tokens of one row.  embed_kernel above (lane = channel) spends ~90 instructions per token — two six-step
+// cross-lane sums for the LayerNorm of every token and 32 of 64 lanes idle on the second channel — and ran at 0.23 of
+// the HBM rate of its 235 MB; here a lane keeps its token's 16 pixels and all 96 channels in registers, the conv weights
+// are wave-uniform (scalar loads), the LayerNorm sums are per-lane and serial, and the [64 tokens x 96] tile leaves through
+// a wave-private LDS image in three 32-channel rounds so that every store instruction writes whole 128-byte lines.
+// The convolution's fmaf chain is the one of embed_kernel (bias, then taps 0..15); the LayerNorm sums run in a different
+// order (serial per lane instead of a butterfly), i.e. the result differs in the last bits.
+__global__ __launch_bounds__(256) void embed_tok_kernel(const float* __restrict__ melbn, int B, int Fc,
+                                                        const float* __restrict__ pw /*[96][16]*/,
+                                                        const float* __restrict__ pb, const float* __restrict__ lnw,
+                                                        const float* __restrict__ lnb, float* __restrict__ x) {
+    __shared__ __attribute__((aligned(16))) float pix[4][4][256];          // [row of the block][mel bin][time column]
+    __shared__ __attribute__((aligned(16))) float tile[4][64 * 36];        // per wave: 64 tokens x 32 channels, 144-byte rows
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x >> 4, i0 = (blockIdx.x & 15) * 4;             // rows i0 .. i0+3: one time block r, 16 mel bins
+    {
+        const int r = i0 >> 4, f0 = (4 * i0) & 63;
+        const int t = r * 256 + threadIdx.x;
+        const float* m = melbn + (size_t)b * Fc * 64 + f0;
+        float4 v[4];
+        if (Fc == MAXF) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(m + (size_t)t * 64 + 4 * q);
+        } else {
+            const float scale = (float)(Fc - 1) / (float)(MAXF - 1);
+            const float src = (float)t * scale;
+            const float fl = floorf(src);
+            const int j0 = (int)fl;
+            const float tt = src - fl;
+            const float w0 = cubic2(tt + 1.f), w1 = cubic1(tt), w2 = cubic1(1.f - tt), w3 = cubic2(2.f - tt);
+            const int a0 = min(max(j0 - 1, 0), Fc - 1), a1 = min(max(j0, 0), Fc - 1), a2 = min(max(j0 + 1, 0), Fc - 1),
+                      a3 = min(max(j0 + 2, 0), Fc - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 q0 = *reinterpret_cast<const float4*>(m + (size_t)a0 * 64 + 4 * q);
+                const float4 q1 = *reinterpret_cast<const float4*>(m + (size_t)a1 * 64 + 4 * q);
+                const float4 q2 = *reinterpret_cast<const float4*>(m + (size_t)a2 * 64 + 4 * q);
+                const float4 q3 = *reinterpret_cast<const float4*>(m + (size_t)a3 * 64 + 4 * q);
+                // same accumulation order as the oracle: taps 0..3 added in turn
+                v[q].x = q0.x * w0; v[q].x += q1.x * w1; v[q].x += q2.x * w2; v[q].x += q3.x * w3;
+                v[q].y = q0.y * w0; v[q].y += q1.y * w1; v[q].y += q2.y * w2; v[q].y += q3.y * w3;
+                v[q].z = q0.z * w0; v[q].z += q1.z * w1; v[q].z += q2.z * w2; v[q].z += q3.z * w3;
+                v[q].w = q0.w * w0; v[q].w += q1.w * w1; v[q].w += q2.w * w2; v[q].w += q3.w * w3;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pix[q][0][threadIdx.x] = v[q].x; pix[q][1][threadIdx.x] = v[q].y;
+            pix[q][2][threadIdx.x] = v[q].z; pix[q][3][threadIdx.x] = v[q].w;
+        }
+    }
+    __syncthreads();
+    // ---- this wave's row, lane = token j: pixel p = (mel bin p >> 2, time column 4 j + (p & 3))
+    float pv[16];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const float4 q = *reinterpret_cast<const float4*>(&pix[wv][rr][4 * lane]);
+        pv[rr * 4 + 0] = q.x; pv[rr * 4 + 1] = q.y; pv[rr * 4 + 2] = q.z; pv[rr * 4 + 3] = q.w;
+    }
+    float y[EMBED];
+#pragma unroll
+    for (int c = 0; c < EMBED; ++c) {
+        float a = pb[c];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) a = fmaf(pw[c * 16 + p], pv[p], a);
+        y[c] = a;
+    }
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < EMBED; ++c) s4[c & 3] += y[c];
+    const float mean = ((s4[0] + s4[1]) + (s4[2] + s4[3])) / (float)EMBED;
+    float q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < EMBED; ++c) { y[c] -= mean; q4[c & 3] = fmaf(y[c], y[c], q4[c & 3]); }
+    const float rstd = rsqrtf(((q4[0] + q4[1]) + (q4[2] + q4[3])) / (float)EMBED + 1e-5f);
+    // ---- out through the wave's image, 32 channels at a time
+    float* tl = tile[wv];
+    float* xrow = x + ((size_t)(b * 64 + i0 + wv) * 64) * EMBED;
+#pragma unroll
+    for (int rd = 0; rd < 3; ++rd) {
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            const int c = rd * 32 + k4 * 4;
+            float4 o;
+            o.x = y[c + 0] * rstd * lnw[c + 0] + lnb[c + 0];
+            o.y = y[c + 1] * rstd * lnw[c + 1] + lnb[c + 1];
+            o.z = y[c + 2] * rstd * lnw[c + 2] + lnb[c + 2];
+            o.w = y[c + 3] * rstd * lnw[c + 3] + lnb[c + 3];
+            *reinterpret_cast<float4*>(tl + lane * 36 + k4 * 4) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int tok = q * 8 + (lane >> 3), seg = lane & 7;
+            const float4 o = *reinterpret_cast<const float4*>(tl + tok * 36 + seg * 4);
+            *reinterpret_cast<float4*>(xrow + (size_t)tok * EMBED + rd * 32 + seg * 4) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -816,8 +922,12 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
                        pf + o.bn_shift, mel, st, 16 /* widest band of the 50..8000 Hz filterbank (pack_htsat_weights asserts it) */)))
         return rc;
     if (g_frontend_only) return WISE_OK;
-    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)(B * 64)), dim3(256), 0, st, mel, B, Fc,
-                       pf + o.pe_w, pf + o.pe_b, pf + o.pe_nw, pf + o.pe_nb, x);
+    if (g_fuse_ln & 8)
+        hipLaunchKernelGGL(embed_tok_kernel, dim3((unsigned)(B * 16)), dim3(256), 0, st, mel, B, Fc,
+                           pf + o.pe_w, pf + o.pe_b, pf + o.pe_nw, pf + o.pe_nb, x);
+    else
+        hipLaunchKernelGGL(embed_kernel, dim3((unsigned)(B * 64)), dim3(256), 0, st, mel, B, Fc,
+                           pf + o.pe_w, pf + o.pe_b, pf + o.pe_nw, pf + o.pe_nb, x);
     WISE_LAUNCH_CHECK("htsat embed_kernel");
 
     int H = 64;
@@ -909,7 +1019,7 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
 
 #ifdef WISE_DEBUG_KNOBS
 extern "C" int wise_debug_set_htsat(int flags) {
-    wise::htsat::g_fuse_ln = 7 & ~(flags & 7);   // flags bit 0: no LayerNorm fusion at all, bit 1: no fused MLP, bit 2: no fused attention half
+    wise::htsat::g_fuse_ln = 15 & ~((flags & 7) | ((flags >> 4) & 1) << 3);   // flags bit 0: no LayerNorm fusion at all, bit 1: no fused MLP, bit 2: no fused attention half, bit 4: lane-per-channel embedding
     wise::htsat::g_frontend_only = (flags >> 3) & 1;   // bit 3: front end only
     return 0;
 }
