@@ -38,7 +38,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--index-rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=512)
