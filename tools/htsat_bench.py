@@ -17,7 +17,7 @@ from wise_amd import _lib  # noqa: E402
 eng = HtsatEngine(random_htsat_state_dict(0), max_batch=B, max_samples=N)
 w = 0.1 * torch.randn(B, N, device="cuda")
 lib = _lib.lib()
-for flags in (0, 16, 0, 16, 4, 6):   # bit 0: no LayerNorm fusion at all, bit 1: no fused MLP, bit 2: no fused attention half (stage 1)
+for flags in (0, 32, 0, 32, 16):   # bit 0: no LayerNorm fusion at all, bit 1: no fused MLP, bit 2: no fused attention half (stage 1)
     lib.wise_debug_set_htsat(flags)
     for _ in range(3):
         o = eng.forward(w)

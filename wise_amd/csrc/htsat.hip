@@ -1021,6 +1021,7 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
 extern "C" int wise_debug_set_htsat(int flags) {
     wise::htsat::g_fuse_ln = 15 & ~((flags & 7) | ((flags >> 4) & 1) << 3);   // flags bit 0: no LayerNorm fusion at all, bit 1: no fused MLP, bit 2: no fused attention half, bit 4: lane-per-channel embedding
     wise::htsat::g_frontend_only = (flags >> 3) & 1;   // bit 3: front end only
+    wise::htsat::frontend_set_variant((flags >> 5) & 1);   // bit 5: the full-length FFT front end
     return 0;
 }
 #endif

@@ -62,6 +62,7 @@ int clap_projection(const bf16_t* lat, const bf16_t* W1, const bf16_t* W2, const
                     int d_in, float* e, bf16_t* g, float* out, hipStream_t st);
 
 namespace htsat {
+void frontend_set_variant(int full_fft);   // (debug) 1: the full-length FFT kernel of rounds 1-2
 // mel + bn0 of the first Fc frames of every clip (htsat_frontend.hip): melbn fp32 [B, Fc, 64]
 int frontend(const float* wave, int B, int samples, int Fc, const float* hann, const float* mel_start,
              const float* mel_len, const float* mel_wt, const float* bn_scale, const float* bn_shift, float* melbn,
