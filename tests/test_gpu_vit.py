@@ -28,6 +28,8 @@ def cosine(a, b):
                                     (6400, 2304, 768), (6400, 3072, 768),
                                     # 256x192 / 128x192 / 128x256 tiles (HTSAT stages 2-4: power-of-two rows, short K)
                                     (32768, 384, 384), (8192, 768, 3072), (16384, 576, 192), (8192, 1536, 384),
+                                    # ... and the two-workgroups-per-CU tiles for short K: 128x192 (above) and 128x128
+                                    (32768, 256, 192),
                                     # HTSAT shapes: N edge (N % 128 != 0) and K % 64 != 0
                                     (256, 288, 96), (128, 96, 384), (384, 192, 96), (256, 576, 192), (128, 36, 32)])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])

@@ -57,15 +57,15 @@ static float host_act(float x, int mode) {
     return x;
 }
 
-template <int MI, int NJ, int SA, int SW>
+template <int MI, int NJ, int SA, int SW, int OCC = 1>
 static void launch_new(int mode, const bf16_t* A, const bf16_t* W, const float* b, int M, int N, int K, void* out, hipStream_t st) {
     using namespace wise;
     switch (mode) {
-        case 0: launch_w4<EPI_BF16, MI, NJ, SA, SW>(A, W, b, M, N, K, out, st); break;
-        case 1: launch_w4<EPI_QUICKGELU, MI, NJ, SA, SW>(A, W, b, M, N, K, out, st); break;
-        case 2: launch_w4<EPI_GELU, MI, NJ, SA, SW>(A, W, b, M, N, K, out, st); break;
-        case 3: launch_w4<EPI_RESID, MI, NJ, SA, SW>(A, W, b, M, N, K, out, st); break;
-        case 4: launch_w4<EPI_F32, MI, NJ, SA, SW>(A, W, b, M, N, K, out, st); break;
+        case 0: launch_w4<EPI_BF16, MI, NJ, SA, SW, OCC>(A, W, b, M, N, K, out, st); break;
+        case 1: launch_w4<EPI_QUICKGELU, MI, NJ, SA, SW, OCC>(A, W, b, M, N, K, out, st); break;
+        case 2: launch_w4<EPI_GELU, MI, NJ, SA, SW, OCC>(A, W, b, M, N, K, out, st); break;
+        case 3: launch_w4<EPI_RESID, MI, NJ, SA, SW, OCC>(A, W, b, M, N, K, out, st); break;
+        case 4: launch_w4<EPI_F32, MI, NJ, SA, SW, OCC>(A, W, b, M, N, K, out, st); break;
     }
 }
 
@@ -154,6 +154,8 @@ int main(int argc, char** argv) {
         if (wise::w4_shape_ok(s.M, s.N, s.K, 7, 6)) vars.push_back({"w4 224x192", 1, 76});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 8, 6)) vars.push_back({"w4 256x192", 1, 86});
         if (wise::w4_shape_ok(s.M, s.N, s.K, 4, 6)) vars.push_back({"w4 128x192", 1, 46});
+        if (wise::w4_shape_ok(s.M, s.N, s.K, 4, 6)) vars.push_back({"w4 128x192 two per CU", 1, 462});
+        if (wise::w4_shape_ok(s.M, s.N, s.K, 4, 4)) vars.push_back({"w4 128x128 two per CU", 1, 442});
         if (wise::w4q_shape_ok(s.M, s.N, s.K, s.mode) && !f32o) vars.push_back({"w4q two-set 128x256", 1, 600});
         if (wise::w4p_shape_ok(s.M, s.N, s.K) && !f32o) vars.push_back({"w4p persistent 160x256", 1, 500});
 
@@ -171,6 +173,8 @@ int main(int argc, char** argv) {
             else if (v.arg == 76) launch_new<7, 6, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 86) launch_new<8, 6, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 46) launch_new<4, 6, 3, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            else if (v.arg == 462) launch_new<4, 6, 2, 2, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
+            else if (v.arg == 442) launch_new<4, 4, 3, 2, 2>(s.mode, A, W, bias, s.M, s.N, s.K, out, st);
             else if (v.arg == 600) {
                 using namespace wise;
                 if (s.mode == 0) launch_w4q<EPI_BF16>(A, W, bias, s.M, s.N, s.K, out, 256, st);

@@ -2190,6 +2190,13 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         case 68: if (w4_shape_ok(M, N, K, 4, 8)) { launch_w4<MODE, 4, 8, 3, 2>(A, Wt, bias, M, N, K, out, st); break; }
                  launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        // 69, 70: 128 x 192 (2 + 2 slots) and 128 x 128 tiles with TWO workgroups per CU (80 KiB of LDS, <= 256 registers per
+        // wave): one workgroup's prologue and epilogue run under the other's K-loop — short-K shapes, where a tile is
+        // mostly prologue and epilogue
+        case 69: if (w4_shape_ok(M, N, K, 4, 6)) { launch_w4<MODE, 4, 6, 2, 2, 2>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
+        case 70: if (w4_shape_ok(M, N, K, 4, 4)) { launch_w4<MODE, 4, 4, 3, 2, 2>(A, Wt, bias, M, N, K, out, st); break; }
+                 launch_gemm<MODE>(A, Wt, bias, M, N, K, out, st); break;
         // 64: its persistent form (160 x 256 tiles, the C tile leaves during the next tile's loop), bf16 outputs
         case 64: if constexpr (bf16_out(MODE)) {
                      if (w4p_shape_ok(M, N, K)) { launch_w4p<MODE>(A, Wt, bias, M, N, K, out, device_cus(), st); break; }
@@ -2203,7 +2210,7 @@ static void launch_variant(int variant, const bf16_t* A, const bf16_t* Wt, const
 
 static int launch_mode(int v, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, int mode,
                        void* out, hipStream_t st) {
-    if (v >= 60 && v <= 68) { /* gemm_w4.h checks its own shape */ }
+    if (v >= 60 && v <= 70) { /* gemm_w4.h checks its own shape */ }
     else if (K % 64 != 0 && v != 40 && v != 42 && v != 45 && v != 46 && v != 48 && v != 50) v = 1;
     else if (N % BN != 0 && v != 1) v = 0;  // N edge is handled by the 128x128 kernels only
     switch (mode) {
@@ -2247,6 +2254,15 @@ static int w4_variant(int M, int N, int K, int mode) {
     // (K >= 192: three 64-deep K-steps.  Short K used to stay with the two-blocks-per-CU kernels; on the HTSAT shapes —
     // K = 192 / 384 at 131072 / 32768 rows — these tiles measured 5-25 % faster than those: tools/gemm_lab.hip htsat)
     if (!g_w4_enabled || K < 192) return 0;
+    // Short K (HTSAT's stages: K = 192 / 384, and K = 768 on its 8192-row stage): a tile is a handful of K-steps between a
+    // prologue and an epilogue that one workgroup per CU cannot overlap with anything.  Two workgroups of 128 x 192 (or
+    // 128 x 128) per CU can: measured 7-22 % faster than the best single tile on the bf16-output shapes and 3-7 % on the
+    // residual ones at K <= 384 (profiles/r03_gemm_lab_htsat_two_per_cu.txt); at K >= 768 with many rows the small tiles
+    // are LDS-bound and lose to the large ones (ViT-B/32: same file, vit section), so the rule stops there.
+    if ((K <= 384 || (K <= 768 && M <= 8192 && bf16_out(mode))) && !(bf16_out(mode) && w4p_shape_ok(M, N, K))) {
+        if (w4_shape_ok(M, N, K, 4, 6) && (long long)(M / 128) * (N / 192) >= 512) return 69;
+        if (w4_shape_ok(M, N, K, 4, 4) && (long long)(M / 128) * (N / 128) >= 512) return 70;
+    }
     struct Cand { int id, mi, nj; double step; bool bf16_only; };
     static const Cand cands[] = {{60, 8, 8, 2560.0, false}, {61, 5, 8, 1700.0, false}, {62, 10, 8, 3250.0, true},
                                  {63, 10, 6, 2430.0, true}, {65, 7, 6, 1720.0, false}, {66, 8, 6, 1950.0, false},
@@ -2257,7 +2273,9 @@ static int w4_variant(int M, int N, int K, int mode) {
     // for HTSAT (66 .. 68) compete only where the choice is inside the family already — one of the older tiles divides the
     // shape — or K < 512, where they were measured against those kernels.  (ViT-L/14 and H/14, M = 129 x 128 and 65 x 128
     // rows with K >= 1024, fit only the new tiles and lose 5 % on them: they stay where they were.)
-    bool family = K < 512;
+    // (... or the row count is a multiple of 4096 — HTSAT's token counts — where the new tiles were measured against those
+    // kernels on every shape: its stage-3 fc2, 32768 x 384 x 1536, has no older tile that divides N = 384: 58 -> 47 us)
+    bool family = K < 512 || M % 4096 == 0;
     for (const Cand& c : cands)
         if (c.id <= 65 && !(c.bf16_only && !bf16_out(mode)) && w4_shape_ok(M, N, K, c.mi, c.nj)) family = true;
     for (const Cand& c : cands) {

@@ -188,8 +188,8 @@ __device__ __forceinline__ void epi_f32_pass(const f32x4 (&acc)[MI][NJ], int i0,
 
 // Block tile (32*MI) x (32*NJ), waves 2 x 2, wave tile (16*MI) x (16*NJ); SA / SW = LDS slots of the activation / weight
 // operand (3 + 2, 2 + 3 or 2 + 2).  M % (32*MI) == 0, N % (32*NJ) == 0, K % 64 == 0, K >= 192.
-template <int MODE, int MI, int NJ, int SA, int SW>
-__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+template <int MODE, int MI, int NJ, int SA, int SW, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                          const float* __restrict__ bias, int M, int N, int K,
                                                          void* __restrict__ out) {
     using namespace w4;
@@ -424,9 +424,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const bf16_t* __restric
     W4_STAMP(3);
 }
 
-template <int MODE, int MI, int NJ, int SA, int SW>
+// OCC = 2: two workgroups per CU (each still one wave per SIMD): their LDS (<= 80 KiB each) and registers (<= 256 per
+// wave) must allow it; one workgroup's prologue and epilogue then run under the other's loop.
+template <int MODE, int MI, int NJ, int SA, int SW, int OCC = 1>
 static void launch_w4(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out, hipStream_t st) {
-    auto kern = gemm_w4_kernel<MODE, MI, NJ, SA, SW>;
+    auto kern = gemm_w4_kernel<MODE, MI, NJ, SA, SW, OCC>;
+    static_assert(OCC == 1 || w4::lds_bytes(MI, NJ, SA, SW) <= 80 * 1024, "two workgroups per CU: 80 KiB of LDS each");
     constexpr int LDS = w4::lds_bytes(MI, NJ, SA, SW) > 4 * 20480 ? w4::lds_bytes(MI, NJ, SA, SW) : 4 * 20480;
     static std::once_flag attr_set;
     std::call_once(attr_set, [&] {
