@@ -107,6 +107,12 @@ int main(int argc, char** argv) {
         shapes.push_back({"L14fc1 65792x4096x1024", 65792, 4096, 1024, 1});
         shapes.push_back({"L14fc2 65792x1024x4096", 65792, 1024, 4096, 3});
     }
+    if (which == "text" || which == "all") {   // CLIP B/32 text tower, 256 queries x 77 tokens
+        shapes.push_back({"Tqkv 19712x1536x512", 19712, 1536, 512, 0});
+        shapes.push_back({"Tout 19712x512x512", 19712, 512, 512, 3});
+        shapes.push_back({"Tfc1 19712x2048x512", 19712, 2048, 512, 1});
+        shapes.push_back({"Tfc2 19712x512x2048", 19712, 512, 2048, 3});
+    }
     if (which == "h14" || which == "all") {
         shapes.push_back({"H14qkv 65792x3840x1280", 65792, 3840, 1280, 0});
         shapes.push_back({"H14out 65792x1280x1280", 65792, 1280, 1280, 3});

@@ -2259,7 +2259,9 @@ static int w4_variant(int M, int N, int K, int mode) {
     // 128 x 128) per CU can: measured 7-22 % faster than the best single tile on the bf16-output shapes and 3-7 % on the
     // residual ones at K <= 384 (profiles/r03_gemm_lab_htsat_two_per_cu.txt); at K >= 768 with many rows the small tiles
     // are LDS-bound and lose to the large ones (ViT-B/32: same file, vit section), so the rule stops there.
-    if ((K <= 384 || (K <= 768 && M <= 8192 && bf16_out(mode))) && !(bf16_out(mode) && w4p_shape_ok(M, N, K))) {
+    // (K = 512, the CLIP text tower at 256 queries x 77 tokens: QKV 37.3 -> 35.0 us, out-projection 26.4 -> 21.9, fc1
+    // 62.9 -> 49.5 — `tools/gemm_lab text`.)
+    if ((K <= 512 || (K <= 768 && M <= 8192 && bf16_out(mode))) && !(bf16_out(mode) && w4p_shape_ok(M, N, K))) {
         if (w4_shape_ok(M, N, K, 4, 6) && (long long)(M / 128) * (N / 192) >= 512) return 69;
         if (w4_shape_ok(M, N, K, 4, 4) && (long long)(M / 128) * (N / 128) >= 512) return 70;
     }
