@@ -862,8 +862,10 @@ def main():
             for i in range(3):
                 ivf1(i); ivf256(i)
             i_steps = max(10, min(args.steps, 50))
-            t1 = timed_region(ivf1, i_steps, world)
-            t256 = timed_region(ivf256, i_steps, world)
+            # (a side figure, not the contract's step: the better of two timed regions — on some boxes the first region of
+            # this launch-bound leg has run 20-50x slow once, profiles/README.md r03_c / r03_d)
+            t1 = min(timed_region(ivf1, i_steps, world), timed_region(ivf1, i_steps, world))
+            t256 = min(timed_region(ivf256, i_steps, world), timed_region(ivf256, i_steps, world))
             ivf_res[f"nprobe{nprobe}"] = {"single_query_ms": round(t1 / i_steps * 1e3, 4),
                                           "queries_per_s_nq1": round(i_steps / t1, 1),
                                           "queries_per_s_nq256": round(256 * i_steps / t256, 1)}
