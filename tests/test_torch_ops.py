@@ -78,6 +78,13 @@ def test_search_operators_equal_the_index_classes():
         D1, I1 = torch.ops.wise_hip.ip_topk_shadow8(X, Xq, scales, norms8, Q[q:q + 1], k, ids, 0, counters)
         assert torch.equal(I1, Ir[q:q + 1]) and torch.allclose(D1, Dr[q:q + 1], atol=2e-6)
     assert counters.tolist() == [4, 0]
+    # wrong dtypes or a strided view are refused, not read as garbage
+    with pytest.raises(ValueError):
+        torch.ops.wise_hip.ip_topk(X, Q, k, ids.to(torch.int32), 0)
+    with pytest.raises(ValueError):
+        torch.ops.wise_hip.ip_topk_shadow(X, Xb[:, ::2], norms, Q[:1], k, ids, 0, counters)
+    with pytest.raises(ValueError):
+        torch.ops.wise_hip.ip_topk_shadow8(X, Xq.to(torch.int16), scales, norms8, Q[:1], k, ids, 0, counters)
     # two half shards merged == the whole
     h = N // 2
     Da, Ia = torch.ops.wise_hip.ip_topk(X[:h], Q, k, ids[:h], 0)

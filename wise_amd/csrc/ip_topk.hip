@@ -1932,11 +1932,11 @@ extern "C" size_t wise_ip_topk_shadow_workspace_bytes(int64_t N, int d, int nq, 
                  align_up((size_t)COLLECT_CAP * sizeof(u64), 256) + 2 * align_up((size_t)RESCORE_CAP * sizeof(u64), 256) +
                  align_up((size_t)SAMPLE_CHUNKS * 512 * sizeof(float), 256) +              // every sampled row's score
                  align_up((size_t)p.grid * 4 * k * sizeof(u64), 256);
-    // batches: see pass_workspace()
-    const size_t many = pass_workspace_bytes(N, d, k);
-    const size_t small = N < COLLECT_MIN_ROWS ? wise_ip_topk_workspace_bytes(N, d, nq, k) : 0;   // answered by the f32 scan
-    size_t best = one > many ? one : many;
-    return best > small ? best : small;
+    // an index too small for a sample is answered by the f32 scan and needs only its workspace
+    if (N < COLLECT_MIN_ROWS) return wise_ip_topk_workspace_bytes(N, d, nq, k);
+    // batches (two queries and more): see pass_workspace() — ~134 MB of per-query lists that a single query never touches
+    const size_t many = nq >= 2 ? pass_workspace_bytes(N, d, k) : 0;
+    return one > many ? one : many;
 }
 
 namespace wise {

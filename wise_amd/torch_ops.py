@@ -66,10 +66,21 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.float32).contiguous()
 
 
+def _req(t, dtype, name: str, op: str, min_numel: int = 0):
+    """tensors whose raw pointer goes to the C ABI as is: right dtype, contiguous, big enough — or an error, not garbage"""
+    if t is None:
+        return
+    if t.dtype != dtype or not t.is_contiguous() or t.numel() < min_numel:
+        raise ValueError(f"wise_hip::{op}: {name} must be a contiguous {dtype} tensor"
+                         + (f" of at least {min_numel} elements" if min_numel else "")
+                         + f" (got {t.dtype}, contiguous={t.is_contiguous()}, numel={t.numel()})")
+
+
 # ---------------------------------------------------------------------------------------------- HP-2
 def _ip_topk(X, Q, k, ids, id_base):
     lib = _lib.lib()
     _dev(X, Q, ids)
+    _req(ids, torch.int64, "ids", "ip_topk", X.shape[0])
     X, Q = _f32c(X), _f32c(Q)
     N, d = X.shape
     nq = Q.shape[0]
@@ -100,6 +111,9 @@ def _ip_shadow_bf16(X):
 def _ip_topk_shadow(X, Xb, norms, Q, k, ids, id_base, counters):
     lib = _lib.lib()
     _dev(X, Xb, norms, Q, ids, counters)
+    _req(Xb, torch.int16, "Xb (bf16 bit patterns)", "ip_topk_shadow", X.numel())
+    _req(norms, torch.float32, "norms", "ip_topk_shadow", 2)
+    _req(ids, torch.int64, "ids", "ip_topk_shadow", X.shape[0])
     X, Q = _f32c(X), _f32c(Q)
     N, d = X.shape
     nq = Q.shape[0]
@@ -134,6 +148,10 @@ def _ip_shadow_i8(X):
 def _ip_topk_shadow8(X, Xq, scales, norms, Q, k, ids, id_base, counters):
     lib = _lib.lib()
     _dev(X, Xq, scales, norms, Q, ids, counters)
+    _req(Xq, torch.int8, "Xq", "ip_topk_shadow8", X.numel())
+    _req(scales, torch.float32, "scales", "ip_topk_shadow8", X.shape[0])
+    _req(norms, torch.float32, "norms", "ip_topk_shadow8", 4)
+    _req(ids, torch.int64, "ids", "ip_topk_shadow8", X.shape[0])
     X, Q = _f32c(X), _f32c(Q)
     N, d = X.shape
     nq = Q.shape[0]
@@ -143,13 +161,11 @@ def _ip_topk_shadow8(X, Xq, scales, norms, Q, k, ids, id_base, counters):
         return D, I
     if counters.dtype != torch.int32 or counters.numel() < 2:
         raise ValueError("wise_hip::ip_topk_shadow8: counters must be an int32 tensor of two elements")
-    if Xq.dtype != torch.int8 or scales.dtype != torch.float32 or norms.numel() < 4:
-        raise ValueError("wise_hip::ip_topk_shadow8: Xq int8 [N,d], scales fp32 [N], norms fp32 [4] (ip_shadow_i8's outputs)")
     need = max(lib.wise_ip_topk_shadow_workspace_bytes(N, d, nq, k), lib.wise_ip_topk_workspace_bytes(N, d, nq, k))
     if need == 0 or d % 16 != 0:
         raise ValueError(f"wise_hip::ip_topk_shadow8: unsupported shape N={N} d={d} nq={nq} k={k}")
     ws = torch.empty(need, dtype=torch.uint8, device=X.device)
-    _check(lib.wise_ip_topk_shadow8_f32(X.data_ptr(), Xq.contiguous().data_ptr(), scales.contiguous().data_ptr(),
+    _check(lib.wise_ip_topk_shadow8_f32(X.data_ptr(), Xq.data_ptr(), scales.data_ptr(),
                                         norms.data_ptr(), N, d, Q.data_ptr(), nq, k, _lib.ptr(ids), id_base, D.data_ptr(),
                                         I.data_ptr(), counters.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
            "wise_ip_topk_shadow8_f32")
@@ -172,6 +188,7 @@ def _topk_merge(Ds, Is, k):
 def _reconstruct_batch(X, ids, id_base, query_ids):
     lib = _lib.lib()
     _dev(X, ids, query_ids)
+    _req(ids, torch.int64, "ids", "reconstruct_batch", X.shape[0])
     X = _f32c(X)
     q = query_ids.to(torch.int64).contiguous()
     out = torch.empty(q.numel(), X.shape[1], dtype=torch.float32, device=X.device)
@@ -203,6 +220,9 @@ def _select_topk(scores, k):
 def _ivf_scan(X, list_off, ids, Q, probes, k):
     lib = _lib.lib()
     _dev(X, list_off, ids, Q, probes)
+    _req(list_off, torch.int64, "list_off", "ivf_scan", 2)
+    _req(ids, torch.int64, "ids", "ivf_scan", X.shape[0])
+    _req(probes, torch.int64, "probes", "ivf_scan")
     X, Q = _f32c(X), _f32c(Q)
     nq, nprobe = probes.shape
     D = torch.empty(nq, k, dtype=torch.float32, device=X.device)
