@@ -37,8 +37,8 @@ METRIC = "frames/sec embedded (ViT-B/32 bs=256) + queries/sec over 10M×512 inde
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--index-rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=512)
@@ -562,7 +562,7 @@ def main():
 
         for i in range(2):
             clap_step_serial(i)
-        a_steps = max(4, min(args.steps, 10))
+        a_steps = max(4, min(args.steps, 30))
         adt_serial = timed_region(clap_step_serial, a_steps, world)
         for i in range(2):
             clap_step(i)
@@ -630,7 +630,7 @@ def main():
 
         for i in range(2):
             cnn_step_serial(i)
-        c_steps = max(4, min(args.steps, 8))
+        c_steps = max(4, min(args.steps, 16))
         cdt_serial = timed_region(cnn_step_serial, c_steps, world)
         for i in range(2):
             cnn_step(i)
@@ -728,7 +728,7 @@ def main():
 
         for i in range(3):
             u8_step(i)
-        u_steps = max(5, min(args.steps, 20))
+        u_steps = max(5, min(args.steps, 40))
         udt = timed_region(u8_step, u_steps, world)
         hold["u"] = hold["uh"].result()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
