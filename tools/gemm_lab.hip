@@ -113,6 +113,12 @@ int main(int argc, char** argv) {
         shapes.push_back({"Tfc1 19712x2048x512", 19712, 2048, 512, 1});
         shapes.push_back({"Tfc2 19712x512x2048", 19712, 512, 2048, 3});
     }
+    if (which == "xlmr" || which == "all") {   // XLM-RoBERTa-large text tower, 256 queries x 77 tokens
+        shapes.push_back({"Xqkv 19712x3072x1024", 19712, 3072, 1024, 0});
+        shapes.push_back({"Xout 19712x1024x1024", 19712, 1024, 1024, 3});
+        shapes.push_back({"Xfc1 19712x4096x1024", 19712, 4096, 1024, 2});
+        shapes.push_back({"Xfc2 19712x1024x4096", 19712, 1024, 4096, 3});
+    }
     if (which == "h14" || which == "all") {
         shapes.push_back({"H14qkv 65792x3840x1280", 65792, 3840, 1280, 0});
         shapes.push_back({"H14out 65792x1280x1280", 65792, 1280, 1280, 3});
