@@ -2265,6 +2265,8 @@ static int w4_variant(int M, int N, int K, int mode) {
         if (w4_shape_ok(M, N, K, 4, 6) && (long long)(M / 128) * (N / 192) >= 512) return 69;
         if (w4_shape_ok(M, N, K, 4, 4) && (long long)(M / 128) * (N / 128) >= 512) return 70;
     }
+    // (Measured and not taken: the same two-per-CU tiles on the output projections of the wide towers — N = K = 1024, fp32
+    // residual: 219 -> 194 us alone on ViT-L/14's shape, but no gain in the tower's step with two batches in flight.)
     struct Cand { int id, mi, nj; double step; bool bf16_only; };
     static const Cand cands[] = {{60, 8, 8, 2560.0, false}, {61, 5, 8, 1700.0, false}, {62, 10, 8, 3250.0, true},
                                  {63, 10, 6, 2430.0, true}, {65, 7, 6, 1720.0, false}, {66, 8, 6, 1950.0, false},
