@@ -67,6 +67,81 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x /* may be
     }
 }
 
+// The same, R rows per wave (W <= 512 with many rows: HTSAT's stages 2-3, the CLIP text tower): a wave that normalises ONE row
+// of 192 floats has a single 768-byte load in flight and lives for two butterflies — 131072 such waves per launch ran at
+// 4.5 TB/s (33 -> 28.6 us with four rows per wave; at W = 768 / 12800 rows the one-row form is as fast: 11.4 vs 11.6 us).
+// Here a wave takes R consecutive rows, all R x NV loads issued before the first sum and the R butterflies interleaved.
+// Per row the arithmetic is layernorm_kernel's, operation for operation (same bits).
+template <int NV, int R>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, int rows, int W, float eps,
+                                                             bf16_t* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    const int w4 = W >> 2;
+    float4 v[R][NV];
+    float s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r < rows ? row0 + r : rows - 1;
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * W);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            v[r][i] = (c < w4) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        s[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s[r] += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] += __shfl_xor(s[r], o, 64);
+    float mean[R], q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mean[r] = s[r] / (float)W;
+        q[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < w4) {
+                float a0 = v[r][i].x - mean[r], a1 = v[r][i].y - mean[r], a2 = v[r][i].z - mean[r], a3 = v[r][i].w - mean[r];
+                q[r] += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[r] += __shfl_xor(q[r], o, 64);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < w4) {
+            const float4 ww = reinterpret_cast<const float4*>(w)[c];
+            const float4 bb = reinterpret_cast<const float4*>(b)[c];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (row0 + r < rows) {
+                    const float rstd = rsqrtf(q[r] / (float)W + eps);
+                    uint2 pk;
+                    const float y0 = (v[r][i].x - mean[r]) * rstd * ww.x + bb.x, y1 = (v[r][i].y - mean[r]) * rstd * ww.y + bb.y;
+                    const float y2 = (v[r][i].z - mean[r]) * rstd * ww.z + bb.z, y3 = (v[r][i].w - mean[r]) * rstd * ww.w + bb.w;
+                    pk.x = pack_bf16x2(y0, y1);
+                    pk.y = pack_bf16x2(y2, y3);
+                    reinterpret_cast<uint2*>(y + (size_t)(row0 + r) * W)[c] = pk;
+                }
+            }
+        }
+    }
+}
+
 // Narrow rows (W <= 128, HTSAT's first stage has W = 96): half a wave per row, so a wave normalises two rows and
 // 24 of every 32 lanes work instead of 24 of 64.  Same two-pass arithmetic; the reductions stay inside 32 lanes.
 __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -112,6 +187,14 @@ int layernorm_f32_bf16(const float* x, const float* w, const float* b, int rows,
         return WISE_OK;
     }
     const int nv = (W / 4 + 63) / 64;
+    // many rows of a hot width: several rows per wave (same bits as one row per wave; ablation bit 4 = one row per wave)
+    if (nv <= 2 && rows >= 16384 && !(g_ablate & 16)) {
+        const dim3 block(256);
+        if (nv == 1) hipLaunchKernelGGL((layernorm_rows_kernel<1, 4>), dim3((rows + 15) / 16), block, 0, st, x, w, b, rows, W, eps, y);
+        else hipLaunchKernelGGL((layernorm_rows_kernel<2, 4>), dim3((rows + 15) / 16), block, 0, st, x, w, b, rows, W, eps, y);
+        WISE_LAUNCH_CHECK("layernorm_rows_kernel");
+        return WISE_OK;
+    }
     const dim3 grid((rows + 3) / 4), block(256);
 #define LN_CASE(n) \
     case n: hipLaunchKernelGGL(layernorm_kernel<n>, grid, block, 0, st, x, w, b, rows, W, eps, y, (float*)nullptr); break;
