@@ -6,7 +6,7 @@ set -u
 TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out
-python3 bench.py --steps 20 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
+python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 echo "bench done"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o stats -- python3 bench.py --steps 20 --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1 || exit 1
 python3 tools/prof_top.py $OUT/${TAG}_stats/stats_results.db 40 --csv $OUT/${TAG}_kernel_stats.csv > $OUT/${TAG}_kernel_stats.txt
