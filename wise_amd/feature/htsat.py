@@ -177,10 +177,10 @@ class HtsatEngine:
             raise ValueError(f"audio too short for a reflect-padded STFT: {N} samples")
         if not hasattr(self, "_slots"):
             self._slots, self._next_slot = [{"stream": torch.cuda.Stream(device=self.device), "ws": None}
-                                            for _ in range(2)], 0
+                                            for _ in range(max(2, int(getattr(self, "batches_in_flight", 2))))], 0
         need = self.lib.wise_htsat_workspace_bytes(B, N)
         slot = self._slots[self._next_slot]
-        self._next_slot ^= 1
+        self._next_slot = (self._next_slot + 1) % len(self._slots)
         if slot["ws"] is None or slot["ws"].numel() < need:
             # the slot's previous forward may still be running in the old workspace (allocated on the caller's stream,
             # used on the slot's): wait for it before the allocator may reuse that block
