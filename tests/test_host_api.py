@@ -304,6 +304,54 @@ def test_webdataset_store_format_and_order(tmp_path):
         FeatureStoreFactory.load_store("image", tmp_path)
 
 
+def test_webdataset_store_cases_of_the_reference_test_file(tmp_path):
+    """src/feature/store/test_feature_store.py:48-102 restated literally: shard_maxcount 3, shard_maxsize 256 bytes, MULTI-ROW adds
+    ([3,4] arrays under ids 0 and 3 — one tar member each, read back whole), then single rows 6, 7, 8; read order [0, 3, 6, 7, 8]."""
+    from wise_amd.feature.store.webdataset_store import WebdatasetStore
+
+    featureA, featureB, featureC = np.array([[1, 2, 3, 4]]), np.array([[5, 6, 7, 8]]), np.array([[9, 10, 11, 12]])
+    feature0 = np.concatenate((featureA, featureB, featureC), axis=0)
+    feature3 = np.concatenate((featureC, featureB, featureA), axis=0)
+    # test_webdataset_store_batch_write (:48-72)
+    d1 = tmp_path / "batch"
+    d1.mkdir()
+    w = WebdatasetStore("wise-store", str(d1))
+    w.enable_write(3, 256)
+    w.add(0, feature0)
+    w.add(3, feature3)
+    w.close()
+    del w
+    r = WebdatasetStore("wise-store", str(d1))
+    r.enable_read(shard_shuffle=False, shuffle_values=False)
+    seen = {}
+    for feature_id, feature_vector in r:
+        seen[int(feature_id)] = feature_vector
+    assert sorted(seen) == [0, 3]
+    assert seen[0].shape == (3, 4) and np.all(np.equal(seen[0], feature0)) and np.all(np.equal(seen[3], feature3))
+    assert r.feature_count == 2                                  # members, not rows (webdataset_store.py:85-91)
+    # test_webdataset_store_read_order (:74-102)
+    d2 = tmp_path / "order"
+    d2.mkdir()
+    w = WebdatasetStore("wise-store", str(d2))
+    w.enable_write(3, 256, verbose=1)
+    w.add(0, feature0)
+    w.add(3, feature3)
+    w.add(6, featureA)
+    w.add(7, featureB)
+    w.add(8, featureC)
+    w.close()
+    del w
+    r = WebdatasetStore("wise-store", str(d2))
+    r.enable_read(shard_shuffle=False, shuffle_values=False)
+    assert [int(i) for i, _ in r] == [0, 3, 6, 7, 8]
+    # a multi-row member cannot go through iter_batch: the reference squeezes axis 0 of every member (:134-137) -> ValueError
+    with pytest.raises(ValueError):
+        list(r.iter_batch(512))
+    # add() before enable_write() (:93-95)
+    with pytest.raises(ValueError, match="enable_write"):
+        WebdatasetStore("wise-store", str(d2)).add(1, featureA)
+
+
 # ---------------------------------------------------------------- SearchIndex surface + .faiss IO
 def test_search_index_factory_and_file_io(tmp_path):
     from wise_amd.feature.store.feature_store_factory import FeatureStoreFactory, FeatureStoreType

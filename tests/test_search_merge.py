@@ -50,3 +50,85 @@ def test_merge_modalities_sums_scores_of_overlapping_hits():
     assert m['match_pts_list'] == [[0.0, 4.0], [8.0, 12.0]]          # hull of point 3.0 with [0,4]; [10,11.5] with [8,12]
     assert m['merged_rank_list'] == [[1, 0], [0, 1]]
     assert m['in'] == ['video', 'audio'] and m['not_in'] == ['image'] and abs(m['search_time_sec'] - 0.3) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Held to the reference's own functions: tests/golden/merge_ref/cases.json holds inputs and the outputs (or the exception)
+# of search.py's does_segment_overlap / merge_a_ranked_result_list / merge0 / merge1 / apply_subtract, produced by
+# oracle/make_golden_merge.py from the reference's function bodies (ast-lifted; search.py itself is not importable).
+import copy
+import json
+from pathlib import Path
+from types import SimpleNamespace
+
+import pytest
+
+from wise_amd.search.merge import merge_each_query, merge_pair, subtract_hits
+
+CASES = json.loads((Path(__file__).parent / "golden" / "merge_ref" / "cases.json").read_text())
+
+
+def _same_or_raises(expected, fn, *a):
+    if "raises" in expected:
+        with pytest.raises(Exception) as e:
+            fn(*a)
+        assert type(e.value).__name__ == expected["raises"]
+        return None
+    return fn(*a)
+
+
+def test_segments_overlap_equals_the_reference_on_408_pairs():
+    assert len(CASES["overlap"]) >= 400
+    for c in CASES["overlap"]:
+        s1, s2 = copy.deepcopy(c["seg1"]), copy.deepcopy(c["seg2"])
+        got = _same_or_raises(c, segments_overlap, s1, s2)
+        if "out" in c:
+            assert got is c["out"], c
+        assert s1 == c["seg1"] and s2 == c["seg2"]          # the pure form leaves its arguments alone
+
+
+def test_merge_ranked_hits_equals_the_reference_on_240_lists():
+    kinds = set()
+    for c in CASES["ranked"]:
+        f, p, s, r = merge_ranked_hits(c["files"], c["pts"], c["scores"], c["pts_tolerance"], c["rank_tolerance"])
+        ef, ep, es, er = c["out"]
+        assert (f, p, s) == (ef, ep, es), c
+        assert r == [sorted(x) for x in er], c                # the reference prints them sorted (search.py:586-599)
+        kinds.add(c["kind"])
+    assert kinds == {"video", "audio", "image"}
+
+
+def test_merge0_then_merge1_flow_equals_the_reference():
+    n_two = n_raise = 0
+    for c in CASES["flow"]:
+        args = SimpleNamespace(**c["args"])
+        inp = copy.deepcopy(c["result"])
+        m0 = merge_each_query(inp, args)
+        assert inp == c["result"]                              # caller's lists untouched
+        exp0 = c["merge0"]["out"]
+        assert len(m0) == len(exp0)
+        for got, exp in zip(m0, exp0):
+            exp = dict(exp, merged_rank_list=[sorted(x) for x in exp["merged_rank_list"]])
+            assert got == exp, c
+        if "merge1" not in c:
+            assert merge_pair(m0, args) is None or len(m0) == 2
+            continue
+        n_two += 1
+        before = copy.deepcopy(m0)
+        got1 = _same_or_raises(c["merge1"], merge_pair, m0, args)
+        assert m0 == before
+        if "raises" in c["merge1"]:
+            n_raise += 1
+            continue
+        exp1 = c["merge1"]["out"]
+        assert len(got1) == 1 and got1[0] == exp1[0], c
+    assert n_two >= 60 and n_raise >= 1                        # the [t] -> [t, t] widening is exercised (ZeroDivisionError cases)
+
+
+def test_subtract_hits_equals_the_reference():
+    dropped = 0
+    for c in CASES["subtract"]:
+        got = subtract_hits(copy.deepcopy(c["search_result"]), copy.deepcopy(c["not_search_result"]))
+        assert got == c["out"], c
+        dropped += len(c["search_result"]["match_filename_list"]) - len(got["match_filename_list"])
+    assert dropped > 50

@@ -5,8 +5,10 @@
   pickle.dumps(np.ndarray[1,D] float32)  (webdataset encodes the `pyd` extension with pickle; the
   reference reads it back with np.load(BytesIO, allow_pickle=True), :72,113,129).
 
-Shard roll-over follows webdataset.ShardWriter: a new shard starts when the current one holds
-`maxcount` records or more than `maxsize` bytes.
+Shard roll-over follows webdataset.ShardWriter.write: before a record is written, a new shard starts when the current one
+already holds `maxcount` records or `maxsize` or more bytes of MEMBER DATA (TarWriter.write returns the sum of the members'
+sizes, headers and padding not counted).  One add() = one member, whatever the array's first dimension is: the reference's
+test writes [3,4] arrays under ids 0 and 3 and reads them back whole (src/feature/store/test_feature_store.py:48-102).
 """
 import glob
 import io
@@ -65,7 +67,7 @@ class WebdatasetStore(FeatureStore):
         ti.gname = 'bigdata'
         self._tar.addfile(ti, io.BytesIO(data))
         self._count += 1
-        self._size += len(data) + 512
+        self._size += len(data)
 
     def close(self):
         if self._tar is not None:
