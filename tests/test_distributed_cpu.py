@@ -177,3 +177,144 @@ def test_rank_sharded_extraction_world2(tmp_path):
             assert np.allclose(vec, ref_by_key[by_id[vid]], atol=1e-6)   # (the fake extractor is batch-dependent in the last bit)
             n += 1
         assert n == rd.feature_count == sum(1 for r in all_rows if r[1] == m)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HP-2 over several ranks THROUGH THE PLUGIN SURFACE (src/index/search_index_factory.py:4-21): SearchIndexFactory(...)
+# .create_index / .load_index / .search under an initialised process group.  The rows of a rank live in a CPU stand-in
+# for FlatIPIndex here (the oracle does the local scan and the merge); on the GPU box tests/test_gpu_sharded.py runs the
+# same wiring with the HIP kernels and RCCL.
+class _CpuFlat:
+    """What FeatureSearchIndex.flat_index_factory must offer: reserve / add_with_ids / search_device / reconstruct_batch."""
+
+    def __init__(self, d):
+        self.d, self.device = int(d), torch.device("cpu")
+        self._X, self._ids = [], []
+
+    def reserve(self, n):
+        self.reserved = int(n)
+
+    def add_with_ids(self, x, ids):
+        self._X.append(np.array(x, dtype=np.float32))
+        self._ids.append(np.array(ids, dtype=np.int64))
+
+    @property
+    def ntotal(self):
+        return sum(len(i) for i in self._ids)
+
+    def _rows(self):
+        if not self._ids:
+            return np.zeros((0, self.d), np.float32), np.zeros((0,), np.int64)
+        return np.concatenate(self._X), np.concatenate(self._ids)
+
+    def search_device(self, q, k):
+        from oracle import ip_topk_ref
+        X, ids = self._rows()
+        D, I = ip_topk_ref.ip_topk(X, q.numpy(), k, ids=ids)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+    def reconstruct_batch(self, want):
+        X, ids = self._rows()
+        out = np.full((len(want), self.d), np.nan, np.float32)
+        for i, w in enumerate(want):
+            hit = np.flatnonzero(ids == w)
+            if len(hit):
+                out[i] = X[hit[0]]
+        return out
+
+    @staticmethod
+    def merge_lists(Ds, Is, k):
+        from oracle import ip_topk_ref
+        D, I = ip_topk_ref.merge_topk(Ds.numpy(), Is.numpy(), k)
+        return torch.from_numpy(D), torch.from_numpy(I)
+
+
+class _FakeTextTower:
+    """extract_text_features: a deterministic unit vector per string (the text tower is not what this test is about)."""
+
+    def __init__(self, d):
+        self.d = d
+
+    def extract_text_features(self, texts):
+        import zlib
+        out = np.stack([np.random.default_rng(zlib.crc32(t.encode())).standard_normal(self.d) for t in texts])
+        return (out / np.linalg.norm(out, axis=1, keepdims=True)).astype(np.float32)
+
+
+def _plugin_worker(rank, world, port, root, N, d):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import wise_amd.index.feature_search_index as fsi
+    from wise_amd.index.search_index_factory import SearchIndexFactory
+    from wise_amd.index.sharded import ShardedFlatIPIndex, shard_range
+
+    fsi.FeatureSearchIndex.flat_index_factory = _CpuFlat
+    fsi.FeatureExtractorFactory = lambda fid: _FakeTextTower(d)
+    root = Path(root)
+    out = {}
+    # (A) the single .faiss file a one-process create-index wrote: each rank takes rows shard_range(N, rank, world)
+    si = SearchIndexFactory("video", "mlfoundations/open_clip/ViT-B-32/seeded-0",
+                            {"features_dir": root / "features", "index_dir": root / "index_single"})
+    assert si.load_index("IndexFlatIP") is True
+    assert isinstance(si.index, ShardedFlatIPIndex)
+    lo, hi = shard_range(N, rank, world)
+    assert si.index.local.ntotal == hi - lo and si.index.local.reserved == hi - lo and si.index.ntotal == N
+    out["A_dist"], out["A_ids"] = si.search("video", "dog", topk=7)
+    Q = np.random.default_rng(6).standard_normal((3, d)).astype(np.float32)
+    out["A_D"], out["A_I"] = si.index.search(Q, 10)                       # the REST call shape (api/routes.py:1407)
+    out["A_rec"] = si.index.reconstruct_batch(np.array([1, N, 500, N + 5], dtype=np.int64))
+    # (B) the sharded build: every rank reads its own tar files only and writes its own part; load takes the part
+    si2 = SearchIndexFactory("video", "mlfoundations/open_clip/ViT-B-32/seeded-0",
+                             {"features_dir": root / "features", "index_dir": root / "index_parts"})
+    si2.create_index("IndexFlatIP")
+    part = si2.get_index_part_filename("IndexFlatIP", rank, world)
+    assert part.exists() and not si2.get_index_filename("IndexFlatIP").exists()
+    dist.barrier()
+    assert si2.load_index("IndexFlatIP") is True
+    out["B_local"] = np.array([si2.index.local.ntotal])
+    assert si2.index.ntotal == N
+    out["B_dist"], out["B_ids"] = si2.search("video", "dog", topk=7)
+    out["B_D"], out["B_I"] = si2.index.search(Q, 10)
+    np.savez(root / f"plugin_rank{rank}.npz", **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_index_through_the_plugin_surface_world2(tmp_path):
+    from oracle import ip_topk_ref
+    from wise_amd.feature.store.feature_store_factory import FeatureStoreFactory, FeatureStoreType
+    from wise_amd.index.search_index_factory import SearchIndexFactory
+
+    N, d, world = 1001, 32, 2
+    X = np.random.default_rng(5).standard_normal((N, d)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    fdir = tmp_path / "features"
+    fdir.mkdir()
+    st = FeatureStoreFactory.create_store(FeatureStoreType.WEBDATASET, "video", str(fdir))
+    st.enable_write(100, 20 * 1024 * 1024)                               # 11 tar files: ranks get 6 and 5 of them
+    for i in range(N):
+        st.add(i + 1, X[i:i + 1])
+    st.close()
+    single = SearchIndexFactory("video", "mlfoundations/open_clip/ViT-B-32/seeded-0",
+                                {"features_dir": fdir, "index_dir": tmp_path / "index_single"})
+    single.create_index("IndexFlatIP")                                   # no process group here: the one-file build
+    mp.spawn(_plugin_worker, args=(world, _free_port(), str(tmp_path), N, d), nprocs=world, join=True)
+
+    ids = np.arange(N, dtype=np.int64) + 1
+    q = _FakeTextTower(d).extract_text_features(["This is a photo of a dog"])
+    D1, I1 = ip_topk_ref.ip_topk(X, q, 7, ids=ids)
+    Q = np.random.default_rng(6).standard_normal((3, d)).astype(np.float32)
+    D3, I3 = ip_topk_ref.ip_topk(X, Q, 10, ids=ids)
+    locals_ = []
+    for r in range(world):
+        g = np.load(tmp_path / f"plugin_rank{r}.npz")
+        for tag in "AB":
+            assert np.array_equal(g[f"{tag}_ids"], I1[0]) and np.array_equal(g[f"{tag}_dist"], D1[0]), (r, tag)
+            assert np.array_equal(g[f"{tag}_I"], I3) and np.array_equal(g[f"{tag}_D"], D3), (r, tag)
+        rec = g["A_rec"]
+        assert np.array_equal(rec[0], X[0]) and np.array_equal(rec[1], X[N - 1]) and np.array_equal(rec[2], X[499])
+        assert np.isnan(rec[3]).all()                                    # an id no rank holds
+        locals_.append(int(g["B_local"][0]))
+    assert locals_ == [501, 500]                                         # tar files 0,2,..,10 (5 x 100 + the 1-row tail) and 1,3,..,9

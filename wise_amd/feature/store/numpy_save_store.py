@@ -85,15 +85,17 @@ class NumpySaveStore(FeatureStore):
             pass
 
     # ------------------------------------------------------------------ reading
-    def enable_read(self, shard_shuffle=False, shuffle_values=False, shuffle_bufsize=10000):
+    def enable_read(self, shard_shuffle=False, shuffle_values=False, shuffle_bufsize=10000, shard_slice=None):
+        """shard_slice (not in the reference): (rank, world) -> this reader sees shard files rank, rank + world, ... of the
+        name-sorted list only — one process per GPU builds its own part of an index (index build)."""
         self.shard_shuffle = shard_shuffle
         self.shuffle_values = shuffle_values
         self.shuffle_bufsize = shuffle_bufsize
-        shards = [p.as_posix() for p in self.store_data_dir.glob(self.store_name + '-*.npz')]
+        shards = sorted(p.as_posix() for p in self.store_data_dir.glob(self.store_name + '-*.npz'))
+        if shard_slice is not None:
+            shards = shards[int(shard_slice[0])::int(shard_slice[1])]
         if shard_shuffle:
             random.shuffle(shards)
-        else:
-            shards.sort()
         self.npz_filename_list = shards
         self.feature_count = 0
         self.feature_dim = -1
@@ -107,6 +109,10 @@ class NumpySaveStore(FeatureStore):
                     self.feature_dim = int(shape[-1])
 
     def _shard_arrays(self, fn):
+        # A shard whose `features` kept a row axis ([n, 1, D]: not something the reference's writer can produce, its buffer is
+        # [shard_maxcount, D], but other tools do) is read as [n, D] ON PURPOSE: iteration yields (1, D) rows for every
+        # shard, where the reference's np.take(features, [i], 0) would hand such a file's rows on as (1, 1, D) and break
+        # its own consumers (pinned by tests/test_host_api.py::test_numpy_save_store_row_axis_shards_are_normalised).
         with np.load(fn) as payload:
             return payload['feature_id'], payload['features'].reshape(-1, self.feature_dim)
 

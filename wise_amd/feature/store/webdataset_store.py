@@ -89,12 +89,16 @@ class WebdatasetStore(FeatureStore):
         files.sort()
         return [fn for _, fn in files]
 
-    def enable_read(self, shard_shuffle=False, shuffle_values=False, shuffle_bufsize=10000):
+    def enable_read(self, shard_shuffle=False, shuffle_values=False, shuffle_bufsize=10000, shard_slice=None):
+        """shard_slice (not in the reference): (rank, world) -> this reader sees tar files rank, rank + world, ... of the
+        number-sorted list only (feature_count counts those) — one process per GPU builds its own part of an index."""
         self.shard_shuffle = shard_shuffle
         self.shuffle_values = shuffle_values
         self.shuffle_bufsize = shuffle_bufsize
         self._files = self._shards()
-        for _, vec in self._records(self._files[:1]):
+        if shard_slice is not None:
+            self._files = self._files[int(shard_slice[0])::int(shard_slice[1])]
+        for _, vec in self._records(self._shards()[:1]):      # the store's dimension, also for a rank whose slice is empty
             self.feature_dim = vec.shape[1]
             break
         # the reference memoises member counts by file size (SURVEY App. B.10); count exactly instead

@@ -12,7 +12,18 @@ Same constructor contract (asserts on 'features_dir'/'index_dir'), prompts, file
 builds the FeatureExtractor, and the prompt quirks of `search`.  Both index types the
 reference offers are built: `IndexFlatIP` (exhaustive, the hot path) and `IndexIVFFlat` (approximate; cell count
 and training-sample size chosen as at feature_search_index.py:55-59, k-means and list scan on the GPU).
+
+**One process per GPU** (the reference has no distributed path).  When `torch.distributed` is initialised
+with more than one rank (or WISE_SHARDED_INDEX=1), the same two calls shard the flat index by rows:
+  * `create_index('IndexFlatIP')`: rank r reads ONLY feature-store shard files r, r + W, ... and writes its own part,
+    `{media_type}-IndexFlatIP.faiss.part-RRR-of-WWW` (same file layout, ids are the store's global ids) — no collective;
+  * `load_index('IndexFlatIP')`: rank r loads its part file if the parts of this world size exist, otherwise rows
+    `shard_range(N, r, W)` of the single `.faiss` file — memory-mapped, so a rank touches only its own rows' pages —
+    and `self.index` is a `ShardedFlatIPIndex`: `search` / `reconstruct_batch` are then collective (every rank calls
+    them with the same arguments and gets the global answer: one all-gather of per-shard top-k + `wise_topk_merge`).
+IndexIVFFlat stays a single-GPU index (every rank loads the whole file; rank 0 alone builds it).
 """
+import os
 from pathlib import Path
 
 import numpy as np
@@ -23,9 +34,23 @@ from . import faiss_io
 from .flat_ip import FlatIPIndex
 from .ivf_flat import IVFFlatIPIndex, reference_nlist
 from .search_index import SearchIndex
+from .sharded import ShardedFlatIPIndex, shard_range
+
+
+def _dist_rank_world():
+    """(rank, world, sharded?) of the default process group; (0, 1, False) outside torch.distributed."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(), dist.get_world_size()
+        return rank, world, world > 1 or os.environ.get('WISE_SHARDED_INDEX') == '1'
+    return 0, 1, False
 
 
 class FeatureSearchIndex(SearchIndex):
+    # the class that holds a rank's rows in HBM; CPU tests of the multi-rank wiring put a stand-in here
+    flat_index_factory = FlatIPIndex
+
     def __init__(self, media_type, asset_id, asset):
         self.media_type = media_type
         self.feature_extractor_id = asset_id
@@ -45,18 +70,31 @@ class FeatureSearchIndex(SearchIndex):
     def get_index_filename(self, index_type):
         return self.index_dir / (self.media_type + '-' + index_type + '.faiss')
 
+    def get_index_part_filename(self, index_type, rank, world):
+        """rank's part of a row-sharded flat index built by `world` processes (not in the reference)."""
+        fn = self.get_index_filename(index_type)
+        return fn.with_name(fn.name + '.part-%03d-of-%03d' % (rank, world))
+
     def create_index(self, index_type, overwrite=False):
         self.index_dir.mkdir(parents=True, exist_ok=True)
         index_fn = self.get_index_filename(index_type)
+        rank, world, sharded = _dist_rank_world()
+        if sharded and index_type == 'IndexFlatIP':
+            index_fn = self.get_index_part_filename(index_type, rank, world)
         if index_fn.exists() and overwrite is False:
             print(f'{index_type} for {self.media_type} already exists')
             return
         if index_type not in ('IndexFlatIP', 'IndexIVFFlat'):
             raise NotImplementedError(f'{index_type}: IndexFlatIP and IndexIVFFlat are the index types WISE builds')
         self.index_type = index_type
+        if sharded and index_type == 'IndexIVFFlat' and rank != 0:
+            return                                  # k-means needs every row: one rank builds the one file
 
         feature_store = FeatureStoreFactory.load_store(self.media_type, self.features_dir)
-        feature_store.enable_read(shard_shuffle=False)
+        if sharded and index_type == 'IndexFlatIP':
+            feature_store.enable_read(shard_shuffle=False, shard_slice=(rank, world))   # this rank's shard files only
+        else:
+            feature_store.enable_read(shard_shuffle=False)
         feature_count = feature_store.feature_count
         feature_dim = feature_store.feature_dim
 
@@ -93,7 +131,9 @@ class FeatureSearchIndex(SearchIndex):
 
     def load_index(self, index_type):
         index_fn = self.get_index_filename(index_type)
-        if not index_fn.exists():
+        rank, world, sharded = _dist_rank_world()
+        part_fn = self.get_index_part_filename(index_type, rank, world)
+        if not index_fn.exists() and not (sharded and part_fn.exists()):
             print(f'  index {index_fn} does not exist')
             print(f'  use create-index.py script to create an index')
         # like the reference (App. B.3) a missing file raises from the reader, it does not return False
@@ -105,11 +145,20 @@ class FeatureSearchIndex(SearchIndex):
             index.adopt_lists(torch.from_numpy(f["X"]), torch.from_numpy(f["ids"]), torch.from_numpy(f["list_off"]))
             index.nprobe = f["nprobe"]
         else:
-            X, ids = faiss_io.read_idmap_flat_ip(index_fn)
-            index = FlatIPIndex(X.shape[1])
-            index.reserve(X.shape[0])                # one [N,d] device tensor, filled slice by slice
-            for s in range(0, X.shape[0], 1 << 20):  # stream the memory-mapped rows into HBM
-                index.add_with_ids(np.ascontiguousarray(X[s:s + (1 << 20)]), ids[s:s + (1 << 20)])
+            if sharded and part_fn.exists():         # built by this many ranks: a rank's part is its shard
+                X, ids = faiss_io.read_idmap_flat_ip(part_fn)
+                lo, hi = 0, X.shape[0]
+            else:
+                X, ids = faiss_io.read_idmap_flat_ip(index_fn)      # rows memory-mapped: only [lo, hi) is ever touched
+                lo, hi = shard_range(X.shape[0], rank, world) if sharded else (0, X.shape[0])
+            index = self.flat_index_factory(X.shape[1])
+            index.reserve(hi - lo)                   # one [n,d] device tensor, filled slice by slice
+            for s in range(lo, hi, 1 << 20):         # stream the memory-mapped rows into HBM
+                e = min(s + (1 << 20), hi)
+                index.add_with_ids(np.ascontiguousarray(X[s:e]), ids[s:e])
+            if sharded:
+                index = ShardedFlatIPIndex(index, merge=getattr(index, 'merge_lists', None),
+                                           always_exchange=os.environ.get('WISE_SHARDED_INDEX') == '1')
         self.index = index
         self.feature_extractor = FeatureExtractorFactory(self.feature_extractor_id)
         return True

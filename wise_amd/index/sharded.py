@@ -39,10 +39,14 @@ class ShardedFlatIPIndex:
     ids already global).  `search_device` is collective: all ranks call it with the same queries."""
 
     def __init__(self, local: FlatIPIndex, group: Optional[dist.ProcessGroup] = None,
-                 local_search: Optional[Callable] = None, merge: Optional[Callable] = None):
+                 local_search: Optional[Callable] = None, merge: Optional[Callable] = None,
+                 always_exchange: bool = False):
+        """always_exchange: run the all-gather and the merge even when the group has ONE rank (the collective and the
+        merge kernel can then be exercised on a one-GPU box: tests/test_gpu_sharded.py)."""
         self.local = local
         self.group = group
         self.d = local.d
+        self.always_exchange = bool(always_exchange)
         # injection points exist for the CPU (gloo) tests only; the product path is the HIP one
         self._local_search = local_search or local.search_device
         self._merge = merge or merge_device
@@ -58,13 +62,13 @@ class ShardedFlatIPIndex:
         n = torch.tensor([self.local.ntotal], dtype=torch.int64,
                          device=self.local.device if dist.is_initialized() and dist.get_backend(self.group) == "nccl"
                          else "cpu")
-        if dist.is_initialized() and self.world > 1:
+        if dist.is_initialized() and (self.world > 1 or self.always_exchange):
             dist.all_reduce(n, group=self.group)
         return int(n.item())
 
     def search_device(self, q: torch.Tensor, k: int):
         D, I = self._local_search(q, k)
-        if not dist.is_initialized() or self.world == 1:
+        if not dist.is_initialized() or (self.world == 1 and not self.always_exchange):
             return D, I
         W = self.world
         nq = D.shape[0]
@@ -86,8 +90,28 @@ class ShardedFlatIPIndex:
         return self._merge(Ds, Is, k)
 
     def search(self, x, k: int):
+        """faiss signature, collective: every rank calls it with the same x and gets the global result."""
         import numpy as np
 
         q = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.local.device)
         D, I = self.search_device(q, int(k))
         return D.cpu().numpy(), I.cpu().numpy()
+
+    def reconstruct_batch(self, ids):
+        """IndexIDMap::reconstruct_batch over the shards (api/routes.py:1078), collective: every rank looks the ids up in
+        its own rows (a row of NaN where it does not hold the id — wise_reconstruct_batch), ONE all-gather of the [n,d]
+        answers, and each row is taken from the rank that had it.  Ids no rank holds stay NaN."""
+        import numpy as np
+
+        mine = torch.from_numpy(np.ascontiguousarray(self.local.reconstruct_batch(ids), dtype=np.float32))
+        if not dist.is_initialized() or (self.world == 1 and not self.always_exchange):
+            return mine.numpy()
+        W = self.world
+        on_device = dist.get_backend(self.group) == "nccl"
+        mine = mine.to(self.local.device) if on_device else mine
+        allr = torch.empty((W,) + tuple(mine.shape), dtype=torch.float32, device=mine.device)
+        dist.all_gather_into_tensor(allr.view(W * mine.shape[0], -1), mine, group=self.group)
+        have = ~torch.isnan(allr[:, :, 0])                        # [W, n]
+        owner = have.to(torch.int8).argmax(dim=0)                 # first rank that holds the id (ids are unique)
+        out = allr[owner, torch.arange(mine.shape[0], device=mine.device)]
+        return out.cpu().numpy()
