@@ -30,7 +30,8 @@ const char* wise_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: per-index counters for the two-stage search,
  * the shadow's error norm, wise_build_flags; 3: wise_vit_config.arch, wise_text_config.no_causal / eps_e6 — the SigLIP
  * towers — and the wise_xlmr_* entry points; 4: wise_xlmr_config.pos_mode / pool / head / eps_e12 — MS-CLAP 2022's BERT
- * caption encoder — and the wise_cnn14_* entry points). */
+ * caption encoder — and the wise_cnn14_* entry points; 5: wise_ip_shadow_i8 / wise_ip_topk_shadow8_f32 (int8 shadow,
+ * norms[4]), wise_ip_topk_shadow_workspace_bytes depends on nq and returns 0 under 2^18 rows, two-stage k up to 1024). */
 int wise_abi_version(void);
 /* Host-side hint for the GEMM tile heuristic (no device work), local to the CALLING THREAD: on != 0 while this thread
  * enqueues batches that will run beside another stream's (two batches in flight); tilings that measured slower there

@@ -66,7 +66,7 @@ def main(tmp):
     res["plugin_search"] = bool(np.array_equal(ids_, Ir[0]) and np.allclose(dist_, Dr[0], atol=2e-5))
     # (B) the sharded build: store -> part file -> load
     Xs = X[:5000]
-    st = FeatureStoreFactory.create_store(FeatureStoreType.NUMPY_SAVE, "audio", str(tmp / "features"))
+    st = FeatureStoreFactory.create_store(FeatureStoreType.NUMPY, "audio", str(tmp / "features"))
     st.enable_write(1000, 0)
     for i in range(5000):
         st.add(i + 1, Xs[i:i + 1])

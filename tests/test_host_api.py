@@ -33,7 +33,7 @@ def test_library_exports_exactly_the_declared_symbols():
     nm = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True)
     exported = {line.split()[-1] for line in nm.stdout.splitlines() if line.strip()}
     assert exported == declared, f"exported but not declared: {sorted(exported - declared)}; missing: {sorted(declared - exported)}"
-    assert lib.wise_abi_version() == 4
+    assert lib.wise_abi_version() == 5
     # the flags of the correctness fix (no packed f32 VALU math) are the ones this very library was compiled with
     flags = lib.wise_build_flags().decode()
     assert "-fno-slp-vectorize" in flags and "-packed-fp32-ops" in flags, flags

@@ -16,7 +16,7 @@ import ctypes as C, sys
 sys.path.insert(0, %(root)r)
 from wise_amd import _lib
 lib = _lib.load(%(lib)r)
-assert lib.wise_abi_version() == 4
+assert lib.wise_abi_version() == 5
 assert b"-fno-slp-vectorize" in lib.wise_build_flags()
 # flat search: planners and refusals
 assert lib.wise_ip_topk_workspace_bytes(1000, 510, 1, 10) > 0

@@ -423,13 +423,12 @@ static int forward(const bf16_t* wb, const float* pf, const float* wave, int B, 
     {   // block 1: both convolutions and the pooling in one kernel (the tensor between them never leaves the CU)
         const int rows2 = B * (T / 2);
         const size_t lds = B1_MEL + 8192;        // six image rows + conv 1's four weight fragments + the log-mel rows in flight
-        static std::once_flag attr_b1;
-        std::call_once(attr_b1, [&] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block1_kernel<0>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static PerDeviceOnce attr_b1;
+        attr_b1([&] {
+            raise_lds_limit(reinterpret_cast<const void*>(conv_block1_kernel<0>), (int)lds);
 #ifdef WISE_DEBUG_KNOBS
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_block1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raise_lds_limit(reinterpret_cast<const void*>(conv_block1_kernel<1>), (int)lds);
+            raise_lds_limit(reinterpret_cast<const void*>(conv_block1_kernel<2>), (int)lds);
 #endif
         });
         auto kern = conv_block1_kernel<0>;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include <mutex>
 
 #include "../../include/wise_hip.h"
@@ -31,6 +32,30 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Function attributes (and __device__ tables) belong to a DEVICE, not to the process: `once(f)` runs f the first time the
+// calling thread's current device comes by, so a process that drives several GPUs sets every one of them up.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> done{0};   // bit d: device d is set up
+    std::mutex mu;
+    template <typename F>
+    void operator()(F&& f) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (done.load(std::memory_order_relaxed) & bit) return;
+        f();
+        done.fetch_or(bit, std::memory_order_release);
+    }
+};
+// Raise a kernel's dynamic-LDS limit on the current device.  A failure is recorded (wise_last_error); the launch behind
+// it then fails with its own error, which WISE_LAUNCH_CHECK reports.
+static inline void raise_lds_limit(const void* kern, int bytes) {
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) set_error("hipFuncSetAttribute(max dynamic LDS = %d): %s", bytes, hipGetErrorString(e));
+}
 
 // Optional per-kernel HIP-event brackets (wise_prof_begin/_end in the C ABI): class 0 = bf16 GEMM
 // (work = flop), class 1 = IP scan (work = algorithmic bytes).  No-ops unless profiling is on.

@@ -63,7 +63,7 @@ extern "C" int wise_prof_end(double* ms_sum, int64_t* launches, double* work_sum
 }
 
 extern "C" const char* wise_last_error(void) { return wise::g_err; }
-extern "C" int wise_abi_version(void) { return 4; }
+extern "C" int wise_abi_version(void) { return 5; }
 #ifndef WISE_BUILD_FLAGS
 #define WISE_BUILD_FLAGS "unknown (not built by wise_amd/build.py)"
 #endif

@@ -380,8 +380,7 @@ extern "C" int wise_debug_vgpr_canary(int blocks, int lds_bytes, int iters, int 
 
 extern "C" int wise_debug_lds_canary(int blocks, int lds_bytes, int iters, int spin, uint32_t* report, void* stream) {
     if (lds_bytes > 65536)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lds_canary_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lds_canary_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL(lds_canary_kernel, dim3(blocks), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, iters, spin,
                        lds_bytes / 4, report);
     return (int)hipGetLastError();

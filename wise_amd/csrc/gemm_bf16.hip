@@ -1247,10 +1247,9 @@ static void launch_gemm_ln(const float* x, const float* lnw, const float* lnb, c
     constexpr size_t TBs = 128 * 64;
     const size_t wreg = (NF * TBs > (size_t)4 * 64 * 144) ? NF * TBs : (size_t)4 * 64 * 144;
     const size_t lds = NF * TBs + wreg;
-    static std::once_flag attr_set;
-    std::call_once(attr_set, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds);
     });
     hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), lds, st, x, lnw, lnb, Wt, bias, M, N, eps, out);
 }
@@ -1260,10 +1259,9 @@ static void launch_ring(const bf16_t* A, const bf16_t* Wt, const float* bias, in
                         hipStream_t st) {
     auto kern = gemm_ring_kernel<MODE, BKT, STAGES, MINB, ABL>;
     const size_t lds = (size_t)STAGES * 2 * 128 * BKT * 2;
-    static std::once_flag attr_set;
-    std::call_once(attr_set, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds);
     });
     const int grid = (M / BM) * ((N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, Wt, bias, M, N, K, out);
@@ -1274,10 +1272,9 @@ static void launch_gemm(const bf16_t* A, const bf16_t* Wt, const float* bias, in
                         hipStream_t st) {
     auto kern = gemm_bf16_kernel<MODE, ABL>;
     const size_t lds = 4 * TILE_BYTES;  // 64 KiB
-    static std::once_flag attr_set;
-    std::call_once(attr_set, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds);
     });
     const int grid = (M / BM) * ((N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, Wt, bias, M, N, K, out);
@@ -1417,10 +1414,9 @@ static void launch_big_pre(const bf16_t* A, const bf16_t* Wt, const float* bias,
     if constexpr (MODE == EPI_RESID) {
         auto kern = gemm_big_kernel<MODE, NT, 0, true>;
         const size_t lds = (size_t)2 * (256 + 64 * NT) * 128;
-        static std::once_flag attr_set;
-        std::call_once(attr_set, [&] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
+        static PerDeviceOnce attr_set;
+        attr_set([&] {
+            raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds);
         });
         const int grid = (M / 256) * (N / (64 * NT));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
@@ -1432,10 +1428,9 @@ static void launch_big(const bf16_t* A, const bf16_t* Wt, const float* bias, int
                        hipStream_t st) {
     auto kern = gemm_big_kernel<MODE, NT, ABL>;
     const size_t lds = (size_t)2 * (256 + 64 * NT) * 128;
-    static std::once_flag attr_set;
-    std::call_once(attr_set, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds);
     });
     const int grid = (M / 256) * (N / (64 * NT));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
@@ -1940,9 +1935,9 @@ template <int MODE>
 static void launch_ppb(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out, hipStream_t st) {
     auto kern = gemm_ppb_kernel<MODE>;
     const size_t lds = 131072;   // six 16-KiB A tiles; the epilogues use up to 128 KiB of the same space
-    static std::once_flag attr_set;
-    std::call_once(attr_set, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds);
     });
     hipLaunchKernelGGL(kern, dim3((M / 256) * (N / 256)), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
 }
@@ -2079,10 +2074,9 @@ static void launch_pp2(const bf16_t* A, const bf16_t* Wt, const float* bias, int
                        hipStream_t st) {
     auto kern = gemm_pp2_kernel<MODE>;
     const size_t lds = (size_t)4 * (256 + 256) * 32 * 2;  // 128 KiB
-    static std::once_flag attr_set;
-    std::call_once(attr_set, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds);
     });
     const int grid = (M / 256) * (N / 256);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
@@ -2098,10 +2092,9 @@ static void launch_pp(const bf16_t* A, const bf16_t* Wt, const float* bias, int 
     constexpr int BMB = (WROWS == 64) ? 256 : (WROWS == 80) ? 320 : 2 * WROWS;
     constexpr int STAGES = STG ? STG : ((WROWS == 64) ? 5 : 4);
     const size_t lds = (size_t)STAGES * (BMB + BNB) * 32 * 2;  // 128 KiB / 120 KiB / 144 KiB
-    static std::once_flag attr_set;
-    std::call_once(attr_set, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds);
     });
     const int grid = (M / BMB) * (N / BNB);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, Wt, bias, M, N, K, out);
@@ -2323,10 +2316,9 @@ int mlp96_fused(float* x, const float* lnw, const float* lnb, const bf16_t* W1, 
     ProfScope prof(PROF_GEMM, 4.0 * (double)M * 96.0 * 384.0, st);
     if (g_mlp96_resident) {
         const size_t ldsr = (size_t)MLPR_W1_BYTES + MLPR_W2_BYTES + (384 + 3 * 96) * sizeof(float);   // 150 KiB
-        static std::once_flag attr_r;
-        std::call_once(attr_r, [&] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp96r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)ldsr);
+        static PerDeviceOnce attr_r;
+        attr_r([&] {
+            raise_lds_limit(reinterpret_cast<const void*>(mlp96r_kernel), (int)ldsr);
         });
         const long long units = M / 32;
         const int grid = units < 8 * 256 ? (int)((units + 7) / 8) : 256;
@@ -2335,10 +2327,9 @@ int mlp96_fused(float* x, const float* lnw, const float* lnb, const bf16_t* W1, 
         return WISE_OK;
     }
     const size_t lds = (size_t)9 * 128 * 64;  // 72 KiB
-    static std::once_flag attr_set;
-    std::call_once(attr_set, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp96_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(mlp96_kernel), (int)lds);
     });
     hipLaunchKernelGGL(mlp96_kernel, dim3(M / 128), dim3(256), lds, st, x, lnw, lnb, W1, b1, W2, b2, eps);
     WISE_LAUNCH_CHECK("mlp96_kernel");
@@ -2399,10 +2390,9 @@ size_t gemm_splitk_bytes(int M, int m_valid, int N, int K) {
 static void splitk_partials(const bf16_t* A, const bf16_t* Wt, int N, int K, int S, float* part, hipStream_t st) {
     constexpr int STAGES = 4;
     const size_t lds = (size_t)STAGES * 2 * 128 * 64 * 2;
-    static std::once_flag attr_set;
-    std::call_once(attr_set, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_splitk_kernel<STAGES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(gemm_splitk_kernel<STAGES>), (int)lds);
     });
     hipLaunchKernelGGL(gemm_splitk_kernel<STAGES>, dim3(N / 128, S), dim3(256), lds, st, A, Wt, N, K, K / S, part);
 }
@@ -2558,14 +2548,16 @@ template <typename K>
 static void conv_launch(K kern, size_t lds, int grid, int threads, const bf16_t* X, const bf16_t* Wt, const float* bias,
                         const bf16_t* zeros, int T, int F, int Cin, int M, int Cout, bf16_t* out, hipStream_t st) {
     static std::mutex mu;
-    static std::vector<const void*> configured;   // kernels whose dynamic-LDS limit has been raised (a handful)
+    static std::vector<std::pair<const void*, int>> configured;   // (kernel, device) whose dynamic-LDS limit has been raised
     {
         std::lock_guard<std::mutex> lk(mu);
-        const void* id = reinterpret_cast<const void*>(kern);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const std::pair<const void*, int> id(reinterpret_cast<const void*>(kern), dev);
         bool seen = false;
-        for (const void* c : configured) seen = seen || c == id;
+        for (const auto& c : configured) seen = seen || c == id;
         if (!seen) {
-            (void)hipFuncSetAttribute(id, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raise_lds_limit(id.first, (int)lds);
             configured.push_back(id);
         }
     }

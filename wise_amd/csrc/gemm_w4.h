@@ -431,9 +431,9 @@ static void launch_w4(const bf16_t* A, const bf16_t* Wt, const float* bias, int 
     auto kern = gemm_w4_kernel<MODE, MI, NJ, SA, SW, OCC>;
     static_assert(OCC == 1 || w4::lds_bytes(MI, NJ, SA, SW) <= 80 * 1024, "two workgroups per CU: 80 KiB of LDS each");
     constexpr int LDS = w4::lds_bytes(MI, NJ, SA, SW) > 4 * 20480 ? w4::lds_bytes(MI, NJ, SA, SW) : 4 * 20480;
-    static std::once_flag attr_set;
-    std::call_once(attr_set, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(kern), LDS);
     });
     const int grid = (M / (32 * MI)) * (N / (32 * NJ));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, A, Wt, bias, M, N, K, out);
@@ -671,9 +671,9 @@ static void launch_w4p(const bf16_t* A, const bf16_t* Wt, const float* bias, int
     if constexpr (bf16_out(MODE)) {
         auto kern = gemm_w4p_kernel<MODE>;
         constexpr int LDS = 3 * 160 * 128 + 2 * 256 * 128 + 4 * 16 * 272;
-        static std::once_flag attr_set;
-        std::call_once(attr_set, [&] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        static PerDeviceOnce attr_set;
+        attr_set([&] {
+            raise_lds_limit(reinterpret_cast<const void*>(kern), LDS);
         });
         const int ntiles = (M / 160) * (N / 256);
         const int grid = ntiles < num_cus ? ntiles : num_cus;

@@ -362,9 +362,9 @@ void frontend_set_variant(int full_fft) { g_frontend_full_fft = full_fft; }
 int frontend(const float* wave, int B, int samples, int Fc, const float* hann, const float* mel_start,
              const float* mel_len, const float* mel_wt, const float* bn_scale, const float* bn_shift, float* melbn,
              hipStream_t st, int max_band) {
-    static std::once_flag once;
+    static PerDeviceOnce once;
     static hipError_t init_err = hipSuccess;
-    std::call_once(once, [&] {   // the twiddle table lives in a __device__ array; complete before any stream reads it
+    once([&] {   // the twiddle table lives in a __device__ array; complete before any stream reads it
         hipLaunchKernelGGL(fft_twiddle_kernel, dim3(4), dim3(256), 0, st);
         init_err = hipGetLastError();
         if (init_err == hipSuccess) init_err = hipStreamSynchronize(st);

@@ -1607,8 +1607,7 @@ static void launch_scan(const ScanPlan& p, const float* X, long long N, int d, c
     }
     auto kern = ip_scan_kernel<NV, NQ, 4>;
     if (p.lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)p.lds);
+        raise_lds_limit(reinterpret_cast<const void*>(kern), (int)p.lds);
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds, st, reinterpret_cast<const f32x4*>(X), N, d / 4, Q, k,
                        p.cap, part, sa);
 }
@@ -1619,8 +1618,7 @@ static void launch_seg_scan(const float* X, int d, const float* Q, int k, int ca
     auto kern = ip_scan_kernel<NV, 1, 4, true>;
     const size_t lds = (size_t)4 * cap * 8;
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+        raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)((long long)seg.nq * seg.nprobe)), dim3(256), lds, st,
                        reinterpret_cast<const f32x4*>(X), 0ll, d / 4, Q, k, cap, part, seg);
 }
@@ -1809,8 +1807,7 @@ extern "C" int wise_ip_topk_f32(const float* X, int64_t N, int d, const float* Q
             WISE_LAUNCH_CHECK("ip_scan_kernel");
         }
         if (mlds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_keys_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds);
+            raise_lds_limit(reinterpret_cast<const void*>(merge_keys_kernel), (int)mlds);
         hipLaunchKernelGGL(merge_keys_kernel, dim3(nqa), dim3(mw * 64), mlds, st, part, N > 0 ? p.grid : 0,
                            p.nq_per_pass, k, p.cap, reinterpret_cast<const long long*>(ids), (long long)id_base, outD,
                            reinterpret_cast<long long*>(outI), q0);
@@ -1861,8 +1858,7 @@ extern "C" int wise_ivf_scan_f32(const float* X, int64_t N, int d, const int64_t
     if (mw > 16) mw = 16;
     const size_t mlds = (size_t)mw * cap * 8;
     if (mlds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_keys_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds);
+        raise_lds_limit(reinterpret_cast<const void*>(merge_keys_kernel), (int)mlds);
     hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(mw * 64), mlds, st, part, nprobe, nq, k, cap,
                        reinterpret_cast<const long long*>(ids), 0ll, outD, reinterpret_cast<long long*>(outI), 0);
     WISE_LAUNCH_CHECK("merge_keys_kernel");

@@ -417,12 +417,10 @@ size_t mfma_scan_part_bytes(long long N, int k) { return (size_t)mfma_scan_lists
 int mfma_scan_launch(const float* X, long long N, int d, const float* qpad, int nq, int k, u64* part, bool split,
                      hipStream_t st) {
     const size_t lds = (size_t)32 * d * 4 + (size_t)WAVES * RING * CHUNK_BYTES + (size_t)WAVES * MFMA_KL * 32 * 8;
-    static std::once_flag attr_set;
-    std::call_once(attr_set, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_mfma_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_mfma_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static PerDeviceOnce attr_set;
+    attr_set([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(ip_scan_mfma_kernel<false>), 160 * 1024);
+        raise_lds_limit(reinterpret_cast<const void*>(ip_scan_mfma_kernel<true>), 160 * 1024);
     });
     if (split && g_split_direct) {
         set_error("mfma_scan_launch: the register-queue scan is launched through split_scan_launch");
@@ -618,10 +616,9 @@ bool split64_supported(int d) { return d % (4 * CW) == 0 && d <= 512; }   // who
 int split64_scan_launch(const float* X, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
                         const u64* tau0, hipStream_t st, const int* gate) {
     const size_t dl = (size_t)QB2 * d * 4 + (size_t)MFMA_KL * QB2 * 8 + QB2 * 4;
-    static std::once_flag dattr;
-    std::call_once(dattr, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_split64_kernel<4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static PerDeviceOnce dattr;
+    dattr([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(ip_scan_split64_kernel<4>), 160 * 1024);
     });
     hipLaunchKernelGGL(ip_scan_split64_kernel<4>, dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, X, N, d, qpad, nq, part,
                        row_offset, tau0, gate);
@@ -844,18 +841,13 @@ int shadow64_scan_launch(const bf16_t* Xb, long long N, int d, const float* qpad
                          long long row_base) {
     const bool lo = !g_shadow_one_piece;
     const size_t dl = (size_t)qb * d * (lo ? 4 : 2);
-    static std::once_flag dattr;
-    std::call_once(dattr, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 64, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 32, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 128, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 64, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 32, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static PerDeviceOnce dattr;
+    dattr([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 64, true>), 160 * 1024);
+        raise_lds_limit(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 32, true>), 160 * 1024);
+        raise_lds_limit(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 128, false>), 160 * 1024);
+        raise_lds_limit(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 64, false>), 160 * 1024);
+        raise_lds_limit(reinterpret_cast<const void*>(ip_scan_shadow64_kernel<4, 32, false>), 160 * 1024);
     });
     WISE_CHECK_ARG(dl <= 160 * 1024 && (qb == 32 || qb == 64 || (qb == 128 && !lo)),
                    "shadow scan: %d queries per pass at d=%d not served", qb, d);
@@ -875,12 +867,10 @@ int shadow64_scan_launch(const bf16_t* Xb, long long N, int d, const float* qpad
 int split_scan_launch(const float* X, long long N, long long row_offset, int d, const float* qpad, int nq, u64* part,
                       const u64* tau0, hipStream_t st) {
     const size_t dl = (size_t)32 * d * 4 + (size_t)WAVES * MFMA_KL * 32 * 8;
-    static std::once_flag dattr;
-    std::call_once(dattr, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_split_direct_kernel<4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ip_scan_split_direct_kernel<3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static PerDeviceOnce dattr;
+    dattr([&] {
+        raise_lds_limit(reinterpret_cast<const void*>(ip_scan_split_direct_kernel<4>), 160 * 1024);
+        raise_lds_limit(reinterpret_cast<const void*>(ip_scan_split_direct_kernel<3>), 160 * 1024);
     });
     if (g_split_direct == 3)
         hipLaunchKernelGGL(ip_scan_split_direct_kernel<3>, dim3(mfma_grid(N)), dim3(WAVES * 64), dl, st, X, N, d, qpad, nq,

@@ -148,9 +148,10 @@ class FlatIPIndex:
             (2 <= nq <= 3 and 1 <= k <= 1024))
         if two_stage and lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k) == 0:
             two_stage = False
-        # the int8 copy answers one query at a time (0.9 ms each at 10M x 512): alone, in small groups — up to five queries
-        # cost less that way than one bf16 matrix-core pass (1.85 ms whatever it carries) —, and wherever no batched
-        # shape applies (k > 128, or k > 12 with two queries).  A batch proper goes through the bf16 passes: with 128
+        # the int8 copy answers one query at a time (0.9 ms each at 10M x 512): alone or in pairs — two queries cost what one
+        # bf16 matrix-core pass costs (1.8 ms whatever it carries), three or more cost more (measured: 1093 q/s at nq = 4
+        # one at a time against 2.09 k through a pass) —, and wherever no batched shape applies (k > 128, or k > 12 with two
+        # queries).  A batch proper goes through the bf16 passes: with 128
         # queries in flight the int8 error band (~0.7 sigma of the score distribution at 10M rows against bf16's 0.25)
         # puts a candidate in most 32-row groups, and the hit path, not the bytes, then sets the pace (measured: 50 k
         # queries/s against 65 k at nq = 256, and k = 100 overflows its lists).
@@ -160,7 +161,7 @@ class FlatIPIndex:
         # band already keeps 13 k of the 16 k rows the re-scoring list holds — any clustering would overflow it into the
         # fp32 scan — and the two are equally fast there (the lists, not the bytes, set the time)
         use8 = (self.shadow and self.shadow8 and self._n >= (1 << 18) and 1 <= k <= 256 and
-                (nq <= 5 or (not batched_shape and nq <= 64)))
+                (nq <= 2 or (not batched_shape and nq <= 64)))
         if use8 and self._ensure_shadow8(lib):
             need = lib.wise_ip_topk_shadow_workspace_bytes(self._n, self.d, nq, k)
             if self._sws is None or self._sws.numel() < need:
