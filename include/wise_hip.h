@@ -185,6 +185,12 @@ typedef struct wise_vit_config {
                            ln_pre, LayerNorm eps 1e-6, final norm over all tokens, attention-pool head (one latent query,
                            projection, y + mlp(norm(y))), no projection (embed_dim == width); u8 input is normalised with
                            mean = std = 0.5.  Weight layout of arch 1: wise_amd/feature/siglip.py:pack_siglip_vision */
+    int32_t ln_fold;    /* (ABI 5) 0 = LayerNorm kernels between the GEMMs; 1 (arch 0 only) = the blocks' LayerNorms folded into
+                           the GEMMs around them: the residual GEMMs also emit bf16(x) and the rows' 1/sqrt(var + eps), the
+                           QKV / fc1 GEMMs scale their rows by it.  The blob layout is the same, but the packer must then store
+                           in_proj / c_fc as gamma-scaled, row-centred weights and their biases as b + W beta
+                           (wise_amd/feature/vit.py:pack_weights); ln_1 / ln_2 slots are not read.  Same results within the
+                           bf16 path's tolerance (not bit-equal to ln_fold = 0). */
 } wise_vit_config;
 
 #define WISE_VIT_IN_F32 0  /* images [B,3,S,S] fp32, already normalised (preprocess_image output) */
@@ -369,6 +375,20 @@ int wise_preproc_taps(int in_size, int out_size, int* ksize, int* first, int* co
  *       5 -> out_bf16 = gelu_tanh(acc+bias) ; 6 -> out_bf16 = relu(acc+bias) */
 int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K,
                    int mode, void* out, void* stream);
+/* (ABI 5) The two GEMMs of wise_vit_config.ln_fold = 1: a LayerNorm between a residual GEMM and the next linear layer is
+ * carried by the GEMMs themselves (open_clip's ln_1 / ln_2 as reached from src/feature/mlfoundation_openclip.py:99).
+ *   wise_gemm_fold_resid: x[M,N] fp32 += A[M,K] @ Wt[N,K]^T + bias; h[M,N] bf16 = bf16(x); stats = one region of
+ *     wise_gemm_fold_stats_bytes(M, N) bytes whose first M floats become rstd[r] = 1 / sqrt(var(x[r,:]) + eps); behind them
+ *     scratch (partial sums per 64 columns, then (M/128 + 1) int arrival counters that must be ZERO on entry and are zero again
+ *     on exit).  The statistics are reduced in one fixed tree, so a row's rstd does not depend on M or on the tile chosen.
+ *   wise_gemm_fold_bf16: out[M,N] bf16 = act(rstd[row] * (A @ Wt^T) + bias[col]), mode 0 / 1 / 2 / 5 as wise_gemm_bf16; with
+ *     A = h, Wt = gamma-scaled row-centred weights and bias = b + W beta this is act(Linear(LayerNorm(x))).
+ * M % 128 == 0, N % 128 == 0, K % 64 == 0, K >= 192. */
+size_t wise_gemm_fold_stats_bytes(int M, int N);
+int wise_gemm_fold_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, const float* rstd, int M, int N, int K,
+                        int mode, uint16_t* out, void* stream);
+int wise_gemm_fold_resid(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, float* x,
+                         uint16_t* h, float* stats, float eps, void* stream);
 /* out[ceil256(B*T*F), cout] bf16 = relu(conv3x3(x [B,T,F,cin] bf16, position-major ("NHWC"), stride 1, zero padding 1)
  * + bias[cout]); with pool != 0 its 2x2 average pooling (floor) instead, out [B*(T/2)*(F/2), cout], computed in the same
  * kernel (the unpooled tensor is never written).  wt [cout, 9*cin] bf16 with k = (kh*3 + kw)*cin + c (BatchNorm folded

@@ -23,7 +23,7 @@ EPI_BF16, EPI_QUICKGELU, EPI_GELU, EPI_RESID, EPI_F32 = range(5)
 
 class VitConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("image_size", "patch", "width", "layers", "heads", "mlp", "embed_dim", "act",
-                                          "arch")]
+                                          "arch", "ln_fold")]
 
 
 class TextConfig(C.Structure):
@@ -88,6 +88,9 @@ SIGNATURES = {
     "wise_preproc_u8": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "wise_preproc_taps": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i]),
     "wise_gemm_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "wise_gemm_fold_stats_bytes": (C.c_size_t, [_i, _i]),
+    "wise_gemm_fold_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "wise_gemm_fold_resid": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp]),
     "wise_mlp96_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
     "wise_gemm_ln_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "wise_layernorm_f32_bf16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),

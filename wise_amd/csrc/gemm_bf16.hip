@@ -2542,6 +2542,72 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
     return launch_mode(auto_variant(M, N, K), A, Wt, bias, M, N, K, mode, out, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The two GEMM forms of the LayerNorm fold (gemm_w4.h FoldArgs; vit.hip's fold mode): every one of them is a one-wave-per-
+// SIMD kernel, whose epilogues live in ONE place, so a row gets the same bits from whatever tile its batch size selects.
+//   consumer:  out bf16 [M,N] = act(rstd[row] * (A @ Wt^T) + bias[col])          (QKV, fc1; A = bf16 copy of the residual rows)
+//   producer:  x += A @ Wt^T + bias;  h = bf16(x);  part / rstd_out = the rows' statistics    (out-projection, fc2)
+// M % 128 == 0, N % 128 == 0, K % 64 == 0, K >= 192.  Tiles with 64- or 128-column wave parts only (the statistics' tree).
+// ---------------------------------------------------------------------------------------------------------------------
+bool gemm_fold_shape_ok(int M, int N, int K) { return M > 0 && M % 128 == 0 && N > 0 && N % 128 == 0 && K % 64 == 0 && K >= 192; }
+
+static int fold_variant(int M, int N, int K, int mode, bool producer) {
+    const int v = w4_variant(M, N, K, mode);
+    if (v == 61 || v == 68 || v == 70 || ((v == 60 || v == 64) && !producer)) return v;   // (the 256 x 256 residual form with statistics spills)
+    if (!producer && w4p_shape_ok(M, N, K) && (long long)(M / 160) * (N / 256) >= device_cus()) return 64;
+    if (w4_shape_ok(M, N, K, 5, 8) && (long long)(M / 160) * (N / 256) >= 192) return 61;
+    if (w4_shape_ok(M, N, K, 4, 8) && (long long)(M / 128) * (N / 256) >= 256) return 68;
+    return 70;
+}
+
+template <int MODE>
+static void launch_fold_consumer(int v, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, bf16_t* out,
+                                 const FoldArgs& fa, hipStream_t st) {
+    switch (v) {
+        case 60: launch_w4<MODE, 8, 8, 3, 2, 1, 1>(A, Wt, bias, M, N, K, out, st, fa); break;
+        case 61: launch_w4<MODE, 5, 8, 3, 2, 1, 1>(A, Wt, bias, M, N, K, out, st, fa); break;
+        case 64: launch_w4p<MODE, 1>(A, Wt, bias, M, N, K, out, device_cus(), st, fa); break;
+        case 68: launch_w4<MODE, 4, 8, 3, 2, 1, 1>(A, Wt, bias, M, N, K, out, st, fa); break;
+        default: launch_w4<MODE, 4, 4, 3, 2, 2, 1>(A, Wt, bias, M, N, K, out, st, fa); break;
+    }
+}
+
+int gemm_fold_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, const float* rstd, int M, int N, int K, int mode,
+                   bf16_t* out, hipStream_t st) {
+    WISE_CHECK_ARG(A && Wt && bias && rstd && out, "gemm_fold_bf16: null pointer");
+    WISE_CHECK_ARG(gemm_fold_shape_ok(M, N, K) && bf16_out(mode) && mode != EPI_RELU, "gemm_fold_bf16: M=%d N=%d K=%d mode=%d", M, N, K, mode);
+    ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
+    FoldArgs fa;
+    fa.stats = const_cast<float*>(rstd);
+    const int v = fold_variant(M, N, K, mode, false);
+    switch (mode) {
+        case EPI_BF16: launch_fold_consumer<EPI_BF16>(v, A, Wt, bias, M, N, K, out, fa, st); break;
+        case EPI_QUICKGELU: launch_fold_consumer<EPI_QUICKGELU>(v, A, Wt, bias, M, N, K, out, fa, st); break;
+        case EPI_GELU: launch_fold_consumer<EPI_GELU>(v, A, Wt, bias, M, N, K, out, fa, st); break;
+        default: launch_fold_consumer<EPI_GELU_TANH>(v, A, Wt, bias, M, N, K, out, fa, st); break;
+    }
+    WISE_LAUNCH_CHECK("gemm_w4_kernel (fold, bf16 out)");
+    return WISE_OK;
+}
+
+size_t gemm_fold_stats_bytes(int M, int N) { return fold_stats_bytes(M, N); }
+
+int gemm_fold_resid(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, float* x, bf16_t* h, float* stats,
+                    float eps, hipStream_t st) {
+    WISE_CHECK_ARG(A && Wt && x && h && stats, "gemm_fold_resid: null pointer");
+    WISE_CHECK_ARG(gemm_fold_shape_ok(M, N, K), "gemm_fold_resid: M=%d N=%d K=%d", M, N, K);
+    ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
+    FoldArgs fa;
+    fa.hcopy = h; fa.stats = stats; fa.eps = eps;
+    switch (fold_variant(M, N, K, EPI_RESID, true)) {
+        case 61: launch_w4<EPI_RESID, 5, 8, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
+        case 68: launch_w4<EPI_RESID, 4, 8, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
+        default: launch_w4<EPI_RESID, 4, 4, 3, 2, 2, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
+    }
+    WISE_LAUNCH_CHECK("gemm_w4_kernel (fold, residual)");
+    return WISE_OK;
+}
+
 static int g_conv_variant = 0;   // (debug knob) 0 = by shape, 1 = the 128-row tile everywhere, 2 = ping-pong wherever it tiles
 
 template <typename K>
@@ -2633,6 +2699,16 @@ extern "C" int wise_gemm_ln_bf16(const float* x, const float* lnw, const float* 
 }
 
 extern "C" void wise_overlap_hint(int on) { wise::gemm_set_overlapped(on != 0); }
+
+extern "C" size_t wise_gemm_fold_stats_bytes(int M, int N) { return wise::gemm_fold_shape_ok(M, N, 192) ? wise::gemm_fold_stats_bytes(M, N) : 0; }
+extern "C" int wise_gemm_fold_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, const float* rstd, int M, int N, int K,
+                                   int mode, uint16_t* out, void* stream) {
+    return wise::gemm_fold_bf16(A, Wt, bias, rstd, M, N, K, mode, out, (hipStream_t)stream);
+}
+extern "C" int wise_gemm_fold_resid(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, float* x,
+                                    uint16_t* h, float* stats, float eps, void* stream) {
+    return wise::gemm_fold_resid(A, Wt, bias, M, N, K, x, h, stats, eps, (hipStream_t)stream);
+}
 
 extern "C" int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, int mode,
                               void* out, void* stream) {

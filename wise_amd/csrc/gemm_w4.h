@@ -34,6 +34,28 @@
 #include "gemm_shared.h"
 
 namespace wise {
+
+// LayerNorm folded into the GEMMs on either side of it (round 4, vit.hip "fold mode").  y = LN(x) W^T + b with
+// LN(x) = (x - mean) rstd gamma + beta is rstd * (x W''^T) + b'' when W'' = gamma W minus its row mean over K (the centring
+// moves into the weights: sum_k (x_k - mean) w_k = sum_k x_k (w_k - mean_k w)) and b'' = b + W beta — both made by the packer.
+//   FOLD = 1 (bf16 outputs: QKV, fc1): the operand is bf16(x) as it stands and the epilogue is fma(acc, rstd[row], b''[col]).
+//   FOLD = 2 (EPI_RESID: out-projection, fc2): besides x += ..., the epilogue writes the bf16 copy of the new rows (the next
+//             GEMM's operand) and per-row partial sums of x and x^2 over aligned 64-column groups, reduced in ONE fixed tree
+//             whatever the tile shape (wave parts are 64 or 128 columns wide: NJ = 4 or 8), so a row's statistics — and with
+//             them every bit downstream — do not depend on the batch it sits in; the LAST workgroup of a row stripe to finish
+//             (arrival counter) adds the N/64 partials in order and writes rstd = rsqrt(var + eps) for the stripe's rows.
+// No LayerNorm launch is left between the two GEMMs, and the fp32 rows are not read a second time.
+struct FoldArgs {
+    // FOLD 1: stats = the [M] row scales (rstd).  FOLD 2: stats = ONE region laid out as rstd_out [M] floats, then the partial
+    // sums [M][N/64][2] floats, then one arrival counter (int) per row stripe of the launch (zero on entry, zero on exit);
+    // hcopy = the [M, N] bf16 copy of the updated rows.  (Few kernel arguments on purpose: they stay live in scalar
+    // registers across a loop whose inline-assembly loads need theirs.)
+    float* stats = nullptr;
+    bf16_t* hcopy = nullptr;
+    float eps = 1e-5f;
+};
+__host__ __device__ inline size_t fold_stats_bytes(int M, int N) { return (size_t)M * 4 + (size_t)M * (N / 64) * 8 + (size_t)(M / 128 + 1) * 4; }
+
 namespace w4 {
 
 // In-kernel s_memtime stamps of block 0 and of the last block (tools/gemm_lab.hip builds with -DW4_STAMPS): slot 0 kernel
@@ -97,27 +119,121 @@ __device__ __forceinline__ void mfma16v(f32x4& acc, const bf16x8& a, const bf16x
 // kernel's own counted waits include it, and s_waitcnt vmcnt(0) stands in front of the first use.
 typedef unsigned rsrc_words_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void load16_to_agpr(f32x4& dst, rsrc_words_t rsrc, int voff, int soff) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    // (readfirstlane: under scalar-register pressure the allocator has handed this "s" operand a vector register)
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(dst) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
 }
 __device__ __forceinline__ void mfma_retire() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 __device__ __forceinline__ void pin_a(f32x4& acc) { asm volatile("" : "+a"(acc)); }
 __device__ __forceinline__ void pin_v(f32x4& acc) { asm volatile("" : "+v"(acc)); }
 
+// ---- the residual prefetch registers --------------------------------------------------------------------------------
+// The 160 x 256 residual kernel parks the fp32 values its tile will be added to in a[160:255], the 96 accumulator-file
+// registers its 40 accumulator tiles leave free, by buffer loads issued between the MFMAs of the last three K-steps.  The
+// registers are NAMED in the assembly text and listed as clobbers of every MFMA statement of such a kernel, so the register
+// allocator never places anything that lives across the loop there and never moves them.  (Round 3 handed the loads
+// compiler-allocated "=a" tuples: the allocator was free to copy or re-home a tuple before its load had landed — it did,
+// with the extra live values of the LayerNorm-fold epilogue, and silently returned stale residual rows.)
+#define W4_HI_AGPRS "a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
+__device__ __forceinline__ void mfma16a_hi(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b) : W4_HI_AGPRS);
+}
+// tuple t (0..23) <- 16 bytes at rsrc + voff + soff.  Not counted by the compiler in vmcnt: the kernel's counted waits include it.
+// s_nop 4: under scalar-register pressure the compiler keeps the row offsets in vector registers and the scalar operand comes
+// out of a v_readfirstlane right in front of the statement — a VALU-writes-SGPR / VMEM-reads-it hazard (5 wait states) that
+// nobody pads for an inline-assembly consumer: tuple 9 was loaded from tuple 8's address.
+__device__ __forceinline__ void rpre_load(int t, rsrc_words_t rsrc, int voff, int soff) {
+    const int so = __builtin_amdgcn_readfirstlane(soff);
+    switch (t) {
+        case 0: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[160:163], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 1: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[164:167], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 2: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[168:171], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 3: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[172:175], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 4: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[176:179], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 5: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[180:183], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 6: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[184:187], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 7: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[188:191], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 8: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[192:195], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 9: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[196:199], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 10: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[200:203], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 11: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[204:207], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 12: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[208:211], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 13: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[212:215], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 14: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[216:219], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 15: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[220:223], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 16: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[224:227], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 17: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[228:231], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 18: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[232:235], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 19: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[236:239], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 20: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[240:243], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 21: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[244:247], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 22: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[248:251], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        case 23: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[252:255], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        default: break;
+    }
+}
+// tuple t after the wait that covers its load.  Every read lists the whole range as clobbered: nothing the allocator wants to
+// keep (a spilled VGPR, say) may sit in a register that a LATER read still has to fetch — it took a[196:199] for a spill
+// between two reads when only the wait carried the list.
+__device__ __forceinline__ float4 rpre_read(int t) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    switch (t) {
+        case 0: asm volatile("v_accvgpr_read_b32 %0, a160\n\tv_accvgpr_read_b32 %1, a161\n\tv_accvgpr_read_b32 %2, a162\n\tv_accvgpr_read_b32 %3, a163" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 1: asm volatile("v_accvgpr_read_b32 %0, a164\n\tv_accvgpr_read_b32 %1, a165\n\tv_accvgpr_read_b32 %2, a166\n\tv_accvgpr_read_b32 %3, a167" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 2: asm volatile("v_accvgpr_read_b32 %0, a168\n\tv_accvgpr_read_b32 %1, a169\n\tv_accvgpr_read_b32 %2, a170\n\tv_accvgpr_read_b32 %3, a171" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 3: asm volatile("v_accvgpr_read_b32 %0, a172\n\tv_accvgpr_read_b32 %1, a173\n\tv_accvgpr_read_b32 %2, a174\n\tv_accvgpr_read_b32 %3, a175" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 4: asm volatile("v_accvgpr_read_b32 %0, a176\n\tv_accvgpr_read_b32 %1, a177\n\tv_accvgpr_read_b32 %2, a178\n\tv_accvgpr_read_b32 %3, a179" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 5: asm volatile("v_accvgpr_read_b32 %0, a180\n\tv_accvgpr_read_b32 %1, a181\n\tv_accvgpr_read_b32 %2, a182\n\tv_accvgpr_read_b32 %3, a183" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 6: asm volatile("v_accvgpr_read_b32 %0, a184\n\tv_accvgpr_read_b32 %1, a185\n\tv_accvgpr_read_b32 %2, a186\n\tv_accvgpr_read_b32 %3, a187" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 7: asm volatile("v_accvgpr_read_b32 %0, a188\n\tv_accvgpr_read_b32 %1, a189\n\tv_accvgpr_read_b32 %2, a190\n\tv_accvgpr_read_b32 %3, a191" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 8: asm volatile("v_accvgpr_read_b32 %0, a192\n\tv_accvgpr_read_b32 %1, a193\n\tv_accvgpr_read_b32 %2, a194\n\tv_accvgpr_read_b32 %3, a195" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 9: asm volatile("v_accvgpr_read_b32 %0, a196\n\tv_accvgpr_read_b32 %1, a197\n\tv_accvgpr_read_b32 %2, a198\n\tv_accvgpr_read_b32 %3, a199" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 10: asm volatile("v_accvgpr_read_b32 %0, a200\n\tv_accvgpr_read_b32 %1, a201\n\tv_accvgpr_read_b32 %2, a202\n\tv_accvgpr_read_b32 %3, a203" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 11: asm volatile("v_accvgpr_read_b32 %0, a204\n\tv_accvgpr_read_b32 %1, a205\n\tv_accvgpr_read_b32 %2, a206\n\tv_accvgpr_read_b32 %3, a207" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 12: asm volatile("v_accvgpr_read_b32 %0, a208\n\tv_accvgpr_read_b32 %1, a209\n\tv_accvgpr_read_b32 %2, a210\n\tv_accvgpr_read_b32 %3, a211" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 13: asm volatile("v_accvgpr_read_b32 %0, a212\n\tv_accvgpr_read_b32 %1, a213\n\tv_accvgpr_read_b32 %2, a214\n\tv_accvgpr_read_b32 %3, a215" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 14: asm volatile("v_accvgpr_read_b32 %0, a216\n\tv_accvgpr_read_b32 %1, a217\n\tv_accvgpr_read_b32 %2, a218\n\tv_accvgpr_read_b32 %3, a219" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 15: asm volatile("v_accvgpr_read_b32 %0, a220\n\tv_accvgpr_read_b32 %1, a221\n\tv_accvgpr_read_b32 %2, a222\n\tv_accvgpr_read_b32 %3, a223" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 16: asm volatile("v_accvgpr_read_b32 %0, a224\n\tv_accvgpr_read_b32 %1, a225\n\tv_accvgpr_read_b32 %2, a226\n\tv_accvgpr_read_b32 %3, a227" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 17: asm volatile("v_accvgpr_read_b32 %0, a228\n\tv_accvgpr_read_b32 %1, a229\n\tv_accvgpr_read_b32 %2, a230\n\tv_accvgpr_read_b32 %3, a231" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 18: asm volatile("v_accvgpr_read_b32 %0, a232\n\tv_accvgpr_read_b32 %1, a233\n\tv_accvgpr_read_b32 %2, a234\n\tv_accvgpr_read_b32 %3, a235" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 19: asm volatile("v_accvgpr_read_b32 %0, a236\n\tv_accvgpr_read_b32 %1, a237\n\tv_accvgpr_read_b32 %2, a238\n\tv_accvgpr_read_b32 %3, a239" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 20: asm volatile("v_accvgpr_read_b32 %0, a240\n\tv_accvgpr_read_b32 %1, a241\n\tv_accvgpr_read_b32 %2, a242\n\tv_accvgpr_read_b32 %3, a243" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 21: asm volatile("v_accvgpr_read_b32 %0, a244\n\tv_accvgpr_read_b32 %1, a245\n\tv_accvgpr_read_b32 %2, a246\n\tv_accvgpr_read_b32 %3, a247" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 22: asm volatile("v_accvgpr_read_b32 %0, a248\n\tv_accvgpr_read_b32 %1, a249\n\tv_accvgpr_read_b32 %2, a250\n\tv_accvgpr_read_b32 %3, a251" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        case 23: asm volatile("v_accvgpr_read_b32 %0, a252\n\tv_accvgpr_read_b32 %1, a253\n\tv_accvgpr_read_b32 %2, a254\n\tv_accvgpr_read_b32 %3, a255" : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w) : : W4_HI_AGPRS); break;
+        default: break;
+    }
+    return r;
+}
+
 // bf16 epilogue of RI row tiles (RI <= 4) x NJ*16 columns: wave-private image of 16*RI rows, then a row-major walk in
 // which every global store instruction writes whole row segments (16 bytes per lane, consecutive lanes consecutive)
-template <int MODE, int MI, int NJ, int RI>
+template <int MODE, int MI, int NJ, int RI, int FOLD = 0>
 __device__ __forceinline__ void epi_bf16_pass(const f32x4 (&acc)[MI][NJ], int i0, const float4 (&bv)[NJ], bf16_t* __restrict__ out,
-                                              int N, int row0, int col0, int lane, unsigned my) {
+                                              int N, int row0, int col0, int lane, unsigned my,
+                                              const float* __restrict__ rstd = nullptr) {
     constexpr int RS = NJ * 32 + 16, CPR = NJ * 2;   // image row bytes, 16-byte chunks per row
     static_assert((RI * 16 * CPR) % 64 == 0, "walk covers the piece in whole wave instructions");
     const int l15 = lane & 15, g = lane >> 4;
+    float rs[RI];
+    if constexpr (FOLD == 1) {
+#pragma unroll
+        for (int ii = 0; ii < RI; ++ii) rs[ii] = rstd[row0 + (i0 + ii) * 16 + l15];
+    }
 #pragma unroll
     for (int j = 0; j < NJ; j += 2)
 #pragma unroll
         for (int ii = 0; ii < RI; ++ii) {          // eight values at a time, stage by stage (act_apply_n)
             const f32x4 a = acc[i0 + ii][j], b = acc[i0 + ii][j + 1];
-            float x[8] = {a[0] + bv[j].x,     a[1] + bv[j].y,     a[2] + bv[j].z,     a[3] + bv[j].w,
-                          b[0] + bv[j + 1].x, b[1] + bv[j + 1].y, b[2] + bv[j + 1].z, b[3] + bv[j + 1].w};
+            float x[8];
+            if constexpr (FOLD == 1) {
+                const float r = rs[ii];
+                x[0] = fmaf(a[0], r, bv[j].x); x[1] = fmaf(a[1], r, bv[j].y); x[2] = fmaf(a[2], r, bv[j].z); x[3] = fmaf(a[3], r, bv[j].w);
+                x[4] = fmaf(b[0], r, bv[j + 1].x); x[5] = fmaf(b[1], r, bv[j + 1].y); x[6] = fmaf(b[2], r, bv[j + 1].z); x[7] = fmaf(b[3], r, bv[j + 1].w);
+            } else {
+                x[0] = a[0] + bv[j].x; x[1] = a[1] + bv[j].y; x[2] = a[2] + bv[j].z; x[3] = a[3] + bv[j].w;
+                x[4] = b[0] + bv[j + 1].x; x[5] = b[1] + bv[j + 1].y; x[6] = b[2] + bv[j + 1].z; x[7] = b[3] + bv[j + 1].w;
+            }
             act_apply_n<MODE, 8>(x);
             W4_LDS(u32x2_t, my + (ii * 16 + l15) * RS + (j * 16 + g * 4) * 2) = u32x2_t{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
             W4_LDS(u32x2_t, my + (ii * 16 + l15) * RS + ((j + 1) * 16 + g * 4) * 2) = u32x2_t{pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
@@ -153,10 +269,12 @@ __device__ __forceinline__ void resid_load(const float* __restrict__ out, int N,
     }
 }
 
-template <int MODE, int MI, int NJ, int RI>
+template <int MODE, int MI, int NJ, int RI, int FOLD = 0>
 __device__ __forceinline__ void epi_f32_pass(const f32x4 (&acc)[MI][NJ], int i0, const float4 (&bv)[NJ], float* __restrict__ out,
                                              int N, int row0, int col0, int lane, unsigned my,
-                                             const float4 (&res)[RI * 16 * NJ * 4 / 64]) {
+                                             const float4 (&res)[RI * 16 * NJ * 4 / 64], bf16_t* __restrict__ hcopy = nullptr,
+                                             float* __restrict__ part = nullptr) {
+    static_assert(FOLD != 2 || NJ == 4 || NJ == 8, "fold statistics: wave parts of 64 or 128 columns");
     constexpr int RS = NJ * 64 + 16, CPR = NJ * 4;
     static_assert((RI * 16 * CPR) % 64 == 0, "walk covers the piece in whole wave instructions");
     const int l15 = lane & 15, g = lane >> 4;
@@ -178,6 +296,20 @@ __device__ __forceinline__ void epi_f32_pass(const f32x4 (&acc)[MI][NJ], int i0,
         float4 v = make_float4(l[0], l[1], l[2], l[3]);
         if (MODE == EPI_RESID) { v.x += res[t].x; v.y += res[t].y; v.z += res[t].z; v.w += res[t].w; }
         *reinterpret_cast<float4*>(out + (size_t)(row0 + i0 * 16 + row) * N + col0 + c * 4) = v;
+        if constexpr (FOLD == 2) {
+            // the next GEMM's operand, and the row's sums over this aligned 64-column group: 4 values in the lane, then the
+            // 16 lanes of the group by an xor butterfly — one tree for every tile shape
+            const size_t grow = (size_t)(row0 + i0 * 16 + row);
+            *reinterpret_cast<u32x2_t*>(hcopy + grow * N + col0 + c * 4) = u32x2_t{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            float s1 = ((v.x + v.y) + v.z) + v.w;
+            float s2 = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
+#pragma unroll
+            for (int o = 1; o <= 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            if ((c & 15) == 0) {
+                const int np = N >> 6;
+                *reinterpret_cast<float2*>(part + (grow * np + ((col0 + c * 4) >> 6)) * 2) = make_float2(s1, s2);
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -188,11 +320,12 @@ __device__ __forceinline__ void epi_f32_pass(const f32x4 (&acc)[MI][NJ], int i0,
 
 // Block tile (32*MI) x (32*NJ), waves 2 x 2, wave tile (16*MI) x (16*NJ); SA / SW = LDS slots of the activation / weight
 // operand (3 + 2, 2 + 3 or 2 + 2).  M % (32*MI) == 0, N % (32*NJ) == 0, K % 64 == 0, K >= 192.
-template <int MODE, int MI, int NJ, int SA, int SW, int OCC = 1>
+template <int MODE, int MI, int NJ, int SA, int SW, int OCC = 1, int FOLD = 0>
 __global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                          const float* __restrict__ bias, int M, int N, int K,
-                                                         void* __restrict__ out) {
+                                                         void* __restrict__ out, const FoldArgs fold) {
     using namespace w4;
+    static_assert(FOLD == 0 || (FOLD == 1 && bf16_out(MODE)) || (FOLD == 2 && MODE == EPI_RESID), "fold: consumer / producer");
     static_assert((SA == 3 && SW == 2) || (SA == 2 && SW == 3) || (SA == 2 && SW == 2), "slot plan");
     static_assert(lds_bytes(MI, NJ, SA, SW) <= 160 * 1024, "LDS");
     constexpr int BMB = 2 * MI * 16, BNB = 2 * NJ * 16;
@@ -263,8 +396,6 @@ __global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restr
     // The stamps of the plain epilogue show it as one HBM-bound burst of 8 bytes per output element (4 read + 4 written)
     // that nothing overlaps; with the reads under the loop it is the 4 written, plus pass 1's reads.
     constexpr bool RESPRE = MODE == EPI_RESID && MI == 5 && NJ == 8;
-    constexpr int NPRE = RESPRE ? 24 : 1;
-    f32x4 rpre[NPRE];
     rsrc_words_t rO = {0u, 0u, 0u, 0u};
     int rvoff = 0, rsoff = 0;
     if constexpr (RESPRE) {
@@ -310,10 +441,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restr
                 if (m >= NM - 8 && (m - (NM - 8)) % 2 == 0) {
                     const int t = RB + (m - (NM - 8)) / 2;           // 0..15: pass 0 (rows 2t, 2t+1); 16..23: pass 2 (rows 64 + ...)
                     const int row = t < 16 ? t * 2 : 64 + (t - 16) * 2;
-                    load16_to_agpr(rpre[t], rO, rvoff, rsoff + row * N * 4);
+                    rpre_load(t, rO, rvoff, rsoff + row * N * 4);
                 }
             }
-            if (m < 64) mfma16a(acc[m / NJ][m % NJ], wf[m % NJ], af[m / NJ]);
+            if constexpr (RESPRE) mfma16a_hi(acc[m / NJ][m % NJ], wf[m % NJ], af[m / NJ]);
+            else if (m < 64) mfma16a(acc[m / NJ][m % NJ], wf[m % NJ], af[m / NJ]);
             else mfma16v(acc[m / NJ][m % NJ], wf[m % NJ], af[m / NJ]);
         }
     };
@@ -378,9 +510,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restr
     if constexpr (bf16_out(MODE)) {
         bf16_t* o = reinterpret_cast<bf16_t*>(out);
         // the tiles that live in VGPRs (rows 64/NJ and up) leave first
-        if constexpr (MI % 4 != 0) epi_bf16_pass<MODE, MI, NJ, MI % 4>(acc, MI - MI % 4, bv, o, N, row0, col0, lane, my);
+        if constexpr (MI % 4 != 0) epi_bf16_pass<MODE, MI, NJ, MI % 4, FOLD>(acc, MI - MI % 4, bv, o, N, row0, col0, lane, my, fold.stats);
 #pragma unroll
-        for (int i0 = (MI / 4 - 1) * 4; i0 >= 0; i0 -= 4) epi_bf16_pass<MODE, MI, NJ, 4>(acc, i0, bv, o, N, row0, col0, lane, my);
+        for (int i0 = (MI / 4 - 1) * 4; i0 >= 0; i0 -= 4) epi_bf16_pass<MODE, MI, NJ, 4, FOLD>(acc, i0, bv, o, N, row0, col0, lane, my, fold.stats);
     } else {
         float* o = reinterpret_cast<float*>(out);
         constexpr int RP = NJ == 8 ? 2 : 1;            // row tiles per pass
@@ -398,26 +530,57 @@ __global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restr
             // passes 0 and 2 come out of the prefetch registers (everything requested has landed behind this wait);
             // pass 1 is loaded here, under pass 0's transposition
             load(1, res[1]);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");       // all but pass 1's NRES loads
-#pragma unroll
-            for (int t = 0; t < NPRE; ++t) pin_a(rpre[t]);     // no copy of a prefetch register may move above the wait
-#pragma unroll
-            for (int t = 0; t < 16; ++t) res[0][t] = make_float4(rpre[t][0], rpre[t][1], rpre[t][2], rpre[t][3]);
-            epi_f32_pass<MODE, MI, NJ, 2>(acc, 0, bv, o, N, row0, col0, lane, my, res[0]);
-            epi_f32_pass<MODE, MI, NJ, 2>(acc, 2, bv, o, N, row0, col0, lane, my, res[1]);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory", W4_HI_AGPRS);       // all but pass 1's NRES loads
             float4 last[NRES / 2];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) last[t] = make_float4(rpre[16 + t][0], rpre[16 + t][1], rpre[16 + t][2], rpre[16 + t][3]);
-            epi_f32_pass<MODE, MI, NJ, 1>(acc, 4, bv, o, N, row0, col0, lane, my, last);
+            for (int t = 0; t < 16; ++t) res[0][t] = rpre_read(t);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) last[t] = rpre_read(16 + t);
+            epi_f32_pass<MODE, MI, NJ, 2, FOLD>(acc, 0, bv, o, N, row0, col0, lane, my, res[0], fold.hcopy, fold.stats + M);
+            epi_f32_pass<MODE, MI, NJ, 2, FOLD>(acc, 2, bv, o, N, row0, col0, lane, my, res[1], fold.hcopy, fold.stats + M);
+            epi_f32_pass<MODE, MI, NJ, 1, FOLD>(acc, 4, bv, o, N, row0, col0, lane, my, last, fold.hcopy, fold.stats + M);
         } else {
             if (MODE == EPI_RESID) load(0, res[0]);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 if (MODE == EPI_RESID && p + 1 < NP) load(p + 1, res[(p + 1) & 1]);
-                if (p * RP + RP <= MI) epi_f32_pass<MODE, MI, NJ, RP>(acc, p * RP, bv, o, N, row0, col0, lane, my, res[p & 1]);
+                if (p * RP + RP <= MI) epi_f32_pass<MODE, MI, NJ, RP, FOLD>(acc, p * RP, bv, o, N, row0, col0, lane, my, res[p & 1], fold.hcopy, fold.stats + M);
                 else if constexpr (RP == 2)
-                    epi_f32_pass<MODE, MI, NJ, 1>(acc, p * RP, bv, o, N, row0, col0, lane, my,
-                                                  reinterpret_cast<const float4 (&)[NRES / 2]>(res[p & 1]));
+                    epi_f32_pass<MODE, MI, NJ, 1, FOLD>(acc, p * RP, bv, o, N, row0, col0, lane, my,
+                                                        reinterpret_cast<const float4 (&)[NRES / 2]>(res[p & 1]), fold.hcopy, fold.stats + M);
+            }
+        }
+    }
+    if constexpr (FOLD == 2) {
+        // The stripe's statistics: every workgroup publishes its partial sums (release), bumps the stripe's counter, and the
+        // one that finds all the others there (acquire) adds the N/64 partials of each row in column order and writes rstd.
+        // The counter goes back to zero for the next launch.
+        // (the flag sits at LDS offset 0: the kernel owns the whole allocation by raw offsets, and every wave is past its
+        //  use of the scratch there at the first barrier)
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int* count = reinterpret_cast<int*>(fold.stats + (size_t)M + (size_t)M * (N >> 6) * 2) + tm;
+            const int seen = __hip_atomic_fetch_add(count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = seen == N / BNB - 1;
+            W4_LDS(int, 0) = last;
+            if (last) __hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (W4_LDS(const int, 0)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int np = N >> 6;
+            const float inv_n = 1.0f / (float)N;
+            for (int r = threadIdx.x; r < BMB; r += 256) {
+                const float* pr = fold.stats + (size_t)M + (size_t)(m0 + r) * np * 2;
+                float s1 = 0.f, s2 = 0.f;
+                for (int q = 0; q < np; ++q) {
+                    s1 += __builtin_nontemporal_load(pr + 2 * q);
+                    s2 += __builtin_nontemporal_load(pr + 2 * q + 1);
+                }
+                const float mean = s1 * inv_n;
+                const float var = fmaxf(fmaf(-mean, mean, s2 * inv_n), 0.f);
+                fold.stats[m0 + r] = rsqrtf(var + fold.eps);
             }
         }
     }
@@ -426,9 +589,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restr
 
 // OCC = 2: two workgroups per CU (each still one wave per SIMD): their LDS (<= 80 KiB each) and registers (<= 256 per
 // wave) must allow it; one workgroup's prologue and epilogue then run under the other's loop.
-template <int MODE, int MI, int NJ, int SA, int SW, int OCC = 1>
-static void launch_w4(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out, hipStream_t st) {
-    auto kern = gemm_w4_kernel<MODE, MI, NJ, SA, SW, OCC>;
+template <int MODE, int MI, int NJ, int SA, int SW, int OCC = 1, int FOLD = 0>
+static void launch_w4(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out, hipStream_t st,
+                      const FoldArgs fold = FoldArgs()) {
+    auto kern = gemm_w4_kernel<MODE, MI, NJ, SA, SW, OCC, FOLD>;
     static_assert(OCC == 1 || w4::lds_bytes(MI, NJ, SA, SW) <= 80 * 1024, "two workgroups per CU: 80 KiB of LDS each");
     constexpr int LDS = w4::lds_bytes(MI, NJ, SA, SW) > 4 * 20480 ? w4::lds_bytes(MI, NJ, SA, SW) : 4 * 20480;
     static PerDeviceOnce attr_set;
@@ -436,7 +600,7 @@ static void launch_w4(const bf16_t* A, const bf16_t* Wt, const float* bias, int 
         raise_lds_limit(reinterpret_cast<const void*>(kern), LDS);
     });
     const int grid = (M / (32 * MI)) * (N / (32 * NJ));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, A, Wt, bias, M, N, K, out);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, A, Wt, bias, M, N, K, out, fold);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -478,12 +642,13 @@ __device__ __forceinline__ void tile_coords_v(int vb, int nwg, int tiles_m, int 
 
 }  // namespace w4
 
-template <int MODE>
+template <int MODE, int FOLD = 0>
 __global__ __launch_bounds__(256, 1) void gemm_w4p_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                           const float* __restrict__ bias, int M, int N, int K,
-                                                          bf16_t* __restrict__ out) {
+                                                          bf16_t* __restrict__ out, const FoldArgs fold) {
     using namespace w4;
     static_assert(bf16_out(MODE), "packed drain: bf16 outputs");
+    static_assert(FOLD == 0 || FOLD == 1, "persistent form: the consumer side of the LayerNorm fold");
     constexpr int MI = 5, NJ = 8, BMB = 160, BNB = 256;
     constexpr int ASZ = BMB * 128, WSZ = BNB * 128, WBASE = 3 * ASZ, SCR = WBASE + 2 * WSZ, SCRW = 16 * 272;
     constexpr int PA = BMB / 32, PW = BNB / 32;
@@ -548,6 +713,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p_kernel(const bf16_t* __restri
         }
     };
     f32x4 bv[NJ];                    // the bias of the tile in flight (loaded in front of its last two steps)
+    float rs[MI];                    // FOLD: rstd of the lane's five rows of that tile (loaded with the bias)
 
     // One phase: 40 MFMAs (INIT: the tile's first, C = 0) with the fragment reads of the next phase, the DMAs of the
     // phase, and DW / DR = the drain's LDS writes / read + store pairs of row tile DI of the packed tile between them.
@@ -628,6 +794,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p_kernel(const bf16_t* __restri
         // the tile's bias: requested in front of the last two steps, so that the wait in front of its first use leaves the
         // DMAs of those steps — the next tile's first operands — in flight
         load_bias(n0, bv);
+        if constexpr (FOLD == 1) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) rs[i] = fold.stats[m0 + wm * 80 + i * 16 + l15];
+        }
         step(F{}, NoDrain{}, rAn, rWn, 0);          // s = nk-2: step 0 of the next tile
         step(F{}, NoDrain{}, rAn, rWn, 128);        // s = nk-1: step 1 of the next tile
         W4P_STAMP(t, 2);
@@ -642,7 +812,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p_kernel(const bf16_t* __restri
             for (int j = 0; j < NJ; j += 2) {       // eight values at a time, stage by stage (act_apply_n)
                 float x[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { x[r] = acc[i][j][r] + bv[j][r]; x[4 + r] = acc[i][j + 1][r] + bv[j + 1][r]; }
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (FOLD == 1) { x[r] = fmaf(acc[i][j][r], rs[i], bv[j][r]); x[4 + r] = fmaf(acc[i][j + 1][r], rs[i], bv[j + 1][r]); }
+                    else { x[r] = acc[i][j][r] + bv[j][r]; x[4 + r] = acc[i][j + 1][r] + bv[j + 1][r]; }
+                }
                 act_apply_n<MODE, 8>(x);
                 packed[i][j] = u32x2_t{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
                 packed[i][j + 1] = u32x2_t{pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
@@ -665,11 +838,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p_kernel(const bf16_t* __restri
     }
 }
 
-template <int MODE>
+template <int MODE, int FOLD = 0>
 static void launch_w4p(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, void* out, int num_cus,
-                       hipStream_t st) {
+                       hipStream_t st, const FoldArgs fold = FoldArgs()) {
     if constexpr (bf16_out(MODE)) {
-        auto kern = gemm_w4p_kernel<MODE>;
+        auto kern = gemm_w4p_kernel<MODE, FOLD>;
         constexpr int LDS = 3 * 160 * 128 + 2 * 256 * 128 + 4 * 16 * 272;
         static PerDeviceOnce attr_set;
         attr_set([&] {
@@ -677,7 +850,7 @@ static void launch_w4p(const bf16_t* A, const bf16_t* Wt, const float* bias, int
         });
         const int ntiles = (M / 160) * (N / 256);
         const int grid = ntiles < num_cus ? ntiles : num_cus;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, A, Wt, bias, M, N, K, reinterpret_cast<bf16_t*>(out));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, A, Wt, bias, M, N, K, reinterpret_cast<bf16_t*>(out), fold);
     }
 }
 

@@ -710,7 +710,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void embed_lnpre_kernel(const float* __restrict__ patch_out,
                                                           const float* __restrict__ cls, const float* __restrict__ pos,
                                                           const float* __restrict__ w, const float* __restrict__ bb,
-                                                          int rows, int T, int W, float eps, float* __restrict__ x) {
+                                                          int rows, int T, int W, float eps, float* __restrict__ x,
+                                                          bf16_t* __restrict__ hcopy, float* __restrict__ rstd_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -749,9 +750,30 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const float* __restric
         if (c < w4) {
             const float4 ww = reinterpret_cast<const float4*>(w)[c];
             const float4 b4 = reinterpret_cast<const float4*>(bb)[c];
-            xr[c] = make_float4((v[i].x - mean) * rstd * ww.x + b4.x, (v[i].y - mean) * rstd * ww.y + b4.y,
-                                (v[i].z - mean) * rstd * ww.z + b4.z, (v[i].w - mean) * rstd * ww.w + b4.w);
+            v[i] = make_float4((v[i].x - mean) * rstd * ww.x + b4.x, (v[i].y - mean) * rstd * ww.y + b4.y,
+                               (v[i].z - mean) * rstd * ww.z + b4.z, (v[i].w - mean) * rstd * ww.w + b4.w);
+            xr[c] = v[i];
         }
+    }
+    if (hcopy) {
+        // fold mode (gemm_w4.h FoldArgs): the first block's QKV GEMM takes bf16(x) as its operand and the row's rstd as a scale
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (i * 64 + lane < w4) s2 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean2 = wave_sum(s2) / (float)W;
+        float q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < w4) {
+                float a0 = v[i].x - mean2, a1 = v[i].y - mean2, a2 = v[i].z - mean2, a3 = v[i].w - mean2;
+                q2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                reinterpret_cast<uint2*>(hcopy + (size_t)row * W)[c] = make_uint2(pack_bf16x2(v[i].x, v[i].y), pack_bf16x2(v[i].z, v[i].w));
+            }
+        }
+        const float r2 = rsqrtf(wave_sum(q2) / (float)W + eps);
+        if (lane == 0) rstd_out[row] = r2;
     }
 }
 
@@ -865,6 +887,40 @@ int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int a
     return WISE_OK;
 }
 
+// The same L pre-LN blocks with every LayerNorm folded into the GEMMs around it (gemm_w4.h FoldArgs): on entry h = bf16(x)
+// and rstd = the rows' 1 / sqrt(var + eps) (embed_lnpre_kernel wrote both); the weights are the packer's folded ones
+// (in_proj / c_fc: gamma-scaled, row-centred; their biases: + W beta).  Seven launches per block become five, the fp32 rows
+// are read once per residual GEMM instead of twice, and no row's result depends on the batch it sits in (one epilogue
+// implementation, one reduction tree).  The attention output goes to `a` (free between fc2 and fc1): h must keep bf16(x)
+// until the out-projection's epilogue replaces it row stripe by row stripe, while other workgroups still read the
+// attention output as their operand.
+static int transformer_blocks_fold(const BlockWeights& bw, int L, int W, int H, int F, int act, int batch, int T, float* x,
+                                   bf16_t* h, bf16_t* qkv, bf16_t* a, float* stats, hipStream_t st, float eps) {
+    const int M = batch * T, Mp = (M + 255) / 256 * 256;
+    int rc;
+    float* rstd = stats;                        // [Mp] row scales; partial sums and arrival counters behind them
+    unsigned char* counters = reinterpret_cast<unsigned char*>(stats) + (size_t)Mp * 4 + (size_t)Mp * (W / 64) * 8;
+    if (hipMemsetAsync(counters, 0, (size_t)(Mp / 128 + 1) * sizeof(int), st) != hipSuccess) {
+        set_error("vit_forward: memset of the fold counters failed");
+        return WISE_E_INVALID;
+    }
+    bf16_t* ao = a;     // attention output [Mp, W]
+    for (int l = 0; l < L; ++l) {
+        const bf16_t* lwb = bw.wb + bw.per_layer_b * l;
+        const float* lpf = bw.pf + bw.per_layer_f * l;
+        if ((rc = gemm_fold_bf16(h, lwb + bw.in_proj, lpf + bw.in_b, rstd, Mp, 3 * W, W, 0, qkv, st))) return rc;
+        if ((rc = attention_bf16(qkv, batch, T, H, ao, st, false, W / H))) return rc;
+        if ((rc = gemm_fold_resid(ao, lwb + bw.out_proj, lpf + bw.out_b, Mp, W, W, x, h, stats, eps, st))) return rc;
+        if ((rc = gemm_fold_bf16(h, lwb + bw.c_fc, lpf + bw.fc_b, rstd, Mp, F, W, act == 0 ? 1 : (act == 1 ? 2 : 5), a, st))) return rc;
+        if (l + 1 < L) {
+            if ((rc = gemm_fold_resid(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, W, F, x, h, stats, eps, st))) return rc;
+        } else if ((rc = gemm_bf16(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, W, F, 3, x, st))) {
+            return rc;
+        }
+    }
+    return WISE_OK;
+}
+
 // out[b,:] = normalize( LN(x[b*T + pos[b], :]) @ proj ), projT bf16 [D,W]; hb bf16 [Bp,W] and e fp32 [Bp,D] scratch
 int pooled_ln(const float* x, const float* ln_w, const float* ln_b, int batch, int T, int W, const int* pos,
               bf16_t* hb, hipStream_t st, float eps) {
@@ -893,7 +949,7 @@ int pooled_head(const float* x, const float* ln_w, const float* ln_b, const bf16
 }
 
 struct VitDims {
-    int S, P, W, L, H, F, D, g, T, K, Kp, arch;
+    int S, P, W, L, H, F, D, g, T, K, Kp, arch, fold;
 };
 static int vit_dims(const wise_vit_config* c, VitDims* d) {
     WISE_CHECK_ARG(c, "vit: null config");
@@ -907,6 +963,9 @@ static int vit_dims(const wise_vit_config* c, VitDims* d) {
     WISE_CHECK_ARG(c->act >= 0 && c->act <= 2, "vit: act must be 0 (quick_gelu), 1 (gelu) or 2 (gelu, tanh form)");
     WISE_CHECK_ARG(c->arch == 0 || c->arch == 1, "vit: arch must be 0 (CLIP) or 1 (timm SigLIP: no class token, attention-pool head)");
     d->arch = c->arch;
+    WISE_CHECK_ARG(c->ln_fold == 0 || (c->ln_fold == 1 && c->arch == 0 && c->layers >= 1 && d->W >= 256),
+                   "vit: ln_fold is 0 or 1, and 1 only for arch 0 with at least one block and width >= 256");
+    d->fold = c->ln_fold;
     WISE_CHECK_ARG(d->arch == 0 || (d->D == d->W && d->H * 64 == d->W), "vit: the attention-pool head has no projection (embed_dim == width) and head dim 64");
     d->g = d->S / d->P; d->T = d->g * d->g + (d->arch == 0 ? 1 : 0); d->K = 3 * d->P * d->P; d->Kp = (d->K + 63) / 64 * 64;
     WISE_CHECK_ARG(d->arch == 0 || d->T <= 1024, "vit: the attention-pool head serves up to 1024 tokens");
@@ -953,7 +1012,7 @@ static VitOffsets vit_offsets(const VitDims& d) {
 }
 
 struct VitWs {
-    size_t x, h, qkv, a, total;
+    size_t x, h, qkv, a, rstd, total;
     int M, Mp, Mpatch, Mpp;
 };
 static VitWs vit_ws(const VitDims& d, int B) {
@@ -971,15 +1030,17 @@ static VitWs vit_ws(const VitDims& d, int B) {
     if (pa_b > a_b) a_b = pa_b;
     if (d.arch == 1 && head_b > a_b) a_b = head_b;
     w.a = off; off += align_up(a_b, 256);
+    // fold mode (gemm_w4.h FoldArgs): row scales, partial row sums per 64 columns, arrival counters per row stripe
+    w.rstd = off; off += align_up(gemm_fold_stats_bytes(w.Mp, d.W), 256);
     w.total = off;
     return w;
 }
 
 template <int NV>
 static void launch_embed(const float* po, const float* cls, const float* pos, const float* w, const float* b, int rows,
-                         int T, int W, float* x, hipStream_t st) {
+                         int T, int W, float* x, hipStream_t st, bf16_t* hcopy, float* rstd_out) {
     hipLaunchKernelGGL(embed_lnpre_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, st, po, cls, pos, w, b, rows, T, W,
-                       1e-5f, x);
+                       1e-5f, x, hcopy, rstd_out);
 }
 
 // one contiguous part of the batch on one stream; `wsb` is that part's own workspace region
@@ -1026,17 +1087,19 @@ static int vit_forward_part(const wise_vit_config* cfg, const VitDims& d, const 
     } else {
 
         const int nv = (W / 4 + 63) / 64;
+        bf16_t* fh = d.fold ? h : nullptr;
+        float* frs = d.fold ? reinterpret_cast<float*>(wsb + ws.rstd) : nullptr;
         const float* cls = pf + o.cls; const float* pos = pf + o.pos;
         const float* lw = pf + o.ln_pre_w; const float* lb = pf + o.ln_pre_b;
         switch (nv) {
-            case 1: launch_embed<1>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
-            case 2: launch_embed<2>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
-            case 3: launch_embed<3>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
-            case 4: launch_embed<4>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
-            case 5: launch_embed<5>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
-            case 6: launch_embed<6>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
-            case 7: launch_embed<7>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
-            case 8: launch_embed<8>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st); break;
+            case 1: launch_embed<1>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
+            case 2: launch_embed<2>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
+            case 3: launch_embed<3>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
+            case 4: launch_embed<4>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
+            case 5: launch_embed<5>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
+            case 6: launch_embed<6>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
+            case 7: launch_embed<7>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
+            case 8: launch_embed<8>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
             default: set_error("vit_forward: width %d too large", W); return WISE_E_UNSUPPORTED;
         }
         WISE_LAUNCH_CHECK("embed_lnpre_kernel");
@@ -1045,8 +1108,12 @@ static int vit_forward_part(const wise_vit_config* cfg, const VitDims& d, const 
     const BlockWeights bw = {wb + o.layer0_b, o.per_layer_b, o.in_proj, o.out_proj, o.c_fc, o.c_proj,
                              pf + o.layer0_f, o.per_layer_f, o.ln1_w, o.ln1_b, o.in_b, o.out_b, o.ln2_w, o.ln2_b,
                              o.fc_b, o.proj_b};
-    if ((rc = transformer_blocks(bw, d.L, W, d.H, d.F, cfg->act, batch, d.T, false, x, h, qkv, a, st,
-                                 d.arch == 1 ? 1e-6f : 1e-5f)))
+    if (d.fold) {
+        if ((rc = transformer_blocks_fold(bw, d.L, W, d.H, d.F, cfg->act, batch, d.T, x, h, qkv, a,
+                                          reinterpret_cast<float*>(wsb + ws.rstd), st, 1e-5f)))
+            return rc;
+    } else if ((rc = transformer_blocks(bw, d.L, W, d.H, d.F, cfg->act, batch, d.T, false, x, h, qkv, a, st,
+                                        d.arch == 1 ? 1e-6f : 1e-5f)))
         return rc;
     if (d.arch == 1) {
         // 4'. timm 'map' head: final norm over every token -> keys | values GEMM -> one latent query per head attends the

@@ -8,8 +8,9 @@ real checkpoint is a pure data problem: `pack_weights(spec, state_dict)`.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
@@ -28,6 +29,7 @@ class VitSpec:
     embed_dim: int
     act: str = "quick_gelu"  # 'quick_gelu' (openai tags) | 'gelu' (laion tags) | 'gelu_tanh'
     arch: int = 0            # 0 = open_clip VisionTransformer; 1 = timm ViT of the SigLIP towers (wise_amd/feature/siglip.py)
+    ln_fold: bool = False    # the blocks' LayerNorms folded into the GEMMs around them (wise_vit_config.ln_fold; pack_weights)
 
     @property
     def grid(self) -> int:
@@ -55,7 +57,8 @@ class VitSpec:
 
     def c_config(self) -> _lib.VitConfig:
         return _lib.VitConfig(self.image_size, self.patch, self.width, self.layers, self.heads, self.mlp,
-                              self.embed_dim, {"quick_gelu": 0, "gelu": 1, "gelu_tanh": 2}[self.act], self.arch)
+                              self.embed_dim, {"quick_gelu": 0, "gelu": 1, "gelu_tanh": 2}[self.act], self.arch,
+                              1 if self.ln_fold else 0)
 
 
 # open_clip model names WISE passes as id token [2]
@@ -173,8 +176,19 @@ def checkpoint_like_state_dict(spec: VitSpec, seed: int = 0) -> Dict[str, torch.
     return sd
 
 
+def fold_layernorm(weight: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """Linear(LayerNorm(x)) with the LayerNorm's affine part and its centring moved into the linear layer:
+    LN(x) W^T + b = rstd * (x W''^T) + b'' with W'' = gamma * W minus its mean over the input dimension (so that
+    sum_k (x_k - mean(x)) w_k = sum_k x_k (w_k - mean_k(w)): the kernel never needs mean(x)) and b'' = b + W beta.
+    What is left for the GEMM's epilogue is one scale per row, rstd = 1 / sqrt(var(x) + eps) (gemm_w4.h FoldArgs)."""
+    wg = weight.double() * gamma.double()[None, :]
+    wg = wg - wg.mean(dim=1, keepdim=True)
+    return wg.to(torch.float32), (bias.double() + weight.double() @ beta.double()).to(torch.float32)
+
+
 def pack_weights(spec: VitSpec, sd: Dict[str, torch.Tensor]):
-    """state dict -> (bf16 blob, fp32 blob) in the layout include/wise_hip.h documents (CPU tensors)."""
+    """state dict -> (bf16 blob, fp32 blob) in the layout include/wise_hip.h documents (CPU tensors).  With spec.ln_fold the
+    in_proj / c_fc slots hold the folded weights and biases (fold_layernorm); the ln_1 / ln_2 slots stay as they are (unread)."""
     W, F = spec.width, spec.mlp
     f32 = lambda k: sd[k].detach().to(torch.float32).cpu()
     conv = torch.zeros(W, spec.kpad, dtype=torch.float32)
@@ -184,11 +198,15 @@ def pack_weights(spec: VitSpec, sd: Dict[str, torch.Tensor]):
           f32("visual.ln_pre.weight"), f32("visual.ln_pre.bias")]
     for i in range(spec.layers):
         p = f"visual.transformer.resblocks.{i}."
-        wb += [f32(p + "attn.in_proj_weight").reshape(-1), f32(p + "attn.out_proj.weight").reshape(-1),
-               f32(p + "mlp.c_fc.weight").reshape(-1), f32(p + "mlp.c_proj.weight").reshape(-1)]
-        pf += [f32(p + "ln_1.weight"), f32(p + "ln_1.bias"), f32(p + "attn.in_proj_bias"),
-               f32(p + "attn.out_proj.bias"), f32(p + "ln_2.weight"), f32(p + "ln_2.bias"), f32(p + "mlp.c_fc.bias"),
-               f32(p + "mlp.c_proj.bias")]
+        w_in, b_in = f32(p + "attn.in_proj_weight"), f32(p + "attn.in_proj_bias")
+        w_fc, b_fc = f32(p + "mlp.c_fc.weight"), f32(p + "mlp.c_fc.bias")
+        if spec.ln_fold:
+            w_in, b_in = fold_layernorm(w_in, b_in, f32(p + "ln_1.weight"), f32(p + "ln_1.bias"))
+            w_fc, b_fc = fold_layernorm(w_fc, b_fc, f32(p + "ln_2.weight"), f32(p + "ln_2.bias"))
+        wb += [w_in.reshape(-1), f32(p + "attn.out_proj.weight").reshape(-1), w_fc.reshape(-1),
+               f32(p + "mlp.c_proj.weight").reshape(-1)]
+        pf += [f32(p + "ln_1.weight"), f32(p + "ln_1.bias"), b_in, f32(p + "attn.out_proj.bias"), f32(p + "ln_2.weight"),
+               f32(p + "ln_2.bias"), b_fc, f32(p + "mlp.c_proj.bias")]
     wb.append(f32("visual.proj").t().contiguous().reshape(-1))  # proj^T [D, W]
     pf += [f32("visual.ln_post.weight"), f32("visual.ln_post.bias")]
     wb_t = torch.cat(wb).to(torch.bfloat16).contiguous()
@@ -216,7 +234,17 @@ class VitEngine:
     """Owns the device copies of the two weight blobs and a workspace; `forward` launches the HIP
     pipeline on the current torch stream and returns a device tensor [B, D] fp32 (L2-normalised)."""
 
-    def __init__(self, spec: VitSpec, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 256):
+    def __init__(self, spec: VitSpec, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 256,
+                 ln_fold: Optional[bool] = None):
+        """ln_fold: fold the blocks' LayerNorms into the GEMMs around them (two launches and one pass over the fp32 rows
+        fewer per LayerNorm).  None = WISE_VIT_LN_FOLD (0 / 1), default: on for the CLIP towers of width 768 (ViT-B/32,
+        B/16), where it was measured; never for the timm towers (arch 1)."""
+        if ln_fold is None:
+            env = os.environ.get("WISE_VIT_LN_FOLD", "")
+            ln_fold = (env == "1") if env in ("0", "1") else (spec.arch == 0 and spec.width == 768)
+        ln_fold = bool(ln_fold) and spec.arch == 0 and spec.layers >= 1 and spec.width >= 256
+        if ln_fold != spec.ln_fold:
+            spec = VitSpec(**{**spec.__dict__, "ln_fold": ln_fold})
         self.spec = spec
         self.lib = _lib.lib()
         self.device = torch.device(device)
