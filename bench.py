@@ -29,7 +29,7 @@ import torch.distributed as dist
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_BF16_TFLOPS = 2516.6  # MI355X dense bf16 MFMA: 256 CUs x 2.4 GHz x 4096 FLOP/clk/CU (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec peak (same table)
 METRIC = "frames/sec embedded (ViT-B/32 bs=256) + queries/sec over 10M×512 index, 1/2/4/8 MI355X"
 
@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the CLAP-HTSAT and ViT-L/14 legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget per CPU baseline leg")
+    ap.add_argument("--pmc-legs", action="store_true",
+                    help="profiling aid for the PMC passes: only the headline shapes run (ViT-B/32 bs=256; 10M x 512 search at "
+                         "nq=1, k=10 and nq=256, k=10; the fp32 scan), so that a per-kernel average of FETCH_SIZE / WRITE_SIZE is "
+                         "the traffic of THOSE launches and not a mean over shard-sized and split launches too")
     ap.add_argument("--roofline-only", action="store_true",
                     help="profiling aid: run only the single-stream, event-bracketed ViT pass (the one `roofline` is "
                          "computed from) so that a rocprofv3 --stats of this command lists exactly those launches")
@@ -246,19 +250,22 @@ def main():
     # what preprocess_image hands over: ToTensor + Normalize of the decoded frames, fp32 [B,3,224,224], resident
     x = ((frames.to(torch.float32) / 255.0 - torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)) /
          torch.tensor(CLIP_STD).view(1, 3, 1, 1)).cuda()
+    # four DISTINCT resident batches, taken in turn: 4 x 154 MB do not fit the 256 MB memory-side cache, so no step finds
+    # its input there (round 3 fed the same tensor every step, which flattered the patch gather)
+    xs = [x] + [torch.roll(x, shifts=17 * (j + 1), dims=0).contiguous() for j in range(3)]
     out_holder = {}
 
     def vit_step(i):
         # one step = one batch of 256 frames through the tower.  Batches arrive in a stream (extract-features.py's
         # loop), so the engine keeps two of them in flight, each on its own stream and workspace
         # (VitEngine.forward_pipelined); every step's work is complete when the timed region's final sync returns.
-        out_holder["h"] = eng.forward_pipelined(x)
+        out_holder["h"] = eng.forward_pipelined(xs[i % 4])
 
     def vit_step_serial(i):
-        out_holder["o"] = eng.forward(x)
+        out_holder["o"] = eng.forward(xs[i % 4])
 
     def vit_step_one_stream(i):   # every launch on the caller's stream (wise_vit_forward_single)
-        out_holder["o"] = eng.forward(x, single_stream=True)
+        out_holder["o"] = eng.forward(xs[i % 4], single_stream=True)
 
     if args.roofline_only:
         vit_step = vit_step_one_stream
@@ -286,8 +293,9 @@ def main():
     g_ms, g_n, g_flop = prof[0]
     gemm_tflops = (g_flop / g_n) / (g_ms / g_n * 1e-3) / 1e12 if g_n else 0.0
     roofline = {
-        "kernel": "bf16 MFMA GEMM family (gemm_w4p_kernel persistent 160x256 for QKV / fc1, gemm_w4_kernel 160x256 for the "
-                  "two residual GEMMs and 224x192 for the patch embedding: one wave per SIMD, MFMA 16x16x32; "
+        "kernel": "bf16 MFMA GEMM family (gemm_w4p_kernel persistent 160x256 for QKV / fc1 with the row scale of the folded "
+                  "LayerNorm in the epilogue, gemm_w4_kernel 160x256 for the two residual GEMMs — which also emit bf16(x) and "
+                  "the rows' statistics — and 224x192 for the patch embedding: one wave per SIMD, MFMA 16x16x32; "
                   "gemm_ring_kernel for the projection): every GEMM launch of the forward, HIP events on the launch "
                   "stream, single-stream pass",
         "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -314,7 +322,8 @@ def main():
         "config": {"workload": "OpenCLIP ViT-B/32 image tower (encode_image + L2 normalise), bs=256 frames per GPU, "
                                "fp32 normalised frames resident in HBM -> [256,512] fp32 unit vectors; "
                                "seeded random weights (no checkpoints offline)",
-                   "batches_in_flight": 2,
+                   "batches_in_flight": 2, "distinct_input_batches": 4,
+                   "layernorm_fold": bool(eng.spec.ln_fold),
                    "one_batch_at_a_time_frames_per_s": (round(world * args.batch * args.steps / serial_dt, 1)
                                                         if serial_dt else None),
                    "global_batch": world * args.batch, "frames_per_gpu": args.batch, "parallelism": f"dp{world}",
@@ -366,21 +375,34 @@ def main():
         s_ms, s_n, s_bytes = sprof[1]
         scan_gbs = (s_bytes / s_n) / (s_ms / s_n * 1e-3) / 1e9 if s_n else 0.0
 
+        # what the reference's caller sees (feature_search_index.py:113: numpy in, numpy out, one call per query): H2D of the
+        # query, the search, D2H of (D, I), host sync — timed call by call on the host
+        lat = []
+        if world == 1:
+            for i in range(5):
+                flat.search(Qh[i:i + 1], k)
+            for i in range(50):
+                t0 = time.perf_counter()
+                Dn, In = flat.search(Qh[100 + i:101 + i], k)
+                lat.append(time.perf_counter() - t0)
+            lat.sort()
+
         def search4(i):
             j = (4 * i) % 996
             res["DI4"] = index.search_device(Q[j:j + 4], k)
-
-        for i in range(3):
-            search4(i)
-        sdt4 = timed_region(search4, s_steps, world)
 
         def search32(i):  # the batched form: 32 queries share one pass over X (matrix cores)
             j = (32 * i) % 960
             res["DI32"] = index.search_device(Q[j:j + 32], k)
 
-        for i in range(3):
-            search32(i)
-        sdt32 = timed_region(search32, s_steps, world)
+        sdt4 = sdt32 = float("nan")
+        if not args.pmc_legs:
+            for i in range(3):
+                search4(i)
+            sdt4 = timed_region(search4, s_steps, world)
+            for i in range(3):
+                search32(i)
+            sdt32 = timed_region(search32, s_steps, world)
 
         def search256(i):  # cfg-3's nq=256 point: eight 32-query passes per call
             j = (256 * i) % 744
@@ -393,7 +415,7 @@ def main():
         # the k the reference's server and evaluations send (REST `end` = 20: api/routes.py:1171,1407; k = 100:
         # docs/Search-Index-Evaluation.md:109; --topk 1000: docs/Retrieval-Evaluation.md:39), nq = 1, same index
         by_k = {}
-        for kk in (20, 100, 1000):
+        for kk in (() if args.pmc_legs else (20, 100, 1000)):
             def search_k(i, kk=kk):
                 j = i % 1000
                 res["DIk"] = index.search_device(Q[j:j + 1], kk)
@@ -409,14 +431,15 @@ def main():
             j = (256 * i) % 744
             res["DI256k"] = index.search_device(Q[j:j + 256], 100)
 
-        for i in range(2):
-            search256_k100(i)
-        s256k = max(4, s_steps // 5)
-        by_k["batched_nq256_k100_queries_per_s"] = round(256 * s256k / timed_region(search256_k100, s256k, world), 2)
+        if not args.pmc_legs:
+            for i in range(2):
+                search256_k100(i)
+            s256k = max(4, s_steps // 5)
+            by_k["batched_nq256_k100_queries_per_s"] = round(256 * s256k / timed_region(search256_k100, s256k, world), 2)
         # ONE rank's share of this index at 8 GPUs (N / 8 rows, nq = 1, k = 10): the strong-scaling number one GPU can
         # measure — the scan shrinks 8-fold, the per-query fixed cost (sample, threshold, finish, gated launches) does not
         shard = None
-        if world == 1 and n_loc >= 8 * (1 << 18):
+        if world == 1 and n_loc >= 8 * (1 << 18) and not args.pmc_legs:
             n8 = n_loc // 8
             sh = FlatIPIndex(d).adopt(X[:n8], None, id_base=1)
 
@@ -440,11 +463,12 @@ def main():
                      "note": "one rank's rows of the 10M x 512 index at 8 GPUs, nq=1, k=10, ids and scores bit-equal to the "
                              "f32 scan of the same rows; the all-gather and merge of the 8-rank exchange are not in it"}
             del sh
-        D32, I32 = index.search_device(Q[:32], k)
-        D1, I1 = index.search_device(Q[:1], k)
-        # the two kernels sum the d products in different orders: same ids, scores to the tested 2e-5
-        assert torch.equal(I32[:1], I1) and bool((D32[:1] - D1).abs().max() <= 2e-5), \
-            "batched and single-query scans disagree"
+        if not args.pmc_legs:
+            D32, I32 = index.search_device(Q[:32], k)
+            D1, I1 = index.search_device(Q[:1], k)
+            # the two kernels sum the d products in different orders: same ids, scores to the tested 2e-5
+            assert torch.equal(I32[:1], I1) and bool((D32[:1] - D1).abs().max() <= 2e-5), \
+                "batched and single-query scans disagree"
         rows_per_rank = [n_loc]
         if world > 1:
             rows_per_rank = [None] * world
@@ -473,6 +497,11 @@ def main():
                                  "fallback scan (fp32_scan_only_queries_per_s: 0.83 of HBM on those bytes)",
                          "fp32_rows_equivalent_gbs": round(n_loc * d * 4 / (s_ms / max(s_n, 1) * 1e-3) / 1e9, 1),
                          **traffic_fields("ip_collect_i8_kernel")},
+            "single_query_latency_ms": ({"median": round(lat[len(lat) // 2] * 1e3, 4), "p90": round(lat[int(len(lat) * 0.9)] * 1e3, 4),
+                                         "min": round(lat[0] * 1e3, 4),
+                                         "note": "FlatIPIndex.search(): numpy [1,d] in, numpy (D, I) out, host-synchronous — the "
+                                                 "reference's call shape (feature_search_index.py:113); `value` above is device "
+                                                 "throughput with queries already resident and no per-query sync"} if lat else None),
             "two_stage": {"answered_from_the_shadow": int(shadow_stats[0]), "handed_to_fp32_scan": int(shadow_stats[1]),
                           "fp32_scan_only_queries_per_s": round(qps_f32, 2)},
             **by_k,
@@ -504,46 +533,48 @@ def main():
         # (they have true neighbours) and random directions, alternating.  Rows are rewritten in place.
         del index, local
         torch.cuda.empty_cache()
-        per = 20
-        for s in range(0, n_loc, 1_000_000):
-            e = min(n_loc, s + 1_000_000)
-            items = (e - s + per - 1) // per
-            base = torch.randn(items, 1, d, generator=gen, device="cuda")
-            blk = (base / base.norm(dim=2, keepdim=True) + (0.03 / d ** 0.5) * torch.randn(items, per, d, generator=gen, device="cuda"))
-            X[s:e] = (blk / blk.norm(dim=2, keepdim=True)).reshape(-1, d)[:e - s]
-        local = FlatIPIndex(d).adopt(X, None, id_base=lo + 1)
-        index = ShardedFlatIPIndex(local)
-        gq = torch.Generator(device="cuda").manual_seed(9)          # the same queries on every rank
-        Qc = torch.randn(200, d, generator=gq, device="cuda")
-        Qc /= Qc.norm(dim=1, keepdim=True)
-        if rank == 0:
-            pick = torch.randint(0, n_loc, (100,), generator=gq, device="cuda")
-            Qc[0::2] = torch.nn.functional.normalize(X[pick] + 0.02 * Qc[0::2], dim=1)
-        if world > 1:
-            dist.broadcast(Qc, src=0)
+        local = index = None
+        if not args.pmc_legs:
+            per = 20
+            for s in range(0, n_loc, 1_000_000):
+                e = min(n_loc, s + 1_000_000)
+                items = (e - s + per - 1) // per
+                base = torch.randn(items, 1, d, generator=gen, device="cuda")
+                blk = (base / base.norm(dim=2, keepdim=True) + (0.03 / d ** 0.5) * torch.randn(items, per, d, generator=gen, device="cuda"))
+                X[s:e] = (blk / blk.norm(dim=2, keepdim=True)).reshape(-1, d)[:e - s]
+            local = FlatIPIndex(d).adopt(X, None, id_base=lo + 1)
+            index = ShardedFlatIPIndex(local)
+            gq = torch.Generator(device="cuda").manual_seed(9)          # the same queries on every rank
+            Qc = torch.randn(200, d, generator=gq, device="cuda")
+            Qc /= Qc.norm(dim=1, keepdim=True)
+            if rank == 0:
+                pick = torch.randint(0, n_loc, (100,), generator=gq, device="cuda")
+                Qc[0::2] = torch.nn.functional.normalize(X[pick] + 0.02 * Qc[0::2], dim=1)
+            if world > 1:
+                dist.broadcast(Qc, src=0)
 
-        def search_clustered(i):
-            res["DIc"] = index.search_device(Qc[i % 200:i % 200 + 1], k)
+            def search_clustered(i):
+                res["DIc"] = index.search_device(Qc[i % 200:i % 200 + 1], k)
 
-        for i in range(3):
-            search_clustered(i)
-        cc0 = local.shadow_counts()
-        cdt = timed_region(search_clustered, s_steps, world)
-        cc1 = local.shadow_counts()
-        Dc, Ic = index.search_device(Qc[:1], k)
-        local.shadow = False
-        Dcf, Icf = index.search_device(Qc[:1], k)
-        assert torch.equal(Ic, Icf) and bool((Dc - Dcf).abs().max() <= 2e-6), "clustered rows: two-stage != f32 scan"
-        result["search"]["clustered"] = {
-            "queries_per_s": round(s_steps / cdt, 2), "ms_per_query": round(cdt / s_steps * 1e3, 4),
-            "answered_from_the_shadow": int(cc1[0] - cc0[0]), "handed_to_fp32_scan": int(cc1[1] - cc0[1]),
-            "workload": f"same N x d, rows in runs of {per} near-duplicates (cosine >= 0.999); queries alternate between "
-                        f"noisy copies of indexed rows and random directions; ids and scores equal the f32 scan's"}
+            for i in range(3):
+                search_clustered(i)
+            cc0 = local.shadow_counts()
+            cdt = timed_region(search_clustered, s_steps, world)
+            cc1 = local.shadow_counts()
+            Dc, Ic = index.search_device(Qc[:1], k)
+            local.shadow = False
+            Dcf, Icf = index.search_device(Qc[:1], k)
+            assert torch.equal(Ic, Icf) and bool((Dc - Dcf).abs().max() <= 2e-6), "clustered rows: two-stage != f32 scan"
+            result["search"]["clustered"] = {
+                "queries_per_s": round(s_steps / cdt, 2), "ms_per_query": round(cdt / s_steps * 1e3, 4),
+                "answered_from_the_shadow": int(cc1[0] - cc0[0]), "handed_to_fp32_scan": int(cc1[1] - cc0[1]),
+                "workload": f"same N x d, rows in runs of {per} near-duplicates (cosine >= 0.999); queries alternate between "
+                            f"noisy copies of indexed rows and random directions; ids and scores equal the f32 scan's"}
         del X, local, index
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ other BASELINE configs (short legs)
-    if not args.no_extra:
+    if not args.no_extra and not args.pmc_legs:
         extra = {}
         # cfg-5: MS-CLAP HTSAT, 10-s clips @48 kHz, bs=128 per GPU (weak scaling, no collective)
         from wise_amd.feature.htsat import HtsatEngine, random_htsat_state_dict
@@ -755,7 +786,69 @@ def main():
                                   "frac": round(pre_bytes / pre_us / 1e3 / PEAK_HBM_GBS, 4),
                                   **traffic_fields("clip_resize_kernel"),
                                   "frames_per_s": round(args.batch / pre_us * 1e6, 0)}}
-        del raw, crop, crops
+        # The same path fed as the reference's callers feed it (extract-features.py:332-341 hands HOST tensors over,
+        # mlfoundation_openclip.py:97,101 moves them in and the result out): pinned host uint8 frames -> H2D -> transform ->
+        # tower -> D2H of the [256,512] embeddings.  Four distinct host batches in turn.  (a) the reference's synchronous call
+        # shape, one batch at a time; (b) the same work with the copy of batch i+1 on a copy stream under the compute of batch i.
+        hraw = [torch.randint(0, 256, (args.batch, 3, fh, fw), dtype=torch.uint8,
+                              generator=torch.Generator().manual_seed(70 + j)).pin_memory() for j in range(4)]
+        dbuf = [torch.empty_like(raw) for _ in range(3)]
+        hout = [torch.empty(args.batch, spec.embed_dim, dtype=torch.float32).pin_memory() for _ in range(3)]
+        frame_bytes = args.batch * 3 * fh * fw
+
+        def host_sync_step(i):
+            d = dbuf[0]
+            d.copy_(hraw[i % 4], non_blocking=True)
+            pre(d, crops[0])
+            hout[0].copy_(eng.forward(crops[0]), non_blocking=False)      # .cpu(): blocks like the reference's call
+
+        copy_s = torch.cuda.Stream()
+        h_users, h_events = [None] * 3, [None] * 3
+
+        def host_async_step(i):
+            j = i % 3
+            if h_users[j] is not None:
+                h_users[j].synchronize()              # slot j's previous embeddings are on the host: its buffers are free
+            with torch.cuda.stream(copy_s):
+                dbuf[j].copy_(hraw[i % 4], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_s)
+            torch.cuda.current_stream().wait_event(ev)
+            pre(dbuf[j], crops[j])
+            pend = eng.forward_pipelined(crops[j])
+            hout[j].copy_(pend.result(), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            h_users[j] = done
+
+        for i in range(3):
+            host_sync_step(i)
+        hs_steps = max(5, min(args.steps, 20))
+        hsdt = timed_region(host_sync_step, hs_steps, world)
+        for i in range(4):
+            host_async_step(i)
+        torch.cuda.synchronize()
+        hadt = timed_region(host_async_step, u_steps, world)
+        assert abs(float(hout[(u_steps - 1) % 3].norm(dim=1).mean()) - 1.0) < 1e-3
+        e0.record()
+        for i in range(8):
+            dbuf[i % 3].copy_(hraw[i % 4], non_blocking=True)
+        e1.record()
+        torch.cuda.synchronize()
+        h2d_gbs = 8 * frame_bytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        extra["host_frames_to_embeddings"] = {
+            "value": round(world * args.batch * u_steps / hadt, 1), "unit": "frames/s",
+            "ms_per_step": round(hadt / u_steps * 1e3, 3), "steps": u_steps,
+            "pcie_gbs_achieved": round(frame_bytes * u_steps / hadt / 1e9, 2),
+            "h2d_copy_alone_gbs": round(h2d_gbs, 2),
+            "synchronous_call_shape": {"frames_per_s": round(world * args.batch * hs_steps / hsdt, 1),
+                                       "ms_per_batch": round(hsdt / hs_steps * 1e3, 3),
+                                       "pcie_gbs_achieved": round(frame_bytes * hs_steps / hsdt / 1e9, 2)},
+            "config": {"workload": f"PINNED HOST uint8 frames [{args.batch},3,{fh},{fw}] (4 distinct batches in turn) -> H2D -> "
+                                   f"clip_resize_kernel -> ViT-B/32 -> D2H of [{args.batch},{spec.embed_dim}] fp32; `value`: copies "
+                                   f"on a copy stream, two batches in flight; `synchronous_call_shape`: copy in, transform, "
+                                   f"forward, copy out, one batch at a time (ref:src/feature/mlfoundation_openclip.py:92-101)"}}
+        del raw, crop, crops, hraw, dbuf, hout
         # f4: the query side — CLIP text tower (ViT-B/32 text), one query at a time and in batches of 256
         from wise_amd.feature.text import EOT_TOKEN, SOT_TOKEN, TextEngine, random_text_state_dict, text_spec_for
 
@@ -862,12 +955,25 @@ def main():
             for i in range(3):
                 ivf1(i); ivf256(i)
             i_steps = max(10, min(args.steps, 50))
-            # (a side figure, not the contract's step: the better of two timed regions — on some boxes the first region of
-            # this launch-bound leg has run 20-50x slow once, profiles/README.md r03_c / r03_d)
-            t1 = min(timed_region(ivf1, i_steps, world), timed_region(ivf1, i_steps, world))
-            t256 = min(timed_region(ivf256, i_steps, world), timed_region(ivf256, i_steps, world))
+            # The FIRST timed region is the figure.  Two round-3 sequences (git: fe9ae72 r03_c_bench.json 9.36 ms/query,
+            # cd12ecb r03_d 3.56 ms) had one stall of 0.2-0.5 s inside it — not reproduced by a replay of this leg alone
+            # (tools/ivf_stall.py: 0.187 ms in every region, no allocator retry, no device allocation inside the regions), so
+            # it is left over from the legs in front of it; a second region and the slowest host-side enqueue of the first are
+            # reported beside the figure so that a stall shows up as what it is instead of being hidden by a minimum.
+            enq = []
+
+            def ivf1_timed(i):
+                t0 = time.perf_counter()
+                ivf1(i)
+                enq.append(time.perf_counter() - t0)
+
+            t1 = timed_region(ivf1_timed, i_steps, world)
+            t1b = timed_region(ivf1, i_steps, world)
+            t256 = timed_region(ivf256, i_steps, world)
             ivf_res[f"nprobe{nprobe}"] = {"single_query_ms": round(t1 / i_steps * 1e3, 4),
                                           "queries_per_s_nq1": round(i_steps / t1, 1),
+                                          "second_region_single_query_ms": round(t1b / i_steps * 1e3, 4),
+                                          "first_region_slowest_enqueue_ms": round(max(enq) * 1e3, 3),
                                           "queries_per_s_nq256": round(256 * i_steps / t256, 1)}
         extra["ivf_flat"] = {"value": ivf_res["nprobe32"]["queries_per_s_nq1"], "unit": "queries/s (nq=1, nprobe=32)",
                              "config": {"workload": f"IndexIVFFlat (inner product), {n_ivf} rows x d={args.dim} in "

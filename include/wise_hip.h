@@ -379,16 +379,20 @@ int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int
  * carried by the GEMMs themselves (open_clip's ln_1 / ln_2 as reached from src/feature/mlfoundation_openclip.py:99).
  *   wise_gemm_fold_resid: x[M,N] fp32 += A[M,K] @ Wt[N,K]^T + bias; h[M,N] bf16 = bf16(x); stats = one region of
  *     wise_gemm_fold_stats_bytes(M, N) bytes whose first M floats become rstd[r] = 1 / sqrt(var(x[r,:]) + eps); behind them
- *     scratch (partial sums per 64 columns, then (M/128 + 1) int arrival counters that must be ZERO on entry and are zero again
- *     on exit).  The statistics are reduced in one fixed tree, so a row's rstd does not depend on M or on the tile chosen.
+ *     wise_gemm_fold_counters_bytes(M) bytes of arrival counters (at byte offset wise_gemm_fold_counters_offset(M)) that must
+ *     be ZERO on entry and are zero again on exit, then scratch (partial sums per 64 columns; per 32 with group32 != 0, which
+ *     widths that are multiples of 192 but not of 128 need).  The statistics are reduced in one fixed tree, so a row's rstd
+ *     does not depend on M or on the tile chosen (for one value of group32).
  *   wise_gemm_fold_bf16: out[M,N] bf16 = act(rstd[row] * (A @ Wt^T) + bias[col]), mode 0 / 1 / 2 / 5 as wise_gemm_bf16; with
  *     A = h, Wt = gamma-scaled row-centred weights and bias = b + W beta this is act(Linear(LayerNorm(x))).
- * M % 128 == 0, N % 128 == 0, K % 64 == 0, K >= 192. */
+ * M % 128 == 0, N % 128 == 0 (or N % 192 == 0 with group32), K % 64 == 0, K >= 192. */
 size_t wise_gemm_fold_stats_bytes(int M, int N);
+size_t wise_gemm_fold_counters_offset(int M);
+size_t wise_gemm_fold_counters_bytes(int M);
 int wise_gemm_fold_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, const float* rstd, int M, int N, int K,
                         int mode, uint16_t* out, void* stream);
 int wise_gemm_fold_resid(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, float* x,
-                         uint16_t* h, float* stats, float eps, void* stream);
+                         uint16_t* h, float* stats, float eps, int group32, void* stream);
 /* out[ceil256(B*T*F), cout] bf16 = relu(conv3x3(x [B,T,F,cin] bf16, position-major ("NHWC"), stride 1, zero padding 1)
  * + bias[cout]); with pool != 0 its 2x2 average pooling (floor) instead, out [B*(T/2)*(F/2), cout], computed in the same
  * kernel (the unpooled tensor is never written).  wt [cout, 9*cin] bf16 with k = (kh*3 + kw)*cin + c (BatchNorm folded

@@ -36,23 +36,31 @@ def _fold_bf16(A, W, bias, rstd, mode):
     return out
 
 
-def _fold_resid(A, W, bias, x, eps=1e-5, stats=None):
+def _counters(stats, M):
+    lib = _lib.lib()
+    o, n = lib.wise_gemm_fold_counters_offset(M) // 4, lib.wise_gemm_fold_counters_bytes(M) // 4
+    return stats.view(torch.int32)[o:o + n]
+
+
+def _fold_resid(A, W, bias, x, eps=1e-5, stats=None, group32=0):
     lib = _lib.lib()
     M, K = A.shape
     N = W.shape[0]
     nbytes = lib.wise_gemm_fold_stats_bytes(M, N)
-    assert nbytes == M * 4 + M * (N // 64) * 8 + (M // 128 + 1) * 4
+    assert nbytes >= M * 4 + M * (N // 32) * 8 + (M // 128 + 1) * 4 and nbytes % 4 == 0
     if stats is None:
-        stats = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
-        stats[: M + M * (N // 64) * 2] = float("nan")          # only the counters must be zero on entry
+        stats = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device="cuda")
+        _counters(stats, M).zero_()                               # only the counters must be zero on entry
     h = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     _lib.check(lib.wise_gemm_fold_resid(A.data_ptr(), W.data_ptr(), bias.data_ptr(), M, N, K, x.data_ptr(), h.data_ptr(),
-                                        stats.data_ptr(), eps, _lib.stream_ptr()), "wise_gemm_fold_resid")
+                                        stats.data_ptr(), eps, group32, _lib.stream_ptr()), "wise_gemm_fold_resid")
     return h, stats
 
 
 @pytest.mark.parametrize("M,N,K", [(12800, 2304, 768), (12800, 3072, 768), (6400, 2304, 768), (2048, 3072, 768), (256, 2304, 768),
-                                    (512, 768, 256), (1280, 3072, 1024), (128, 128, 192)])
+                                    (512, 768, 256), (1280, 3072, 1024), (128, 128, 192),
+                                    # HTSAT: QKV and fc1 of stages 2 - 4
+                                    (131072, 576, 192), (131072, 768, 192), (32768, 1152, 384), (32768, 1536, 384), (8192, 2304, 768)])
 @pytest.mark.parametrize("mode", [0, 1, 2, 5])
 def test_gemm_fold_consumer(M, N, K, mode):
     if M > 2048 and mode in (2, 5):
@@ -68,9 +76,12 @@ def test_gemm_fold_consumer(M, N, K, mode):
     assert err <= max(3e-2, float(ref.abs().max()) * 2.0 ** -8), err      # one bf16 rounding of the result
 
 
-@pytest.mark.parametrize("M,N,K", [(12800, 768, 768), (12800, 768, 3072), (6400, 768, 768), (2048, 768, 3072), (256, 768, 768),
-                                    (1280, 1024, 4096), (128, 128, 192), (384, 256, 256)])
-def test_gemm_fold_producer(M, N, K):
+@pytest.mark.parametrize("M,N,K,g32", [(12800, 768, 768, 0), (12800, 768, 3072, 0), (6400, 768, 768, 0), (2048, 768, 3072, 0),
+                                        (256, 768, 768, 0), (1280, 1024, 4096, 0), (128, 128, 192, 0), (384, 256, 256, 0),
+                                        # MS-CLAP HTSAT's stages (statistics per 32 columns: 96-column wave parts)
+                                        (131072, 192, 192, 1), (131072, 192, 768, 1), (32768, 384, 384, 1), (32768, 384, 1536, 1),
+                                        (8192, 768, 768, 1), (8192, 768, 3072, 1), (1024, 192, 768, 1), (256, 384, 384, 1)])
+def test_gemm_fold_producer(M, N, K, g32):
     g = torch.Generator().manual_seed(M + N + K)
     A = bf16_round(torch.randn(M, K, generator=g))
     W = bf16_round(torch.randn(N, K, generator=g) * K ** -0.5)
@@ -81,7 +92,7 @@ def test_gemm_fold_producer(M, N, K):
     ref = x0.double() + A.double() @ W.double().t() + bias.double()
     x = x0.clone().cuda()
     Ad, Wd, bd = A.to(torch.bfloat16).cuda(), W.to(torch.bfloat16).cuda(), bias.cuda()
-    h, stats = _fold_resid(Ad, Wd, bd, x)
+    h, stats = _fold_resid(Ad, Wd, bd, x, group32=g32)
     torch.cuda.synchronize()
     xc = x.cpu()
     assert torch.allclose(xc.double(), ref, atol=2e-3, rtol=1e-5)
@@ -89,11 +100,10 @@ def test_gemm_fold_producer(M, N, K):
     rstd = stats[:M].cpu().double()
     want = 1.0 / torch.sqrt(xc.double().var(dim=1, unbiased=False) + 1e-5)
     assert ((rstd - want).abs() / want).max().item() <= 2e-5
-    counters = stats.view(torch.int32)[M + M * (N // 64) * 2:].cpu()
-    assert int(counters.abs().max()) == 0                      # left at zero for the next launch
+    assert int(_counters(stats, M).abs().max()) == 0           # left at zero for the next launch
     # ... which is the same launch again on the same scratch: same bits
     x2 = x0.clone().cuda()
-    h2, stats2 = _fold_resid(Ad, Wd, bd, x2, stats=stats.clone())
+    h2, stats2 = _fold_resid(Ad, Wd, bd, x2, stats=stats.clone(), group32=g32)
     assert torch.equal(x2, x) and torch.equal(h2, h) and torch.equal(stats2[:M], stats[:M])
 
 

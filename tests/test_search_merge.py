@@ -132,3 +132,44 @@ def test_subtract_hits_equals_the_reference():
         assert got == c["out"], c
         dropped += len(c["search_result"]["match_filename_list"]) - len(got["match_filename_list"])
     assert dropped > 50
+
+
+def test_batched_text_search_equals_one_search_per_query():
+    """wise_amd/search/batch_queries.py against FeatureSearchIndex.search called row by row (the reference's --queries-from loop,
+    search.py:894-950), with a stand-in text tower and the oracle as the index: same prompts, same (dist, ids) per query."""
+    import zlib
+
+    import numpy as np
+
+    from oracle import ip_topk_ref
+    from wise_amd.index.feature_search_index import FeatureSearchIndex
+
+    d = 32
+    X = np.random.default_rng(1).standard_normal((500, d)).astype(np.float32)
+    seen = []
+
+    class Tower:
+        def extract_text_features(self, texts):
+            seen.append(list(texts))
+            out = np.stack([np.random.default_rng(zlib.crc32(t.encode())).standard_normal(d) for t in texts])
+            return (out / np.linalg.norm(out, axis=1, keepdims=True)).astype(np.float32)
+
+    class Index:
+        def search(self, q, k):
+            return ip_topk_ref.ip_topk(X, q, k, ids=np.arange(500, dtype=np.int64) + 1)
+
+    for media in ("video", "audio"):
+        si = FeatureSearchIndex(media, "mlfoundations/open_clip/ViT-B-32/seeded-0", {"features_dir": ".", "index_dir": "."})
+        si.index, si.feature_extractor = Index(), Tower()
+        queries = [f"query number {i}" for i in range(300)]
+        seen.clear()
+        got = si.search_batch(media, queries, topk=7)
+        assert [len(b) for b in seen] == [256, 44]                     # two text-tower batches, not 300 calls
+        assert seen[0][0] == ("query number 0" if media == "audio" else "This is a photo of a query number 0")
+        assert len(got) == 300
+        for i in (0, 1, 255, 256, 299):
+            dist, ids = si.search(media, queries[i], topk=7)
+            assert np.array_equal(got[i][1], ids) and np.allclose(got[i][0], dist, atol=2e-5)   # (BLAS sums a batch in another order)
+    import pytest
+    with pytest.raises(ValueError):
+        si.search_batch("audio", ["a"], query_type="image")

@@ -19,7 +19,7 @@ echo "roofline stats done"
 # averages are those of the ViT-B/32 GEMMs and the 10M x 512 scans; the image-transform kernel from its own tool
 for C in FETCH_SIZE WRITE_SIZE; do
   L=$(echo $C | tr 'A-Z' 'a-z' | cut -d_ -f1)
-  timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$L -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_pmc_$L.log 2>&1 || exit 1
+  timeout -k 10 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$L -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --pmc-legs > $OUT/${TAG}_pmc_$L.log 2>&1 || exit 1
   timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_${L}_pre -- python3 tools/preproc_bench.py 64 > $OUT/${TAG}_pmc_${L}_pre.log 2>&1 || exit 1
   cp "$(find $OUT/${TAG}_pmc_$L -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_pmc_${L}_counter_collection.csv
   cp "$(find $OUT/${TAG}_pmc_${L}_pre -name '*counter_collection.csv' | head -1)" $OUT/${TAG}_pmc_${L}_pre_counter_collection.csv

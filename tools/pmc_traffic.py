@@ -15,8 +15,12 @@ from collections import defaultdict
 from pathlib import Path
 
 
+BY_GRID = {}   # counter -> {(kernel, grid size): (mean, launches)}: launches of one kernel on different problem sizes apart
+
+
 def per_kernel(paths, counter):
     acc = defaultdict(lambda: [0.0, 0])
+    accg = defaultdict(lambda: [0.0, 0])
     seen = set()
     for path in paths.split(","):
         for r in csv.DictReader(open(path)):
@@ -24,9 +28,12 @@ def per_kernel(paths, counter):
                 continue
             key = (path, r["Dispatch_Id"], r["Kernel_Name"])
             acc[r["Kernel_Name"]][0] += float(r["Counter_Value"])
+            accg[(r["Kernel_Name"], int(r["Grid_Size"]))][0] += float(r["Counter_Value"])
             if key not in seen:
                 seen.add(key)
                 acc[r["Kernel_Name"]][1] += 1
+                accg[(r["Kernel_Name"], int(r["Grid_Size"]))][1] += 1
+    BY_GRID[counter] = {k: (v[0] / max(v[1], 1), v[1]) for k, v in accg.items()}
     return {k: (v[0] / max(v[1], 1), v[1]) for k, v in acc.items()}
 
 
@@ -41,6 +48,14 @@ def main():
         out[short] = {"launches": max(nf, nw), "fetch_size_kib_raw": round(f, 1), "write_size_kib": round(w, 1),
                       "hbm_read_bytes_per_launch": round(f * 1024 * 2), "hbm_write_bytes_per_launch": round(w * 1024),
                       "hbm_bytes_per_launch": round(f * 1024 * 2 + w * 1024)}
+    # the same per (kernel, grid size): one kernel launched on several problem sizes (GEMM tiles of different shapes: the grid
+    # tells them apart; the search kernels run a fixed grid — their passes are kept like-for-like by `bench.py --pmc-legs`,
+    # which launches the headline shapes only)
+    for (name, grid), (f, nf) in sorted(BY_GRID.get("FETCH_SIZE", {}).items()):
+        short = name.split("(")[0].replace("void ", "").replace("wise::", "")
+        w, nw = BY_GRID.get("WRITE_SIZE", {}).get((name, grid), (0.0, 0))
+        out[short].setdefault("by_grid", {})[str(grid)] = {"launches": max(nf, nw), "hbm_read_bytes_per_launch": round(f * 2048),
+                                                           "hbm_write_bytes_per_launch": round(w * 1024)}
     # aggregate keys bench.py looks up
     def agg(prefix, per=1):
         # "ip_scan_kernel" = the flat scan only; its inverted-list instantiation (last template argument true) is

@@ -2549,11 +2549,15 @@ int gemm_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N
 //   producer:  x += A @ Wt^T + bias;  h = bf16(x);  part / rstd_out = the rows' statistics    (out-projection, fc2)
 // M % 128 == 0, N % 128 == 0, K % 64 == 0, K >= 192.  Tiles with 64- or 128-column wave parts only (the statistics' tree).
 // ---------------------------------------------------------------------------------------------------------------------
-bool gemm_fold_shape_ok(int M, int N, int K) { return M > 0 && M % 128 == 0 && N > 0 && N % 128 == 0 && K % 64 == 0 && K >= 192; }
+bool gemm_fold_shape_ok(int M, int N, int K) { return M > 0 && M % 128 == 0 && N > 0 && (N % 128 == 0 || N % 192 == 0) && K % 64 == 0 && K >= 192; }
 
-static int fold_variant(int M, int N, int K, int mode, bool producer) {
+static int fold_variant(int M, int N, int K, int mode, bool producer, bool wide96 = false) {
     const int v = w4_variant(M, N, K, mode);
     if (v == 61 || v == 68 || v == 70 || ((v == 60 || v == 64) && !producer)) return v;   // (the 256 x 256 residual form with statistics spills)
+    // tiles with 96-column wave parts (256 x 192, 128 x 192, 128 x 192 at two workgroups per CU): any consumer; a producer
+    // only where the model's statistics are kept per 32 columns (FoldArgs.group32: MS-CLAP's HTSAT, widths 192 / 384 / 768)
+    if ((v == 66 || v == 67 || v == 69) && (!producer || wide96)) return v;
+    if (N % 128 != 0) return w4_shape_ok(M, N, K, 4, 6) ? ((long long)(M / 128) * (N / 192) >= 512 ? 69 : 67) : 0;
     if (!producer && w4p_shape_ok(M, N, K) && (long long)(M / 160) * (N / 256) >= device_cus()) return 64;
     if (w4_shape_ok(M, N, K, 5, 8) && (long long)(M / 160) * (N / 256) >= 192) return 61;
     if (w4_shape_ok(M, N, K, 4, 8) && (long long)(M / 128) * (N / 256) >= 256) return 68;
@@ -2568,6 +2572,9 @@ static void launch_fold_consumer(int v, const bf16_t* A, const bf16_t* Wt, const
         case 61: launch_w4<MODE, 5, 8, 3, 2, 1, 1>(A, Wt, bias, M, N, K, out, st, fa); break;
         case 64: launch_w4p<MODE, 1>(A, Wt, bias, M, N, K, out, device_cus(), st, fa); break;
         case 68: launch_w4<MODE, 4, 8, 3, 2, 1, 1>(A, Wt, bias, M, N, K, out, st, fa); break;
+        case 66: launch_w4<MODE, 8, 6, 3, 2, 1, 1>(A, Wt, bias, M, N, K, out, st, fa); break;
+        case 67: launch_w4<MODE, 4, 6, 3, 2, 1, 1>(A, Wt, bias, M, N, K, out, st, fa); break;
+        case 69: launch_w4<MODE, 4, 6, 2, 2, 2, 1>(A, Wt, bias, M, N, K, out, st, fa); break;
         default: launch_w4<MODE, 4, 4, 3, 2, 2, 1>(A, Wt, bias, M, N, K, out, st, fa); break;
     }
 }
@@ -2580,6 +2587,7 @@ int gemm_fold_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, const f
     FoldArgs fa;
     fa.stats = const_cast<float*>(rstd);
     const int v = fold_variant(M, N, K, mode, false);
+    WISE_CHECK_ARG(v != 0, "gemm_fold_bf16: no tile for M=%d N=%d K=%d", M, N, K);
     switch (mode) {
         case EPI_BF16: launch_fold_consumer<EPI_BF16>(v, A, Wt, bias, M, N, K, out, fa, st); break;
         case EPI_QUICKGELU: launch_fold_consumer<EPI_QUICKGELU>(v, A, Wt, bias, M, N, K, out, fa, st); break;
@@ -2591,17 +2599,23 @@ int gemm_fold_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, const f
 }
 
 size_t gemm_fold_stats_bytes(int M, int N) { return fold_stats_bytes(M, N); }
+size_t gemm_fold_counters_bytes(int M) { return fold_count_slots(M) * 4; }
 
 int gemm_fold_resid(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, float* x, bf16_t* h, float* stats,
-                    float eps, hipStream_t st) {
+                    float eps, hipStream_t st, int group32) {
     WISE_CHECK_ARG(A && Wt && x && h && stats, "gemm_fold_resid: null pointer");
-    WISE_CHECK_ARG(gemm_fold_shape_ok(M, N, K), "gemm_fold_resid: M=%d N=%d K=%d", M, N, K);
+    WISE_CHECK_ARG(gemm_fold_shape_ok(M, N, K) && (group32 || N % 128 == 0), "gemm_fold_resid: M=%d N=%d K=%d group32=%d", M, N, K, group32);
     ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
     FoldArgs fa;
-    fa.hcopy = h; fa.stats = stats; fa.eps = eps;
-    switch (fold_variant(M, N, K, EPI_RESID, true)) {
+    fa.hcopy = h; fa.stats = stats; fa.eps = eps; fa.group32 = group32 ? 1 : 0;
+    const int v = fold_variant(M, N, K, EPI_RESID, true, group32 != 0);
+    WISE_CHECK_ARG(v != 0, "gemm_fold_resid: no tile for M=%d N=%d K=%d", M, N, K);
+    switch (v) {
         case 61: launch_w4<EPI_RESID, 5, 8, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
         case 68: launch_w4<EPI_RESID, 4, 8, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
+        case 66: launch_w4<EPI_RESID, 8, 6, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
+        case 67: launch_w4<EPI_RESID, 4, 6, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
+        case 69: launch_w4<EPI_RESID, 4, 6, 2, 2, 2, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
         default: launch_w4<EPI_RESID, 4, 4, 3, 2, 2, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
     }
     WISE_LAUNCH_CHECK("gemm_w4_kernel (fold, residual)");
@@ -2701,13 +2715,15 @@ extern "C" int wise_gemm_ln_bf16(const float* x, const float* lnw, const float* 
 extern "C" void wise_overlap_hint(int on) { wise::gemm_set_overlapped(on != 0); }
 
 extern "C" size_t wise_gemm_fold_stats_bytes(int M, int N) { return wise::gemm_fold_shape_ok(M, N, 192) ? wise::gemm_fold_stats_bytes(M, N) : 0; }
+extern "C" size_t wise_gemm_fold_counters_offset(int M) { return (size_t)M * 4; }
+extern "C" size_t wise_gemm_fold_counters_bytes(int M) { return wise::fold_count_slots(M) * 4; }
 extern "C" int wise_gemm_fold_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, const float* rstd, int M, int N, int K,
                                    int mode, uint16_t* out, void* stream) {
     return wise::gemm_fold_bf16(A, Wt, bias, rstd, M, N, K, mode, out, (hipStream_t)stream);
 }
 extern "C" int wise_gemm_fold_resid(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, float* x,
-                                    uint16_t* h, float* stats, float eps, void* stream) {
-    return wise::gemm_fold_resid(A, Wt, bias, M, N, K, x, h, stats, eps, (hipStream_t)stream);
+                                    uint16_t* h, float* stats, float eps, int group32, void* stream) {
+    return wise::gemm_fold_resid(A, Wt, bias, M, N, K, x, h, stats, eps, (hipStream_t)stream, group32);
 }
 
 extern "C" int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, int mode,

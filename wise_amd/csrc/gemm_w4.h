@@ -46,15 +46,19 @@ namespace wise {
 //             (arrival counter) adds the N/64 partials in order and writes rstd = rsqrt(var + eps) for the stripe's rows.
 // No LayerNorm launch is left between the two GEMMs, and the fp32 rows are not read a second time.
 struct FoldArgs {
-    // FOLD 1: stats = the [M] row scales (rstd).  FOLD 2: stats = ONE region laid out as rstd_out [M] floats, then the partial
-    // sums [M][N/64][2] floats, then one arrival counter (int) per row stripe of the launch (zero on entry, zero on exit);
-    // hcopy = the [M, N] bf16 copy of the updated rows.  (Few kernel arguments on purpose: they stay live in scalar
-    // registers across a loop whose inline-assembly loads need theirs.)
+    // FOLD 1: stats = the [M] row scales (rstd).  FOLD 2: stats = ONE region laid out as rstd_out [M] floats, then one arrival
+    // counter (int) per row stripe of the launch ((M/128 + 1) of them rounded up to 64: zero on entry, zero on exit), then
+    // the partial sums [M][N/G][2] floats, G = 64 or 32 columns per group (group32: widths that are not a multiple of 128
+    // columns, i.e. tiles with 96-column wave parts — MS-CLAP's HTSAT stages; a model uses ONE group size for a given N
+    // whatever tile a batch size selects); hcopy = the [M, N] bf16 copy of the updated rows.  (Few kernel arguments on
+    // purpose: they stay live in scalar registers across a loop whose inline-assembly loads need theirs.)
     float* stats = nullptr;
     bf16_t* hcopy = nullptr;
     float eps = 1e-5f;
+    int group32 = 0;
 };
-__host__ __device__ inline size_t fold_stats_bytes(int M, int N) { return (size_t)M * 4 + (size_t)M * (N / 64) * 8 + (size_t)(M / 128 + 1) * 4; }
+__host__ __device__ inline size_t fold_count_slots(int M) { return (size_t)((M / 128 + 1 + 63) / 64 * 64); }
+__host__ __device__ inline size_t fold_stats_bytes(int M, int N) { return (size_t)M * 4 + fold_count_slots(M) * 4 + (size_t)M * (N / 32) * 8; }
 
 namespace w4 {
 
@@ -206,6 +210,12 @@ __device__ __forceinline__ float4 rpre_read(int t) {
     return r;
 }
 
+// v + (v of the lane the DPP control selects within its row of 16)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 // bf16 epilogue of RI row tiles (RI <= 4) x NJ*16 columns: wave-private image of 16*RI rows, then a row-major walk in
 // which every global store instruction writes whole row segments (16 bytes per lane, consecutive lanes consecutive)
 template <int MODE, int MI, int NJ, int RI, int FOLD = 0>
@@ -269,12 +279,14 @@ __device__ __forceinline__ void resid_load(const float* __restrict__ out, int N,
     }
 }
 
-template <int MODE, int MI, int NJ, int RI, int FOLD = 0>
+// `res_at(t)`: the residual values of walk step t (an array filled by resid_load a pass earlier, or — the 160 x 256 residual
+// kernel — the prefetch registers, fetched one tuple at a time right where it is added, so that no copy of them lives in VGPRs)
+template <int MODE, int MI, int NJ, int RI, int FOLD = 0, typename RES>
 __device__ __forceinline__ void epi_f32_pass(const f32x4 (&acc)[MI][NJ], int i0, const float4 (&bv)[NJ], float* __restrict__ out,
                                              int N, int row0, int col0, int lane, unsigned my,
-                                             const float4 (&res)[RI * 16 * NJ * 4 / 64], bf16_t* __restrict__ hcopy = nullptr,
-                                             float* __restrict__ part = nullptr) {
-    static_assert(FOLD != 2 || NJ == 4 || NJ == 8, "fold statistics: wave parts of 64 or 128 columns");
+                                             RES&& res_at, bf16_t* __restrict__ hcopy = nullptr,
+                                             float* __restrict__ part = nullptr, int group32 = 0) {
+    static_assert(FOLD != 2 || NJ == 4 || NJ == 6 || NJ == 8, "fold statistics: wave parts of 64, 96 or 128 columns");
     constexpr int RS = NJ * 64 + 16, CPR = NJ * 4;
     static_assert((RI * 16 * CPR) % 64 == 0, "walk covers the piece in whole wave instructions");
     const int l15 = lane & 15, g = lane >> 4;
@@ -294,7 +306,7 @@ __device__ __forceinline__ void epi_f32_pass(const f32x4 (&acc)[MI][NJ], int i0,
         const int idx = t * 64 + lane, row = idx / CPR, c = idx % CPR;
         const f32x4 l = W4_LDS(const f32x4, my + row * RS + c * 16);
         float4 v = make_float4(l[0], l[1], l[2], l[3]);
-        if (MODE == EPI_RESID) { v.x += res[t].x; v.y += res[t].y; v.z += res[t].z; v.w += res[t].w; }
+        if (MODE == EPI_RESID) { const float4 r = res_at(t); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
         *reinterpret_cast<float4*>(out + (size_t)(row0 + i0 * 16 + row) * N + col0 + c * 4) = v;
         if constexpr (FOLD == 2) {
             // the next GEMM's operand, and the row's sums over this aligned 64-column group: 4 values in the lane, then the
@@ -303,11 +315,19 @@ __device__ __forceinline__ void epi_f32_pass(const f32x4 (&acc)[MI][NJ], int i0,
             *reinterpret_cast<u32x2_t*>(hcopy + grow * N + col0 + c * 4) = u32x2_t{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
             float s1 = ((v.x + v.y) + v.z) + v.w;
             float s2 = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
-#pragma unroll
-            for (int o = 1; o <= 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-            if ((c & 15) == 0) {
-                const int np = N >> 6;
-                *reinterpret_cast<float2*>(part + (grow * np + ((col0 + c * 4) >> 6)) * 2) = make_float2(s1, s2);
+            // pairs, quads (quad permutes), the two quads of a half (row_half_mirror), the two halves (row_mirror): the xor
+            // butterfly's tree on the VALU's data-parallel-primitive path — no LDS round trips
+            s1 = dpp_add<0xB1>(s1); s2 = dpp_add<0xB1>(s2);
+            s1 = dpp_add<0x4E>(s1); s2 = dpp_add<0x4E>(s2);
+            s1 = dpp_add<0x141>(s1); s2 = dpp_add<0x141>(s2);
+            if (NJ != 6 && !group32) { s1 = dpp_add<0x140>(s1); s2 = dpp_add<0x140>(s2); }     // 64-column groups: the two halves
+            const int gsh = (NJ == 6 || group32) ? 5 : 6;
+            if ((c & ((1 << (gsh - 2)) - 1)) == 0) {
+                // agent-scope stores: written through to where every XCD reads the same value — no cache write-back fence later
+                const int np = N >> gsh;
+                float* pp = part + (grow * np + ((col0 + c * 4) >> gsh)) * 2;
+                __hip_atomic_store(pp, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pp + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -531,52 +551,53 @@ __global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restr
             // pass 1 is loaded here, under pass 0's transposition
             load(1, res[1]);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory", W4_HI_AGPRS);       // all but pass 1's NRES loads
-            float4 last[NRES / 2];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) res[0][t] = rpre_read(t);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) last[t] = rpre_read(16 + t);
-            epi_f32_pass<MODE, MI, NJ, 2, FOLD>(acc, 0, bv, o, N, row0, col0, lane, my, res[0], fold.hcopy, fold.stats + M);
-            epi_f32_pass<MODE, MI, NJ, 2, FOLD>(acc, 2, bv, o, N, row0, col0, lane, my, res[1], fold.hcopy, fold.stats + M);
-            epi_f32_pass<MODE, MI, NJ, 1, FOLD>(acc, 4, bv, o, N, row0, col0, lane, my, last, fold.hcopy, fold.stats + M);
+            epi_f32_pass<MODE, MI, NJ, 2, FOLD>(acc, 0, bv, o, N, row0, col0, lane, my, [](int t) { return rpre_read(t); }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32);
+            epi_f32_pass<MODE, MI, NJ, 2, FOLD>(acc, 2, bv, o, N, row0, col0, lane, my, [&](int t) { return res[1][t]; }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32);
+            epi_f32_pass<MODE, MI, NJ, 1, FOLD>(acc, 4, bv, o, N, row0, col0, lane, my, [](int t) { return rpre_read(16 + t); }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32);
         } else {
             if (MODE == EPI_RESID) load(0, res[0]);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 if (MODE == EPI_RESID && p + 1 < NP) load(p + 1, res[(p + 1) & 1]);
-                if (p * RP + RP <= MI) epi_f32_pass<MODE, MI, NJ, RP, FOLD>(acc, p * RP, bv, o, N, row0, col0, lane, my, res[p & 1], fold.hcopy, fold.stats + M);
+                const float4 (&rp)[NRES] = res[p & 1];
+                if (p * RP + RP <= MI) epi_f32_pass<MODE, MI, NJ, RP, FOLD>(acc, p * RP, bv, o, N, row0, col0, lane, my, [&](int t) { return rp[t]; }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32);
                 else if constexpr (RP == 2)
-                    epi_f32_pass<MODE, MI, NJ, 1, FOLD>(acc, p * RP, bv, o, N, row0, col0, lane, my,
-                                                        reinterpret_cast<const float4 (&)[NRES / 2]>(res[p & 1]), fold.hcopy, fold.stats + M);
+                    epi_f32_pass<MODE, MI, NJ, 1, FOLD>(acc, p * RP, bv, o, N, row0, col0, lane, my, [&](int t) { return rp[t]; }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32);
             }
         }
     }
     if constexpr (FOLD == 2) {
-        // The stripe's statistics: every workgroup publishes its partial sums (release), bumps the stripe's counter, and the
-        // one that finds all the others there (acquire) adds the N/64 partials of each row in column order and writes rstd.
-        // The counter goes back to zero for the next launch.
-        // (the flag sits at LDS offset 0: the kernel owns the whole allocation by raw offsets, and every wave is past its
-        //  use of the scratch there at the first barrier)
-        __threadfence();
+        // The stripe's statistics: every workgroup's partial sums are agent-scope stores (above); once they are acknowledged
+        // (vmcnt 0) it bumps the stripe's counter, and the workgroup that finds all the others there reads the N/64 partials of
+        // each row with agent-scope loads, adds them in column order and writes rstd.  No release / acquire FENCES: on this
+        // chip they write back and invalidate a whole XCD's L2 (measured: +50 us per launch with 240 workgroups doing so).
+        // The counter goes back to zero for the next launch.  (The flag sits at LDS offset 0: the kernel owns the whole
+        // allocation by raw offsets, and every wave is past its use of the scratch there at the first barrier.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            int* count = reinterpret_cast<int*>(fold.stats + (size_t)M + (size_t)M * (N >> 6) * 2) + tm;
-            const int seen = __hip_atomic_fetch_add(count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            int* count = reinterpret_cast<int*>(fold.stats + (size_t)M) + tm;
+            const int seen = __hip_atomic_fetch_add(count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = seen == N / BNB - 1;
             W4_LDS(int, 0) = last;
             if (last) __hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (W4_LDS(const int, 0)) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const int np = N >> 6;
+            const int np = N >> ((NJ == 6 || fold.group32) ? 5 : 6);
             const float inv_n = 1.0f / (float)N;
             for (int r = threadIdx.x; r < BMB; r += 256) {
-                const float* pr = fold.stats + (size_t)M + (size_t)(m0 + r) * np * 2;
+                const float* pr = fold.stats + (size_t)M + fold_count_slots(M) + (size_t)(m0 + r) * np * 2;
                 float s1 = 0.f, s2 = 0.f;
-                for (int q = 0; q < np; ++q) {
-                    s1 += __builtin_nontemporal_load(pr + 2 * q);
-                    s2 += __builtin_nontemporal_load(pr + 2 * q + 1);
+                const unsigned long long* pq = reinterpret_cast<const unsigned long long*>(pr);
+                for (int base = 0; base < np; base += 16) {       // 16 (sum, sum of squares) pairs per trip, all loads in flight
+                    unsigned long long v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        v[k] = (base + k < np) ? __hip_atomic_load(pq + base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (base + k < np) { s1 += __uint_as_float((unsigned)v[k]); s2 += __uint_as_float((unsigned)(v[k] >> 32)); }
                 }
                 const float mean = s1 * inv_n;
                 const float var = fmaxf(fmaf(-mean, mean, s2 * inv_n), 0.f);

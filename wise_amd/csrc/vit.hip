@@ -898,9 +898,8 @@ static int transformer_blocks_fold(const BlockWeights& bw, int L, int W, int H, 
                                    bf16_t* h, bf16_t* qkv, bf16_t* a, float* stats, hipStream_t st, float eps) {
     const int M = batch * T, Mp = (M + 255) / 256 * 256;
     int rc;
-    float* rstd = stats;                        // [Mp] row scales; partial sums and arrival counters behind them
-    unsigned char* counters = reinterpret_cast<unsigned char*>(stats) + (size_t)Mp * 4 + (size_t)Mp * (W / 64) * 8;
-    if (hipMemsetAsync(counters, 0, (size_t)(Mp / 128 + 1) * sizeof(int), st) != hipSuccess) {
+    float* rstd = stats;                        // [Mp] row scales; arrival counters and partial sums behind them
+    if (hipMemsetAsync(stats + Mp, 0, gemm_fold_counters_bytes(Mp), st) != hipSuccess) {
         set_error("vit_forward: memset of the fold counters failed");
         return WISE_E_INVALID;
     }

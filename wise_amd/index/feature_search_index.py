@@ -178,3 +178,12 @@ class FeatureSearchIndex(SearchIndex):
         query_features = self.feature_extractor.extract_text_features(media_query_text)
         dist, ids = self.index.search(query_features, topk)
         return dist[0], ids[0]
+
+    def search_batch(self, media_type, queries, topk=5, query_type='text'):
+        """Not in the reference: what `search` returns for every string of `queries`, from ONE text-tower batch and ONE
+        batched index search per 256 of them (wise_amd/search/batch_queries.py; the --queries-from loop of search.py:894-950
+        calls `search` row by row)."""
+        if query_type != 'text':
+            raise ValueError('query_type={query_type} not implemented')
+        from ..search.batch_queries import batched_text_search
+        return batched_text_search(self, media_type, queries, topk)
