@@ -186,8 +186,8 @@ typedef struct wise_vit_config {
                            projection, y + mlp(norm(y))), no projection (embed_dim == width); u8 input is normalised with
                            mean = std = 0.5.  Weight layout of arch 1: wise_amd/feature/siglip.py:pack_siglip_vision */
     int32_t ln_fold;    /* (ABI 5) 0 = LayerNorm kernels between the GEMMs; 1 (arch 0 only) = the blocks' LayerNorms folded into
-                           the GEMMs around them: the residual GEMMs also emit bf16(x) and the rows' 1/sqrt(var + eps), the
-                           QKV / fc1 GEMMs scale their rows by it.  The blob layout is the same, but the packer must then store
+                           the GEMMs around them: the residual stream is kept as bf16 hi + lo, the residual GEMMs also emit the
+                           rows' 1/sqrt(var + eps), the QKV / fc1 GEMMs take hi as their operand and scale their rows by it.  The blob layout is the same, but the packer must then store
                            in_proj / c_fc as gamma-scaled, row-centred weights and their biases as b + W beta
                            (wise_amd/feature/vit.py:pack_weights); ln_1 / ln_2 slots are not read.  Same results within the
                            bf16 path's tolerance (not bit-equal to ln_fold = 0). */
@@ -377,7 +377,9 @@ int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int
                    int mode, void* out, void* stream);
 /* (ABI 5) The two GEMMs of wise_vit_config.ln_fold = 1: a LayerNorm between a residual GEMM and the next linear layer is
  * carried by the GEMMs themselves (open_clip's ln_1 / ln_2 as reached from src/feature/mlfoundation_openclip.py:99).
- *   wise_gemm_fold_resid: x[M,N] fp32 += A[M,K] @ Wt[N,K]^T + bias; h[M,N] bf16 = bf16(x); stats = one region of
+ *   wise_gemm_fold_resid: x += A[M,K] @ Wt[N,K]^T + bias on a residual stream kept as TWO bf16 arrays, x = hi + lo
+ *     (hi = bf16(x), lo = bf16(x - hi), lo = hi + lo_off elements, lo_off >= M*N: 16 significand bits in the 4 bytes per
+ *     element an fp32 stream takes — and hi is the next GEMM's operand as it stands); stats = one region of
  *     wise_gemm_fold_stats_bytes(M, N) bytes whose first M floats become rstd[r] = 1 / sqrt(var(x[r,:]) + eps); behind them
  *     wise_gemm_fold_counters_bytes(M) bytes of arrival counters (at byte offset wise_gemm_fold_counters_offset(M)) that must
  *     be ZERO on entry and are zero again on exit, then scratch (partial sums per 64 columns; per 32 with group32 != 0, which
@@ -391,8 +393,8 @@ size_t wise_gemm_fold_counters_offset(int M);
 size_t wise_gemm_fold_counters_bytes(int M);
 int wise_gemm_fold_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, const float* rstd, int M, int N, int K,
                         int mode, uint16_t* out, void* stream);
-int wise_gemm_fold_resid(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, float* x,
-                         uint16_t* h, float* stats, float eps, int group32, void* stream);
+int wise_gemm_fold_resid(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, uint16_t* hi,
+                         int64_t lo_off, float* stats, float eps, int group32, void* stream);
 /* out[ceil256(B*T*F), cout] bf16 = relu(conv3x3(x [B,T,F,cin] bf16, position-major ("NHWC"), stride 1, zero padding 1)
  * + bias[cout]); with pool != 0 its 2x2 average pooling (floor) instead, out [B*(T/2)*(F/2), cout], computed in the same
  * kernel (the unpooled tensor is never written).  wt [cout, 9*cin] bf16 with k = (kh*3 + kw)*cin + c (BatchNorm folded

@@ -42,7 +42,14 @@ def _counters(stats, M):
     return stats.view(torch.int32)[o:o + n]
 
 
-def _fold_resid(A, W, bias, x, eps=1e-5, stats=None, group32=0):
+def hilo(x):
+    """fp32 [M,N] -> the residual stream's storage: one bf16 tensor [2,M,N], hi = bf16(x), lo = bf16(x - hi)"""
+    hi = x.to(torch.bfloat16)
+    return torch.stack([hi, (x - hi.float()).to(torch.bfloat16)])
+
+
+def _fold_resid(A, W, bias, xs, eps=1e-5, stats=None, group32=0):
+    """xs: [2,M,N] bf16 (hi, lo), updated in place.  -> stats"""
     lib = _lib.lib()
     M, K = A.shape
     N = W.shape[0]
@@ -51,10 +58,10 @@ def _fold_resid(A, W, bias, x, eps=1e-5, stats=None, group32=0):
     if stats is None:
         stats = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device="cuda")
         _counters(stats, M).zero_()                               # only the counters must be zero on entry
-    h = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    _lib.check(lib.wise_gemm_fold_resid(A.data_ptr(), W.data_ptr(), bias.data_ptr(), M, N, K, x.data_ptr(), h.data_ptr(),
+    assert xs.is_contiguous() and xs.shape == (2, M, N)
+    _lib.check(lib.wise_gemm_fold_resid(A.data_ptr(), W.data_ptr(), bias.data_ptr(), M, N, K, xs.data_ptr(), M * N,
                                         stats.data_ptr(), eps, group32, _lib.stream_ptr()), "wise_gemm_fold_resid")
-    return h, stats
+    return stats
 
 
 @pytest.mark.parametrize("M,N,K", [(12800, 2304, 768), (12800, 3072, 768), (6400, 2304, 768), (2048, 3072, 768), (256, 2304, 768),
@@ -89,22 +96,27 @@ def test_gemm_fold_producer(M, N, K, g32):
     x0 = torch.randn(M, N, generator=g) * 2.0
     x0[:, 7] += 60.0                                           # a massive-activation channel
     x0[:, :] += torch.randn(M, 1, generator=g)                 # and rows whose mean is not zero
-    ref = x0.double() + A.double() @ W.double().t() + bias.double()
-    x = x0.clone().cuda()
+    xs0 = hilo(x0)
+    start = xs0[0].double() + xs0[1].double()                  # what the stream holds: x0 to 16 significand bits
+    assert (start - x0.double()).abs().max().item() <= 2.0 ** -16 * 70
+    ref = start + A.double() @ W.double().t() + bias.double()
+    xs = xs0.clone().cuda()
     Ad, Wd, bd = A.to(torch.bfloat16).cuda(), W.to(torch.bfloat16).cuda(), bias.cuda()
-    h, stats = _fold_resid(Ad, Wd, bd, x, group32=g32)
+    stats = _fold_resid(Ad, Wd, bd, xs, group32=g32)
     torch.cuda.synchronize()
-    xc = x.cpu()
-    assert torch.allclose(xc.double(), ref, atol=2e-3, rtol=1e-5)
-    assert torch.equal(h.cpu(), xc.to(torch.bfloat16))        # the copy is the rounding of exactly what was stored
+    hi, lo = xs[0].cpu(), xs[1].cpu()
+    xc = hi.double() + lo.double()
+    assert torch.allclose(xc, ref, atol=2e-3, rtol=2e-5)      # fp32 sum, then the hi + lo split (2^-17 relative)
+    assert (hi != ref.to(torch.bfloat16)).float().mean().item() < 2e-3      # hi IS the bf16 rounding of the new row (ties aside)
+    assert (lo.float().abs() <= hi.float().abs() * 2.0 ** -8 + 1e-30).all()  # and lo what that rounding left
     rstd = stats[:M].cpu().double()
-    want = 1.0 / torch.sqrt(xc.double().var(dim=1, unbiased=False) + 1e-5)
+    want = 1.0 / torch.sqrt(ref.var(dim=1, unbiased=False) + 1e-5)
     assert ((rstd - want).abs() / want).max().item() <= 2e-5
     assert int(_counters(stats, M).abs().max()) == 0           # left at zero for the next launch
     # ... which is the same launch again on the same scratch: same bits
-    x2 = x0.clone().cuda()
-    h2, stats2 = _fold_resid(Ad, Wd, bd, x2, stats=stats.clone(), group32=g32)
-    assert torch.equal(x2, x) and torch.equal(h2, h) and torch.equal(stats2[:M], stats[:M])
+    xs2 = xs0.clone().cuda()
+    stats2 = _fold_resid(Ad, Wd, bd, xs2, stats=stats.clone(), group32=g32)
+    assert torch.equal(xs2, xs) and torch.equal(stats2[:M], stats[:M])
 
 
 def test_fold_gemms_do_not_depend_on_the_row_count():
@@ -123,13 +135,13 @@ def test_fold_gemms_do_not_depend_on_the_row_count():
     Ah = bf16_round(torch.randn(M, F, generator=g)).to(torch.bfloat16).cuda()
     Wp = bf16_round(torch.randn(W_, F, generator=g) * F ** -0.5).to(torch.bfloat16).cuda()
     bp = torch.randn(W_, generator=g).cuda()
-    x0 = (torch.randn(M, W_, generator=g) * 2).cuda()
-    xb = x0.clone()
-    hb, sb = _fold_resid(Ah, Wp, bp, xb)
+    xs0 = hilo(torch.randn(M, W_, generator=g) * 2).cuda()
+    xb = xs0.clone()
+    sb = _fold_resid(Ah, Wp, bp, xb)
     for rows in (256, 2048, 6400):
-        xs = x0[:rows].clone()
-        hs, ss = _fold_resid(Ah[:rows].contiguous(), Wp, bp, xs)
-        assert torch.equal(xs, xb[:rows]) and torch.equal(hs, hb[:rows]) and torch.equal(ss[:rows], sb[:rows]), rows
+        xs = xs0[:, :rows].contiguous()
+        ss = _fold_resid(Ah[:rows].contiguous(), Wp, bp, xs)
+        assert torch.equal(xs, xb[:, :rows]) and torch.equal(ss[:rows], sb[:rows]), rows
 
 
 def test_fold_layernorm_weights_are_the_layernorm():

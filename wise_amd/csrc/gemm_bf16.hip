@@ -2601,13 +2601,17 @@ int gemm_fold_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, const f
 size_t gemm_fold_stats_bytes(int M, int N) { return fold_stats_bytes(M, N); }
 size_t gemm_fold_counters_bytes(int M) { return fold_count_slots(M) * 4; }
 
-int gemm_fold_resid(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, float* x, bf16_t* h, float* stats,
-                    float eps, hipStream_t st, int group32) {
-    WISE_CHECK_ARG(A && Wt && x && h && stats, "gemm_fold_resid: null pointer");
+int gemm_fold_resid(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, bf16_t* hi, long long lo_off,
+                    float* stats, float eps, hipStream_t st, int group32) {
+    WISE_CHECK_ARG(A && Wt && hi && stats, "gemm_fold_resid: null pointer");
     WISE_CHECK_ARG(gemm_fold_shape_ok(M, N, K) && (group32 || N % 128 == 0), "gemm_fold_resid: M=%d N=%d K=%d group32=%d", M, N, K, group32);
+    // lo sits BEHIND hi, within the 2 GiB a buffer descriptor's scalar offset reaches (the residual prefetch addresses it so)
+    WISE_CHECK_ARG(lo_off >= (long long)M * N && lo_off % 4 == 0 && (lo_off + (long long)M * N) * 2 < 0x7fffffffLL,
+                   "gemm_fold_resid: lo must follow hi by at least M*N elements and stay within 2 GiB of it (lo_off=%lld)", lo_off);
     ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
+    float* x = nullptr;
     FoldArgs fa;
-    fa.hcopy = h; fa.stats = stats; fa.eps = eps; fa.group32 = group32 ? 1 : 0;
+    fa.hcopy = hi; fa.lo_off = (int)lo_off; fa.stats = stats; fa.eps = eps; fa.group32 = group32 ? 1 : 0;
     const int v = fold_variant(M, N, K, EPI_RESID, true, group32 != 0);
     WISE_CHECK_ARG(v != 0, "gemm_fold_resid: no tile for M=%d N=%d K=%d", M, N, K);
     switch (v) {
@@ -2721,9 +2725,9 @@ extern "C" int wise_gemm_fold_bf16(const uint16_t* A, const uint16_t* Wt, const 
                                    int mode, uint16_t* out, void* stream) {
     return wise::gemm_fold_bf16(A, Wt, bias, rstd, M, N, K, mode, out, (hipStream_t)stream);
 }
-extern "C" int wise_gemm_fold_resid(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, float* x,
-                                    uint16_t* h, float* stats, float eps, int group32, void* stream) {
-    return wise::gemm_fold_resid(A, Wt, bias, M, N, K, x, h, stats, eps, (hipStream_t)stream, group32);
+extern "C" int wise_gemm_fold_resid(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, uint16_t* hi,
+                                    int64_t lo_off, float* stats, float eps, int group32, void* stream) {
+    return wise::gemm_fold_resid(A, Wt, bias, M, N, K, hi, lo_off, stats, eps, (hipStream_t)stream, group32);
 }
 
 extern "C" int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, int mode,

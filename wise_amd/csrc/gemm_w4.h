@@ -39,8 +39,8 @@ namespace wise {
 // LN(x) = (x - mean) rstd gamma + beta is rstd * (x W''^T) + b'' when W'' = gamma W minus its row mean over K (the centring
 // moves into the weights: sum_k (x_k - mean) w_k = sum_k x_k (w_k - mean_k w)) and b'' = b + W beta — both made by the packer.
 //   FOLD = 1 (bf16 outputs: QKV, fc1): the operand is bf16(x) as it stands and the epilogue is fma(acc, rstd[row], b''[col]).
-//   FOLD = 2 (EPI_RESID: out-projection, fc2): besides x += ..., the epilogue writes the bf16 copy of the new rows (the next
-//             GEMM's operand) and per-row partial sums of x and x^2 over aligned 64-column groups, reduced in ONE fixed tree
+//   FOLD = 2 (EPI_RESID: out-projection, fc2): x += ... on a residual stream stored as hi + lo (two bf16 arrays; hi is the next
+//             GEMM's operand as it stands), and per-row partial sums of x and x^2 over aligned 64-column groups, reduced in ONE fixed tree
 //             whatever the tile shape (wave parts are 64 or 128 columns wide: NJ = 4 or 8), so a row's statistics — and with
 //             them every bit downstream — do not depend on the batch it sits in; the LAST workgroup of a row stripe to finish
 //             (arrival counter) adds the N/64 partials in order and writes rstd = rsqrt(var + eps) for the stripe's rows.
@@ -52,10 +52,14 @@ struct FoldArgs {
     // columns, i.e. tiles with 96-column wave parts — MS-CLAP's HTSAT stages; a model uses ONE group size for a given N
     // whatever tile a batch size selects); hcopy = the [M, N] bf16 copy of the updated rows.  (Few kernel arguments on
     // purpose: they stay live in scalar registers across a loop whose inline-assembly loads need theirs.)
+    // FOLD 2 keeps the residual stream itself as TWO bf16 arrays, x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 significand
+    // bits, 4 bytes per element like the fp32 rows it replaces): hcopy = hi [M, N] — which IS the next GEMM's operand, so the
+    // fold writes nothing extra — and lo = hcopy + lo_off elements.  The kernel's `out` argument is not used then.
     float* stats = nullptr;
     bf16_t* hcopy = nullptr;
     float eps = 1e-5f;
     int group32 = 0;
+    int lo_off = 0;
 };
 __host__ __device__ inline size_t fold_count_slots(int M) { return (size_t)((M / 128 + 1 + 63) / 64 * 64); }
 __host__ __device__ inline size_t fold_stats_bytes(int M, int N) { return (size_t)M * 4 + fold_count_slots(M) * 4 + (size_t)M * (N / 32) * 8; }
@@ -145,6 +149,7 @@ __device__ __forceinline__ void mfma16a_hi(f32x4& acc, const bf16x8& a, const bf
 // s_nop 4: under scalar-register pressure the compiler keeps the row offsets in vector registers and the scalar operand comes
 // out of a v_readfirstlane right in front of the statement — a VALU-writes-SGPR / VMEM-reads-it hazard (5 wait states) that
 // nobody pads for an inline-assembly consumer: tuple 9 was loaded from tuple 8's address.
+__device__ __forceinline__ void rpre_load_hilo(int t, rsrc_words_t rsrc, int voff, int soff_hi, int soff_lo);
 __device__ __forceinline__ void rpre_load(int t, rsrc_words_t rsrc, int voff, int soff) {
     const int so = __builtin_amdgcn_readfirstlane(soff);
     switch (t) {
@@ -172,6 +177,37 @@ __device__ __forceinline__ void rpre_load(int t, rsrc_words_t rsrc, int voff, in
         case 21: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[244:247], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
         case 22: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[248:251], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
         case 23: asm volatile("s_nop 4\n\tbuffer_load_dwordx4 a[252:255], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(so) : "memory"); break;
+        default: break;
+    }
+}
+// the hi + lo form: 8 bytes of hi into the tuple's first two registers, 8 bytes of lo into the other two (TWO loads in vmcnt)
+__device__ __forceinline__ void rpre_load_hilo(int t, rsrc_words_t rsrc, int voff, int soff_hi, int soff_lo) {
+    const int sh = __builtin_amdgcn_readfirstlane(soff_hi), sl = __builtin_amdgcn_readfirstlane(soff_lo);
+    switch (t) {
+        case 0: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[160:161], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[162:163], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 1: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[164:165], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[166:167], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 2: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[168:169], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[170:171], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 3: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[172:173], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[174:175], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 4: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[176:177], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[178:179], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 5: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[180:181], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[182:183], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 6: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[184:185], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[186:187], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 7: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[188:189], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[190:191], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 8: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[192:193], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[194:195], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 9: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[196:197], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[198:199], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 10: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[200:201], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[202:203], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 11: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[204:205], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[206:207], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 12: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[208:209], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[210:211], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 13: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[212:213], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[214:215], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 14: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[216:217], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[218:219], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 15: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[220:221], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[222:223], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 16: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[224:225], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[226:227], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 17: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[228:229], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[230:231], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 18: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[232:233], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[234:235], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 19: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[236:237], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[238:239], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 20: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[240:241], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[242:243], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 21: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[244:245], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[246:247], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 22: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[248:249], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[250:251], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
+        case 23: asm volatile("s_nop 4\n\tbuffer_load_dwordx2 a[252:253], %0, %1, %2 offen\n\tbuffer_load_dwordx2 a[254:255], %0, %1, %3 offen" ::"v"(voff), "s"(rsrc), "s"(sh), "s"(sl) : "memory"); break;
         default: break;
     }
 }
@@ -279,13 +315,39 @@ __device__ __forceinline__ void resid_load(const float* __restrict__ out, int N,
     }
 }
 
+// hi + lo residual rows: raw = {hi(c0,c1), hi(c2,c3), lo(c0,c1), lo(c2,c3)} (two bf16 per dword, first element low)
+__device__ __forceinline__ float4 hilo_join(const float4 rawf) {
+    const unsigned h0 = __float_as_uint(rawf.x), h1 = __float_as_uint(rawf.y), l0 = __float_as_uint(rawf.z), l1 = __float_as_uint(rawf.w);
+    return make_float4(__uint_as_float(h0 << 16) + __uint_as_float(l0 << 16),
+                       __uint_as_float(h0 & 0xffff0000u) + __uint_as_float(l0 & 0xffff0000u),
+                       __uint_as_float(h1 << 16) + __uint_as_float(l1 << 16),
+                       __uint_as_float(h1 & 0xffff0000u) + __uint_as_float(l1 & 0xffff0000u));
+}
+__device__ __forceinline__ void hilo_split(const float4 v, u32x2_t& hi, u32x2_t& lo) {
+    hi = u32x2_t{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+    lo = u32x2_t{pack_bf16x2(v.x - __uint_as_float(hi[0] << 16), v.y - __uint_as_float(hi[0] & 0xffff0000u)),
+                 pack_bf16x2(v.z - __uint_as_float(hi[1] << 16), v.w - __uint_as_float(hi[1] & 0xffff0000u))};
+}
+template <int NJ, int RI>
+__device__ __forceinline__ void resid_load_hilo(const bf16_t* __restrict__ hi, int lo_off, int N, int row0, int col0, int lane,
+                                                float4 (&res)[RI * 16 * NJ * 4 / 64]) {
+    constexpr int CPR = NJ * 4;
+#pragma unroll
+    for (int t = 0; t < RI * 16 * CPR / 64; ++t) {
+        const int idx = t * 64 + lane, row = idx / CPR, c = idx % CPR;
+        const bf16_t* p = hi + (size_t)(row0 + row) * N + col0 + c * 4;
+        const u32x2_t h = *reinterpret_cast<const u32x2_t*>(p), l = *reinterpret_cast<const u32x2_t*>(p + lo_off);
+        res[t] = make_float4(__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(l[0]), __uint_as_float(l[1]));
+    }
+}
+
 // `res_at(t)`: the residual values of walk step t (an array filled by resid_load a pass earlier, or — the 160 x 256 residual
 // kernel — the prefetch registers, fetched one tuple at a time right where it is added, so that no copy of them lives in VGPRs)
 template <int MODE, int MI, int NJ, int RI, int FOLD = 0, typename RES>
 __device__ __forceinline__ void epi_f32_pass(const f32x4 (&acc)[MI][NJ], int i0, const float4 (&bv)[NJ], float* __restrict__ out,
                                              int N, int row0, int col0, int lane, unsigned my,
                                              RES&& res_at, bf16_t* __restrict__ hcopy = nullptr,
-                                             float* __restrict__ part = nullptr, int group32 = 0) {
+                                             float* __restrict__ part = nullptr, int group32 = 0, int lo_off = 0) {
     static_assert(FOLD != 2 || NJ == 4 || NJ == 6 || NJ == 8, "fold statistics: wave parts of 64, 96 or 128 columns");
     constexpr int RS = NJ * 64 + 16, CPR = NJ * 4;
     static_assert((RI * 16 * CPR) % 64 == 0, "walk covers the piece in whole wave instructions");
@@ -306,13 +368,19 @@ __device__ __forceinline__ void epi_f32_pass(const f32x4 (&acc)[MI][NJ], int i0,
         const int idx = t * 64 + lane, row = idx / CPR, c = idx % CPR;
         const f32x4 l = W4_LDS(const f32x4, my + row * RS + c * 16);
         float4 v = make_float4(l[0], l[1], l[2], l[3]);
-        if (MODE == EPI_RESID) { const float4 r = res_at(t); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-        *reinterpret_cast<float4*>(out + (size_t)(row0 + i0 * 16 + row) * N + col0 + c * 4) = v;
+        if (MODE == EPI_RESID) {
+            const float4 r = FOLD == 2 ? hilo_join(res_at(t)) : res_at(t);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if constexpr (FOLD != 2) *reinterpret_cast<float4*>(out + (size_t)(row0 + i0 * 16 + row) * N + col0 + c * 4) = v;
         if constexpr (FOLD == 2) {
-            // the next GEMM's operand, and the row's sums over this aligned 64-column group: 4 values in the lane, then the
-            // 16 lanes of the group by an xor butterfly — one tree for every tile shape
+            // the new rows as hi + lo (hi is the next GEMM's operand), and the row's sums over this aligned 64-column group: 4
+            // values in the lane, then the lanes of the group by an xor butterfly — one tree for every tile shape
             const size_t grow = (size_t)(row0 + i0 * 16 + row);
-            *reinterpret_cast<u32x2_t*>(hcopy + grow * N + col0 + c * 4) = u32x2_t{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            u32x2_t hi2, lo2;
+            hilo_split(v, hi2, lo2);
+            *reinterpret_cast<u32x2_t*>(hcopy + grow * N + col0 + c * 4) = hi2;
+            *reinterpret_cast<u32x2_t*>(hcopy + lo_off + grow * N + col0 + c * 4) = lo2;
             float s1 = ((v.x + v.y) + v.z) + v.w;
             float s2 = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
             // pairs, quads (quad permutes), the two quads of a half (row_half_mirror), the two halves (row_mirror): the xor
@@ -418,11 +486,13 @@ __global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restr
     constexpr bool RESPRE = MODE == EPI_RESID && MI == 5 && NJ == 8;
     rsrc_words_t rO = {0u, 0u, 0u, 0u};
     int rvoff = 0, rsoff = 0;
+    constexpr int RBYTES = FOLD == 2 ? 2 : 4;       // bytes per residual element and array: hi / lo bf16, or fp32
+    constexpr int RLOADS = FOLD == 2 ? 2 : 1;       // vector-memory loads per prefetched tuple
     if constexpr (RESPRE) {
-        const unsigned long long ob = (unsigned long long)(uintptr_t)out;
+        const unsigned long long ob = (unsigned long long)(uintptr_t)(FOLD == 2 ? (void*)fold.hcopy : out);
         rO = rsrc_words_t{(unsigned)ob, (unsigned)(ob >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
-        rvoff = ((lane >> 5) * N + (lane & 31) * 4) * 4;                       // walk order of epi_f32_pass / resid_load
-        rsoff = ((m0 + wm * MI * 16) * N + n0 + wn * NJ * 16) * 4;
+        rvoff = ((lane >> 5) * N + (lane & 31) * 4) * RBYTES;                  // walk order of epi_f32_pass / resid_load
+        rsoff = ((m0 + wm * MI * 16) * N + n0 + wn * NJ * 16) * RBYTES;
     }
 
     // One phase: NM = MI*NJ MFMAs on (af, wf) in i-major order, with the phase's fragment reads (first the NJ weight
@@ -461,7 +531,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restr
                 if (m >= NM - 8 && (m - (NM - 8)) % 2 == 0) {
                     const int t = RB + (m - (NM - 8)) / 2;           // 0..15: pass 0 (rows 2t, 2t+1); 16..23: pass 2 (rows 64 + ...)
                     const int row = t < 16 ? t * 2 : 64 + (t - 16) * 2;
-                    rpre_load(t, rO, rvoff, rsoff + row * N * 4);
+                    if constexpr (FOLD == 2) rpre_load_hilo(t, rO, rvoff, rsoff + row * N * 2, rsoff + row * N * 2 + fold.lo_off * 2);
+                    else rpre_load(t, rO, rvoff, rsoff + row * N * 4);
                 }
             }
             if constexpr (RESPRE) mfma16a_hi(acc[m / NJ][m % NJ], wf[m % NJ], af[m / NJ]);
@@ -505,8 +576,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restr
         // phase-A DMAs + 4 loads; step nk-2 needs W(nk-1), requested in phase B of step nk-3 — the 4 loads issued behind
         // those DMAs and the 4 of its own phase A may still fly; step nk-1 needs nothing new.
         for (int s = 0; s < nk - 3; ++s) step(T{}, T{}, VMS{}, N1{}, N1{});
-        step(T{}, T{}, std::integral_constant<int, NDMA_A + 4>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-        step(F{}, T{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 12>{});
+        step(T{}, T{}, std::integral_constant<int, NDMA_A + 4 * RLOADS>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        step(F{}, T{}, std::integral_constant<int, 8 * RLOADS>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 12>{});
         step(F{}, F{}, N1{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 20>{});
     } else {
         for (int s = 0; s < nk - 2; ++s) step(T{}, T{}, VMS{}, N1{}, N1{});
@@ -540,29 +611,32 @@ __global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restr
         static_assert(MI % RP == 0 || RP == 2, "passes");
         float4 res[2][NRES];
         auto load = [&](int p, float4 (&r)[NRES]) {
-            if (p * RP + RP <= MI) resid_load<NJ, RP>(o, N, row0 + p * RP * 16, col0, lane, r);
-            else if constexpr (RP == 2) {
+            if (p * RP + RP <= MI) {
+                if constexpr (FOLD == 2) resid_load_hilo<NJ, RP>(fold.hcopy, fold.lo_off, N, row0 + p * RP * 16, col0, lane, r);
+                else resid_load<NJ, RP>(o, N, row0 + p * RP * 16, col0, lane, r);
+            } else if constexpr (RP == 2) {
                 float4 (&h)[NRES / 2] = reinterpret_cast<float4 (&)[NRES / 2]>(r);
-                resid_load<NJ, 1>(o, N, row0 + p * RP * 16, col0, lane, h);
+                if constexpr (FOLD == 2) resid_load_hilo<NJ, 1>(fold.hcopy, fold.lo_off, N, row0 + p * RP * 16, col0, lane, h);
+                else resid_load<NJ, 1>(o, N, row0 + p * RP * 16, col0, lane, h);
             }
         };
         if constexpr (RESPRE) {
             // passes 0 and 2 come out of the prefetch registers (everything requested has landed behind this wait);
             // pass 1 is loaded here, under pass 0's transposition
             load(1, res[1]);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory", W4_HI_AGPRS);       // all but pass 1's NRES loads
-            epi_f32_pass<MODE, MI, NJ, 2, FOLD>(acc, 0, bv, o, N, row0, col0, lane, my, [](int t) { return rpre_read(t); }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32);
-            epi_f32_pass<MODE, MI, NJ, 2, FOLD>(acc, 2, bv, o, N, row0, col0, lane, my, [&](int t) { return res[1][t]; }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32);
-            epi_f32_pass<MODE, MI, NJ, 1, FOLD>(acc, 4, bv, o, N, row0, col0, lane, my, [](int t) { return rpre_read(16 + t); }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES * RLOADS) : "memory", W4_HI_AGPRS);       // all but pass 1's loads
+            epi_f32_pass<MODE, MI, NJ, 2, FOLD>(acc, 0, bv, o, N, row0, col0, lane, my, [](int t) { return rpre_read(t); }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32, fold.lo_off);
+            epi_f32_pass<MODE, MI, NJ, 2, FOLD>(acc, 2, bv, o, N, row0, col0, lane, my, [&](int t) { return res[1][t]; }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32, fold.lo_off);
+            epi_f32_pass<MODE, MI, NJ, 1, FOLD>(acc, 4, bv, o, N, row0, col0, lane, my, [](int t) { return rpre_read(16 + t); }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32, fold.lo_off);
         } else {
             if (MODE == EPI_RESID) load(0, res[0]);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 if (MODE == EPI_RESID && p + 1 < NP) load(p + 1, res[(p + 1) & 1]);
                 const float4 (&rp)[NRES] = res[p & 1];
-                if (p * RP + RP <= MI) epi_f32_pass<MODE, MI, NJ, RP, FOLD>(acc, p * RP, bv, o, N, row0, col0, lane, my, [&](int t) { return rp[t]; }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32);
+                if (p * RP + RP <= MI) epi_f32_pass<MODE, MI, NJ, RP, FOLD>(acc, p * RP, bv, o, N, row0, col0, lane, my, [&](int t) { return rp[t]; }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32, fold.lo_off);
                 else if constexpr (RP == 2)
-                    epi_f32_pass<MODE, MI, NJ, 1, FOLD>(acc, p * RP, bv, o, N, row0, col0, lane, my, [&](int t) { return rp[t]; }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32);
+                    epi_f32_pass<MODE, MI, NJ, 1, FOLD>(acc, p * RP, bv, o, N, row0, col0, lane, my, [&](int t) { return rp[t]; }, fold.hcopy, fold.stats + M + fold_count_slots(M), fold.group32, fold.lo_off);
             }
         }
     }

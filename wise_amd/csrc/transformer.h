@@ -24,8 +24,9 @@ int conv3x3_bf16(const bf16_t* X, const bf16_t* Wt, const float* bias, const bf1
 int gemm_resid_ln_rows(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int m_valid, int ln_rows, int N, int K,
                        float* x, const float* ln_w, const float* ln_b, float eps, bool post_ln, bf16_t* h, hipStream_t st,
                        float* sk = nullptr, size_t sk_bytes = 0);
-// The LayerNorm fold (gemm_w4.h FoldArgs): out = act(rstd[row] * (A @ Wt^T) + bias) as bf16, and the residual GEMM that also
-// writes h = bf16(x) and the rows' rstd for the next such call.  stats: gemm_fold_stats_bytes(M, N) bytes — rstd [M] first (what
+// The LayerNorm fold (gemm_w4.h FoldArgs): out = act(rstd[row] * (A @ Wt^T) + bias) as bf16, and the residual GEMM over a
+// residual stream kept as hi + lo (two bf16 arrays, lo = hi + lo_off elements: x = hi + lo; hi is the next such call's operand)
+// that also writes the rows' rstd for it.  stats: gemm_fold_stats_bytes(M, N) bytes — rstd [M] first (what
 // gemm_fold_bf16 takes), then the arrival counters (fold_count_slots(M) ints at byte offset 4 M: zero on entry), then partial
 // sums.  group32: statistics kept per 32 columns instead of 64 (any width that is a multiple of 192 as well as of 128: ONE
 // choice per model and width, so that every tile gives a row the same bits)
@@ -33,8 +34,8 @@ bool gemm_fold_shape_ok(int M, int N, int K);
 int gemm_fold_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, const float* rstd, int M, int N, int K, int mode,
                    bf16_t* out, hipStream_t st);
 size_t gemm_fold_stats_bytes(int M, int N);
-int gemm_fold_resid(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, float* x, bf16_t* h, float* stats,
-                    float eps, hipStream_t st, int group32 = 0);
+int gemm_fold_resid(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, bf16_t* hi, long long lo_off,
+                    float* stats, float eps, hipStream_t st, int group32 = 0);
 size_t gemm_fold_counters_bytes(int M);
 // hint for the tile heuristic: the calling THREAD is about to enqueue GEMMs on several streams that overlap in time
 // (thread-local: two host threads driving two engines do not see each other's hint)

@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const float* __restric
                                                           const float* __restrict__ cls, const float* __restrict__ pos,
                                                           const float* __restrict__ w, const float* __restrict__ bb,
                                                           int rows, int T, int W, float eps, float* __restrict__ x,
-                                                          bf16_t* __restrict__ hcopy, float* __restrict__ rstd_out) {
+                                                          bf16_t* __restrict__ hcopy, float* __restrict__ rstd_out, long long lo_off) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -752,11 +752,12 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const float* __restric
             const float4 b4 = reinterpret_cast<const float4*>(bb)[c];
             v[i] = make_float4((v[i].x - mean) * rstd * ww.x + b4.x, (v[i].y - mean) * rstd * ww.y + b4.y,
                                (v[i].z - mean) * rstd * ww.z + b4.z, (v[i].w - mean) * rstd * ww.w + b4.w);
-            xr[c] = v[i];
+            if (!hcopy) xr[c] = v[i];
         }
     }
     if (hcopy) {
-        // fold mode (gemm_w4.h FoldArgs): the first block's QKV GEMM takes bf16(x) as its operand and the row's rstd as a scale
+        // fold mode (gemm_w4.h FoldArgs): the residual stream is hi + lo (two bf16 arrays where the fp32 rows would be); the
+        // first block's QKV GEMM takes hi as its operand and the row's rstd as a scale
         float s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
@@ -769,7 +770,11 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const float* __restric
             if (c < w4) {
                 float a0 = v[i].x - mean2, a1 = v[i].y - mean2, a2 = v[i].z - mean2, a3 = v[i].w - mean2;
                 q2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-                reinterpret_cast<uint2*>(hcopy + (size_t)row * W)[c] = make_uint2(pack_bf16x2(v[i].x, v[i].y), pack_bf16x2(v[i].z, v[i].w));
+                const unsigned h0 = pack_bf16x2(v[i].x, v[i].y), h1 = pack_bf16x2(v[i].z, v[i].w);
+                reinterpret_cast<uint2*>(hcopy + (size_t)row * W)[c] = make_uint2(h0, h1);
+                reinterpret_cast<uint2*>(hcopy + lo_off + (size_t)row * W)[c] =
+                    make_uint2(pack_bf16x2(v[i].x - __uint_as_float(h0 << 16), v[i].y - __uint_as_float(h0 & 0xffff0000u)),
+                               pack_bf16x2(v[i].z - __uint_as_float(h1 << 16), v[i].w - __uint_as_float(h1 & 0xffff0000u)));
             }
         }
         const float r2 = rsqrtf(wave_sum(q2) / (float)W + eps);
@@ -887,13 +892,13 @@ int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int a
     return WISE_OK;
 }
 
-// The same L pre-LN blocks with every LayerNorm folded into the GEMMs around it (gemm_w4.h FoldArgs): on entry h = bf16(x)
-// and rstd = the rows' 1 / sqrt(var + eps) (embed_lnpre_kernel wrote both); the weights are the packer's folded ones
-// (in_proj / c_fc: gamma-scaled, row-centred; their biases: + W beta).  Seven launches per block become five, the fp32 rows
-// are read once per residual GEMM instead of twice, and no row's result depends on the batch it sits in (one epilogue
-// implementation, one reduction tree).  The attention output goes to `a` (free between fc2 and fc1): h must keep bf16(x)
-// until the out-projection's epilogue replaces it row stripe by row stripe, while other workgroups still read the
-// attention output as their operand.
+// The same L pre-LN blocks with every LayerNorm folded into the GEMMs around it (gemm_w4.h FoldArgs).  The residual stream is
+// hi + lo — two bf16 arrays in the region the fp32 rows would take: hi [Mp, W], then lo [Mp, W] — and on entry rstd holds the
+// rows' 1 / sqrt(var + eps) (embed_lnpre_kernel wrote all three); the weights are the packer's folded ones (in_proj / c_fc:
+// gamma-scaled, row-centred; their biases: + W beta).  Seven launches per block become five, a residual GEMM reads and
+// writes 4 bytes per element as before and NOTHING else touches the rows (the LayerNorm's pass over them is gone, and hi is
+// the next GEMM's operand as it stands), and no row's result depends on the batch it sits in (one epilogue implementation,
+// one reduction tree).  The attention output goes to `h`, which the unfolded form uses for the LayerNorm output.
 static int transformer_blocks_fold(const BlockWeights& bw, int L, int W, int H, int F, int act, int batch, int T, float* x,
                                    bf16_t* h, bf16_t* qkv, bf16_t* a, float* stats, hipStream_t st, float eps) {
     const int M = batch * T, Mp = (M + 255) / 256 * 256;
@@ -903,19 +908,17 @@ static int transformer_blocks_fold(const BlockWeights& bw, int L, int W, int H, 
         set_error("vit_forward: memset of the fold counters failed");
         return WISE_E_INVALID;
     }
-    bf16_t* ao = a;     // attention output [Mp, W]
+    bf16_t* hi = reinterpret_cast<bf16_t*>(x);
+    const long long lo_off = (long long)Mp * W;
+    bf16_t* ao = h;     // attention output [Mp, W]
     for (int l = 0; l < L; ++l) {
         const bf16_t* lwb = bw.wb + bw.per_layer_b * l;
         const float* lpf = bw.pf + bw.per_layer_f * l;
-        if ((rc = gemm_fold_bf16(h, lwb + bw.in_proj, lpf + bw.in_b, rstd, Mp, 3 * W, W, 0, qkv, st))) return rc;
+        if ((rc = gemm_fold_bf16(hi, lwb + bw.in_proj, lpf + bw.in_b, rstd, Mp, 3 * W, W, 0, qkv, st))) return rc;
         if ((rc = attention_bf16(qkv, batch, T, H, ao, st, false, W / H))) return rc;
-        if ((rc = gemm_fold_resid(ao, lwb + bw.out_proj, lpf + bw.out_b, Mp, W, W, x, h, stats, eps, st))) return rc;
-        if ((rc = gemm_fold_bf16(h, lwb + bw.c_fc, lpf + bw.fc_b, rstd, Mp, F, W, act == 0 ? 1 : (act == 1 ? 2 : 5), a, st))) return rc;
-        if (l + 1 < L) {
-            if ((rc = gemm_fold_resid(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, W, F, x, h, stats, eps, st))) return rc;
-        } else if ((rc = gemm_bf16(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, W, F, 3, x, st))) {
-            return rc;
-        }
+        if ((rc = gemm_fold_resid(ao, lwb + bw.out_proj, lpf + bw.out_b, Mp, W, W, hi, lo_off, stats, eps, st))) return rc;
+        if ((rc = gemm_fold_bf16(hi, lwb + bw.c_fc, lpf + bw.fc_b, rstd, Mp, F, W, act == 0 ? 1 : (act == 1 ? 2 : 5), a, st))) return rc;
+        if ((rc = gemm_fold_resid(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, W, F, hi, lo_off, stats, eps, st))) return rc;
     }
     return WISE_OK;
 }
@@ -1037,9 +1040,19 @@ static VitWs vit_ws(const VitDims& d, int B) {
 
 template <int NV>
 static void launch_embed(const float* po, const float* cls, const float* pos, const float* w, const float* b, int rows,
-                         int T, int W, float* x, hipStream_t st, bf16_t* hcopy, float* rstd_out) {
+                         int T, int W, float* x, hipStream_t st, bf16_t* hcopy, float* rstd_out, long long lo_off) {
     hipLaunchKernelGGL(embed_lnpre_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, st, po, cls, pos, w, b, rows, T, W,
-                       1e-5f, x, hcopy, rstd_out);
+                       1e-5f, x, hcopy, rstd_out, lo_off);
+}
+
+// rows r * stride of a hi + lo residual stream -> fp32 [n, W] (the class rows in front of ln_post; the parity tap)
+__global__ __launch_bounds__(256) void hilo_rows_kernel(const bf16_t* __restrict__ hi, long long lo_off, int n, int stride, int W,
+                                                        float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)n * W) return;
+    const int r = (int)(i / W), c = (int)(i % W);
+    const size_t src = (size_t)r * stride * W + c;
+    out[i] = bf16_to_f32(hi[src]) + bf16_to_f32(hi[src + lo_off]);
 }
 
 // one contiguous part of the batch on one stream; `wsb` is that part's own workspace region
@@ -1086,19 +1099,21 @@ static int vit_forward_part(const wise_vit_config* cfg, const VitDims& d, const 
     } else {
 
         const int nv = (W / 4 + 63) / 64;
-        bf16_t* fh = d.fold ? h : nullptr;
+        // fold mode: the fp32 rows' region holds the residual stream as hi [Mp, W] bf16, then lo [Mp, W] bf16
+        bf16_t* fh = d.fold ? reinterpret_cast<bf16_t*>(x) : nullptr;
         float* frs = d.fold ? reinterpret_cast<float*>(wsb + ws.rstd) : nullptr;
+        const long long flo = (long long)ws.Mp * W;
         const float* cls = pf + o.cls; const float* pos = pf + o.pos;
         const float* lw = pf + o.ln_pre_w; const float* lb = pf + o.ln_pre_b;
         switch (nv) {
-            case 1: launch_embed<1>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
-            case 2: launch_embed<2>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
-            case 3: launch_embed<3>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
-            case 4: launch_embed<4>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
-            case 5: launch_embed<5>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
-            case 6: launch_embed<6>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
-            case 7: launch_embed<7>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
-            case 8: launch_embed<8>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs); break;
+            case 1: launch_embed<1>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs, flo); break;
+            case 2: launch_embed<2>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs, flo); break;
+            case 3: launch_embed<3>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs, flo); break;
+            case 4: launch_embed<4>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs, flo); break;
+            case 5: launch_embed<5>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs, flo); break;
+            case 6: launch_embed<6>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs, flo); break;
+            case 7: launch_embed<7>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs, flo); break;
+            case 8: launch_embed<8>(patch_out, cls, pos, lw, lb, ws.M, d.T, W, x, st, fh, frs, flo); break;
             default: set_error("vit_forward: width %d too large", W); return WISE_E_UNSUPPORTED;
         }
         WISE_LAUNCH_CHECK("embed_lnpre_kernel");
@@ -1133,6 +1148,15 @@ static int vit_forward_part(const wise_vit_config* cfg, const VitDims& d, const 
         return l2norm_rows(y, batch, W, out, st);
     }
     // 4. ln_post(cls) -> bf16 [Bp,W] (aliases h) ; @ proj -> fp32 [Bp,D] (aliases qkv) ; L2 normalise rows
+    if (d.fold) {   // the class rows of the hi + lo stream as fp32 [batch, W] (in `a`, free now), then the same head with T = 1
+        float* xc = reinterpret_cast<float*>(a);
+        const long long n = (long long)batch * W;
+        hipLaunchKernelGGL(hilo_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(x),
+                           (long long)ws.Mp * W, batch, d.T, W, xc);
+        WISE_LAUNCH_CHECK("hilo_rows_kernel");
+        return pooled_head(xc, pf + o.ln_post_w, pf + o.ln_post_b, wb + o.projT, batch, 1, W, d.D, nullptr, h,
+                           reinterpret_cast<float*>(qkv), out, st);
+    }
     if ((rc = pooled_head(x, pf + o.ln_post_w, pf + o.ln_post_b, wb + o.projT, batch, d.T, W, d.D, nullptr, h,
                           reinterpret_cast<float*>(qkv), out, st)))
         return rc;
@@ -1311,9 +1335,16 @@ extern "C" int wise_vit_tap_residual(const wise_vit_config* cfg, int batch, cons
         int lo, hi;
         part_range(batch, parts, i, &lo, &hi);
         const VitWs ws = vit_ws(d, hi - lo);
-        hipError_t e = hipMemcpyAsync(dp, wsb + base + ws.x, (size_t)ws.M * d.W * 4, hipMemcpyDeviceToDevice,
-                                      (hipStream_t)stream);
-        if (e != hipSuccess) { set_error("vit_tap_residual: %s", hipGetErrorString(e)); return (int)e; }
+        if (d.fold) {
+            const long long n = (long long)ws.M * d.W;
+            hipLaunchKernelGGL(hilo_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               reinterpret_cast<const bf16_t*>(wsb + base + ws.x), (long long)ws.Mp * d.W, ws.M, 1, d.W, dp);
+            WISE_LAUNCH_CHECK("hilo_rows_kernel");
+        } else {
+            hipError_t e = hipMemcpyAsync(dp, wsb + base + ws.x, (size_t)ws.M * d.W * 4, hipMemcpyDeviceToDevice,
+                                          (hipStream_t)stream);
+            if (e != hipSuccess) { set_error("vit_tap_residual: %s", hipGetErrorString(e)); return (int)e; }
+        }
         dp += (size_t)ws.M * d.W;
         base += ws.total;
     }
