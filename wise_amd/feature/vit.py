@@ -236,12 +236,16 @@ class VitEngine:
 
     def __init__(self, spec: VitSpec, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 256,
                  ln_fold: Optional[bool] = None):
-        """ln_fold: fold the blocks' LayerNorms into the GEMMs around them (two launches and one pass over the fp32 rows
-        fewer per LayerNorm).  None = WISE_VIT_LN_FOLD (0 / 1), default: on for the CLIP towers of width 768 (ViT-B/32,
-        B/16), where it was measured; never for the timm towers (arch 1)."""
+        """ln_fold: fold the blocks' LayerNorms into the GEMMs around them and keep the residual stream as bf16 hi + lo (two
+        launches and a whole pass over the rows fewer per LayerNorm; results within the same tolerance of the fp32 path, not
+        bit-equal to the unfolded form).  None = WISE_VIT_LN_FOLD (0 / 1); default: on where it measured faster — ViT-B/32
+        (width 768, 50 tokens: bs=256 two batches in flight 2.85 -> 2.57 ms per step, bs=8 .. 64 one stream 9 - 15 % faster) —
+        and off where it measured slower: B/16 (-2 %), L/14 (-2.5 %), H/14 (-3 %), whose row counts are no multiple of the 160-row
+        tiles, so that the folded GEMMs fall to 128-row tiles (tools/vit_fold_ab.py, profiles/r04_fold_ab.txt).  Never for
+        the timm towers (arch 1)."""
         if ln_fold is None:
             env = os.environ.get("WISE_VIT_LN_FOLD", "")
-            ln_fold = (env == "1") if env in ("0", "1") else (spec.arch == 0 and spec.width == 768)
+            ln_fold = (env == "1") if env in ("0", "1") else (spec.arch == 0 and spec.width == 768 and spec.tokens <= 64)
         ln_fold = bool(ln_fold) and spec.arch == 0 and spec.layers >= 1 and spec.width >= 256
         if ln_fold != spec.ln_fold:
             spec = VitSpec(**{**spec.__dict__, "ln_fold": ln_fold})
