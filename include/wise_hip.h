@@ -227,8 +227,14 @@ int wise_htsat_layout(int64_t* wb_elems, int64_t* pf_elems);
 size_t wise_htsat_workspace_bytes(int batch, int samples);
 int wise_htsat_forward(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
                        float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* (ABI 5) wise_htsat_forward with flags.  bit 0: the LayerNorms of stages 2 - 4 folded into the GEMMs around them (the
+ * residual stream of those stages as bf16 hi + lo; see wise_gemm_fold_resid) — the packer must then store the folded qkv / fc1
+ * weights and biases of those stages (wise_amd/feature/htsat.py:pack_htsat_weights(fold=True)).  flags 0 = wise_htsat_forward. */
+int wise_htsat_forward2(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
+                        float* out, void* workspace, size_t workspace_bytes, int flags, void* stream);
 /* parity tap after a forward with the same (batch, samples): what 0 = BatchNorm'd log-mel
- * [B*frames,64], 1 = residual stream; copies `count` floats. */
+ * [B*frames,64], 1 = residual stream (fp32 rows), 2 = the last stage's residual stream of a flags-bit-0 forward (hi + lo,
+ * returned as fp32); copies `count` floats. */
 int wise_htsat_tap(int what, const void* workspace, int batch, int samples, float* dst, int64_t count,
                    void* stream);
 
@@ -387,7 +393,8 @@ int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int
  *     does not depend on M or on the tile chosen (for one value of group32).
  *   wise_gemm_fold_bf16: out[M,N] bf16 = act(rstd[row] * (A @ Wt^T) + bias[col]), mode 0 / 1 / 2 / 5 as wise_gemm_bf16; with
  *     A = h, Wt = gamma-scaled row-centred weights and bias = b + W beta this is act(Linear(LayerNorm(x))).
- * M % 128 == 0, N % 128 == 0 (or N % 192 == 0 with group32), K % 64 == 0, K >= 192. */
+ * M % 128 == 0, N % 128 == 0 (or N % 192 == 0 with group32), K % 64 == 0, K >= 192.  group32: bit 0 = statistics per 32
+ * columns; bit 1 = the rows START the stream (x = A @ Wt^T + bias: nothing is read from hi / lo). */
 size_t wise_gemm_fold_stats_bytes(int M, int N);
 size_t wise_gemm_fold_counters_offset(int M);
 size_t wise_gemm_fold_counters_bytes(int M);

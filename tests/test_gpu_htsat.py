@@ -58,13 +58,16 @@ def test_golden_4s_clips(engine, waves, golden_dir):
     assert cosine(x[:, :4, :].reshape(-1, 768), torch.from_numpy(g["tap4"]).reshape(-1, 768)) >= 1 - 1e-3
 
 
-def test_checkpoint_like_golden(golden_dir):
-    """Parity on weights with the statistics of trained checkpoints (massive channels switched on by fc2 biases, log-normal
+@pytest.mark.parametrize("fold", [True, False])
+def test_checkpoint_like_golden(golden_dir, fold):
+    """(both with stages 2 - 4's LayerNorms folded into their GEMMs over a hi + lo residual stream — the default — and without)
+    Parity on weights with the statistics of trained checkpoints (massive channels switched on by fc2 biases, log-normal
     LayerNorm gains, near one-hot window attention): the oracle pinned to transformers' ClapAudioModel on the same
     weights, the bf16 HIP path held to the fp32 contract of src/feature/microsoft_clap.py:49-50 at cosine >= 1 - 1e-3."""
     g = np.load(golden_dir / "htsat_stress.npz")
     assert float(g["largest_residual"]) >= 40.0
-    eng = HtsatEngine(checkpoint_like_htsat_state_dict(int(g["weight_seed"])), max_batch=2, max_samples=192000)
+    eng = HtsatEngine(checkpoint_like_htsat_state_dict(int(g["weight_seed"])), max_batch=2, max_samples=192000, ln_fold=fold)
+    assert eng.ln_fold is fold
     rng = np.random.default_rng(int(g["wave_seed"]))
     wave = torch.from_numpy((0.1 * rng.standard_normal((2, 192000))).astype(np.float32))
     out = eng.forward(wave).cpu()
@@ -72,6 +75,19 @@ def test_checkpoint_like_golden(golden_dir):
     assert c >= 1 - 1e-3, c
     x = eng.tap(1, 2 * 64, 768).cpu().reshape(2, 64, 768)
     assert cosine(x[:, :4, :].reshape(-1, 768), torch.from_numpy(g["tap4"]).reshape(-1, 768)) >= 1 - 1e-3
+
+
+def test_golden_4s_clips_without_the_fold(waves, golden_dir):
+    """the unfolded form (LayerNorm launches, fp32 rows) stays available and inside the same tolerance"""
+    w4, _ = waves
+    g = np.load(golden_dir / "htsat.npz")
+    eng = HtsatEngine(random_htsat_state_dict(0), max_batch=4, max_samples=480000, ln_fold=False)
+    out = eng.forward(w4).cpu()
+    assert cosine(out, torch.from_numpy(g["out"])) >= 1 - 1e-3
+    x = eng.tap(1, 2 * 64, 768).cpu().reshape(2, 64, 768)
+    assert cosine(x[:, :4, :].reshape(-1, 768), torch.from_numpy(g["tap4"]).reshape(-1, 768)) >= 1 - 1e-3
+    folded = HtsatEngine(random_htsat_state_dict(0), max_batch=4, max_samples=480000, ln_fold=True).forward(w4).cpu()
+    assert cosine(out, folded) >= 1 - 1e-4
 
 
 def test_golden_10s_clip_and_batch_independence(engine, waves, golden_dir):

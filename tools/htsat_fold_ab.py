@@ -1,0 +1,33 @@
+"""MS-CLAP HTSAT bs=128 x 10 s with and without the LayerNorm fold of stages 2 - 4: python tools/htsat_fold_ab.py [steps=20]"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from wise_amd.feature.htsat import HtsatEngine, random_htsat_state_dict  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+engs = {f: HtsatEngine(random_htsat_state_dict(0), max_batch=128, max_samples=480000, ln_fold=f) for f in (False, True)}
+wav = 0.1 * torch.randn(128, 480000, generator=torch.Generator(device="cuda").manual_seed(4), device="cuda")
+hold = {}
+
+
+def timed(fn):
+    for i in range(3):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+for rnd in range(3):
+    for f, eng in engs.items():
+        s = timed(lambda i: hold.__setitem__("o", eng.forward(wav)))
+        p = timed(lambda i: hold.__setitem__("p", eng.forward_pipelined(wav)))
+        print(f"round {rnd} fold={int(f)}: one at a time {s:.3f} ms ({128 / s:.1f} k clips/s)  two in flight {p:.3f} ms ({128 / p:.1f} k clips/s)", flush=True)
+a, b = engs[False].forward(wav).double(), engs[True].forward(wav).double()
+print("1 - cosine between the two modes (max over 128 clips):", float((1 - (a * b).sum(1)).max()))

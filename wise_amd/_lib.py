@@ -68,6 +68,7 @@ SIGNATURES = {
     "wise_htsat_layout": (_i, [C.POINTER(_i64), C.POINTER(_i64)]),
     "wise_htsat_workspace_bytes": (_sz, [_i, _i]),
     "wise_htsat_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "wise_htsat_forward2": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _i, _vp]),
     "wise_htsat_tap": (_i, [_i, _vp, _i, _i, _vp, _i64, _vp]),
     "wise_cnn14_layout": (_i, [C.POINTER(_i64), C.POINTER(_i64)]),
     "wise_cnn14_workspace_bytes": (_sz, [_i, _i]),

@@ -2601,27 +2601,37 @@ int gemm_fold_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, const f
 size_t gemm_fold_stats_bytes(int M, int N) { return fold_stats_bytes(M, N); }
 size_t gemm_fold_counters_bytes(int M) { return fold_count_slots(M) * 4; }
 
+template <int MODE>
+static void launch_fold_producer(int v, const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, const FoldArgs& fa,
+                                 hipStream_t st) {
+    float* x = nullptr;
+    switch (v) {
+        case 61: if constexpr (MODE == EPI_RESID) { launch_w4<MODE, 5, 8, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break; }
+        case 68: launch_w4<MODE, 4, 8, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
+        case 66: launch_w4<MODE, 8, 6, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
+        case 67: launch_w4<MODE, 4, 6, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
+        case 69: launch_w4<MODE, 4, 6, 2, 2, 2, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
+        default: launch_w4<MODE, 4, 4, 3, 2, 2, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
+    }
+}
+
+// accumulate: x += ... (the residual GEMM of a block); otherwise x = ... (the rows that START a hi + lo stream: MS-CLAP HTSAT's
+// patch-merging projection in front of a stage)
 int gemm_fold_resid(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, bf16_t* hi, long long lo_off,
-                    float* stats, float eps, hipStream_t st, int group32) {
+                    float* stats, float eps, hipStream_t st, int group32, bool accumulate) {
     WISE_CHECK_ARG(A && Wt && hi && stats, "gemm_fold_resid: null pointer");
     WISE_CHECK_ARG(gemm_fold_shape_ok(M, N, K) && (group32 || N % 128 == 0), "gemm_fold_resid: M=%d N=%d K=%d group32=%d", M, N, K, group32);
     // lo sits BEHIND hi, within the 2 GiB a buffer descriptor's scalar offset reaches (the residual prefetch addresses it so)
     WISE_CHECK_ARG(lo_off >= (long long)M * N && lo_off % 4 == 0 && (lo_off + (long long)M * N) * 2 < 0x7fffffffLL,
                    "gemm_fold_resid: lo must follow hi by at least M*N elements and stay within 2 GiB of it (lo_off=%lld)", lo_off);
     ProfScope prof(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
-    float* x = nullptr;
     FoldArgs fa;
     fa.hcopy = hi; fa.lo_off = (int)lo_off; fa.stats = stats; fa.eps = eps; fa.group32 = group32 ? 1 : 0;
-    const int v = fold_variant(M, N, K, EPI_RESID, true, group32 != 0);
+    int v = fold_variant(M, N, K, accumulate ? EPI_RESID : EPI_F32, true, group32 != 0);
     WISE_CHECK_ARG(v != 0, "gemm_fold_resid: no tile for M=%d N=%d K=%d", M, N, K);
-    switch (v) {
-        case 61: launch_w4<EPI_RESID, 5, 8, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
-        case 68: launch_w4<EPI_RESID, 4, 8, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
-        case 66: launch_w4<EPI_RESID, 8, 6, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
-        case 67: launch_w4<EPI_RESID, 4, 6, 3, 2, 1, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
-        case 69: launch_w4<EPI_RESID, 4, 6, 2, 2, 2, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
-        default: launch_w4<EPI_RESID, 4, 4, 3, 2, 2, 2>(A, Wt, bias, M, N, K, x, st, fa); break;
-    }
+    if (!accumulate && v == 61) v = w4_shape_ok(M, N, K, 4, 8) ? 68 : 70;
+    if (accumulate) launch_fold_producer<EPI_RESID>(v, A, Wt, bias, M, N, K, fa, st);
+    else launch_fold_producer<EPI_F32>(v, A, Wt, bias, M, N, K, fa, st);
     WISE_LAUNCH_CHECK("gemm_w4_kernel (fold, residual)");
     return WISE_OK;
 }
@@ -2727,7 +2737,7 @@ extern "C" int wise_gemm_fold_bf16(const uint16_t* A, const uint16_t* Wt, const 
 }
 extern "C" int wise_gemm_fold_resid(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, uint16_t* hi,
                                     int64_t lo_off, float* stats, float eps, int group32, void* stream) {
-    return wise::gemm_fold_resid(A, Wt, bias, M, N, K, hi, lo_off, stats, eps, (hipStream_t)stream, group32);
+    return wise::gemm_fold_resid(A, Wt, bias, M, N, K, hi, lo_off, stats, eps, (hipStream_t)stream, group32 & 1, !(group32 & 2));
 }
 
 extern "C" int wise_gemm_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, int mode,

@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_w4_kernel(const bf16_t* __restr
                                                          const float* __restrict__ bias, int M, int N, int K,
                                                          void* __restrict__ out, const FoldArgs fold) {
     using namespace w4;
-    static_assert(FOLD == 0 || (FOLD == 1 && bf16_out(MODE)) || (FOLD == 2 && MODE == EPI_RESID), "fold: consumer / producer");
+    static_assert(FOLD == 0 || (FOLD == 1 && bf16_out(MODE)) || (FOLD == 2 && (MODE == EPI_RESID || MODE == EPI_F32)),
+                  "fold: consumer / producer (EPI_F32: the stream's first rows, nothing to add to)");
     static_assert((SA == 3 && SW == 2) || (SA == 2 && SW == 3) || (SA == 2 && SW == 2), "slot plan");
     static_assert(lds_bytes(MI, NJ, SA, SW) <= 160 * 1024, "LDS");
     constexpr int BMB = 2 * MI * 16, BNB = 2 * NJ * 16;

@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void swin96_block_attn_kernel(float* __rest
 template <int NV>
 __global__ __launch_bounds__(256) void merge_ln_kernel(const float* __restrict__ x, int B, int H, int W, int C,
                                                        const float* __restrict__ w, const float* __restrict__ bb,
-                                                       bf16_t* __restrict__ y) {
+                                                       bf16_t* __restrict__ y, long long lo_off /* != 0: x is a hi + lo bf16 stream */) {
     const int lane = threadIdx.x & 63;
     const int H2 = H >> 1, W2 = W >> 1;
     const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -710,7 +710,16 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const float* __restrict__
         if (idx < C) {
             const int seg = idx / c4, off = idx % c4;
             const int yy = 2 * i + (seg & 1), xx = 2 * j + (seg >> 1);
-            v[u] = reinterpret_cast<const float4*>(x + (((size_t)b * H + yy) * W + xx) * C)[off];
+            const size_t e0 = (((size_t)b * H + yy) * W + xx) * C;
+            if (lo_off) {
+                const bf16_t* hp = reinterpret_cast<const bf16_t*>(x) + e0 + 4 * off;
+                const uint2 hv = *reinterpret_cast<const uint2*>(hp), lv = *reinterpret_cast<const uint2*>(hp + lo_off);
+                v[u] = make_float4(__uint_as_float(hv.x << 16) + __uint_as_float(lv.x << 16),
+                                   __uint_as_float(hv.x & 0xffff0000u) + __uint_as_float(lv.x & 0xffff0000u),
+                                   __uint_as_float(hv.y << 16) + __uint_as_float(lv.y << 16),
+                                   __uint_as_float(hv.y & 0xffff0000u) + __uint_as_float(lv.y & 0xffff0000u));
+            } else
+                v[u] = reinterpret_cast<const float4*>(x + e0)[off];
         } else
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
@@ -746,9 +755,15 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 
+__global__ __launch_bounds__(256) void hilo_to_f32_kernel(const bf16_t* __restrict__ hi, long long lo_off, long long n,
+                                                          float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = bf16_to_f32(hi[i]) + bf16_to_f32(hi[i + lo_off]);
+}
+
 // latent: block per clip. x [B*64, 768] fp32 -> final LN -> token mean -> bf16 [B, 768]
 __global__ __launch_bounds__(256) void latent_kernel(const float* __restrict__ x, const float* __restrict__ nw,
-                                                     const float* __restrict__ nb, bf16_t* __restrict__ lat) {
+                                                     const float* __restrict__ nb, bf16_t* __restrict__ lat, long long lo_off) {
     __shared__ float part[4][LATENT];  // per-wave partial token sums, added in a fixed order (deterministic)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* xb = x + (size_t)blockIdx.x * 64 * LATENT;
@@ -757,9 +772,13 @@ __global__ __launch_bounds__(256) void latent_kernel(const float* __restrict__ x
     for (int u = 0; u < 12; ++u) accl[u] = 0.f;
     for (int t = wv; t < 64; t += 4) {
         const float* r = xb + (size_t)t * LATENT;
+        const bf16_t* rh = reinterpret_cast<const bf16_t*>(x) + ((size_t)blockIdx.x * 64 + t) * LATENT;
         float v[12], s = 0.f;
 #pragma unroll
-        for (int u = 0; u < 12; ++u) { v[u] = r[u * 64 + lane]; s += v[u]; }
+        for (int u = 0; u < 12; ++u) {
+            v[u] = lo_off ? bf16_to_f32(rh[u * 64 + lane]) + bf16_to_f32(rh[u * 64 + lane + lo_off]) : r[u * 64 + lane];
+            s += v[u];
+        }
         const float mean = wave_sum(s) / (float)LATENT;
         float q = 0.f;
 #pragma unroll
@@ -860,7 +879,7 @@ static Offsets offsets() {
 }
 
 struct Ws {
-    size_t mel, x, h, qkv, a, total;
+    size_t mel, x, h, qkv, a, stats, total;
     int Fc;
 };
 static Ws workspace(int B, int N) {
@@ -874,6 +893,8 @@ static Ws workspace(int B, int N) {
     w.h = off; off += align_up(rows1 * EMBED * 2, 256);
     w.qkv = off; off += align_up(rows1 * EMBED * 3 * 2, 256);
     w.a = off; off += align_up(rows1 * EMBED * 4 * 2, 256);
+    // fold mode (stages 2 - 4): row scales, arrival counters, partial sums per 32 columns; rows * width halves per stage
+    w.stats = off; off += align_up(gemm_fold_stats_bytes((int)((rows1 / 4 + 127) / 128 * 128), 2 * EMBED), 256);
     w.total = off;
     return w;
 }
@@ -896,9 +917,10 @@ extern "C" size_t wise_htsat_workspace_bytes(int batch, int samples) {
     return workspace(batch, samples).total;
 }
 
-extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
-                                  float* out, void* workspace_ptr, size_t workspace_bytes, void* stream) {
+static int htsat_forward_impl(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
+                              float* out, void* workspace_ptr, size_t workspace_bytes, void* stream, int flags) {
     WISE_CHECK_ARG(wb && pf && wave && out, "htsat_forward: null pointer");
+    WISE_CHECK_ARG((flags & ~1) == 0, "htsat_forward: unknown flags %d", flags);
     WISE_CHECK_ARG(batch >= 1 && samples >= N_FFT / 2 + 1, "htsat_forward: batch=%d samples=%d", batch, samples);
     const Ws ws = workspace(batch, samples);
     if (!workspace_ptr || workspace_bytes < ws.total) {
@@ -930,6 +952,12 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
                            pf + o.pe_w, pf + o.pe_b, pf + o.pe_nw, pf + o.pe_nb, x);
     WISE_LAUNCH_CHECK("htsat embed_kernel");
 
+    // flags bit 0: stages 2 - 4 with their LayerNorms folded into the GEMMs (gemm_w4.h FoldArgs; the packer stored the folded
+    // qkv / fc1 weights and biases): the residual stream of those stages is bf16 hi + lo where the fp32 rows would be, started
+    // by the patch-merging projection in front of the stage; norm1 / norm2 launches are gone and nothing reads the rows twice
+    const bool fold_on = (flags & 1) != 0;
+    float* stats = reinterpret_cast<float*>(wsb + ws.stats);
+    long long x_lo_off = 0;     // != 0: x currently holds a hi + lo stream, lo that many elements behind hi
     int H = 64;
     for (int i = 0; i < 4; ++i) {
         const int C = EMBED << i, heads = HEADS[i];
@@ -944,6 +972,19 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
             const bf16_t* wproj = wq + (size_t)3 * C * C; const bf16_t* wf1 = wproj + (size_t)C * C;
             const bf16_t* wf2 = wf1 + (size_t)4 * C * C;
             const int shift = (j % 2 == 1 && H > 8) ? 4 : 0;
+            if (fold_on && i >= 1) {
+                bf16_t* hi = reinterpret_cast<bf16_t*>(x);
+                const long long lo_off = (long long)Mp * C;
+                if ((rc = gemm_fold_bf16(hi, wq, qb, stats, Mp, 3 * C, C, 0, qkv, st))) return rc;
+                const long long items = (long long)B * (H / 8) * (H / 8) * heads;
+                hipLaunchKernelGGL(swin_attention_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, qkv, B, H,
+                                   H, C, heads, shift, rb, h);
+                WISE_LAUNCH_CHECK("htsat swin_attention_kernel");
+                if ((rc = gemm_fold_resid(h, wproj, pb, Mp, C, C, hi, lo_off, stats, 1e-5f, st, 1))) return rc;
+                if ((rc = gemm_fold_bf16(hi, wf1, f1b, stats, Mp, 4 * C, C, 2, a, st))) return rc;
+                if ((rc = gemm_fold_resid(a, wf2, f2b, Mp, C, 4 * C, hi, lo_off, stats, 1e-5f, st, 1))) return rc;
+                continue;
+            }
             // stage 1 (C = 96): a block holds whole rows, so LayerNorm happens inside the GEMM's A-tile build and the
             // normalised activations never travel through HBM (LN 71 + GEMM 151 us -> 142 us; LN 71 + 200 -> 205).
             // At C = 192 the fused kernel (one block per CU) loses to LayerNorm + the tuned GEMMs (113 vs 93 us,
@@ -995,26 +1036,44 @@ extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const flo
             const long long toks = (long long)B * (H / 2) * (H / 2);
             const dim3 grid((unsigned)((toks + 3) / 4)), block(256);
             switch ((C + 63) / 64) {
-                case 2: hipLaunchKernelGGL(merge_ln_kernel<2>, grid, block, 0, st, x, B, H, H, C, mp, mp + 4 * C, h); break;
-                case 3: hipLaunchKernelGGL(merge_ln_kernel<3>, grid, block, 0, st, x, B, H, H, C, mp, mp + 4 * C, h); break;
-                case 6: hipLaunchKernelGGL(merge_ln_kernel<6>, grid, block, 0, st, x, B, H, H, C, mp, mp + 4 * C, h); break;
+                case 2: hipLaunchKernelGGL(merge_ln_kernel<2>, grid, block, 0, st, x, B, H, H, C, mp, mp + 4 * C, h, x_lo_off); break;
+                case 3: hipLaunchKernelGGL(merge_ln_kernel<3>, grid, block, 0, st, x, B, H, H, C, mp, mp + 4 * C, h, x_lo_off); break;
+                case 6: hipLaunchKernelGGL(merge_ln_kernel<6>, grid, block, 0, st, x, B, H, H, C, mp, mp + 4 * C, h, x_lo_off); break;
                 default: set_error("htsat: unexpected C=%d", C); return WISE_E_UNSUPPORTED;
             }
             WISE_LAUNCH_CHECK("htsat merge_ln_kernel");
             const int M2 = (int)toks, M2p = (M2 + 127) / 128 * 128;
-            if ((rc = gemm_bf16(h, wb + o.merge_b[i], nullptr, M2p, 2 * C, 4 * C, 4, x, st))) return rc;
+            if (fold_on) {   // the projection STARTS the next stage's hi + lo stream and its first statistics
+                if (hipMemsetAsync(stats + M2p, 0, gemm_fold_counters_bytes(M2p), st) != hipSuccess) {
+                    set_error("htsat_forward: memset of the fold counters failed");
+                    return WISE_E_INVALID;
+                }
+                x_lo_off = (long long)M2p * 2 * C;
+                if ((rc = gemm_fold_resid(h, wb + o.merge_b[i], nullptr, M2p, 2 * C, 4 * C, reinterpret_cast<bf16_t*>(x), x_lo_off,
+                                          stats, 1e-5f, st, 1, false)))
+                    return rc;
+            } else if ((rc = gemm_bf16(h, wb + o.merge_b[i], nullptr, M2p, 2 * C, 4 * C, 4, x, st))) return rc;
             H >>= 1;
         }
     }
     // head: final LN + token mean -> latent bf16 [Bp,768] (aliases h); then the msclap Projection
     {
-        hipLaunchKernelGGL(latent_kernel, dim3(B), dim3(256), 0, st, x, pf + o.fin_nw, pf + o.fin_nb, h);
+        hipLaunchKernelGGL(latent_kernel, dim3(B), dim3(256), 0, st, x, pf + o.fin_nw, pf + o.fin_nb, h, x_lo_off);
         WISE_LAUNCH_CHECK("htsat latent_kernel");
         if ((rc = clap_projection(h, wb + o.pj_w1, wb + o.pj_w2, pf + o.pj_lw, pf + o.pj_lb, B, LATENT,
                                   reinterpret_cast<float*>(qkv), a, out, st)))
             return rc;
     }
     return WISE_OK;
+}
+
+extern "C" int wise_htsat_forward(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
+                                  float* out, void* workspace_ptr, size_t workspace_bytes, void* stream) {
+    return htsat_forward_impl(wb, pf, wave, batch, samples, out, workspace_ptr, workspace_bytes, stream, 0);
+}
+extern "C" int wise_htsat_forward2(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
+                                   float* out, void* workspace_ptr, size_t workspace_bytes, int flags, void* stream) {
+    return htsat_forward_impl(wb, pf, wave, batch, samples, out, workspace_ptr, workspace_bytes, stream, flags);
 }
 
 #ifdef WISE_DEBUG_KNOBS
@@ -1031,6 +1090,13 @@ extern "C" int wise_htsat_tap(int what, const void* workspace_ptr, int batch, in
     WISE_CHECK_ARG(workspace_ptr && dst && count > 0 && batch >= 1, "htsat_tap: bad argument");
     const Ws ws = workspace(batch, samples);
     const unsigned char* wsb = reinterpret_cast<const unsigned char*>(workspace_ptr);
+    if (what == 2) {   // the last stage's rows of a fold-mode forward: hi + lo -> fp32
+        const long long Mp = ((long long)batch * 64 + 127) / 128 * 128;
+        hipLaunchKernelGGL(hilo_to_f32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const bf16_t*>(wsb + ws.x), Mp * LATENT, (long long)count, dst);
+        WISE_LAUNCH_CHECK("hilo_to_f32_kernel");
+        return WISE_OK;
+    }
     const size_t off = (what == 0) ? ws.mel : ws.x;
     hipError_t e = hipMemcpyAsync(dst, wsb + off, (size_t)count * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("htsat_tap: %s", hipGetErrorString(e)); return (int)e; }

@@ -35,7 +35,7 @@ int gemm_fold_bf16(const bf16_t* A, const bf16_t* Wt, const float* bias, const f
                    bf16_t* out, hipStream_t st);
 size_t gemm_fold_stats_bytes(int M, int N);
 int gemm_fold_resid(const bf16_t* A, const bf16_t* Wt, const float* bias, int M, int N, int K, bf16_t* hi, long long lo_off,
-                    float* stats, float eps, hipStream_t st, int group32 = 0);
+                    float* stats, float eps, hipStream_t st, int group32 = 0, bool accumulate = true /* false: x = ..., no rows read */);
 size_t gemm_fold_counters_bytes(int M);
 // hint for the tile heuristic: the calling THREAD is about to enqueue GEMMs on several streams that overlap in time
 // (thread-local: two host threads driving two engines do not see each other's hint)

@@ -8,6 +8,7 @@ checkpoint is a pure data problem.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Tuple
 
 import torch
@@ -124,12 +125,24 @@ class HtsatEngine:
     tensor, L2-normalised (microsoft_clap.py:49-50)."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 128,
-                 max_samples: int = 480000):
+                 max_samples: int = 480000, ln_fold=None):
+        """ln_fold: stages 2 - 4 with their LayerNorms folded into the GEMMs around them and the residual stream as bf16
+        hi + lo (wise_htsat_forward2 flags bit 0; same tolerance of the fp32 path, not bit-equal to the unfolded form).
+        None = WISE_HTSAT_LN_FOLD (0 / 1), default OFF: built, parity-green and measured slower here (bs=128 x 10 s: 3.62 ->
+        3.66 ms one batch at a time, 3.33 -> 3.67 ms with two in flight; profiles/r04_htsat_fold_ab.txt).  A stage-2 / -3 block
+        does lose its two LayerNorm launches (-34 / -10 us), but these stages are bound by the bytes of their own operands
+        (K = 192 / 384: three to six K-steps per tile), and the fold's epilogue — hi + lo join and split, the statistics'
+        tree — is ~45 vector instructions per 16 bytes in a kernel with one wave per SIMD: it stops hiding under the store
+        burst (projection 23.8 -> 35.0 us, patch-merging GEMMs +14 .. +30 us), and beside a second batch it holds the CU."""
         self.lib = _lib.lib()
         self.device = torch.device(device)
+        if ln_fold is None:
+            ln_fold = os.environ.get("WISE_HTSAT_LN_FOLD", "0") == "1"
+        self.ln_fold = bool(ln_fold)
+        self._flags = 1 if self.ln_fold else 0
         nb, nf = C.c_int64(), C.c_int64()
         _lib.check(self.lib.wise_htsat_layout(C.byref(nb), C.byref(nf)), "wise_htsat_layout")
-        wb, pf = pack_htsat_weights(sd)
+        wb, pf = pack_htsat_weights(sd, fold=self.ln_fold)
         if wb.numel() != nb.value or pf.numel() != nf.value:
             raise RuntimeError(f"HTSAT blob size mismatch: packed {wb.numel()}/{pf.numel()}, "
                                f"library expects {nb.value}/{nf.value}")
@@ -158,8 +171,8 @@ class HtsatEngine:
             raise ValueError(f"audio too short for a reflect-padded STFT: {N} samples")
         self.reserve(B, N)
         out = torch.empty(B, OUT_DIM, dtype=torch.float32, device=self.device)
-        rc = self.lib.wise_htsat_forward(self.wb.data_ptr(), self.pf.data_ptr(), x.data_ptr(), B, N, out.data_ptr(),
-                                         self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr())
+        rc = self.lib.wise_htsat_forward2(self.wb.data_ptr(), self.pf.data_ptr(), x.data_ptr(), B, N, out.data_ptr(),
+                                          self._ws.data_ptr(), self._ws.numel(), self._flags, _lib.stream_ptr())
         _lib.check(rc, "wise_htsat_forward")
         self._last = (B, N)
         return out
@@ -191,8 +204,8 @@ class HtsatEngine:
         x.record_stream(slot["stream"])
         out.record_stream(slot["stream"])
         self.lib.wise_overlap_hint(1)      # this batch runs beside the other slot's: tile for co-residency
-        rc = self.lib.wise_htsat_forward(self.wb.data_ptr(), self.pf.data_ptr(), x.data_ptr(), B, N, out.data_ptr(),
-                                         slot["ws"].data_ptr(), slot["ws"].numel(), slot["stream"].cuda_stream)
+        rc = self.lib.wise_htsat_forward2(self.wb.data_ptr(), self.pf.data_ptr(), x.data_ptr(), B, N, out.data_ptr(),
+                                          slot["ws"].data_ptr(), slot["ws"].numel(), self._flags, slot["stream"].cuda_stream)
         self.lib.wise_overlap_hint(0)
         _lib.check(rc, "wise_htsat_forward")
         done = torch.cuda.Event()
@@ -202,13 +215,17 @@ class HtsatEngine:
     def tap(self, what: int, rows: int, cols: int) -> torch.Tensor:
         """parity taps: 0 = log-mel+bn [B*frames,64] fp32, 1 = residual stream x fp32 [rows, cols]."""
         out = torch.empty(rows, cols, dtype=torch.float32, device=self.device)
+        if what == 1 and self.ln_fold:
+            what = 2                      # the last stage's rows are a hi + lo stream in fold mode
         _lib.check(self.lib.wise_htsat_tap(what, self._ws.data_ptr(), self._last[0], self._last[1], out.data_ptr(),
                                            rows * cols, _lib.stream_ptr()), "wise_htsat_tap")
         return out
 
 
-def pack_htsat_weights(sd: Dict[str, torch.Tensor]):
+def pack_htsat_weights(sd: Dict[str, torch.Tensor], fold: bool = False):
     """state dict -> (bf16 blob, fp32 blob) in the order wise_htsat_layout() documents (CPU tensors).
+    fold: the qkv / fc1 weights and biases of stages 2 - 4 with norm1 / norm2 folded in (vit.fold_layernorm: gamma-scaled,
+    row-centred weights, bias + W beta) — what wise_htsat_forward2 flags bit 0 expects; the norm slots stay (unread there).
 
     bf16: per block qkv [3C,C], proj [C,C], fc1 [4C,C], fc2 [C,4C]; per stage<3 reduction [2C,4C];
           then projection.linear1 [1024,768], linear2 [1024,1024]
@@ -234,12 +251,18 @@ def pack_htsat_weights(sd: Dict[str, torch.Tensor]):
     for i, depth in enumerate(DEPTHS):
         for j in range(depth):
             p = f"{pre}layers.{i}.blocks.{j}."
-            wb += [f32(p + "attn.qkv.weight").reshape(-1), f32(p + "attn.proj.weight").reshape(-1),
-                   f32(p + "mlp.fc1.weight").reshape(-1), f32(p + "mlp.fc2.weight").reshape(-1)]
+            w_qkv, b_qkv = f32(p + "attn.qkv.weight"), f32(p + "attn.qkv.bias")
+            w_fc1, b_fc1 = f32(p + "mlp.fc1.weight"), f32(p + "mlp.fc1.bias")
+            if fold and i >= 1:
+                from .vit import fold_layernorm
+                w_qkv, b_qkv = fold_layernorm(w_qkv, b_qkv, f32(p + "norm1.weight"), f32(p + "norm1.bias"))
+                w_fc1, b_fc1 = fold_layernorm(w_fc1, b_fc1, f32(p + "norm2.weight"), f32(p + "norm2.bias"))
+            wb += [w_qkv.reshape(-1), f32(p + "attn.proj.weight").reshape(-1), w_fc1.reshape(-1),
+                   f32(p + "mlp.fc2.weight").reshape(-1)]
             bias = f32(p + "attn.relative_position_bias_table")[rel_idx].reshape(64, 64, HEADS[i]).permute(2, 0, 1)
             pf += [f32(p + "norm1.weight"), f32(p + "norm1.bias"), bias.contiguous().reshape(-1),
-                   f32(p + "attn.qkv.bias"), f32(p + "attn.proj.bias"), f32(p + "norm2.weight"),
-                   f32(p + "norm2.bias"), f32(p + "mlp.fc1.bias"), f32(p + "mlp.fc2.bias")]
+                   b_qkv, f32(p + "attn.proj.bias"), f32(p + "norm2.weight"),
+                   f32(p + "norm2.bias"), b_fc1, f32(p + "mlp.fc2.bias")]
         if i < 3:
             p = f"{pre}layers.{i}.downsample."
             wb.append(f32(p + "reduction.weight").reshape(-1))
