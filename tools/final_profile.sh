@@ -4,8 +4,11 @@
 #   usage (from the repo root on the box):  bash tools/final_profile.sh <tag>
 set -u
 TAG=${1:-rXX}
+PART=${2:-all}     # "a": bench line + the two kernel-stats passes; "b": the PMC passes (a gpurun call lasts 20 minutes at most)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out
+mkdir -p $OUT
+if [ "$PART" != "b" ]; then
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 echo "bench done"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o stats -- python3 bench.py --steps 20 --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1 || exit 1
@@ -15,6 +18,8 @@ echo "stats done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_roofstats -o roof -- python3 bench.py --steps 20 --roofline-only > $OUT/${TAG}_roofline_only.json 2> $OUT/${TAG}_roofline_only.err || exit 1
 python3 tools/prof_top.py $OUT/${TAG}_roofstats/roof_results.db 12 --csv $OUT/${TAG}_roofline_kernel_stats.csv > $OUT/${TAG}_roofline_kernel_stats.txt
 echo "roofline stats done"
+fi
+if [ "$PART" = "a" ]; then ls -la $OUT | tail -8; exit 0; fi
 # PMC passes (one counter per run, kernel-trace only): the headline legs without the extras, so that the per-kernel
 # averages are those of the ViT-B/32 GEMMs and the 10M x 512 scans; the image-transform kernel from its own tool
 for C in FETCH_SIZE WRITE_SIZE; do
