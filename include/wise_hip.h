@@ -357,7 +357,10 @@ typedef struct wise_preproc_plan {
     int32_t ndh, ndv;           /* dwords of padded taps per output column / row */
     int32_t max_cols4, max_rows4; /* staged input rectangle of the worst tile: column dwords, rows / 4 */
     int32_t lds_bytes;
-    int32_t reserved;           /* geometry: 0 = Resize(shorter side) + CenterCrop, 1 = squash (set by the _init functions) */
+    int32_t reserved;           /* bit 0 (set by the _init functions): 0 = Resize(shorter side) + CenterCrop, 1 = squash.  bit 1 (set by
+                                   them too): the table blob carries the integer matrix-core form's tables and wise_preproc_u8
+                                   uses that kernel; a caller may clear it (dot-product kernel) or set bit 2 with it (four waves per
+                                   tile instead of one).  The three kernels return the same bytes. */
     uint64_t table_bytes;       /* size of the tap-table blob */
 } wise_preproc_plan;
 int wise_preproc_plan_init(int H, int W, int S, wise_preproc_plan* plan);

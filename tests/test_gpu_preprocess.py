@@ -19,11 +19,14 @@ def pre224():
     return ClipPreprocessor(224)
 
 
+@pytest.mark.parametrize("matrix_cores", [1, 4, False, "auto"])
 @pytest.mark.parametrize("H,W,S,seed", CASES)
-def test_kernel_reproduces_pillow_golden(H, W, S, seed):
+def test_kernel_reproduces_pillow_golden(H, W, S, seed, matrix_cores):
+    """every form of the kernel: the integer matrix-core form with one and with four waves per tile (where the plan offers it:
+    moderate scales), the dot-product form (everywhere), and whichever the first call's measurement picks"""
     from wise_amd.feature.preprocess import ClipPreprocessor
     frame = torch.from_numpy(case_input(H, W, seed))[None].cuda()
-    out = ClipPreprocessor(S)(frame)
+    out = ClipPreprocessor(S, matrix_cores=matrix_cores)(frame)
     torch.cuda.synchronize()
     got = out.cpu().numpy()[0]
     want = GOLD[f"out_{H}x{W}_{S}_{seed}"]
@@ -38,6 +41,23 @@ def test_batches_match_oracle(pre224, H, W, n):
     got = pre224(dev)
     torch.cuda.synchronize()
     assert np.array_equal(got.cpu().numpy(), ref.clip_preprocess_u8(frames, 224))
+
+
+def test_matrix_core_form_is_what_runs_on_video_frames_and_equals_the_dot_product_form():
+    """240p ... 1080p frames (and a squashed SigLIP geometry) are offered the matrix-core kernel (plan.reserved bit 1); a 4K frame
+    does not fit its LDS budget and stays on the dot-product kernel.  Same bytes from all three, whichever "auto" picks."""
+    from wise_amd.feature.preprocess import ClipPreprocessor, make_plan
+    for (H, W, S, squash, want_mfma) in [(240, 320, 224, False, True), (480, 854, 224, False, True), (720, 1280, 224, False, True),
+                                         (1080, 1920, 224, False, True), (360, 640, 384, True, True), (2160, 3840, 224, False, False)]:
+        assert bool(make_plan(H, W, S, squash).reserved & 2) is want_mfma, (H, W, S)
+        frames = torch.from_numpy(np.random.default_rng(H + W).integers(0, 256, (3, 3, H, W), dtype=np.uint8)).cuda()
+        auto = ClipPreprocessor(S, squash=squash)
+        a = auto(frames)
+        assert auto.chosen[(H, W)] in ("dot products", "matrix cores, one wave per tile", "matrix cores, four waves per tile")
+        assert want_mfma or auto.chosen[(H, W)] == "dot products"
+        for mc in (False, 1, 4):
+            assert torch.equal(a, ClipPreprocessor(S, squash=squash, matrix_cores=mc)(frames)), (H, W, S, mc)
+        assert torch.equal(a, auto(frames))
 
 
 def test_constant_and_extreme_frames(pre224):

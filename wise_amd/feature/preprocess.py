@@ -66,10 +66,16 @@ class ClipPreprocessor:
     """Callable: device uint8 [n,3,H,W] -> device uint8 [n,3,S,S].  Plans and device tables are cached per
     frame geometry (a video collection has a handful of distinct sizes)."""
 
-    def __init__(self, size: int, device: str = "cuda", squash: bool = False):
+    def __init__(self, size: int, device: str = "cuda", squash: bool = False, matrix_cores="auto"):
+        """matrix_cores: which of the three kernels a geometry takes — they return the same bytes.  "auto" (default): measured
+        once per (H, W) on the first call, on that call's own frames (the dot-product kernel, the integer matrix-core kernel with
+        one wave per 32 x 32 tile, the same with four): small frames are served best by lone waves, 1080p by four, 720p by the
+        dot products (tools/preproc_bench.py).  False: the dot-product kernel; True / 1: matrix cores, one wave; 4: four waves."""
         self.size = int(size)
         self.device = device
         self.squash = bool(squash)     # the SigLIP models' transform: Resize((S, S)), no crop
+        self.matrix_cores = matrix_cores
+        self.chosen: Dict[Tuple[int, int], str] = {}     # (H, W) -> the kernel in use
         self._plans: Dict[Tuple[int, int], Tuple[PreprocPlan, torch.Tensor]] = {}
 
     def _plan(self, H: int, W: int):
@@ -78,9 +84,45 @@ class ClipPreprocessor:
         if hit is None:
             plan = make_plan(H, W, self.size, self.squash)
             tables = torch.from_numpy(plan_tables(plan)).to(self.device)
+            offered = bool(plan.reserved & 2)    # wise_preproc_plan.reserved bit 1: the blob carries the matrix-core tables
+            mc = self.matrix_cores
+            if not offered or mc is False:
+                plan.reserved &= ~6
+                self.chosen[key] = "dot products"
+            elif mc == 4:
+                plan.reserved |= 4
+                self.chosen[key] = "matrix cores, four waves per tile"
+            elif mc == "auto":
+                self.chosen[key] = None          # decided by the first call (it has frames to measure on)
+            else:
+                self.chosen[key] = "matrix cores, one wave per tile"
             hit = (plan, tables)
             self._plans[key] = hit
         return hit
+
+    def _autotune(self, key, plan, tables, frames, out):
+        """Time the three kernels on (up to 64 of) the caller's frames and keep the fastest for this geometry."""
+        lib = _lib.lib()
+        stream = torch.cuda.current_stream().cuda_stream
+        n = min(int(frames.shape[0]), 64)
+        base = plan.reserved & ~6
+        best = None
+        for name, bits in (("dot products", 0), ("matrix cores, one wave per tile", 2), ("matrix cores, four waves per tile", 6)):
+            plan.reserved = base | bits
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for rep in range(3):
+                if rep == 1:
+                    e0.record()
+                rc = lib.wise_preproc_u8(C.byref(plan), tables.data_ptr(), frames.data_ptr(), n, out.data_ptr(), stream)
+                if rc != 0:
+                    raise RuntimeError(lib.wise_last_error().decode())
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best is None or t < best[0]:
+                best = (t, name, bits)
+        plan.reserved = base | best[2]
+        self.chosen[key] = best[1]
 
     def __call__(self, frames: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         if not isinstance(frames, torch.Tensor) or frames.dtype != torch.uint8 or frames.dim() != 4 \
@@ -93,6 +135,8 @@ class ClipPreprocessor:
         S = self.size
         if out is None:
             out = torch.empty((n, 3, S, S), dtype=torch.uint8, device=self.device)
+        if self.chosen.get((H, W), "") is None:
+            self._autotune((H, W), plan, tables, frames, out)
         stream = torch.cuda.current_stream().cuda_stream
         rc = lib.wise_preproc_u8(C.byref(plan), tables.data_ptr(), frames.data_ptr(), n, out.data_ptr(), stream)
         if rc != 0:
