@@ -1195,7 +1195,9 @@ static int parts_for(int batch, int streams) {
     while (p > 1 && batch / p < 32) --p;  // keep every part at least 32 images
     return p;
 }
-static int vit_parts(int batch) { return parts_for(batch, g_vit_streams); }
+// (fold mode: ONE part — a half batch's row counts are no multiple of the 160-row tiles the folded GEMMs are fastest on, and the
+//  whole batch on one stream measured faster than two halves on two: 2.97 against 3.06 ms at bs = 256, tools/vit_fold_ab.py)
+static int vit_parts(int batch, int fold = 0) { return fold ? 1 : parts_for(batch, g_vit_streams); }
 static void part_range(int batch, int parts, int i, int* lo, int* hi) {
     *lo = (int)((long long)batch * i / parts);
     *hi = (int)((long long)batch * (i + 1) / parts);
@@ -1252,7 +1254,7 @@ extern "C" int wise_vit_forward(const wise_vit_config* cfg, const uint16_t* wb, 
     WISE_CHECK_ARG(wb && pf && images && out, "vit_forward: null pointer");
     WISE_CHECK_ARG(batch >= 1, "vit_forward: batch=%d", batch);
     WISE_CHECK_ARG(in_kind == WISE_VIT_IN_F32 || in_kind == WISE_VIT_IN_U8, "vit_forward: in_kind=%d", in_kind);
-    const int parts = vit_parts(batch);
+    const int parts = vit_parts(batch, d.fold);
     const size_t need = total_ws_for(d, batch, parts);
     if (!workspace || workspace_bytes < need) {
         set_error("vit_forward: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -1328,7 +1330,7 @@ extern "C" int wise_vit_tap_residual(const wise_vit_config* cfg, int batch, cons
     if (rc) return rc;
     WISE_CHECK_ARG(workspace && dst && batch >= 1, "vit_tap_residual: bad argument");
     const unsigned char* wsb = reinterpret_cast<const unsigned char*>(workspace);
-    const int parts = vit_parts(batch);
+    const int parts = vit_parts(batch, d.fold);
     size_t base = 0;
     float* dp = dst;
     for (int i = 0; i < parts; ++i) {
