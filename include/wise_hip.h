@@ -190,7 +190,9 @@ typedef struct wise_vit_config {
                            rows' 1/sqrt(var + eps), the QKV / fc1 GEMMs take hi as their operand and scale their rows by it.  The blob layout is the same, but the packer must then store
                            in_proj / c_fc as gamma-scaled, row-centred weights and their biases as b + W beta
                            (wise_amd/feature/vit.py:pack_weights); ln_1 / ln_2 slots are not read.  Same results within the
-                           bf16 path's tolerance (not bit-equal to ln_fold = 0). */
+                           bf16 path's tolerance (not bit-equal to ln_fold = 0).
+                           2 = 1 with a block's attention, out-projection, residual add and row statistics in ONE kernel
+                           (wise_attention_oproj_fold: up to 64 tokens, 12 heads of 64 — ViT-B/32); bit-equal to ln_fold = 1. */
 } wise_vit_config;
 
 #define WISE_VIT_IN_F32 0  /* images [B,3,S,S] fp32, already normalised (preprocess_image output) */
@@ -405,6 +407,14 @@ int wise_gemm_fold_bf16(const uint16_t* A, const uint16_t* Wt, const float* bias
                         int mode, uint16_t* out, void* stream);
 int wise_gemm_fold_resid(const uint16_t* A, const uint16_t* Wt, const float* bias, int M, int N, int K, uint16_t* hi,
                          int64_t lo_off, float* stats, float eps, int group32, void* stream);
+/* (ABI 5) wise_attention_bf16 followed by wise_gemm_fold_resid (N = K = 64 H) as ONE kernel, for sequences of up to 64
+ * tokens and H = 12: per frame b, rows b*T .. b*T+T-1 of the hi + lo stream become x + softmax(q k^T / 8) v @ Wt^T + bias and
+ * rstd[row] = 1 / sqrt(var(x[row,:]) + eps) — bit for bit what the two calls produce (same MFMA order, same reduction tree),
+ * without the attention output's round trip through HBM, the arrival counters or the scratch region.  qkv [B*T, 3*64*H]
+ * as wise_attention_bf16 takes it; Wt [64H, 64H], bias [64H]; rows past B*T are not touched.  Stands behind
+ * open_clip's ResidualAttentionBlock.attention + ls_1 + residual as reached from src/feature/mlfoundation_openclip.py:99. */
+int wise_attention_oproj_fold(const uint16_t* qkv, int B, int T, int H, const uint16_t* Wt, const float* bias, uint16_t* hi,
+                              int64_t lo_off, float* rstd, float eps, void* stream);
 /* out[ceil256(B*T*F), cout] bf16 = relu(conv3x3(x [B,T,F,cin] bf16, position-major ("NHWC"), stride 1, zero padding 1)
  * + bias[cout]); with pool != 0 its 2x2 average pooling (floor) instead, out [B*(T/2)*(F/2), cout], computed in the same
  * kernel (the unpooled tensor is never written).  wt [cout, 9*cin] bf16 with k = (kh*3 + kw)*cin + c (BatchNorm folded

@@ -11,7 +11,7 @@ import torch
 from oracle import vit_ref
 from tests.test_gpu_vit import COS_TOL, bf16_round, cosine, load_golden
 from wise_amd import _lib
-from wise_amd.feature.vit import VitEngine, checkpoint_like_state_dict, fold_layernorm, random_state_dict
+from wise_amd.feature.vit import VitEngine, checkpoint_like_state_dict, fold_layernorm, random_state_dict, tile_out_proj
 
 pytestmark = pytest.mark.gpu
 
@@ -161,15 +161,17 @@ def test_fold_layernorm_weights_are_the_layernorm():
 
 @pytest.mark.parametrize("name,stress", [("vit_b32.npz", False), ("vit_b16.npz", False), ("vit_l14.npz", False),
                                          ("vit_b32_stress.npz", True), ("vit_l14_stress.npz", True)])
-@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("fold", [2, 1, 0])
 def test_vit_golden_in_both_modes(golden_dir, name, stress, fold):
     """The tower with and without the fold against the committed golden vectors (the oracle pinned to transformers' CLIP),
     seeded and checkpoint-like weights; the residual stream of the last block too.  The two modes are NOT bit-equal (the
     fold rounds gamma * W instead of the normalised row) — both sit within the same tolerance of the fp32 path."""
     spec, g, frames = load_golden(golden_dir, name)
+    if fold == 2 and not (spec.tokens <= 64 and spec.heads == 12):
+        pytest.skip("attention + out-projection as one kernel: up to 64 tokens, 12 heads")
     sd = (checkpoint_like_state_dict if stress else random_state_dict)(spec, int(g["weight_seed"]))
     eng = VitEngine(spec, sd, max_batch=frames.shape[0], ln_fold=fold)
-    assert eng.spec.ln_fold is fold and eng.cfg.ln_fold == int(fold)
+    assert eng.spec.ln_fold == fold and eng.cfg.ln_fold == fold
     gold = torch.from_numpy(g["out"])
     out = eng.forward(vit_ref.normalize_u8(frames)).cpu()
     assert cosine(out, gold) >= 1 - COS_TOL, cosine(out, gold)
@@ -186,10 +188,95 @@ def test_fold_mode_defaults_and_refusals():
     from wise_amd.feature.siglip import SIGLIP_VISION
 
     b32 = spec_for("ViT-B-32", "openai")
-    assert VitEngine(b32, random_state_dict(b32, 0), max_batch=2).spec.ln_fold is True            # width 768: measured, on
+    from wise_amd.feature.vit import DEFAULT_FOLD_B32
+    assert VitEngine(b32, random_state_dict(b32, 0), max_batch=2).spec.ln_fold == DEFAULT_FOLD_B32 >= 1   # width 768: measured, on
     l14 = spec_for("ViT-L-14", "openai")
-    assert VitEngine(l14, random_state_dict(l14, 0), max_batch=2).spec.ln_fold is False
+    assert VitEngine(l14, random_state_dict(l14, 0), max_batch=2).spec.ln_fold == 0
+    with pytest.raises(ValueError):
+        VitEngine(l14, random_state_dict(l14, 0), max_batch=2, ln_fold=2)                          # 257 tokens, 16 heads
+    bad2 = _lib.VitConfig(224, 16, 768, 2, 12, 3072, 512, 0, 0, 2)                                 # 197 tokens
+    import ctypes as C2
+    assert _lib.lib().wise_vit_workspace_bytes(C2.byref(bad2), 1) == 0 and b"ln_fold = 2" in _lib.lib().wise_last_error()
     lib = _lib.lib()
     bad = _lib.VitConfig(224, 16, 768, 2, 12, 3072, 768, 1, 1, 1)                                 # the timm tower has no fold
     import ctypes as C
     assert lib.wise_vit_workspace_bytes(C.byref(bad), 1) == 0 and b"ln_fold" in lib.wise_last_error()
+
+
+def _attn_oproj_pair(B, T, seed, fused):
+    """One block's attention half on a hi + lo stream, as the two calls (attention, folded residual GEMM) or as the one kernel."""
+    lib = _lib.lib()
+    H, W = 12, 768
+    M = B * T
+    Mp = (M + 255) // 256 * 256
+    g = torch.Generator().manual_seed(seed)
+    qkv = torch.zeros(Mp, 3 * W, dtype=torch.bfloat16)
+    qkv[:M] = (torch.randn(M, 3 * W, generator=g) * 1.5).to(torch.bfloat16)
+    Wt = bf16_round(torch.randn(W, W, generator=g) * W ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(W, generator=g)
+    x0 = torch.zeros(Mp, W)
+    x0[:M] = torch.randn(M, W, generator=g) * 2 + 0.3
+    xs = hilo(x0).cuda().contiguous()
+    qkv, Wt, bias = qkv.cuda(), Wt.cuda(), bias.cuda()
+    if fused:
+        rstd = torch.full((Mp,), float("nan"), dtype=torch.float32, device="cuda")
+        Wtiled = tile_out_proj(Wt)
+        _lib.check(lib.wise_attention_oproj_fold(qkv.data_ptr(), B, T, H, Wtiled.data_ptr(), bias.data_ptr(), xs.data_ptr(), Mp * W,
+                                                 rstd.data_ptr(), 1e-5, _lib.stream_ptr()), "wise_attention_oproj_fold")
+    else:
+        ao = torch.zeros(Mp, W, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.wise_attention_bf16(qkv.data_ptr(), B, T, H, ao.data_ptr(), _lib.stream_ptr()), "wise_attention_bf16")
+        stats = _fold_resid(ao, Wt, bias, xs)
+        rstd = stats[:Mp].clone()
+    torch.cuda.synchronize()
+    return xs.cpu(), rstd.cpu(), (qkv.cpu(), Wt.cpu(), bias.cpu(), x0)
+
+
+@pytest.mark.parametrize("B,T", [(256, 50), (37, 50), (1, 50), (5, 64), (8, 33), (16, 17), (3, 1)])
+def test_attention_and_out_projection_as_one_kernel(B, T):
+    """wise_attention_oproj_fold against the two calls it replaces — BIT for bit (hi, lo and rstd of every real row; rows past
+    B*T untouched) — and against a float64 reference of softmax(q k^T / 8) v W_o^T + b + x."""
+    M = B * T
+    xs1, r1, (qkv, Wt, bias, x0) = _attn_oproj_pair(B, T, 100 + B + T, fused=True)
+    xs0, r0, _ = _attn_oproj_pair(B, T, 100 + B + T, fused=False)
+    assert torch.equal(xs1[:, :M].view(torch.int16), xs0[:, :M].view(torch.int16))
+    assert torch.equal(r1[:M].view(torch.int32), r0[:M].view(torch.int32))
+    assert torch.equal(xs1[:, M:].view(torch.int16), hilo(x0)[:, M:].view(torch.int16))           # padding rows as they were
+    assert torch.isnan(r1[M:]).all()
+    q, k, v = (qkv[:M].double().reshape(B, T, 3, 12, 64).permute(2, 0, 3, 1, 4))
+    o = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v                                   # [B, 12, T, 64]
+    o = o.permute(0, 2, 1, 3).reshape(M, 768)
+    want = x0[:M].double() + o @ Wt.double().t() + bias.double()
+    got = xs1[0, :M].double() + xs1[1, :M].double()
+    assert (got - want).abs().max().item() <= 0.03 * max(1.0, want.abs().max().item() / 8)        # bf16 attention output
+    want_rstd = 1.0 / torch.sqrt(got.var(1, unbiased=False) + 1e-5)
+    assert ((r1[:M].double() - want_rstd).abs() / want_rstd).max().item() <= 1e-4
+
+
+def test_one_kernel_form_does_not_depend_on_the_batch():
+    """a frame's rows after wise_attention_oproj_fold are the same bits alone and inside a batch (one workgroup per frame)"""
+    xs_all, r_all, (qkv, Wt, bias, x0) = _attn_oproj_pair(24, 50, 7, fused=True)
+    lib = _lib.lib()
+    for b in (0, 11, 23):
+        q1 = torch.zeros(256, 2304, dtype=torch.bfloat16)
+        q1[:50] = qkv[b * 50:(b + 1) * 50]
+        x1 = torch.zeros(256, 768)
+        x1[:50] = x0[b * 50:(b + 1) * 50]
+        xs = hilo(x1).cuda().contiguous()
+        rstd = torch.zeros(256, device="cuda")
+        q1, Wd, bd = q1.cuda(), tile_out_proj(Wt).cuda(), bias.cuda()
+        _lib.check(lib.wise_attention_oproj_fold(q1.data_ptr(), 1, 50, 12, Wd.data_ptr(), bd.data_ptr(), xs.data_ptr(), 256 * 768,
+                                                 rstd.data_ptr(), 1e-5, _lib.stream_ptr()), "wise_attention_oproj_fold")
+        torch.cuda.synchronize()
+        assert torch.equal(xs.cpu()[:, :50].view(torch.int16), xs_all[:, b * 50:(b + 1) * 50].view(torch.int16))
+        assert torch.equal(rstd.cpu()[:50], r_all[b * 50:(b + 1) * 50])
+
+
+def test_tower_with_the_one_kernel_form_equals_the_two_kernel_fold():
+    from wise_amd.feature.vit import spec_for
+    spec = spec_for("ViT-B-32", "openai")
+    sd = random_state_dict(spec, 3)
+    x = torch.randn(37, 3, 224, 224, generator=torch.Generator().manual_seed(5)).cuda()
+    a = VitEngine(spec, sd, max_batch=64, ln_fold=1).forward(x).cpu()
+    b = VitEngine(spec, sd, max_batch=64, ln_fold=2).forward(x).cpu()
+    assert torch.equal(a, b)

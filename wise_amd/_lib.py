@@ -98,6 +98,7 @@ SIGNATURES = {
     "wise_gemm_ln_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "wise_layernorm_f32_bf16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "wise_attention_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "wise_attention_oproj_fold": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _f, _vp]),
     "wise_attention_dh_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "wise_attention_lens_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "wise_attention_causal_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),

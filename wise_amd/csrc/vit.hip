@@ -12,6 +12,7 @@
 //   qkv  bf16 [Mp, 3W]   in_proj output;       also patch-embed fp32 output [Mpp, W] before layer 0
 //   a    bf16 [Mp, F]    MLP hidden;           also the im2col patches bf16 [Mpp, Kp] before layer 0
 #include "transformer.h"
+#include "gemm_w4.h"   // the volatile-asm MFMA statement and its retire / pin helpers (attn_oproj_fold_kernel)
 
 namespace wise {
 extern int g_ablate;  // timing-only ablation switches (wise_debug_set_gemm_flags)
@@ -552,6 +553,316 @@ int attention_bf16(const bf16_t* qkv, int B, int T, int H, bf16_t* o, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fold mode, T <= 64 (ViT-B/32: 50 tokens): attention, out-projection, residual add and the rows' statistics in ONE kernel —
+// replaces attention_kernel + gemm_w4_kernel<EPI_RESID, .., FOLD 2> of a block.  One workgroup per
+// FRAME, one wave per head (H waves, H / 4 per SIMD):
+//   A. wave h: the head's V rows into LDS, then its 64 query rows in two chunks of 32 (S^T = K Q^T, softmax, O^T = V^T P^T:
+//      the arithmetic of attention_kernel<2> statement for statement); O_h as bf16 into columns 64h .. 64h+63 of an LDS image
+//      [64 rows][W] — the very bytes its V rows occupied (a head's V image IS that column block: nothing else in LDS);
+//   B. the frame's 64 x W rows times W_o^T: wave w owns output columns 64w .. 64w+63 (16 accumulator tiles), the weights come
+//      straight from L2 as MFMA operands (a W x W bf16 matrix is 1.2 MB, resident in every XCD's L2; each workgroup reads it
+//      once), three K-steps of them in flight; the activation fragments are ds_read_b128 from the image;
+//   C. x = (acc + bias) + (hi + lo), written back as hi + lo; the row's sums over the wave's 64 columns by the SAME tree as
+//      the GEMM epilogue's (gemm_w4.h epi_f32_pass: quads of columns, then 4-chunk groups, pairs of groups), the H partials
+//      added in column order, rstd = rsqrt(var + eps).  The whole row lives in this workgroup: no arrival counter, no second
+//      pass — and every bit equals the two-kernel form's (tests/test_gpu_vit_fold.py holds it to that).
+// Time: the QKV rows are read once (59 MB at bs 256), the attention output never reaches HBM (-39 MB), one launch instead of
+// two, and a frame's rows wait for nobody else's.  Roofline: HBM for phase A and C, L2 -> CU bandwidth + MFMA for phase B.
+// ------------------------------------------------------------------------------------------------
+// (debug twin only: phase ablation — bit 0 / 1 / 2 skip phase A / B / C — and s_memtime stamps of workgroup 0's waves, bit 3;
+//  tools/attn_oproj_bench.py.  In the product `dbg` is the constant 0 and all of it folds away.)
+#ifdef WISE_DEBUG_KNOBS
+__device__ unsigned long long g_ao_stamps[12][8];
+static int g_ao_dbg = 0;
+#define AO_STAMP(k) do { if ((dbg & 8) && blockIdx.x == 0 && lane == 0) g_ao_stamps[wave][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define AO_DBG_PARAM , int dbg
+#define AO_DBG_ARG , g_ao_dbg
+#else
+#define AO_STAMP(k) do {} while (0)
+#define AO_DBG_PARAM
+#define AO_DBG_ARG
+constexpr int dbg = 0;
+#endif
+template <int H>
+__global__ __launch_bounds__(64 * H, 1) void attn_oproj_fold_kernel(const bf16_t* __restrict__ qkv, int T,
+                                                                    const bf16_t* __restrict__ Wt, const float* __restrict__ bias,
+                                                                    bf16_t* __restrict__ hi, long long lo_off,
+                                                                    float* __restrict__ rstd, float eps AO_DBG_PARAM) {
+    constexpr int W = 64 * H, W3 = 3 * W, ARS = 2 * W + 16;    // image row stride in bytes: +16 keeps ds_read_b128 of 16 rows conflict-free
+    extern __shared__ __attribute__((aligned(16))) unsigned char ao_smem[];
+    unsigned char* aimg = ao_smem;
+    float* part = reinterpret_cast<float*>(ao_smem + 64 * ARS);   // [64 rows][H waves][2]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: it addresses the weights' descriptor)
+    const int l15 = lane & 15, g = lane >> 4;
+    const size_t row_first = (size_t)blockIdx.x * T;
+    const bf16_t* base = qkv + row_first * W3;
+
+    AO_STAMP(0);
+    // ---- A: attention of head `wave`
+    if (!(dbg & 1)) {
+        const int h = wave;
+        unsigned char* vimg = aimg + h * 128;
+        // every load of the head up front: V rows, K fragments, the Q fragments of both chunks (one round trip, not five)
+        uint4 vr[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int c = p * 64 + lane, key = c >> 3, part8 = c & 7;
+            const int t = key < T ? key : T - 1;
+            vr[p] = *reinterpret_cast<const uint4*>(base + (size_t)t * W3 + 2 * W + h * 64 + part8 * 8);
+            if (key >= T) vr[p] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        bf16x8 kf[4][2], qfa[2][2][2];   // (the second chunk's Q is asked for once the first chunk's scores are out: registers)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            int t = kt * 16 + l15;
+            if (t >= T) t = T - 1;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) kf[kt][s2] = *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + W + h * 64 + s2 * 32 + g * 8);
+        }
+        auto load_q = [&](int qc) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                int t = qc * 32 + qt * 16 + l15;
+                if (t >= T) t = T - 1;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) qfa[qc][qt][s] = *reinterpret_cast<const bf16x8*>(base + (size_t)t * W3 + h * 64 + s * 32 + g * 8);
+            }
+        };
+        load_q(0);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int c = p * 64 + lane, key = c >> 3, part8 = c & 7;
+            *reinterpret_cast<uint4*>(vimg + key * ARS + part8 * 16) = vr[p];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint2 okeep[2][2][4];   // [chunk][qt][dt]: both chunks' O, written once the V rows they overwrite have been read
+#pragma unroll
+        for (int qc = 0; qc < 2; ++qc) {
+            const bf16x8 (&qf)[2][2] = qfa[qc];
+            f32x4 oacc[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+            f32x4 sacc[4][2];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][s2], qf[qt][s2], c, 0, 0, 0);
+                    sacc[kt][qt] = c;
+                }
+            if (qc == 0) load_q(1);
+            bf16x8 pf[2][2];
+            {
+                const int klim[2] = {T, T};
+                if (T < 64) {
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (kt * 16 + g * 4 + r >= T) sacc[kt][qt][r] = -INFINITY;
+                }
+                softmax_block<2, false, 4>(sacc, pf, oacc, mrun, lrun, g * 4, klim);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const unsigned char* blk = vimg + (ks * 32 + g * 4 + (l15 >> 2)) * ARS + (dt * 16 + (l15 & 3) * 4) * 2;
+                    const short4v lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(blk));
+                    const short4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(blk + 16 * ARS));
+                    union { short8 s; bf16x8 f; } cv;
+                    cv.s = short8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cv.f, pf[ks][qt], oacc[dt][qt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                float l = lrun[qt];
+                l += __shfl_xor(l, 16, 64);
+                l += __shfl_xor(l, 32, 64);
+                const float inv = 1.f / l;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    okeep[qc][qt][dt].x = pack_bf16x2(oacc[dt][qt][0] * inv, oacc[dt][qt][1] * inv);
+                    okeep[qc][qt][dt].y = pack_bf16x2(oacc[dt][qt][2] * inv, oacc[dt][qt][3] * inv);
+                }
+            }
+        }
+        // every transposed read of the V rows is behind us (their results fed the MFMAs above): O_h takes their place
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int qc = 0; qc < 2; ++qc)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<uint2*>(aimg + (qc * 32 + qt * 16 + l15) * ARS + (h * 64 + dt * 16 + g * 4) * 2) = okeep[qc][qt][dt];
+    }
+    AO_STAMP(1);
+    __syncthreads();
+    AO_STAMP(2);
+
+    // ---- B: C[64, 64w .. 64w+63] = A_img[64, W] @ Wt[64w .. , :]^T.  Weights as the MFMA A operand: a lane ends up with
+    //      C[row = i*16 + l15][col = 64w + j*16 + 4g + r] in acc[i][j][r], like the GEMM family.
+    const int n0 = wave * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(dbg & 2)) {
+        // the weights in TILE order (wise_hip.h, wise_attention_oproj_fold): the fragment of (wave, K-step, k-half, column tile) is
+        // 1 KiB contiguous, lane l's 16 bytes at l * 16 — every load instruction reads eight whole 128-byte lines, and
+        // consecutive instructions walk forward through memory.  (Row-major W_o: 16 half-lines per instruction at a 1536-byte
+        // stride, every wave of every workgroup of an XCD on the same few L2 channels at the same moment — measured 10 TB/s of
+        // L2 hits chip-wide, 30 us for this phase, whatever the prefetch depth.)
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(Wt + (size_t)n0 * W), 0, 64 * W * 2, 0x00020000);
+        const int wv = lane * 16;
+        const unsigned char* ap = aimg + l15 * ARS + g * 16;
+        auto wload = [&](int j, int s32) {      // s32 = 2 * K-step + k-half
+            union { w4::u32x4_t u; bf16x8 f; } cv;
+            cv.u = __builtin_amdgcn_raw_buffer_load_b128(rW, wv, (s32 * 4 + j) * 1024, 0);
+            return cv.f;
+        };
+        // K-steps of 64: a column tile's two fragments are the two halves of the same 128-byte lines, requested back to back
+        // (32-deep steps asked for the second half a step later, when 12 waves' lines had long pushed it out of the 32 KiB L1).
+        // ONE set of fragment registers per operand, one step ahead: the MFMAs run column tile by column tile, and a tile's
+        // registers take the fragments of step s + 1 as soon as its four MFMAs have issued; the activation fragments of a
+        // k-half likewise once the half's sixteen MFMAs have issued.
+        constexpr int KS2 = W / 64;
+        bf16x8 wf[2][4], af[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wf[0][j] = wload(j, 0); wf[1][j] = wload(j, 1); }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[h2][i] = *reinterpret_cast<const bf16x8*>(ap + i * 16 * ARS + h2 * 64);
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w4::mfma16v(acc[i][j], wf[h2][j], af[h2][i]);
+                    if (s + 1 < KS2) wf[h2][j] = wload(j, 2 * (s + 1) + h2);
+                }
+                if (s + 1 < KS2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[h2][i] = *reinterpret_cast<const bf16x8*>(ap + i * 16 * ARS + (s + 1) * 128 + h2 * 64);
+                }
+            }
+        }
+        w4::mfma_retire();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w4::pin_v(acc[i][j]);
+    }
+
+    AO_STAMP(3);
+    // ---- C: residual add on hi + lo, the rows' statistics
+    if (!(dbg & 4)) {
+        // lane coordinates recomputed from an opaque copy of the thread index: nothing derived from them up there has to stay in
+        // a register through phases A and B (at 168 registers per wave one such value went to scratch)
+        int tid_c = threadIdx.x;
+        asm volatile("" : "+v"(tid_c));
+        const int l15 = tid_c & 15, g = (tid_c >> 4) & 3;
+        float4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const float4*>(bias + n0 + j * 16 + g * 4);
+        // the tile's residual values, all 32 loads in flight at once (the weights' registers are free now)
+        uint2 rha[4][4], rla[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 16 + l15;
+            const bf16_t* ph = hi + (row_first + (row < T ? row : T - 1)) * W + n0 + g * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rha[i][j] = *reinterpret_cast<const uint2*>(ph + j * 16);
+                rla[i][j] = *reinterpret_cast<const uint2*>(ph + lo_off + j * 16);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 16 + l15;
+            const bool valid = row < T;
+            bf16_t* ph = hi + (row_first + (valid ? row : T - 1)) * W + n0 + g * 4;
+            const uint2 (&rh)[4] = rha[i];
+            const uint2 (&rl)[4] = rla[i];
+            float q1[4], q2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a = acc[i][j];
+                float4 v = make_float4(a[0] + bv[j].x, a[1] + bv[j].y, a[2] + bv[j].z, a[3] + bv[j].w);
+                v.x += __uint_as_float(rh[j].x << 16) + __uint_as_float(rl[j].x << 16);
+                v.y += __uint_as_float(rh[j].x & 0xffff0000u) + __uint_as_float(rl[j].x & 0xffff0000u);
+                v.z += __uint_as_float(rh[j].y << 16) + __uint_as_float(rl[j].y << 16);
+                v.w += __uint_as_float(rh[j].y & 0xffff0000u) + __uint_as_float(rl[j].y & 0xffff0000u);
+                uint2 h2, l2;
+                h2.x = pack_bf16x2(v.x, v.y); h2.y = pack_bf16x2(v.z, v.w);
+                l2.x = pack_bf16x2(v.x - __uint_as_float(h2.x << 16), v.y - __uint_as_float(h2.x & 0xffff0000u));
+                l2.y = pack_bf16x2(v.z - __uint_as_float(h2.y << 16), v.w - __uint_as_float(h2.y & 0xffff0000u));
+                if (valid) {
+                    *reinterpret_cast<uint2*>(ph + j * 16) = h2;
+                    *reinterpret_cast<uint2*>(ph + lo_off + j * 16) = l2;
+                }
+                // chunk (4 columns) -> pair of chunks (g ^ 1) -> the four chunks of this 16-column tile (g ^ 2)
+                float s1 = ((v.x + v.y) + v.z) + v.w;
+                float s2 = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
+                s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                q1[j] = s1; q2[j] = s2;
+            }
+            if (g == 0) {
+                part[(row * H + wave) * 2] = (q1[0] + q1[1]) + (q1[2] + q1[3]);
+                part[(row * H + wave) * 2 + 1] = (q2[0] + q2[1]) + (q2[2] + q2[3]);
+            }
+        }
+    }
+    AO_STAMP(4);
+    __syncthreads();
+    AO_STAMP(5);
+    if (threadIdx.x < 64 && (int)threadIdx.x < T) {
+        const int row = threadIdx.x;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < H; ++w) { s1 += part[(row * H + w) * 2]; s2 += part[(row * H + w) * 2 + 1]; }
+        const float inv_n = 1.0f / (float)W;
+        const float mean = s1 * inv_n;
+        const float var = fmaxf(fmaf(-mean, mean, s2 * inv_n), 0.f);
+        rstd[row_first + row] = rsqrtf(var + eps);
+    }
+    AO_STAMP(6);
+}
+
+static PerDeviceOnce g_attn_oproj_once;
+bool attention_oproj_fold_ok(int T, int H, int dh) { return T >= 1 && T <= 64 && H == 12 && dh == 64; }
+int attention_oproj_fold(const bf16_t* qkv, int B, int T, int H, const bf16_t* Wt, const float* bias, bf16_t* hi, long long lo_off,
+                         float* rstd, float eps, hipStream_t st) {
+    WISE_CHECK_ARG(qkv && Wt && bias && hi && rstd && B > 0, "attention_oproj_fold: bad argument");
+    WISE_CHECK_ARG(attention_oproj_fold_ok(T, H, 64), "attention_oproj_fold: 1 <= T <= 64 and 12 heads of 64 (T=%d, H=%d)", T, H);
+    constexpr int HH = 12;
+    const int lds = 64 * (2 * 64 * HH + 16) + 64 * HH * 2 * 4;
+    g_attn_oproj_once([&] { raise_lds_limit(reinterpret_cast<const void*>(attn_oproj_fold_kernel<HH>), lds); });
+    hipLaunchKernelGGL((attn_oproj_fold_kernel<HH>), dim3((unsigned)B), dim3(64 * HH), (size_t)lds, st, qkv, T, Wt, bias, hi, lo_off, rstd, eps AO_DBG_ARG);
+    WISE_LAUNCH_CHECK("attn_oproj_fold_kernel");
+    return WISE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // patch gather (im2col): images [B,3,S,S] fp32 or u8 -> patches bf16 [B*g*g, Kp], k = c*P*P + py*P + px
 // u8 input applies (x/255 - mean)/std of the OpenAI CLIP transform (mlfoundation_openclip.py:81-90)
 // ------------------------------------------------------------------------------------------------
@@ -900,7 +1211,7 @@ int transformer_blocks(const BlockWeights& bw, int L, int W, int H, int F, int a
 // the next GEMM's operand as it stands), and no row's result depends on the batch it sits in (one epilogue implementation,
 // one reduction tree).  The attention output goes to `h`, which the unfolded form uses for the LayerNorm output.
 static int transformer_blocks_fold(const BlockWeights& bw, int L, int W, int H, int F, int act, int batch, int T, float* x,
-                                   bf16_t* h, bf16_t* qkv, bf16_t* a, float* stats, hipStream_t st, float eps) {
+                                   bf16_t* h, bf16_t* qkv, bf16_t* a, float* stats, hipStream_t st, float eps, bool fuse_attn) {
     const int M = batch * T, Mp = (M + 255) / 256 * 256;
     int rc;
     float* rstd = stats;                        // [Mp] row scales; arrival counters and partial sums behind them
@@ -915,8 +1226,12 @@ static int transformer_blocks_fold(const BlockWeights& bw, int L, int W, int H, 
         const bf16_t* lwb = bw.wb + bw.per_layer_b * l;
         const float* lpf = bw.pf + bw.per_layer_f * l;
         if ((rc = gemm_fold_bf16(hi, lwb + bw.in_proj, lpf + bw.in_b, rstd, Mp, 3 * W, W, 0, qkv, st))) return rc;
-        if ((rc = attention_bf16(qkv, batch, T, H, ao, st, false, W / H))) return rc;
-        if ((rc = gemm_fold_resid(ao, lwb + bw.out_proj, lpf + bw.out_b, Mp, W, W, hi, lo_off, stats, eps, st))) return rc;
+        if (fuse_attn) {   // ln_fold = 2: attention, out-projection, residual add and statistics of a frame in one workgroup
+            if ((rc = attention_oproj_fold(qkv, batch, T, H, lwb + bw.out_proj, lpf + bw.out_b, hi, lo_off, rstd, eps, st))) return rc;
+        } else {
+            if ((rc = attention_bf16(qkv, batch, T, H, ao, st, false, W / H))) return rc;
+            if ((rc = gemm_fold_resid(ao, lwb + bw.out_proj, lpf + bw.out_b, Mp, W, W, hi, lo_off, stats, eps, st))) return rc;
+        }
         if ((rc = gemm_fold_bf16(hi, lwb + bw.c_fc, lpf + bw.fc_b, rstd, Mp, F, W, act == 0 ? 1 : (act == 1 ? 2 : 5), a, st))) return rc;
         if ((rc = gemm_fold_resid(a, lwb + bw.c_proj, lpf + bw.proj_b, Mp, W, F, hi, lo_off, stats, eps, st))) return rc;
     }
@@ -965,12 +1280,14 @@ static int vit_dims(const wise_vit_config* c, VitDims* d) {
     WISE_CHECK_ARG(c->act >= 0 && c->act <= 2, "vit: act must be 0 (quick_gelu), 1 (gelu) or 2 (gelu, tanh form)");
     WISE_CHECK_ARG(c->arch == 0 || c->arch == 1, "vit: arch must be 0 (CLIP) or 1 (timm SigLIP: no class token, attention-pool head)");
     d->arch = c->arch;
-    WISE_CHECK_ARG(c->ln_fold == 0 || (c->ln_fold == 1 && c->arch == 0 && c->layers >= 1 && d->W >= 256),
-                   "vit: ln_fold is 0 or 1, and 1 only for arch 0 with at least one block and width >= 256");
+    WISE_CHECK_ARG(c->ln_fold == 0 || ((c->ln_fold == 1 || c->ln_fold == 2) && c->arch == 0 && c->layers >= 1 && d->W >= 256),
+                   "vit: ln_fold is 0, 1 or 2, and not 0 only for arch 0 with at least one block and width >= 256");
     d->fold = c->ln_fold;
     WISE_CHECK_ARG(d->arch == 0 || (d->D == d->W && d->H * 64 == d->W), "vit: the attention-pool head has no projection (embed_dim == width) and head dim 64");
     d->g = d->S / d->P; d->T = d->g * d->g + (d->arch == 0 ? 1 : 0); d->K = 3 * d->P * d->P; d->Kp = (d->K + 63) / 64 * 64;
     WISE_CHECK_ARG(d->arch == 0 || d->T <= 1024, "vit: the attention-pool head serves up to 1024 tokens");
+    WISE_CHECK_ARG(d->fold != 2 || attention_oproj_fold_ok(d->T, d->H, d->W / d->H),
+                   "vit: ln_fold = 2 (attention and out-projection in one kernel) serves up to 64 tokens and 12 heads of 64 (T=%d, H=%d)", d->T, d->H);
     return WISE_OK;
 }
 
@@ -1124,7 +1441,7 @@ static int vit_forward_part(const wise_vit_config* cfg, const VitDims& d, const 
                              o.fc_b, o.proj_b};
     if (d.fold) {
         if ((rc = transformer_blocks_fold(bw, d.L, W, d.H, d.F, cfg->act, batch, d.T, x, h, qkv, a,
-                                          reinterpret_cast<float*>(wsb + ws.rstd), st, 1e-5f)))
+                                          reinterpret_cast<float*>(wsb + ws.rstd), st, 1e-5f, d.fold == 2)))
             return rc;
     } else if ((rc = transformer_blocks(bw, d.L, W, d.H, d.F, cfg->act, batch, d.T, false, x, h, qkv, a, st,
                                         d.arch == 1 ? 1e-6f : 1e-5f)))
@@ -1360,6 +1677,18 @@ extern "C" int wise_layernorm_f32_bf16(const float* x, const float* w, const flo
 
 extern "C" int wise_attention_bf16(const uint16_t* qkv, int B, int T, int H, uint16_t* o, void* stream) {
     return attention_bf16(qkv, B, T, H, o, (hipStream_t)stream, false, 64);
+}
+
+#ifdef WISE_DEBUG_KNOBS
+extern "C" int wise_debug_ao_set(int flags) { wise::g_ao_dbg = flags & 15; return 0; }
+extern "C" int wise_debug_ao_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(wise::g_ao_stamps), sizeof(unsigned long long) * 96) == hipSuccess ? 0 : -1;
+}
+#endif
+extern "C" int wise_attention_oproj_fold(const uint16_t* qkv, int B, int T, int H, const uint16_t* Wt, const float* bias,
+                                         uint16_t* hi, int64_t lo_off, float* rstd, float eps, void* stream) {
+    WISE_CHECK_ARG(lo_off >= (int64_t)B * T * H * 64, "attention_oproj_fold: lo_off %lld overlaps the hi rows", (long long)lo_off);
+    return attention_oproj_fold(qkv, B, T, H, Wt, bias, hi, (long long)lo_off, rstd, eps, (hipStream_t)stream);
 }
 
 extern "C" int wise_attention_dh_bf16(const uint16_t* qkv, int B, int T, int H, int dh, uint16_t* o, void* stream) {

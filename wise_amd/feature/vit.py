@@ -29,7 +29,8 @@ class VitSpec:
     embed_dim: int
     act: str = "quick_gelu"  # 'quick_gelu' (openai tags) | 'gelu' (laion tags) | 'gelu_tanh'
     arch: int = 0            # 0 = open_clip VisionTransformer; 1 = timm ViT of the SigLIP towers (wise_amd/feature/siglip.py)
-    ln_fold: bool = False    # the blocks' LayerNorms folded into the GEMMs around them (wise_vit_config.ln_fold; pack_weights)
+    ln_fold: int = 0         # 1: the blocks' LayerNorms folded into the GEMMs around them (wise_vit_config.ln_fold; pack_weights);
+                             # 2: that, with attention + out-projection + residual add as one kernel (<= 64 tokens, 12 heads of 64)
 
     @property
     def grid(self) -> int:
@@ -58,7 +59,7 @@ class VitSpec:
     def c_config(self) -> _lib.VitConfig:
         return _lib.VitConfig(self.image_size, self.patch, self.width, self.layers, self.heads, self.mlp,
                               self.embed_dim, {"quick_gelu": 0, "gelu": 1, "gelu_tanh": 2}[self.act], self.arch,
-                              1 if self.ln_fold else 0)
+                              int(self.ln_fold))
 
 
 # open_clip model names WISE passes as id token [2]
@@ -188,7 +189,8 @@ def fold_layernorm(weight: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor
 
 def pack_weights(spec: VitSpec, sd: Dict[str, torch.Tensor]):
     """state dict -> (bf16 blob, fp32 blob) in the layout include/wise_hip.h documents (CPU tensors).  With spec.ln_fold the
-    in_proj / c_fc slots hold the folded weights and biases (fold_layernorm); the ln_1 / ln_2 slots stay as they are (unread)."""
+    in_proj / c_fc slots hold the folded weights and biases (fold_layernorm); the ln_1 / ln_2 slots stay as they are (unread);
+    with spec.ln_fold == 2 the out_proj slot holds W_o in tile order (tile_out_proj)."""
     W, F = spec.width, spec.mlp
     f32 = lambda k: sd[k].detach().to(torch.float32).cpu()
     conv = torch.zeros(W, spec.kpad, dtype=torch.float32)
@@ -203,7 +205,10 @@ def pack_weights(spec: VitSpec, sd: Dict[str, torch.Tensor]):
         if spec.ln_fold:
             w_in, b_in = fold_layernorm(w_in, b_in, f32(p + "ln_1.weight"), f32(p + "ln_1.bias"))
             w_fc, b_fc = fold_layernorm(w_fc, b_fc, f32(p + "ln_2.weight"), f32(p + "ln_2.bias"))
-        wb += [w_in.reshape(-1), f32(p + "attn.out_proj.weight").reshape(-1), w_fc.reshape(-1),
+        w_out = f32(p + "attn.out_proj.weight")
+        if spec.ln_fold == 2:       # the one-kernel attention half streams W_o in tile order
+            w_out = tile_out_proj(w_out)
+        wb += [w_in.reshape(-1), w_out.reshape(-1), w_fc.reshape(-1),
                f32(p + "mlp.c_proj.weight").reshape(-1)]
         pf += [f32(p + "ln_1.weight"), f32(p + "ln_1.bias"), b_in, f32(p + "attn.out_proj.bias"), f32(p + "ln_2.weight"),
                f32(p + "ln_2.bias"), b_fc, f32(p + "mlp.c_proj.bias")]
@@ -230,12 +235,25 @@ class PendingEmbeddings:
         return self._out
 
 
+def tile_out_proj(w: torch.Tensor) -> torch.Tensor:
+    """W_o [W, W] (out, in) -> the same elements in the order wise_attention_oproj_fold streams them (include/wise_hip.h):
+    [wave = out // 64][K-step = in // 64][k-half][column tile j][lane = 16 * g + l][8], the element being
+    W_o[64 * wave + 16 * j + l, 64 * step + 32 * half + 8 * g + e] — a (wave, step, half, j) fragment is 1 KiB contiguous."""
+    W = w.shape[0]
+    assert w.shape == (W, W) and W % 64 == 0
+    t = w.reshape(W // 64, 4, 16, W // 64, 2, 4, 8)          # wave, j, l, step, half, g, e
+    return t.permute(0, 3, 4, 1, 5, 2, 6).contiguous().reshape(W, W)
+
+
+DEFAULT_FOLD_B32 = 1   # what VitEngine picks for the ViT-B/32 shape (see its ln_fold argument)
+
+
 class VitEngine:
     """Owns the device copies of the two weight blobs and a workspace; `forward` launches the HIP
     pipeline on the current torch stream and returns a device tensor [B, D] fp32 (L2-normalised)."""
 
     def __init__(self, spec: VitSpec, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 256,
-                 ln_fold: Optional[bool] = None):
+                 ln_fold: Optional[int] = None):
         """ln_fold: fold the blocks' LayerNorms into the GEMMs around them and keep the residual stream as bf16 hi + lo (two
         launches and a whole pass over the rows fewer per LayerNorm; results within the same tolerance of the fp32 path, not
         bit-equal to the unfolded form).  None = WISE_VIT_LN_FOLD (0 / 1); default: on where it measured faster — ViT-B/32
@@ -243,10 +261,13 @@ class VitEngine:
         and off where it measured slower: B/16 (-2 %), L/14 (-2.5 %), H/14 (-3 %), whose row counts are no multiple of the 160-row
         tiles, so that the folded GEMMs fall to 128-row tiles (tools/vit_fold_ab.py, profiles/r04_fold_ab.txt).  Never for
         the timm towers (arch 1)."""
+        fused_ok = spec.heads == 12 and spec.width == 768 and spec.tokens <= 64
         if ln_fold is None:
             env = os.environ.get("WISE_VIT_LN_FOLD", "")
-            ln_fold = (env == "1") if env in ("0", "1") else (spec.arch == 0 and spec.width == 768 and spec.tokens <= 64)
-        ln_fold = bool(ln_fold) and spec.arch == 0 and spec.layers >= 1 and spec.width >= 256
+            ln_fold = int(env) if env in ("0", "1", "2") else (DEFAULT_FOLD_B32 if spec.arch == 0 and fused_ok else 0)
+        ln_fold = int(ln_fold) if (spec.arch == 0 and spec.layers >= 1 and spec.width >= 256) else 0
+        if ln_fold not in (0, 1, 2) or (ln_fold == 2 and not fused_ok):
+            raise ValueError(f"ln_fold={ln_fold}: 0, 1, or 2 (2: up to 64 tokens and 12 heads of 64 only)")
         if ln_fold != spec.ln_fold:
             spec = VitSpec(**{**spec.__dict__, "ln_fold": ln_fold})
         self.spec = spec
