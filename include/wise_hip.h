@@ -415,6 +415,18 @@ int wise_gemm_fold_resid(const uint16_t* A, const uint16_t* Wt, const float* bia
  * open_clip's ResidualAttentionBlock.attention + ls_1 + residual as reached from src/feature/mlfoundation_openclip.py:99. */
 int wise_attention_oproj_fold(const uint16_t* qkv, int B, int T, int H, const uint16_t* Wt, const float* bias, uint16_t* hi,
                               int64_t lo_off, float* rstd, float eps, void* stream);
+/* (ABI 5) x[M,C] fp32 += fc2(GELU(fc1(h))) — erf GELU, h [M,C] bf16 (the LayerNorm'd rows), fc1: C -> 4C, fc2: 4C -> C — as ONE
+ * kernel: the 4C-wide hidden activations stay in registers (rounded to bf16 where the two-GEMM form stores them).  C = 384
+ * with M % 128 == 0, or C = 192 with M % 256 == 0: the MLP of a Swin block of HTSAT's stages 3 and 2 (msclap HTSAT
+ * SwinTransformerBlock.mlp as reached from src/feature/microsoft_clap.py:49-50).  b1 [4C], b2 [C] fp32.  ws = both weight
+ * matrices as ONE bf16 stream of 8 C^2 elements in the order the kernel consumes them: for every step s of 32 hidden units
+ * (s < C/8) first the 2 * C/32 fc1 fragments (j = 0, 1; ks < C/32) and then the C/16 fc2 fragments (jn < C/16), a fragment
+ * being 64 lanes x 8 elements with lane = 16 g + l:
+ *   fc1 fragment (j, ks):  W1[32 s + 16 j + l][32 ks + 8 g + e],                        e < 8
+ *   fc2 fragment (jn):     W2[16 jn + l][32 s + 4 g + e] for e < 4,  W2[16 jn + l][32 s + 16 + 4 g + (e - 4)] for e >= 4
+ * (wise_amd/feature/htsat.py:mlp_stream_weights builds it). */
+int wise_mlp_stream(const uint16_t* h, const uint16_t* ws, const float* b1, const float* b2, float* x, int M, int C,
+                    void* stream);
 /* out[ceil256(B*T*F), cout] bf16 = relu(conv3x3(x [B,T,F,cin] bf16, position-major ("NHWC"), stride 1, zero padding 1)
  * + bias[cout]); with pool != 0 its 2x2 average pooling (floor) instead, out [B*(T/2)*(F/2), cout], computed in the same
  * kernel (the unpooled tensor is never written).  wt [cout, 9*cin] bf16 with k = (kh*3 + kw)*cin + c (BatchNorm folded

@@ -1,24 +1,34 @@
-"""HTSAT (128 clips x 10 s): the weight-resident stage-1 MLP kernel against the staged one (debug library), one batch at a time"""
-import os, sys, time
-from pathlib import Path
+"""MS-CLAP HTSAT bs=128 x 10 s with the MLPs of stages 2 and 3 as two GEMMs each or as one kernel each (wise_mlp_stream,
+wise_htsat_forward2 flags bit 1), same process, interleaved rounds:  python tools/htsat_mlp_ab.py [steps=20]"""
+import sys
+import time
+
 import torch
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-os.environ.setdefault("WISE_AMD_DEBUG_LIB", "1")
-from wise_amd import _lib
-from wise_amd.feature.htsat import HtsatEngine, random_htsat_state_dict
-lib = _lib.lib()
-eng = HtsatEngine(random_htsat_state_dict(0), max_batch=128, max_samples=480000)
-w = 0.1 * torch.randn(128, 480000, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
-outs = {}
-for rep in range(2):
-    for name, fl in (("weight-resident MLP", 0), ("staged MLP", 1 << 7)):
-        lib.wise_debug_set_gemm_flags(fl)
-        for _ in range(3): o = eng.forward(w)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(10): o = eng.forward(w)
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-        outs[name] = o.clone()
-        print(f"{name:22s}: {dt * 1e3:.3f} ms/forward  {128 / dt:.0f} clips/s", flush=True)
-a, b = outs["weight-resident MLP"], outs["staged MLP"]
-print("cosine between the two:", float(torch.nn.functional.cosine_similarity(a, b).min()), " max |diff|", float((a - b).abs().max()))
-lib.wise_debug_set_gemm_flags(0)
+
+sys.path.insert(0, ".")
+from wise_amd.feature.htsat import HtsatEngine, random_htsat_state_dict  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+engs = {f: HtsatEngine(random_htsat_state_dict(0), max_batch=128, max_samples=480000, ln_fold=False, mlp_stream=f) for f in (False, True)}
+wav = 0.1 * torch.randn(128, 480000, generator=torch.Generator(device="cuda").manual_seed(4), device="cuda")
+hold = {}
+
+
+def timed(fn):
+    for i in range(3):
+        fn(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+for rnd in range(3):
+    for f, eng in engs.items():
+        s = timed(lambda i: hold.__setitem__("o", eng.forward(wav)))
+        p = timed(lambda i: hold.__setitem__("p", eng.forward_pipelined(wav)))
+        print(f"round {rnd} mlp_stream={int(f)}: one at a time {s:.3f} ms ({128 / s:.1f} k clips/s)  two in flight {p:.3f} ms ({128 / p:.1f} k clips/s)", flush=True)
+a, b = engs[False].forward(wav).double(), engs[True].forward(wav).double()
+print("1 - cosine between the two modes (max over 128 clips):", float((1 - (a * b).sum(1)).max()))

@@ -920,7 +920,7 @@ extern "C" size_t wise_htsat_workspace_bytes(int batch, int samples) {
 static int htsat_forward_impl(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
                               float* out, void* workspace_ptr, size_t workspace_bytes, void* stream, int flags) {
     WISE_CHECK_ARG(wb && pf && wave && out, "htsat_forward: null pointer");
-    WISE_CHECK_ARG((flags & ~1) == 0, "htsat_forward: unknown flags %d", flags);
+    WISE_CHECK_ARG((flags & ~3) == 0 && flags != 3, "htsat_forward: flags %d (bit 0: LayerNorm fold, bit 1: one-kernel MLP of stages 2 and 3; not both)", flags);
     WISE_CHECK_ARG(batch >= 1 && samples >= N_FFT / 2 + 1, "htsat_forward: batch=%d samples=%d", batch, samples);
     const Ws ws = workspace(batch, samples);
     if (!workspace_ptr || workspace_bytes < ws.total) {
@@ -1022,6 +1022,13 @@ static int htsat_forward_impl(const uint16_t* wb, const float* pf, const float* 
                 // the whole MLP in one kernel: the 384-wide hidden activations (403 MB at batch 128) stay on chip
                 if ((rc = mlp96_fused(x, n2w, n2b, wf1, f1b, wf2, f2b, Mp, 1e-5f, st))) return rc;
             } else {
+                if ((flags & 2) && (C == 192 || C == 384)) {
+                    // flags bit 1: fc1, GELU and fc2 in one kernel, the hidden activations never written (mlp_stream.hip); the
+                    // packer stored the two matrices as that kernel's stream in the fc1 + fc2 slots
+                    if ((rc = layernorm_f32_bf16(x, n2w, n2b, M, C, 1e-5f, h, st))) return rc;
+                    if ((rc = mlp_stream(h, wf1, f1b, f2b, x, Mp, C, st))) return rc;
+                    continue;
+                }
                 if (fuse_ln) {
                     if ((rc = gemm_ln_bf16(x, n2w, n2b, wf1, f1b, Mp, 4 * C, C, 1e-5f, 2, a, st))) return rc;
                 } else {

@@ -70,6 +70,11 @@ int pooled_head(const float* x, const float* ln_w, const float* ln_b, const bf16
                 int D, const int* pos, bf16_t* hb, float* e, float* out, hipStream_t st, float eps = 1e-5f,
                 const float* proj_bias = nullptr /*[D]: text_projection as a Linear with bias (SigLIP)*/);
 
+// x[M,C] += fc2(GELU(fc1(h))) in one kernel, the hidden activations never leaving the register file (mlp_stream.hip): C = 384
+// (M % 128 == 0) or 192 (M % 256 == 0); ws = fc1 and fc2 as one stream in the kernel's order (wise_hip.h wise_mlp_stream)
+bool mlp_stream_ok(int M, int C);
+int mlp_stream(const bf16_t* h, const bf16_t* ws, const float* b1, const float* b2, float* x, int M, int C, hipStream_t st);
+
 // msclap Projection head (htsat.hip): lat bf16 [Bp, d_in] -> out fp32 [B, 1024], L2-normalised
 int clap_projection(const bf16_t* lat, const bf16_t* W1, const bf16_t* W2, const float* lw, const float* lb, int B,
                     int d_in, float* e, bf16_t* g, float* out, hipStream_t st);

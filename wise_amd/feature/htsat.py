@@ -120,12 +120,15 @@ def checkpoint_like_htsat_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
     return sd
 
 
+DEFAULT_MLP_STREAM = False   # what HtsatEngine picks for mlp_stream=None (see its docstring)
+
+
 class HtsatEngine:
     """Device copies of the packed weights + workspace; forward(wave [B,N] fp32) -> [B,1024] fp32 device
     tensor, L2-normalised (microsoft_clap.py:49-50)."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 128,
-                 max_samples: int = 480000, ln_fold=None):
+                 max_samples: int = 480000, ln_fold=None, mlp_stream=None):
         """ln_fold: stages 2 - 4 with their LayerNorms folded into the GEMMs around them and the residual stream as bf16
         hi + lo (wise_htsat_forward2 flags bit 0; same tolerance of the fp32 path, not bit-equal to the unfolded form).
         None = WISE_HTSAT_LN_FOLD (0 / 1), default OFF: built, parity-green and measured slower here (bs=128 x 10 s: 3.62 ->
@@ -133,16 +136,24 @@ class HtsatEngine:
         does lose its two LayerNorm launches (-34 / -10 us), but these stages are bound by the bytes of their own operands
         (K = 192 / 384: three to six K-steps per tile), and the fold's epilogue — hi + lo join and split, the statistics'
         tree — is ~45 vector instructions per 16 bytes in a kernel with one wave per SIMD: it stops hiding under the store
-        burst (projection 23.8 -> 35.0 us, patch-merging GEMMs +14 .. +30 us), and beside a second batch it holds the CU."""
+        burst (projection 23.8 -> 35.0 us, patch-merging GEMMs +14 .. +30 us), and beside a second batch it holds the CU.
+
+        mlp_stream: the MLP of every block of stages 2 and 3 as one kernel whose 4C-wide hidden activations never reach HBM
+        (wise_mlp_stream; wise_htsat_forward2 flags bit 1; the fc1 / fc2 slots then hold that kernel's weight stream).
+        None = WISE_HTSAT_MLP_STREAM (0 / 1), default DEFAULT_MLP_STREAM.  Not together with ln_fold."""
         self.lib = _lib.lib()
         self.device = torch.device(device)
         if ln_fold is None:
             ln_fold = os.environ.get("WISE_HTSAT_LN_FOLD", "0") == "1"
         self.ln_fold = bool(ln_fold)
-        self._flags = 1 if self.ln_fold else 0
+        if mlp_stream is None:
+            env = os.environ.get("WISE_HTSAT_MLP_STREAM", "")
+            mlp_stream = (env == "1") if env in ("0", "1") else DEFAULT_MLP_STREAM
+        self.mlp_stream = bool(mlp_stream) and not self.ln_fold
+        self._flags = (1 if self.ln_fold else 0) | (2 if self.mlp_stream else 0)
         nb, nf = C.c_int64(), C.c_int64()
         _lib.check(self.lib.wise_htsat_layout(C.byref(nb), C.byref(nf)), "wise_htsat_layout")
-        wb, pf = pack_htsat_weights(sd, fold=self.ln_fold)
+        wb, pf = pack_htsat_weights(sd, fold=self.ln_fold, mlp_stream=self.mlp_stream)
         if wb.numel() != nb.value or pf.numel() != nf.value:
             raise RuntimeError(f"HTSAT blob size mismatch: packed {wb.numel()}/{pf.numel()}, "
                                f"library expects {nb.value}/{nf.value}")
@@ -222,10 +233,24 @@ class HtsatEngine:
         return out
 
 
-def pack_htsat_weights(sd: Dict[str, torch.Tensor], fold: bool = False):
+def mlp_stream_weights(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """fc1 [4C, C] and fc2 [C, 4C] -> ONE tensor of 8 C^2 elements in the order wise_mlp_stream consumes them (include/wise_hip.h):
+    per step s of 32 hidden units the 2 * C/32 fc1 fragments (j, ks) and then the C/16 fc2 fragments (jn), a fragment being
+    [lane = 16 g + l][8]:  fc1: W1[32 s + 16 j + l, 32 ks + 8 g + e];  fc2: W2[16 jn + l, 32 s + 16 (e // 4) + 4 g + e % 4]."""
+    F, C = w1.shape
+    assert F == 4 * C and w2.shape == (C, F) and C % 32 == 0
+    ns = F // 32
+    a = w1.reshape(ns, 2, 16, C // 32, 4, 8).permute(0, 1, 3, 4, 2, 5)          # s, j, ks, g, l, e
+    b = w2.reshape(C // 16, 16, ns, 2, 4, 4).permute(2, 0, 4, 1, 3, 5)          # s, jn, g, l, half, e4
+    return torch.cat([a.reshape(ns, -1), b.reshape(ns, -1)], dim=1).reshape(-1).contiguous()
+
+
+def pack_htsat_weights(sd: Dict[str, torch.Tensor], fold: bool = False, mlp_stream: bool = False):
     """state dict -> (bf16 blob, fp32 blob) in the order wise_htsat_layout() documents (CPU tensors).
     fold: the qkv / fc1 weights and biases of stages 2 - 4 with norm1 / norm2 folded in (vit.fold_layernorm: gamma-scaled,
     row-centred weights, bias + W beta) — what wise_htsat_forward2 flags bit 0 expects; the norm slots stay (unread there).
+    mlp_stream: the fc1 + fc2 slots of stages 2 and 3 (C = 192, 384) hold the two matrices as wise_mlp_stream's weight stream
+    (mlp_stream_weights) — what flags bit 1 expects.
 
     bf16: per block qkv [3C,C], proj [C,C], fc1 [4C,C], fc2 [C,4C]; per stage<3 reduction [2C,4C];
           then projection.linear1 [1024,768], linear2 [1024,1024]
@@ -257,8 +282,12 @@ def pack_htsat_weights(sd: Dict[str, torch.Tensor], fold: bool = False):
                 from .vit import fold_layernorm
                 w_qkv, b_qkv = fold_layernorm(w_qkv, b_qkv, f32(p + "norm1.weight"), f32(p + "norm1.bias"))
                 w_fc1, b_fc1 = fold_layernorm(w_fc1, b_fc1, f32(p + "norm2.weight"), f32(p + "norm2.bias"))
-            wb += [w_qkv.reshape(-1), f32(p + "attn.proj.weight").reshape(-1), w_fc1.reshape(-1),
-                   f32(p + "mlp.fc2.weight").reshape(-1)]
+            w_fc2 = f32(p + "mlp.fc2.weight")
+            if mlp_stream and i in (1, 2):
+                mlp = [mlp_stream_weights(w_fc1, w_fc2)]
+            else:
+                mlp = [w_fc1.reshape(-1), w_fc2.reshape(-1)]
+            wb += [w_qkv.reshape(-1), f32(p + "attn.proj.weight").reshape(-1)] + mlp
             bias = f32(p + "attn.relative_position_bias_table")[rel_idx].reshape(64, 64, HEADS[i]).permute(2, 0, 1)
             pf += [f32(p + "norm1.weight"), f32(p + "norm1.bias"), bias.contiguous().reshape(-1),
                    b_qkv, f32(p + "attn.proj.bias"), f32(p + "norm2.weight"),
