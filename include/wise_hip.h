@@ -31,7 +31,9 @@ const char* wise_last_error(void);
  * the shadow's error norm, wise_build_flags; 3: wise_vit_config.arch, wise_text_config.no_causal / eps_e6 — the SigLIP
  * towers — and the wise_xlmr_* entry points; 4: wise_xlmr_config.pos_mode / pool / head / eps_e12 — MS-CLAP 2022's BERT
  * caption encoder — and the wise_cnn14_* entry points; 5: wise_ip_shadow_i8 / wise_ip_topk_shadow8_f32 (int8 shadow,
- * norms[4]), wise_ip_topk_shadow_workspace_bytes depends on nq and returns 0 under 2^18 rows, two-stage k up to 1024). */
+ * norms[4]), wise_ip_topk_shadow_workspace_bytes depends on nq and returns 0 under 2^18 rows, two-stage k up to 1024; and,
+ * added within 5: wise_vit_config.ln_fold, the wise_gemm_fold_* entry points, wise_attention_oproj_fold, wise_htsat_forward2,
+ * wise_mlp_stream). */
 int wise_abi_version(void);
 /* Host-side hint for the GEMM tile heuristic (no device work), local to the CALLING THREAD: on != 0 while this thread
  * enqueues batches that will run beside another stream's (two batches in flight); tilings that measured slower there
@@ -231,7 +233,10 @@ int wise_htsat_forward(const uint16_t* wb, const float* pf, const float* wave, i
                        float* out, void* workspace, size_t workspace_bytes, void* stream);
 /* (ABI 5) wise_htsat_forward with flags.  bit 0: the LayerNorms of stages 2 - 4 folded into the GEMMs around them (the
  * residual stream of those stages as bf16 hi + lo; see wise_gemm_fold_resid) — the packer must then store the folded qkv / fc1
- * weights and biases of those stages (wise_amd/feature/htsat.py:pack_htsat_weights(fold=True)).  flags 0 = wise_htsat_forward. */
+ * weights and biases of those stages (wise_amd/feature/htsat.py:pack_htsat_weights(fold=True)).  bit 1: the MLP of every block
+ * of stages 2 and 3 through wise_mlp_stream (one kernel, hidden activations in registers) — the packer must then store those
+ * blocks' fc1 + fc2 slots as that kernel's weight stream (pack_htsat_weights(mlp_stream=True)).  Not both bits.
+ * flags 0 = wise_htsat_forward. */
 int wise_htsat_forward2(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
                         float* out, void* workspace, size_t workspace_bytes, int flags, void* stream);
 /* parity tap after a forward with the same (batch, samples): what 0 = BatchNorm'd log-mel

@@ -18,14 +18,17 @@
 // registers once per wave (ds_read_b128 into a ring of fragment registers, each fragment feeding RT MFMAs).  The packer stores
 // fc1 / fc2 as ONE stream in the order the kernel consumes it (include/wise_hip.h, wise_mlp_stream): a step is C/8 KiB
 // contiguous, a fragment 1 KiB with lane l's 16 bytes at 16 l — the DMA is lane-linear, the reads conflict-free, no swizzle.
-//   C = 192: four waves x 2 row tiles (128 rows per workgroup, two workgroups per CU); C = 384: eight waves x 1 row tile.
+//   C = 192: four waves x 2 row tiles (128 rows per workgroup); C = 384: eight waves x 1 row tile.  Each instantiation stays
+//   inside the register file it is given WITHOUT compiler spills into the other half of the file: a build of the C = 192 form
+//   for two workgroups per CU (256 registers per wave: 24 values parked in AGPRs by the compiler, its copies next to the
+//   inline-assembly MFMAs whose hazards it does not know) returned garbage rows; tools/kernel_resources.py must show
+//   a96 / a192 and no scratch for these kernels.
 //
 // Measured (profiles/r04_mlp_stream_study.txt; 128 clips): stage 2 (M = 131072) 174 -> 114 us per block, stage 3 (M = 32768)
-// 102 -> 97 us; the tower one batch at a time 3.61 -> 3.37 ms, with two batches in flight 3.36 -> 3.43 ms (the two-GEMM form's
-// memory-bound epilogues already run under the other stream's loops, and this kernel shares a CU with nobody): an opt-in
-// (wise_htsat_forward2 flags bit 1).  What bounds it is in the study: a lone wave's instruction stream is additive here
-// (MFMA ~22 cycles each + 16 per fragment read + the GELU's ~72 per value + 60 - 180 per DMA), and with two waves per SIMD the
-// fragment reads (one per MFMA at one row tile per wave) fill the LDS pipe.
+// 102 -> 97 us; the tower one batch at a time 3.55 -> 3.40 ms, with two batches in flight 3.33 -> 3.21 ms (38.4 k -> 40.0 k
+// clips/s): the default (wise_htsat_forward2 flags bit 1).  What bounds it is in the study: a lone wave's instruction stream
+// is additive here (MFMA ~22 cycles each + 16 per fragment read + the GELU's ~72 per value + 60 - 180 per DMA), and with two
+// waves per SIMD the fragment reads (one per MFMA at one row tile per wave) fill the LDS pipe.
 // Roofline: MFMA (HBM: h read once, x read and written once: 10 bytes per element instead of 26).
 #include <utility>
 #include "gemm_w4.h"
@@ -87,7 +90,7 @@ __device__ __forceinline__ void gelu_stage(GeluGroup& q, const f32x4& a, const f
 }
 
 template <int C, int RT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, (C == 192 && WAVES == 4) ? 2 : 1) void mlp_stream_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ws,
+__global__ __launch_bounds__(64 * WAVES, 1) void mlp_stream_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ws,
                                                             const float* __restrict__ b1, const float* __restrict__ b2,
                                                             float* __restrict__ x) {
     using namespace w4;

@@ -179,8 +179,8 @@ class Cnn14Engine:
         if need == 0:
             raise ValueError(f"Cnn14: batch {B} x {N} samples unsupported")
         if not hasattr(self, "_slots"):
-            self._slots, self._next_slot = [{"stream": torch.cuda.Stream(device=self.device), "ws": None}
-                                            for _ in range(2)], 0
+            from .._streams import concurrent_streams   # streams SEEN to run side by side (two on one hardware queue: no overlap)
+            self._slots, self._next_slot = [{"stream": st, "ws": None} for st in concurrent_streams(2, self.device)], 0
         slot = self._slots[self._next_slot]
         self._next_slot ^= 1
         if slot["ws"] is None or slot["ws"].numel() < need:

@@ -120,7 +120,7 @@ def checkpoint_like_htsat_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
     return sd
 
 
-DEFAULT_MLP_STREAM = False   # what HtsatEngine picks for mlp_stream=None (see its docstring)
+DEFAULT_MLP_STREAM = True    # what HtsatEngine picks for mlp_stream=None (see its docstring)
 
 
 class HtsatEngine:
@@ -131,8 +131,10 @@ class HtsatEngine:
                  max_samples: int = 480000, ln_fold=None, mlp_stream=None):
         """ln_fold: stages 2 - 4 with their LayerNorms folded into the GEMMs around them and the residual stream as bf16
         hi + lo (wise_htsat_forward2 flags bit 0; same tolerance of the fp32 path, not bit-equal to the unfolded form).
-        None = WISE_HTSAT_LN_FOLD (0 / 1), default OFF: built, parity-green and measured slower here (bs=128 x 10 s: 3.62 ->
-        3.66 ms one batch at a time, 3.33 -> 3.67 ms with two in flight; profiles/r04_htsat_fold_ab.txt).  A stage-2 / -3 block
+        None = WISE_HTSAT_LN_FOLD (0 / 1), default OFF: built, parity-green and measured no faster here (bs=128 x 10 s: 3.53 ->
+        3.58 ms one batch at a time, 3.28 -> 3.28 ms with two in flight; profiles/r04_htsat_fold_ab.txt — its first
+        measurement, 3.33 -> 3.67 ms in flight, was an artefact: that engine's two streams shared a hardware queue, see
+        wise_amd/_streams.py).  A stage-2 / -3 block
         does lose its two LayerNorm launches (-34 / -10 us), but these stages are bound by the bytes of their own operands
         (K = 192 / 384: three to six K-steps per tile), and the fold's epilogue — hi + lo join and split, the statistics'
         tree — is ~45 vector instructions per 16 bytes in a kernel with one wave per SIMD: it stops hiding under the store
@@ -140,7 +142,8 @@ class HtsatEngine:
 
         mlp_stream: the MLP of every block of stages 2 and 3 as one kernel whose 4C-wide hidden activations never reach HBM
         (wise_mlp_stream; wise_htsat_forward2 flags bit 1; the fc1 / fc2 slots then hold that kernel's weight stream).
-        None = WISE_HTSAT_MLP_STREAM (0 / 1), default DEFAULT_MLP_STREAM.  Not together with ln_fold."""
+        None = WISE_HTSAT_MLP_STREAM (0 / 1), default ON: bs=128 x 10 s 3.55 -> 3.40 ms one batch at a time, 3.33 -> 3.21 ms
+        with two in flight (38.4 k -> 40.0 k clips/s; profiles/r04_mlp_stream_study.txt).  Not together with ln_fold."""
         self.lib = _lib.lib()
         self.device = torch.device(device)
         if ln_fold is None:
@@ -200,8 +203,9 @@ class HtsatEngine:
         if N < N_FFT // 2 + 1:
             raise ValueError(f"audio too short for a reflect-padded STFT: {N} samples")
         if not hasattr(self, "_slots"):
-            self._slots, self._next_slot = [{"stream": torch.cuda.Stream(device=self.device), "ws": None}
-                                            for _ in range(max(2, int(getattr(self, "batches_in_flight", 2))))], 0
+            from .._streams import concurrent_streams   # streams SEEN to run side by side (two on one hardware queue: no overlap)
+            self._slots, self._next_slot = [{"stream": st, "ws": None} for st in concurrent_streams(
+                max(2, int(getattr(self, "batches_in_flight", 2))), self.device)], 0
         need = self.lib.wise_htsat_workspace_bytes(B, N)
         slot = self._slots[self._next_slot]
         self._next_slot = (self._next_slot + 1) % len(self._slots)

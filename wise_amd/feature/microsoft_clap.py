@@ -130,7 +130,8 @@ class MicrosoftClap(FeatureExtractor):
         """Handle whose `.result()` is what `extract_audio_features` returns; two batches in flight on the GPU."""
         from .mlfoundation_openclip import _AsyncFeatures
         x = preprocessed_audio.reshape(preprocessed_audio.shape[0], preprocessed_audio.shape[2])
-        return _AsyncFeatures(self._get_engine().forward_pipelined(x))
+        eng = self._get_engine()
+        return _AsyncFeatures(eng.forward_pipelined(x), eng)
 
     def extract_text_features(self, text: List[str]) -> np.ndarray:
         """caption_encoder + L2 normalise (microsoft_clap.py:53-58) on the HIP text-tower kernels."""

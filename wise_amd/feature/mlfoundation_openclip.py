@@ -95,19 +95,24 @@ def to_pil_image(pic: torch.Tensor) -> Image.Image:
 
 class _AsyncFeatures:
     """Embeddings on their way to the host: copy queued behind the forward on a side stream, `.result()` waits for it."""
-    _copy_stream = None
 
-    def __init__(self, pending):
+    def __init__(self, pending, engine=None):
         dev = pending.device
-        if _AsyncFeatures._copy_stream is None:
-            _AsyncFeatures._copy_stream = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(_AsyncFeatures._copy_stream):
+        holder = engine if engine is not None else _AsyncFeatures
+        cs = getattr(holder, "_d2h_stream", None)
+        if cs is None:
+            # a stream SEEN to run beside the engine's own (on the hardware queue of one of them the copy of batch i would
+            # sit behind batch i + 1's forward)
+            from .._streams import concurrent_streams
+            cs = concurrent_streams(1, dev, beside=[sl["stream"] for sl in getattr(engine, "_slots", [])])[0]
+            holder._d2h_stream = cs
+        with torch.cuda.stream(cs):
             out = pending.result()                     # orders the copy stream after the forward
             self._host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
             self._host.copy_(out, non_blocking=True)
-            out.record_stream(_AsyncFeatures._copy_stream)
+            out.record_stream(cs)
             self._done = torch.cuda.Event()
-            self._done.record(_AsyncFeatures._copy_stream)
+            self._done.record(cs)
 
     def result(self) -> np.ndarray:
         self._done.synchronize()
@@ -222,8 +227,9 @@ class MlfoundationOpenClip(FeatureExtractor):
         never waits on an idle GPU (wise_amd/extract.py does)."""
         if not isinstance(images, torch.Tensor):
             raise ValueError('input to extract_features() must be an instance of torch.Tensor')
-        pending = self._get_engine().forward_pipelined(images.to(torch.float32) if images.dtype != torch.uint8 else images)
-        return _AsyncFeatures(pending)
+        eng = self._get_engine()
+        pending = eng.forward_pipelined(images.to(torch.float32) if images.dtype != torch.uint8 else images)
+        return _AsyncFeatures(pending, eng)
 
     @property
     def tokenizer(self):

@@ -340,8 +340,12 @@ class VitEngine:
             self._slots, self._next_slot = [], 0
         need = self.lib.wise_vit_workspace_bytes(C.byref(self.cfg), B)
         nslots = getattr(self, "pipeline_depth", 2)
-        while len(self._slots) < nslots:
-            self._slots.append({"stream": torch.cuda.Stream(device=self.device), "ws": None})
+        if len(self._slots) < nslots:
+            from .._streams import concurrent_streams   # streams SEEN to run side by side (two on one hardware queue: no overlap)
+            if self._slots:
+                torch.cuda.synchronize(self.device)      # (depth raised on a live engine: nothing may still run in the old slots)
+            self._slots = [{"stream": st, "ws": None} for st in concurrent_streams(nslots, self.device)]
+            self._next_slot = 0
         slot = self._slots[self._next_slot]
         self._next_slot = (self._next_slot + 1) % nslots
         if slot["ws"] is None or slot["ws"].numel() < need:
