@@ -33,7 +33,7 @@ const char* wise_last_error(void);
  * caption encoder — and the wise_cnn14_* entry points; 5: wise_ip_shadow_i8 / wise_ip_topk_shadow8_f32 (int8 shadow,
  * norms[4]), wise_ip_topk_shadow_workspace_bytes depends on nq and returns 0 under 2^18 rows, two-stage k up to 1024; and,
  * added within 5: wise_vit_config.ln_fold, the wise_gemm_fold_* entry points, wise_attention_oproj_fold, wise_htsat_forward2,
- * wise_mlp_stream). */
+ * wise_mlp_stream, wise_mlp_stream_ln). */
 int wise_abi_version(void);
 /* Host-side hint for the GEMM tile heuristic (no device work), local to the CALLING THREAD: on != 0 while this thread
  * enqueues batches that will run beside another stream's (two batches in flight); tilings that measured slower there
@@ -432,6 +432,10 @@ int wise_attention_oproj_fold(const uint16_t* qkv, int B, int T, int H, const ui
  * (wise_amd/feature/htsat.py:mlp_stream_weights builds it). */
 int wise_mlp_stream(const uint16_t* h, const uint16_t* ws, const float* b1, const float* b2, float* x, int M, int C,
                     void* stream);
+/* the same with h = LayerNorm(x; lnw, lnb, eps) computed inside the kernel from the fp32 rows (norm2 of the block: two-pass
+ * statistics in registers) — no LayerNorm launch and no h array; what wise_htsat_forward2 flags bit 1 runs. */
+int wise_mlp_stream_ln(const float* lnw, const float* lnb, float eps, const uint16_t* ws, const float* b1, const float* b2,
+                       float* x, int M, int C, void* stream);
 /* out[ceil256(B*T*F), cout] bf16 = relu(conv3x3(x [B,T,F,cin] bf16, position-major ("NHWC"), stride 1, zero padding 1)
  * + bias[cout]); with pool != 0 its 2x2 average pooling (floor) instead, out [B*(T/2)*(F/2), cout], computed in the same
  * kernel (the unpooled tensor is never written).  wt [cout, 9*cin] bf16 with k = (kh*3 + kw)*cin + c (BatchNorm folded

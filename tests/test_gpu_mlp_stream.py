@@ -76,3 +76,34 @@ def test_mlp_stream_refuses_other_shapes():
     assert lib.wise_mlp_stream(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 128, 768, _lib.stream_ptr()) != 0
     assert b"mlp_stream" in lib.wise_last_error()
     assert lib.wise_mlp_stream(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 64, 192, _lib.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("M,C", [(256, 384), (32768, 384), (128, 192), (131072, 192)])
+def test_mlp_stream_with_the_layernorm_inside(M, C):
+    """wise_mlp_stream_ln: h = LayerNorm(x) computed in the kernel — against wise_layernorm_f32_bf16 + wise_mlp_stream (the rows may
+    differ where a normalised value sits on a bf16 rounding boundary: the statistics are summed in another order)"""
+    lib = _lib.lib()
+    _, w1, w2, b1, b2, x = _inputs(M, C, M + C + 1)
+    g = torch.Generator().manual_seed(3)
+    lnw, lnb = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    x = x * (torch.rand(M, 1, generator=g) * 3 + 0.2) + torch.randn(M, 1, generator=g)          # rows of different scale and offset
+    ws = mlp_stream_weights(w1, w2).to(torch.bfloat16).cuda()
+    b1d, b2d, lwd, lbd = b1.cuda(), b2.cuda(), lnw.cuda(), lnb.cuda()
+    st = _lib.stream_ptr()
+    xa, xb = x.clone().cuda(), x.clone().cuda()
+    h = torch.empty(M, C, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.wise_layernorm_f32_bf16(xa.data_ptr(), lwd.data_ptr(), lbd.data_ptr(), M, C, 1e-5, h.data_ptr(), st), "ln")
+    _lib.check(lib.wise_mlp_stream(h.data_ptr(), ws.data_ptr(), b1d.data_ptr(), b2d.data_ptr(), xa.data_ptr(), M, C, st), "mlp")
+    _lib.check(lib.wise_mlp_stream_ln(lwd.data_ptr(), lbd.data_ptr(), 1e-5, ws.data_ptr(), b1d.data_ptr(), b2d.data_ptr(),
+                                      xb.data_ptr(), M, C, st), "mlp_ln")
+    torch.cuda.synchronize()
+    d = (xa - xb).abs().cpu()
+    assert d.max().item() <= 3e-2 and d.mean().item() <= 2e-4
+    n = min(M, 1024)
+    xd = x[:n].double()
+    hn = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-5) * lnw.double() + lnb.double()
+    hid = bf16_round(hn.float()).double() @ w1.double().t() + b1.double()
+    hid = bf16_round((0.5 * hid * (1 + torch.erf(hid / 2 ** 0.5))).float()).double()
+    want = xd + hid @ w2.double().t() + b2.double()
+    assert (xb.cpu()[:n].double() - want).abs().max().item() <= 4e-2
+    assert (xb.cpu()[:n].double() - want).abs().mean().item() <= 2e-3

@@ -1025,8 +1025,8 @@ static int htsat_forward_impl(const uint16_t* wb, const float* pf, const float* 
                 if ((flags & 2) && (C == 192 || C == 384)) {
                     // flags bit 1: fc1, GELU and fc2 in one kernel, the hidden activations never written (mlp_stream.hip); the
                     // packer stored the two matrices as that kernel's stream in the fc1 + fc2 slots
-                    if ((rc = layernorm_f32_bf16(x, n2w, n2b, M, C, 1e-5f, h, st))) return rc;
-                    if ((rc = mlp_stream(h, wf1, f1b, f2b, x, Mp, C, st))) return rc;
+                    // (norm2 happens inside the kernel, on the way into its operand registers: no LayerNorm launch, no h)
+                    if ((rc = mlp_stream(nullptr, wf1, f1b, f2b, x, Mp, C, st, n2w, n2b, 1e-5f))) return rc;
                     continue;
                 }
                 if (fuse_ln) {

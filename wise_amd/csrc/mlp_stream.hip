@@ -89,10 +89,14 @@ __device__ __forceinline__ void gelu_stage(GeluGroup& q, const f32x4& a, const f
     }
 }
 
-template <int C, int RT, int WAVES>
+// LN: the kernel reads the fp32 rows themselves and applies norm2 on the way into its operand registers (h, lnw, lnb: the
+// LayerNorm's weight and bias; two-pass statistics in registers, the four lanes that share a row exchanging two sums) — the
+// LayerNorm launch, its write of h and this kernel's read of it are gone.  !LN: h = the LayerNorm'd rows as bf16.
+template <int C, int RT, int WAVES, bool LN>
 __global__ __launch_bounds__(64 * WAVES, 1) void mlp_stream_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ ws,
                                                             const float* __restrict__ b1, const float* __restrict__ b2,
-                                                            float* __restrict__ x) {
+                                                            float* x, const float* __restrict__ lnw,
+                                                            const float* __restrict__ lnb, float eps) {
     using namespace w4;
     constexpr int KS = C / 32, NJ2 = C / 16, F = 4 * C, NSTEP = F / 32;
     constexpr int W1F = 2 * KS, NF = W1F + NJ2;          // 1-KiB fragments of a step in the stream: fc1's, then fc2's
@@ -128,11 +132,54 @@ __global__ __launch_bounds__(64 * WAVES, 1) void mlp_stream_kernel(const bf16_t*
 
     // the wave's rows of h as MFMA operands: lane (l15, g) holds h[row0 + 16 i + l15][32 ks + 8 g .. + 7]
     bf16x8 af[RT][KS];
+    if constexpr (LN) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+        for (int i = 0; i < RT; ++i) {
+            const float* xr = x + (row0 + i * 16 + l15) * C + g * 8;
+            float4 v[KS][2];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            af[i][ks] = *reinterpret_cast<const bf16x8*>(h + (row0 + i * 16 + l15) * C + ks * 32 + g * 8);
+            for (int ks = 0; ks < KS; ++ks) {
+                v[ks][0] = *reinterpret_cast<const float4*>(xr + ks * 32);
+                v[ks][1] = *reinterpret_cast<const float4*>(xr + ks * 32 + 4);
+            }
+            float sm = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                sm += ((v[ks][0].x + v[ks][0].y) + (v[ks][0].z + v[ks][0].w)) + ((v[ks][1].x + v[ks][1].y) + (v[ks][1].z + v[ks][1].w));
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            const float mean = sm * (1.0f / (float)C);
+            float q = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    v[ks][t].x -= mean; v[ks][t].y -= mean; v[ks][t].z -= mean; v[ks][t].w -= mean;
+                    q = fmaf(v[ks][t].x, v[ks][t].x, q); q = fmaf(v[ks][t].y, v[ks][t].y, q);
+                    q = fmaf(v[ks][t].z, v[ks][t].z, q); q = fmaf(v[ks][t].w, v[ks][t].w, q);
+                }
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            const float rstd = rsqrtf(q * (1.0f / (float)C) + eps);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float4 w0 = *reinterpret_cast<const float4*>(lnw + ks * 32 + g * 8), w1 = *reinterpret_cast<const float4*>(lnw + ks * 32 + g * 8 + 4);
+                const float4 c0 = *reinterpret_cast<const float4*>(lnb + ks * 32 + g * 8), c1 = *reinterpret_cast<const float4*>(lnb + ks * 32 + g * 8 + 4);
+                union { unsigned u[4]; bf16x8 f; } cv;
+                cv.u[0] = pack_bf16x2(fmaf(v[ks][0].x * rstd, w0.x, c0.x), fmaf(v[ks][0].y * rstd, w0.y, c0.y));
+                cv.u[1] = pack_bf16x2(fmaf(v[ks][0].z * rstd, w0.z, c0.z), fmaf(v[ks][0].w * rstd, w0.w, c0.w));
+                cv.u[2] = pack_bf16x2(fmaf(v[ks][1].x * rstd, w1.x, c1.x), fmaf(v[ks][1].y * rstd, w1.y, c1.y));
+                cv.u[3] = pack_bf16x2(fmaf(v[ks][1].z * rstd, w1.z, c1.z), fmaf(v[ks][1].w * rstd, w1.w, c1.w));
+                af[i][ks] = cv.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                af[i][ks] = *reinterpret_cast<const bf16x8*>(h + (row0 + i * 16 + l15) * C + ks * 32 + g * 8);
+    }
     req_w1(0); req_w1(1); req_b(0);
 
     f32x4 acc[RT][NJ2];
@@ -281,19 +328,28 @@ static PerDeviceOnce g_mlp_stream_once;
 bool mlp_stream_ok(int M, int C) { return (C == 384 || C == 192) && M > 0 && M % 128 == 0; }
 
 // ws: fc1 [4C, C] and fc2 [C, 4C] as one stream (wise_hip.h wise_mlp_stream; wise_amd/feature/htsat.py:mlp_stream_weights)
-int mlp_stream(const bf16_t* h, const bf16_t* ws, const float* b1, const float* b2, float* x, int M, int C, hipStream_t st) {
-    WISE_CHECK_ARG(h && ws && b1 && b2 && x, "mlp_stream: null pointer");
+// h != null: the LayerNorm'd rows as bf16.  h == null: lnw / lnb / eps given, the kernel normalises the fp32 rows itself.
+int mlp_stream(const bf16_t* h, const bf16_t* ws, const float* b1, const float* b2, float* x, int M, int C, hipStream_t st,
+               const float* lnw, const float* lnb, float eps) {
+    WISE_CHECK_ARG(ws && b1 && b2 && x && (h || (lnw && lnb)), "mlp_stream: null pointer");
     WISE_CHECK_ARG(mlp_stream_ok(M, C), "mlp_stream: C = 384 or 192, M %% 128 == 0 (M=%d, C=%d)", M, C);
     constexpr int L384 = 3 * (2 * 12 + 24) * 1024 + 3 * 8 * 256, L192 = 3 * (2 * 6 + 12) * 1024 + 3 * 8 * 256;
     g_mlp_stream_once([&] {
-        raise_lds_limit(reinterpret_cast<const void*>(mlp_stream_kernel<384, 1, 8>), L384);
-        raise_lds_limit(reinterpret_cast<const void*>(mlp_stream_kernel<192, 2, 4>), L192);
+        raise_lds_limit(reinterpret_cast<const void*>(mlp_stream_kernel<384, 1, 8, false>), L384);
+        raise_lds_limit(reinterpret_cast<const void*>(mlp_stream_kernel<192, 2, 4, false>), L192);
+        raise_lds_limit(reinterpret_cast<const void*>(mlp_stream_kernel<384, 1, 8, true>), L384);
+        raise_lds_limit(reinterpret_cast<const void*>(mlp_stream_kernel<192, 2, 4, true>), L192);
     });
     ProfScope prof(PROF_GEMM, 2.0 * (double)M * C * 4.0 * C * 2.0, st);
-    if (C == 384)
-        hipLaunchKernelGGL((mlp_stream_kernel<384, 1, 8>), dim3((unsigned)(M / 128)), dim3(512), (size_t)L384, st, h, ws, b1, b2, x);
+    const dim3 grid((unsigned)(M / 128));
+    if (C == 384 && h)
+        hipLaunchKernelGGL((mlp_stream_kernel<384, 1, 8, false>), grid, dim3(512), (size_t)L384, st, h, ws, b1, b2, x, lnw, lnb, eps);
+    else if (C == 384)
+        hipLaunchKernelGGL((mlp_stream_kernel<384, 1, 8, true>), grid, dim3(512), (size_t)L384, st, h, ws, b1, b2, x, lnw, lnb, eps);
+    else if (h)
+        hipLaunchKernelGGL((mlp_stream_kernel<192, 2, 4, false>), grid, dim3(256), (size_t)L192, st, h, ws, b1, b2, x, lnw, lnb, eps);
     else
-        hipLaunchKernelGGL((mlp_stream_kernel<192, 2, 4>), dim3((unsigned)(M / 128)), dim3(256), (size_t)L192, st, h, ws, b1, b2, x);
+        hipLaunchKernelGGL((mlp_stream_kernel<192, 2, 4, true>), grid, dim3(256), (size_t)L192, st, h, ws, b1, b2, x, lnw, lnb, eps);
     WISE_LAUNCH_CHECK("mlp_stream_kernel");
     return WISE_OK;
 }
@@ -302,5 +358,11 @@ int mlp_stream(const bf16_t* h, const bf16_t* ws, const float* b1, const float* 
 
 extern "C" int wise_mlp_stream(const uint16_t* h, const uint16_t* ws, const float* b1, const float* b2, float* x, int M, int C,
                                void* stream) {
-    return wise::mlp_stream(h, ws, b1, b2, x, M, C, (hipStream_t)stream);
+    WISE_CHECK_ARG(h, "mlp_stream: null pointer");
+    return wise::mlp_stream(h, ws, b1, b2, x, M, C, (hipStream_t)stream, nullptr, nullptr, 0.f);
+}
+extern "C" int wise_mlp_stream_ln(const float* lnw, const float* lnb, float eps, const uint16_t* ws, const float* b1, const float* b2,
+                                  float* x, int M, int C, void* stream) {
+    WISE_CHECK_ARG(lnw && lnb, "mlp_stream_ln: null pointer");
+    return wise::mlp_stream(nullptr, ws, b1, b2, x, M, C, (hipStream_t)stream, lnw, lnb, eps);
 }

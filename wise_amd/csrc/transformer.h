@@ -73,7 +73,9 @@ int pooled_head(const float* x, const float* ln_w, const float* ln_b, const bf16
 // x[M,C] += fc2(GELU(fc1(h))) in one kernel, the hidden activations never leaving the register file (mlp_stream.hip): C = 384
 // (M % 128 == 0) or 192 (M % 256 == 0); ws = fc1 and fc2 as one stream in the kernel's order (wise_hip.h wise_mlp_stream)
 bool mlp_stream_ok(int M, int C);
-int mlp_stream(const bf16_t* h, const bf16_t* ws, const float* b1, const float* b2, float* x, int M, int C, hipStream_t st);
+int mlp_stream(const bf16_t* h /* or null: the kernel applies LayerNorm(lnw, lnb, eps) to x itself */, const bf16_t* ws, const float* b1,
+               const float* b2, float* x, int M, int C, hipStream_t st, const float* lnw = nullptr, const float* lnb = nullptr,
+               float eps = 1e-5f);
 
 // msclap Projection head (htsat.hip): lat bf16 [Bp, d_in] -> out fp32 [B, 1024], L2-normalised
 int clap_projection(const bf16_t* lat, const bf16_t* W1, const bf16_t* W2, const float* lw, const float* lb, int B,
