@@ -110,9 +110,13 @@ def test_feature_operators_equal_the_engines(golden_dir):
     frames = torch.from_numpy(np.random.default_rng(1).integers(0, 256, size=(5, 3, 64, 64), dtype=np.uint8)).cuda()
     cfg = [spec.image_size, spec.patch, spec.width, spec.layers, spec.heads, spec.mlp, spec.embed_dim, 0]
     assert torch.equal(torch.ops.wise_hip.vit_forward(frames, eng.wb, eng.pf, cfg), eng.forward(frames))
-    heng = HtsatEngine(random_htsat_state_dict(0), max_batch=2, max_samples=192000)
+    # (the operator takes the blobs in wise_htsat_layout()'s plain order = wise_htsat_forward; the engine's default packs the
+    #  stage-2 / -3 MLP weights as wise_mlp_stream's stream for wise_htsat_forward2 flags bit 1)
+    heng = HtsatEngine(random_htsat_state_dict(0), max_batch=2, max_samples=192000, ln_fold=False, mlp_stream=False)
     w = 0.1 * torch.randn(2, 192000, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
     assert torch.equal(torch.ops.wise_hip.htsat_forward(w, heng.wb, heng.pf), heng.forward(w))
+    dflt = HtsatEngine(random_htsat_state_dict(0), max_batch=2, max_samples=192000).forward(w)
+    assert float((1 - (dflt.double() * heng.forward(w).double()).sum(1)).max()) <= 1e-4
     from wise_amd.feature.cnn14 import Cnn14Engine, conv3x3_relu, random_cnn14_state_dict
     ceng = Cnn14Engine(random_cnn14_state_dict(0), max_batch=2, max_samples=192000)
     assert torch.equal(torch.ops.wise_hip.cnn14_forward(w, ceng.wb, ceng.pf), ceng.forward(w))
