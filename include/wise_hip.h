@@ -33,7 +33,7 @@ const char* wise_last_error(void);
  * caption encoder — and the wise_cnn14_* entry points; 5: wise_ip_shadow_i8 / wise_ip_topk_shadow8_f32 (int8 shadow,
  * norms[4]), wise_ip_topk_shadow_workspace_bytes depends on nq and returns 0 under 2^18 rows, two-stage k up to 1024; and,
  * added within 5: wise_vit_config.ln_fold, the wise_gemm_fold_* entry points, wise_attention_oproj_fold, wise_htsat_forward2,
- * wise_mlp_stream, wise_mlp_stream_ln). */
+ * wise_mlp_stream, wise_mlp_stream_ln, wise_swin_qkv_attn). */
 int wise_abi_version(void);
 /* Host-side hint for the GEMM tile heuristic (no device work), local to the CALLING THREAD: on != 0 while this thread
  * enqueues batches that will run beside another stream's (two batches in flight); tilings that measured slower there
@@ -235,7 +235,9 @@ int wise_htsat_forward(const uint16_t* wb, const float* pf, const float* wave, i
  * residual stream of those stages as bf16 hi + lo; see wise_gemm_fold_resid) — the packer must then store the folded qkv / fc1
  * weights and biases of those stages (wise_amd/feature/htsat.py:pack_htsat_weights(fold=True)).  bit 1: the MLP of every block
  * of stages 2 and 3 through wise_mlp_stream (one kernel, hidden activations in registers) — the packer must then store those
- * blocks' fc1 + fc2 slots as that kernel's weight stream (pack_htsat_weights(mlp_stream=True)).  Not both bits.
+ * blocks' fc1 + fc2 slots as that kernel's weight stream (pack_htsat_weights(mlp_stream=True)).  bit 2: norm1 + QKV projection
+ * + window attention of every block of stages 2 and 3 through wise_swin_qkv_attn — the packer must then store those blocks'
+ * qkv weight and bias slots as that kernel's stream (pack_htsat_weights(attn_stream=True)).  Bit 0 excludes bits 1 and 2.
  * flags 0 = wise_htsat_forward. */
 int wise_htsat_forward2(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
                         float* out, void* workspace, size_t workspace_bytes, int flags, void* stream);
@@ -436,6 +438,17 @@ int wise_mlp_stream(const uint16_t* h, const uint16_t* ws, const float* b1, cons
  * statistics in registers) — no LayerNorm launch and no h array; what wise_htsat_forward2 flags bit 1 runs. */
 int wise_mlp_stream_ln(const float* lnw, const float* lnb, float eps, const uint16_t* ws, const float* b1, const float* b2,
                        float* x, int M, int C, void* stream);
+/* (ABI 5) norm1 + QKV projection + window attention of a Swin block of HTSAT's stages 2 / 3 (C = 192 / 384: 8 / 16 heads of 24,
+ * windows of 8 x 8 tokens on an H x H grid, cyclic shift 0 or 4) as ONE kernel: o [B*H*H, C] bf16 (original token order) =
+ * softmax(q k^T / sqrt(24) + relb[head] (+ the shift mask)) v with q | k | v = LayerNorm(x; lnw, lnb, eps) W_qkv^T + b — what
+ * wise_layernorm_f32_bf16 + wise_gemm_bf16 + the tower's window-attention kernel compute, without the normalised rows and the
+ * qkv rows ever reaching HBM (msclap HTSAT WindowAttention as reached from src/feature/microsoft_clap.py:49-50).
+ * x [B*H*H, C] fp32; relb [heads][64][64] fp32 (the expanded relative-position bias); B * (H/8)^2 even.
+ * ws = W_qkv [3C, C] as a stream of 3 * C/48 steps, step s = 3 p + t (p: pair of heads, t: 0 q, 1 k, 2 v) holding weight rows
+ * t*C + 48 p .. + 47 as 3 * C/32 fragments (j < 3, ks < C/32) of [lane = 16 g + l][8]: W[t*C + 48 p + 16 j + l][32 ks + 8 g + e];
+ * bq = the qkv bias in the same step order, 48 floats per step (wise_amd/feature/htsat.py:swin_qkv_stream builds both). */
+int wise_swin_qkv_attn(const float* x, const float* lnw, const float* lnb, float eps, const uint16_t* ws, const float* bq,
+                       const float* relb, uint16_t* o, int B, int H, int C, int shift, void* stream);
 /* out[ceil256(B*T*F), cout] bf16 = relu(conv3x3(x [B,T,F,cin] bf16, position-major ("NHWC"), stride 1, zero padding 1)
  * + bias[cout]); with pool != 0 its 2x2 average pooling (floor) instead, out [B*(T/2)*(F/2), cout], computed in the same
  * kernel (the unpooled tensor is never written).  wt [cout, 9*cin] bf16 with k = (kh*3 + kw)*cin + c (BatchNorm folded

@@ -99,6 +99,30 @@ def test_golden_with_the_one_kernel_mlp(waves, golden_dir, stress):
     assert cosine(out, plain) >= 1 - 1e-4
 
 
+@pytest.mark.parametrize("stress", [False, True])
+def test_golden_with_the_one_kernel_attention(waves, golden_dir, stress):
+    """wise_htsat_forward2 flags bit 2 (with bit 1): norm1 + QKV + window attention of stages 2 and 3 as one kernel each
+    (wise_swin_qkv_attn), shifted and unshifted blocks, against the same golden vectors at the same tolerance"""
+    if stress:
+        g = np.load(golden_dir / "htsat_stress.npz")
+        sd = checkpoint_like_htsat_state_dict(int(g["weight_seed"]))
+        rng = np.random.default_rng(int(g["wave_seed"]))
+        wave = torch.from_numpy((0.1 * rng.standard_normal((2, 192000))).astype(np.float32))
+    else:
+        g = np.load(golden_dir / "htsat.npz")
+        sd, wave = random_htsat_state_dict(0), waves[0]
+    eng = HtsatEngine(sd, max_batch=4, max_samples=480000, ln_fold=False, mlp_stream=True, attn_stream=True)
+    assert eng.attn_stream and eng._flags == 6
+    out = eng.forward(wave).cpu()
+    assert cosine(out, torch.from_numpy(g["out"])) >= 1 - 1e-3
+    x = eng.tap(1, 2 * 64, 768).cpu().reshape(2, 64, 768)
+    assert cosine(x[:, :4, :].reshape(-1, 768), torch.from_numpy(g["tap4"]).reshape(-1, 768)) >= 1 - 1e-3
+    plain = HtsatEngine(sd, max_batch=4, max_samples=480000, ln_fold=False, mlp_stream=False, attn_stream=False).forward(wave).cpu()
+    assert cosine(out, plain) >= 1 - 1e-4
+    only = HtsatEngine(sd, max_batch=4, max_samples=480000, ln_fold=False, mlp_stream=False, attn_stream=True)
+    assert only._flags == 4 and cosine(only.forward(wave).cpu(), plain) >= 1 - 1e-4
+
+
 def test_golden_4s_clips_without_the_fold(waves, golden_dir):
     """the unfolded form (LayerNorm launches, fp32 rows) stays available and inside the same tolerance"""
     w4, _ = waves

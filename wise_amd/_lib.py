@@ -94,6 +94,7 @@ SIGNATURES = {
     "wise_gemm_fold_counters_offset": (C.c_size_t, [_i]),
     "wise_gemm_fold_counters_bytes": (C.c_size_t, [_i]),
     "wise_gemm_fold_resid": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _f, _i, _vp]),
+    "wise_swin_qkv_attn": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wise_mlp_stream": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "wise_mlp_stream_ln": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "wise_mlp96_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),

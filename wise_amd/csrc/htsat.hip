@@ -920,7 +920,8 @@ extern "C" size_t wise_htsat_workspace_bytes(int batch, int samples) {
 static int htsat_forward_impl(const uint16_t* wb, const float* pf, const float* wave, int batch, int samples,
                               float* out, void* workspace_ptr, size_t workspace_bytes, void* stream, int flags) {
     WISE_CHECK_ARG(wb && pf && wave && out, "htsat_forward: null pointer");
-    WISE_CHECK_ARG((flags & ~3) == 0 && flags != 3, "htsat_forward: flags %d (bit 0: LayerNorm fold, bit 1: one-kernel MLP of stages 2 and 3; not both)", flags);
+    WISE_CHECK_ARG((flags & ~7) == 0 && (!(flags & 1) || flags == 1),
+                   "htsat_forward: flags %d (bit 0: LayerNorm fold — alone; bit 1: one-kernel MLP, bit 2: one-kernel norm1 + QKV + window attention of stages 2 and 3)", flags);
     WISE_CHECK_ARG(batch >= 1 && samples >= N_FFT / 2 + 1, "htsat_forward: batch=%d samples=%d", batch, samples);
     const Ws ws = workspace(batch, samples);
     if (!workspace_ptr || workspace_bytes < ws.total) {
@@ -1003,6 +1004,11 @@ static int htsat_forward_impl(const uint16_t* wb, const float* pf, const float* 
                     hipLaunchKernelGGL(swin96_block_attn_kernel<0>, dim3(grid), dim3(256), 0, st, x, B, n1w, n1b, wq, qb, rb,
                                        wproj, pb);
                 WISE_LAUNCH_CHECK("htsat swin96_block_attn_kernel");
+            } else if ((flags & 4) && swin_qkv_attn_ok(C, H)) {
+                // flags bit 2: norm1, the QKV projection and the window attention in one kernel (swin_stream.hip: the normalised rows
+                // and the qkv rows never written); the packer stored W_qkv and its bias as that kernel's stream
+                if ((rc = swin_qkv_attn(x, n1w, n1b, 1e-5f, wq, qb, rb, h, B, H, C, shift, st))) return rc;
+                if ((rc = gemm_bf16(h, wproj, pb, Mp, C, C, 3, x, st))) return rc;
             } else {
             if (fuse_ln) {
                 if ((rc = gemm_ln_bf16(x, n1w, n1b, wq, qb, Mp, 3 * C, C, 1e-5f, 0, qkv, st))) return rc;

@@ -77,6 +77,11 @@ int mlp_stream(const bf16_t* h /* or null: the kernel applies LayerNorm(lnw, lnb
                const float* b2, float* x, int M, int C, hipStream_t st, const float* lnw = nullptr, const float* lnb = nullptr,
                float eps = 1e-5f);
 
+// norm1 + QKV projection + window attention of a Swin block (HTSAT stages 2, 3) in one kernel (swin_stream.hip): o [B*H*H, C] bf16
+bool swin_qkv_attn_ok(int C, int H);
+int swin_qkv_attn(const float* x, const float* lnw, const float* lnb, float eps, const bf16_t* ws, const float* bq,
+                  const float* relb, bf16_t* o, int B, int H, int C, int shift, hipStream_t st);
+
 // msclap Projection head (htsat.hip): lat bf16 [Bp, d_in] -> out fp32 [B, 1024], L2-normalised
 int clap_projection(const bf16_t* lat, const bf16_t* W1, const bf16_t* W2, const float* lw, const float* lb, int B,
                     int d_in, float* e, bf16_t* g, float* out, hipStream_t st);

@@ -120,6 +120,7 @@ def checkpoint_like_htsat_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
     return sd
 
 
+DEFAULT_ATTN_STREAM = False  # what HtsatEngine picks for attn_stream=None
 DEFAULT_MLP_STREAM = True    # what HtsatEngine picks for mlp_stream=None (see its docstring)
 
 
@@ -128,7 +129,7 @@ class HtsatEngine:
     tensor, L2-normalised (microsoft_clap.py:49-50)."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], device: str = "cuda", max_batch: int = 128,
-                 max_samples: int = 480000, ln_fold=None, mlp_stream=None):
+                 max_samples: int = 480000, ln_fold=None, mlp_stream=None, attn_stream=None):
         """ln_fold: stages 2 - 4 with their LayerNorms folded into the GEMMs around them and the residual stream as bf16
         hi + lo (wise_htsat_forward2 flags bit 0; same tolerance of the fp32 path, not bit-equal to the unfolded form).
         None = WISE_HTSAT_LN_FOLD (0 / 1), default OFF: built, parity-green and measured no faster here (bs=128 x 10 s: 3.53 ->
@@ -143,7 +144,12 @@ class HtsatEngine:
         mlp_stream: the MLP of every block of stages 2 and 3 as one kernel whose 4C-wide hidden activations never reach HBM
         (wise_mlp_stream; wise_htsat_forward2 flags bit 1; the fc1 / fc2 slots then hold that kernel's weight stream).
         None = WISE_HTSAT_MLP_STREAM (0 / 1), default ON: bs=128 x 10 s 3.55 -> 3.40 ms one batch at a time, 3.33 -> 3.21 ms
-        with two in flight (38.4 k -> 40.0 k clips/s; profiles/r04_mlp_stream_study.txt).  Not together with ln_fold."""
+        with two in flight (38.4 k -> 40.0 k clips/s; profiles/r04_mlp_stream_study.txt).  Not together with ln_fold.
+
+        attn_stream: norm1 + QKV projection + window attention of every block of stages 2 and 3 as one kernel (wise_swin_qkv_attn,
+        flags bit 2; the qkv slots then hold that kernel's stream).  None = WISE_HTSAT_ATTN_STREAM (0 / 1), default OFF: bs=128 x
+        10 s 3.27 -> 3.21 ms one batch at a time, 3.01 -> 3.01 ms with two in flight (profiles/r04_swin_stream_study.txt).  Not
+        together with ln_fold."""
         self.lib = _lib.lib()
         self.device = torch.device(device)
         if ln_fold is None:
@@ -153,10 +159,14 @@ class HtsatEngine:
             env = os.environ.get("WISE_HTSAT_MLP_STREAM", "")
             mlp_stream = (env == "1") if env in ("0", "1") else DEFAULT_MLP_STREAM
         self.mlp_stream = bool(mlp_stream) and not self.ln_fold
-        self._flags = (1 if self.ln_fold else 0) | (2 if self.mlp_stream else 0)
+        if attn_stream is None:
+            env = os.environ.get("WISE_HTSAT_ATTN_STREAM", "")
+            attn_stream = (env == "1") if env in ("0", "1") else DEFAULT_ATTN_STREAM
+        self.attn_stream = bool(attn_stream) and not self.ln_fold
+        self._flags = (1 if self.ln_fold else 0) | (2 if self.mlp_stream else 0) | (4 if self.attn_stream else 0)
         nb, nf = C.c_int64(), C.c_int64()
         _lib.check(self.lib.wise_htsat_layout(C.byref(nb), C.byref(nf)), "wise_htsat_layout")
-        wb, pf = pack_htsat_weights(sd, fold=self.ln_fold, mlp_stream=self.mlp_stream)
+        wb, pf = pack_htsat_weights(sd, fold=self.ln_fold, mlp_stream=self.mlp_stream, attn_stream=self.attn_stream)
         if wb.numel() != nb.value or pf.numel() != nf.value:
             raise RuntimeError(f"HTSAT blob size mismatch: packed {wb.numel()}/{pf.numel()}, "
                                f"library expects {nb.value}/{nf.value}")
@@ -249,7 +259,18 @@ def mlp_stream_weights(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     return torch.cat([a.reshape(ns, -1), b.reshape(ns, -1)], dim=1).reshape(-1).contiguous()
 
 
-def pack_htsat_weights(sd: Dict[str, torch.Tensor], fold: bool = False, mlp_stream: bool = False):
+def swin_qkv_stream(w_qkv: torch.Tensor, b_qkv: torch.Tensor):
+    """W_qkv [3C, C], b [3C] -> (the weights as wise_swin_qkv_attn's stream, the bias in its step order): step s = 3 p + t (p: pair of
+    heads, t: q / k / v) holds rows t*C + 48 p .. + 47 as fragments (j < 3, ks) of [lane = 16 g + l][8] (include/wise_hip.h)."""
+    C3, C = w_qkv.shape
+    assert C3 == 3 * C and C % 96 == 0
+    npair = C // 48
+    w = w_qkv.reshape(3, npair, 3, 16, C // 32, 4, 8).permute(1, 0, 2, 4, 5, 3, 6)      # p, t, j, ks, g, l, e
+    b = b_qkv.reshape(3, npair, 48).permute(1, 0, 2)
+    return w.reshape(-1).contiguous(), b.reshape(-1).contiguous()
+
+
+def pack_htsat_weights(sd: Dict[str, torch.Tensor], fold: bool = False, mlp_stream: bool = False, attn_stream: bool = False):
     """state dict -> (bf16 blob, fp32 blob) in the order wise_htsat_layout() documents (CPU tensors).
     fold: the qkv / fc1 weights and biases of stages 2 - 4 with norm1 / norm2 folded in (vit.fold_layernorm: gamma-scaled,
     row-centred weights, bias + W beta) — what wise_htsat_forward2 flags bit 0 expects; the norm slots stay (unread there).
@@ -286,6 +307,8 @@ def pack_htsat_weights(sd: Dict[str, torch.Tensor], fold: bool = False, mlp_stre
                 from .vit import fold_layernorm
                 w_qkv, b_qkv = fold_layernorm(w_qkv, b_qkv, f32(p + "norm1.weight"), f32(p + "norm1.bias"))
                 w_fc1, b_fc1 = fold_layernorm(w_fc1, b_fc1, f32(p + "norm2.weight"), f32(p + "norm2.bias"))
+            if attn_stream and i in (1, 2):      # W_qkv and its bias as wise_swin_qkv_attn's stream (same sizes, another order)
+                w_qkv, b_qkv = swin_qkv_stream(w_qkv, b_qkv)
             w_fc2 = f32(p + "mlp.fc2.weight")
             if mlp_stream and i in (1, 2):
                 mlp = [mlp_stream_weights(w_fc1, w_fc2)]
