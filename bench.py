@@ -617,7 +617,9 @@ def main():
             ln_fused = False                # (LayerNorm inside the GEMM's A-tile build: only stage 1 used it, and stage 1 is now
             mlp_fused = C_ == 96            #  two kernels per block:) the attention half and the whole MLP, one kernel each
             mlp_stream = heng.mlp_stream and C_ in (192, 384)      # LayerNorm launch + wise_mlp_stream: the hidden rows never written
-            attn_half = 2 * x32 if C_ == 96 else (x32 + a16 + a16 + 3 * a16) + (3 * a16 + a16) + (a16 + 2 * x32)
+            attn_stream = heng.attn_stream and C_ in (192, 384)    # wise_swin_qkv_attn (x in, attention output out) + the projection GEMM
+            attn_half = 2 * x32 if C_ == 96 else ((x32 + a16) + (a16 + 2 * x32) if attn_stream else
+                                                  (x32 + a16 + a16 + 3 * a16) + (3 * a16 + a16) + (a16 + 2 * x32))
             mlp_half = 2 * x32 if mlp_fused else ((x32 + a16) + (a16 + 2 * x32) if mlp_stream else
                                                   ((x32 + 4 * a16 if ln_fused else x32 + a16 + a16 + 4 * a16) + 4 * a16 + 2 * x32))
             blocks += depth * (attn_half + mlp_half)
@@ -631,7 +633,8 @@ def main():
                                "one_batch_at_a_time_clips_per_s": round(world * ab * a_steps / adt_serial, 1),
                                "config": {"workload": "MS-CLAP 2023 HTSAT audio encoder + projection, 10-s clips "
                                                       "(480000 samples @48 kHz), bs=128 per GPU", "dtype": "bf16",
-                                          "gflop_per_clip": 11.82, "one_kernel_mlp_stages_2_3": bool(heng.mlp_stream)},
+                                          "gflop_per_clip": 11.82, "one_kernel_mlp_stages_2_3": bool(heng.mlp_stream),
+                                          "one_kernel_attention_stages_2_3": bool(heng.attn_stream)},
                                "tflops": round(world * ab * a_steps / adt * 11.82e9 / 1e12 / world, 2),
                                "roofline": {
                                    "kernel": "whole forward, one batch at a time (front end + 12 Swin blocks + head)",

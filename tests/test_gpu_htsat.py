@@ -89,13 +89,13 @@ def test_golden_with_the_one_kernel_mlp(waves, golden_dir, stress):
     else:
         g = np.load(golden_dir / "htsat.npz")
         sd, wave = random_htsat_state_dict(0), waves[0]
-    eng = HtsatEngine(sd, max_batch=4, max_samples=480000, ln_fold=False, mlp_stream=True)
+    eng = HtsatEngine(sd, max_batch=4, max_samples=480000, ln_fold=False, mlp_stream=True, attn_stream=False)
     assert eng.mlp_stream and eng._flags == 2
     out = eng.forward(wave).cpu()
     assert cosine(out, torch.from_numpy(g["out"])) >= 1 - 1e-3
     x = eng.tap(1, 2 * 64, 768).cpu().reshape(2, 64, 768)
     assert cosine(x[:, :4, :].reshape(-1, 768), torch.from_numpy(g["tap4"]).reshape(-1, 768)) >= 1 - 1e-3
-    plain = HtsatEngine(sd, max_batch=4, max_samples=480000, ln_fold=False, mlp_stream=False).forward(wave).cpu()
+    plain = HtsatEngine(sd, max_batch=4, max_samples=480000, ln_fold=False, mlp_stream=False, attn_stream=False).forward(wave).cpu()
     assert cosine(out, plain) >= 1 - 1e-4
 
 

@@ -41,7 +41,7 @@ def _reference(x, lnw, lnb, w, bq, relb, B, H, C, shift):
     return o.reshape(B * H * H, C)
 
 
-@pytest.mark.parametrize("B,H,C,shift", [(2, 16, 384, 0), (2, 16, 384, 4), (1, 32, 192, 0), (2, 32, 192, 4), (128, 16, 384, 4)])
+@pytest.mark.parametrize("B,H,C,shift", [(2, 16, 384, 0), (2, 16, 384, 4), (1, 32, 192, 0), (2, 32, 192, 4), (128, 16, 384, 4), (64, 32, 192, 4), (3, 16, 192, 4), (2, 8, 192, 0), (6, 8, 192, 4)])
 def test_swin_qkv_attn_against_float64(B, H, C, shift):
     lib = _lib.lib()
     heads = C // 24

@@ -112,7 +112,7 @@ def test_feature_operators_equal_the_engines(golden_dir):
     assert torch.equal(torch.ops.wise_hip.vit_forward(frames, eng.wb, eng.pf, cfg), eng.forward(frames))
     # (the operator takes the blobs in wise_htsat_layout()'s plain order = wise_htsat_forward; the engine's default packs the
     #  stage-2 / -3 MLP weights as wise_mlp_stream's stream for wise_htsat_forward2 flags bit 1)
-    heng = HtsatEngine(random_htsat_state_dict(0), max_batch=2, max_samples=192000, ln_fold=False, mlp_stream=False)
+    heng = HtsatEngine(random_htsat_state_dict(0), max_batch=2, max_samples=192000, ln_fold=False, mlp_stream=False, attn_stream=False)
     w = 0.1 * torch.randn(2, 192000, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
     assert torch.equal(torch.ops.wise_hip.htsat_forward(w, heng.wb, heng.pf), heng.forward(w))
     dflt = HtsatEngine(random_htsat_state_dict(0), max_batch=2, max_samples=192000).forward(w)

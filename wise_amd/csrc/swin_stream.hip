@@ -6,7 +6,8 @@
 // SwinTransformerBlock).  The three-kernel form (LayerNorm, QKV GEMM, swin_attention_kernel) writes the normalised rows and the
 // 3C-wide qkv rows to HBM and reads them back (stage 3: 2 x 25 + 2 x 75 MB per block, stage 2: 2 x 50 + 2 x 151 MB at 128
 // clips) — after the one-kernel MLP (mlp_stream.hip) the largest remaining item of the tower's excess traffic, and 39 % of
-// its time.  Here a workgroup owns TWO windows (4 waves, one per SIMD; a wave = 32 of a window's 64 tokens):
+// its time.  Here a workgroup owns TWO windows (4 waves, one per SIMD; C = 192: FOUR windows, 8 waves — one wave's softmax under
+// the other's MFMAs: stage 2 one batch at a time -4 %); a wave = 32 of a window's 64 tokens:
 //   prologue  the wave gathers its rows of x by the window / cyclic-shift mapping, normalises them (two-pass statistics in
 //             registers) and keeps them as MFMA operand fragments for the whole kernel (in the accumulator file: 96 registers);
 //   steps     the weights arrive as a stream of 48-column blocks — the q, then k, then v columns of a PAIR of heads (head dim 24:
@@ -47,8 +48,10 @@ __device__ __forceinline__ void static_for(Fn&& fn) { static_for_impl(std::make_
 
 constexpr int VRS = 144;     // bytes per key row of the v image (48 head dims of a pair + room for the second head's 16-wide tiles)
 
-template <int C>
-__global__ __launch_bounds__(256, 1) void swin_qkv_attn_kernel(const float* __restrict__ x, const float* __restrict__ lnw,
+// NWIN windows per workgroup, two waves each (NWIN = 2: one wave per SIMD; NWIN = 4: two per SIMD — one wave's softmax runs under
+// the other's MFMAs, and a step's weight fragments serve twice the rows)
+template <int C, int NWIN>
+__global__ __launch_bounds__(128 * NWIN, 1) void swin_qkv_attn_kernel(const float* __restrict__ x, const float* __restrict__ lnw,
                                                                const float* __restrict__ lnb, float eps,
                                                                const bf16_t* __restrict__ ws, const float* __restrict__ bq,
                                                                const float* __restrict__ relb, bf16_t* __restrict__ o,
@@ -56,16 +59,18 @@ __global__ __launch_bounds__(256, 1) void swin_qkv_attn_kernel(const float* __re
     using namespace w4;
     constexpr int HEADS = C / 24, NP = HEADS / 2, NSTEP = 3 * NP, KS = C / 32;
     constexpr int NF = 3 * KS, STEP = NF * 1024;             // fragments (1 KiB) and bytes of a step: 48 weight rows x C
-    constexpr int PW = (NF + 3) / 4, NW = PW + 1;             // DMAs per wave and step
-    constexpr int RB = 3 * STEP, KV = RB + 3 * 1024;          // bias ring (4 waves x 256 B per slot), then the k / v images
+    constexpr int WAVES = 2 * NWIN;
+    constexpr int PW = (NF + WAVES - 1) / WAVES, NW = PW + 1; // DMAs per wave and step
+    constexpr int BSL = WAVES * 256;                          // a bias slot: every wave's own 256-byte copy
+    constexpr int RB = 3 * STEP, KV = RB + 3 * BSL;           // bias ring, then the k / v images
     constexpr int KIMG = 8 * 1024, VIMG = 64 * VRS, WIN = KIMG + VIMG;   // per window: [head of pair][key tile][1 KiB], [key][VRS]
-    static_assert(KV + 2 * WIN <= 160 * 1024 && HEADS % 2 == 0, "shape");
+    static_assert(KV + NWIN * WIN <= 160 * 1024 && HEADS % 2 == 0, "shape");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const int wsel = wave >> 1, half = wave & 1;              // which of the workgroup's two windows, which half of its tokens
     const int W = H, nwx = W >> 3, nwin = (H >> 3) * nwx;
-    const long long wing = (long long)blockIdx.x * 2 + wsel;
+    const long long wing = (long long)blockIdx.x * NWIN + wsel;
     const int b = (int)(wing / nwin), win = (int)(wing % nwin);
     const int wy = win / nwx, wx = win % nwx;
     // token p (0..63) of this window -> row in the original layout, and its shift-region id (as swin_attention_kernel)
@@ -91,8 +96,8 @@ __global__ __launch_bounds__(256, 1) void swin_qkv_attn_kernel(const float* __re
     auto request = [&](int t) {
         const unsigned slot = (t % 3) * STEP;
 #pragma unroll
-        for (int k = 0; k < PW; ++k) { const int u = (k * 4 + wave) % NF; dma16(rS, slot + u * 1024, lane * 16, t * STEP + u * 1024); }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(uintptr_t)(RB + (t % 3) * 1024 + wave * 256), 4, lane * 4, t * 192, 0, 0);
+        for (int k = 0; k < PW; ++k) { const int u = (k * WAVES + wave) % NF; dma16(rS, slot + u * 1024, lane * 16, t * STEP + u * 1024); }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(uintptr_t)(RB + (t % 3) * BSL + wave * 256), 4, lane * 4, t * 192, 0, 0);
     };
 
     // ---- prologue: gather, LayerNorm, operand fragments: lane (l15, g) holds LN(x)[row][32 ks + 8 g .. + 7]
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void swin_qkv_attn_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             bv[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(
-                (lds_cptr)(uintptr_t)(RB + (s % 3) * 1024 + wave * 256 + (j * 16 + g * 4) * 4));
+                (lds_cptr)(uintptr_t)(RB + (s % 3) * BSL + wave * 256 + (j * 16 + g * 4) * 4));
         mfma_retire();
         unsigned pk[2][3][2];
 #pragma unroll
@@ -352,17 +357,20 @@ int swin_qkv_attn(const float* x, const float* lnw, const float* lnb, float eps,
     WISE_CHECK_ARG(swin_qkv_attn_ok(C, H) && (shift == 0 || shift == 4), "swin_qkv_attn: C = 192 or 384, H %% 8 == 0, shift 0 or 4 (C=%d, H=%d, shift=%d)", C, H, shift);
     const long long nwin = (long long)B * (H / 8) * (H / 8);
     WISE_CHECK_ARG(nwin % 2 == 0, "swin_qkv_attn: an even number of windows (%lld)", nwin);
-    constexpr int L384 = 3 * 36 * 1024 + 3 * 1024 + 2 * (8 * 1024 + 64 * VRS), L192 = 3 * 18 * 1024 + 3 * 1024 + 2 * (8 * 1024 + 64 * VRS);
+    constexpr int WINB = 8 * 1024 + 64 * VRS;
+    constexpr int L384 = 3 * 36 * 1024 + 3 * 4 * 256 + 2 * WINB, L192 = 3 * 18 * 1024 + 3 * 4 * 256 + 2 * WINB, L192W = 3 * 18 * 1024 + 3 * 8 * 256 + 4 * WINB;
     g_once([&] {
-        raise_lds_limit(reinterpret_cast<const void*>(swin_qkv_attn_kernel<384>), L384);
-        raise_lds_limit(reinterpret_cast<const void*>(swin_qkv_attn_kernel<192>), L192);
+        raise_lds_limit(reinterpret_cast<const void*>(swin_qkv_attn_kernel<384, 2>), L384);
+        raise_lds_limit(reinterpret_cast<const void*>(swin_qkv_attn_kernel<192, 2>), L192);
+        raise_lds_limit(reinterpret_cast<const void*>(swin_qkv_attn_kernel<192, 4>), L192W);
     });
     ProfScope prof(PROF_GEMM, 2.0 * (double)B * H * H * C * 3.0 * C, st);
-    const dim3 grid((unsigned)(nwin / 2));
     if (C == 384)
-        hipLaunchKernelGGL(swin_qkv_attn_kernel<384>, grid, dim3(256), (size_t)L384, st, x, lnw, lnb, eps, ws, bq, relb, o, H, shift);
+        hipLaunchKernelGGL((swin_qkv_attn_kernel<384, 2>), dim3((unsigned)(nwin / 2)), dim3(256), (size_t)L384, st, x, lnw, lnb, eps, ws, bq, relb, o, H, shift);
+    else if (nwin % 4 == 0)
+        hipLaunchKernelGGL((swin_qkv_attn_kernel<192, 4>), dim3((unsigned)(nwin / 4)), dim3(512), (size_t)L192W, st, x, lnw, lnb, eps, ws, bq, relb, o, H, shift);
     else
-        hipLaunchKernelGGL(swin_qkv_attn_kernel<192>, grid, dim3(256), (size_t)L192, st, x, lnw, lnb, eps, ws, bq, relb, o, H, shift);
+        hipLaunchKernelGGL((swin_qkv_attn_kernel<192, 2>), dim3((unsigned)(nwin / 2)), dim3(256), (size_t)L192, st, x, lnw, lnb, eps, ws, bq, relb, o, H, shift);
     WISE_LAUNCH_CHECK("swin_qkv_attn_kernel");
     return WISE_OK;
 }

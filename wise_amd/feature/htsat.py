@@ -120,7 +120,7 @@ def checkpoint_like_htsat_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
     return sd
 
 
-DEFAULT_ATTN_STREAM = False  # what HtsatEngine picks for attn_stream=None
+DEFAULT_ATTN_STREAM = True   # what HtsatEngine picks for attn_stream=None
 DEFAULT_MLP_STREAM = True    # what HtsatEngine picks for mlp_stream=None (see its docstring)
 
 
@@ -147,8 +147,8 @@ class HtsatEngine:
         with two in flight (38.4 k -> 40.0 k clips/s; profiles/r04_mlp_stream_study.txt).  Not together with ln_fold.
 
         attn_stream: norm1 + QKV projection + window attention of every block of stages 2 and 3 as one kernel (wise_swin_qkv_attn,
-        flags bit 2; the qkv slots then hold that kernel's stream).  None = WISE_HTSAT_ATTN_STREAM (0 / 1), default OFF: bs=128 x
-        10 s 3.27 -> 3.21 ms one batch at a time, 3.01 -> 3.01 ms with two in flight (profiles/r04_swin_stream_study.txt).  Not
+        flags bit 2; the qkv slots then hold that kernel's stream).  None = WISE_HTSAT_ATTN_STREAM (0 / 1), default ON: bs=128 x
+        10 s 3.46 -> 3.31 ms one batch at a time, 3.13 -> 3.10 ms with two in flight (profiles/r04_swin_stream_study.txt).  Not
         together with ln_fold."""
         self.lib = _lib.lib()
         self.device = torch.device(device)
