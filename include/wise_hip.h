@@ -33,7 +33,7 @@ const char* wise_last_error(void);
  * caption encoder — and the wise_cnn14_* entry points; 5: wise_ip_shadow_i8 / wise_ip_topk_shadow8_f32 (int8 shadow,
  * norms[4]), wise_ip_topk_shadow_workspace_bytes depends on nq and returns 0 under 2^18 rows, two-stage k up to 1024; and,
  * added within 5: wise_vit_config.ln_fold, the wise_gemm_fold_* entry points, wise_attention_oproj_fold, wise_htsat_forward2,
- * wise_mlp_stream, wise_mlp_stream_ln, wise_swin_qkv_attn). */
+ * wise_mlp_stream, wise_mlp_stream_ln, wise_swin_qkv_attn, the wise_ivf_* build entry points). */
 int wise_abi_version(void);
 /* Host-side hint for the GEMM tile heuristic (no device work), local to the CALLING THREAD: on != 0 while this thread
  * enqueues batches that will run beside another stream's (two batches in flight); tilings that measured slower there
@@ -148,6 +148,28 @@ int wise_ip_scores_f32(const float* X, int64_t N, int d, const float* Q, int nq,
  * index order, -1 padding when n < k.  The second half of the coarse stage (scores from wise_ip_scores_f32).  NaN
  * scores are not supported. */
 int wise_select_topk_f32(const float* scores, int rows, int n, int k, int64_t* out, void* stream);
+/* (ABI 5) Building an IndexIVFFlat on the device without a vendor kernel: the bookkeeping of `index.train(features)` (spherical
+ * k-means) and of `index.add_with_ids(...)` / the grouping by list (src/index/feature_search_index.py:53-76; faiss Clustering,
+ * IndexIVF.add).  All deterministic: the same inputs give the same bits run after run.
+ *   wise_ivf_argmax: out[r] = argmax_c scores[r, c] (ties: the lowest c; a row of NaNs: 0).
+ *   wise_ivf_group: order [n] = the row numbers grouped by list, STABLE (rows of a list in ascending row number), list_off
+ *     [nlist + 1] their offsets, counts [nlist] (or null); assign values in [0, nlist), nlist <= 2^24; workspace of
+ *     wise_ivf_group_workspace_bytes(n, nlist) bytes.
+ *   wise_ivf_list_sums: sums[c, :] = the sum of x[order[i], :] over list c's entries, added in that order (d % 4 == 0).
+ *   wise_ivf_normalize_rows: out[r, :] = in[r, :] / max(||in[r, :]||, 1e-20) (may be in place).
+ *   wise_ivf_reseed: sums[empty[e], :] = sums[donor[e], :] * (1 + 1e-3 sign(.)).
+ *   wise_ivf_gather_rows / _i64: out[i] = x[idx[i]] (rows of d floats, d % 4 == 0 / int64 scalars).
+ *   wise_ivf_expand_lists: out[list_off[c] .. list_off[c + 1]) = c. */
+int wise_ivf_argmax(const float* scores, int rows, int n, int64_t* out, void* stream);
+size_t wise_ivf_group_workspace_bytes(int64_t n, int nlist);
+int wise_ivf_group(const int64_t* assign, int64_t n, int nlist, int64_t* order, int64_t* list_off, int64_t* counts, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int wise_ivf_list_sums(const float* x, const int64_t* order, const int64_t* list_off, int nlist, int d, float* sums, void* stream);
+int wise_ivf_normalize_rows(const float* in, int rows, int d, float* out, void* stream);
+int wise_ivf_reseed(float* sums, const int64_t* empty, const int64_t* donor, int n_empty, int d, void* stream);
+int wise_ivf_gather_rows(const float* x, const int64_t* idx, int64_t n, int d, float* out, void* stream);
+int wise_ivf_gather_i64(const int64_t* a, const int64_t* idx, int64_t n, int64_t* out, void* stream);
+int wise_ivf_expand_lists(const int64_t* list_off, int nlist, int64_t* out, void* stream);
 
 /* Merge `parts` partial top-k lists (e.g. one per GPU after the RCCL all-gather) into one.
  * inD [parts,nq,k] fp32, inI [parts,nq,k] int64 (entries with id -1 are padding) -> outD/outI [nq,k].

@@ -94,6 +94,15 @@ SIGNATURES = {
     "wise_gemm_fold_counters_offset": (C.c_size_t, [_i]),
     "wise_gemm_fold_counters_bytes": (C.c_size_t, [_i]),
     "wise_gemm_fold_resid": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _f, _i, _vp]),
+    "wise_ivf_argmax": (_i, [_vp, _i, _i, _vp, _vp]),
+    "wise_ivf_group_workspace_bytes": (_sz, [_i64, _i]),
+    "wise_ivf_group": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "wise_ivf_list_sums": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "wise_ivf_normalize_rows": (_i, [_vp, _i, _i, _vp, _vp]),
+    "wise_ivf_reseed": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "wise_ivf_gather_rows": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "wise_ivf_gather_i64": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "wise_ivf_expand_lists": (_i, [_vp, _i, _vp, _vp]),
     "wise_swin_qkv_attn": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wise_mlp_stream": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "wise_mlp_stream_ln": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp]),

@@ -29,7 +29,7 @@ LIB = LIBDIR / "libwise_hip.so"
 LIB_DEBUG = LIBDIR / "libwise_hip_debug.so"
 HEADER = ROOT / "include" / "wise_hip.h"
 HIP_SOURCES = ["common.hip", "ip_topk.hip", "ip_topk_mfma.hip", "gemm_bf16.hip", "vit.hip", "htsat.hip",
-               "htsat_frontend.hip", "preprocess.hip", "text.hip", "xlmr_text.hip", "cnn14.hip", "mlp_stream.hip", "swin_stream.hip"]
+               "htsat_frontend.hip", "preprocess.hip", "text.hip", "xlmr_text.hip", "cnn14.hip", "mlp_stream.hip", "swin_stream.hip", "ivf_build.hip"]
 DEBUG_ONLY_SOURCES = ["debug_probe.hip"]
 ARCH = "gfx950"
 # No packed f32 VALU math in the product kernels.  Kernels that use v_pk_{fma,mul,add}_f32 have twice been caught

@@ -71,44 +71,75 @@ class IVFFlatIPIndex:
         _lib.lib()  # raises without a gfx950 device: there is no CPU path
 
     # -- training -------------------------------------------------------------------------------
+    # Everything numeric below is this library's own kernels (csrc/ivf_build.hip, wise_ip_scores_f32): torch only allocates,
+    # concatenates and draws the seeding permutation on the host.
     @staticmethod
     def _assign(x: torch.Tensor, centroids: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
-        """nearest centroid of every row by inner product: this library's exact-f32 score kernel (wise_ip_scores_f32,
-        the coarse stage's own) + an argmax — no vendor GEMM in training or assignment either"""
+        """nearest centroid of every row by inner product: the exact-f32 score kernel (the coarse stage's own) + wise_ivf_argmax"""
         lib = _lib.lib()
         c = centroids.contiguous()
         out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
         scores = torch.empty(min(chunk, max(x.shape[0], 1)), c.shape[0], dtype=torch.float32, device=x.device)
+        st = _lib.stream_ptr()
         for s in range(0, x.shape[0], chunk):
-            q = x[s:s + chunk].contiguous()
+            q = x[s:s + chunk]                       # (a slice of whole rows of a contiguous tensor: contiguous)
             _lib.check(lib.wise_ip_scores_f32(c.data_ptr(), c.shape[0], c.shape[1], q.data_ptr(), q.shape[0],
-                                              scores.data_ptr(), _lib.stream_ptr()), "wise_ip_scores_f32")
-            out[s:s + chunk] = scores[: q.shape[0]].argmax(dim=1)
+                                              scores.data_ptr(), st), "wise_ip_scores_f32")
+            _lib.check(lib.wise_ivf_argmax(scores.data_ptr(), q.shape[0], c.shape[0], out[s:].data_ptr(), st), "wise_ivf_argmax")
+        return out
+
+    def _group(self, assign: torch.Tensor):
+        """(order, list_off, counts): the rows grouped by list, stable (wise_ivf_group: a radix sort on the device)"""
+        lib = _lib.lib()
+        n = assign.shape[0]
+        order = torch.empty(n, dtype=torch.int64, device=self.device)
+        list_off = torch.empty(self.nlist + 1, dtype=torch.int64, device=self.device)
+        counts = torch.empty(self.nlist, dtype=torch.int64, device=self.device)
+        ws = torch.empty(lib.wise_ivf_group_workspace_bytes(n, self.nlist), dtype=torch.uint8, device=self.device)
+        _lib.check(lib.wise_ivf_group(assign.data_ptr(), n, self.nlist, order.data_ptr(), list_off.data_ptr(), counts.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "wise_ivf_group")
+        return order, list_off, counts
+
+    def _gather_rows(self, x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(idx.shape[0], x.shape[1], dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().wise_ivf_gather_rows(x.data_ptr(), idx.data_ptr(), idx.shape[0], x.shape[1], out.data_ptr(),
+                                                   _lib.stream_ptr()), "wise_ivf_gather_rows")
         return out
 
     def train(self, x) -> None:
         self._need_gpu()
+        lib = _lib.lib()
         x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)) if not torch.is_tensor(x) else x
-        x = x.to(self.device, torch.float32)
+        x = x.to(self.device, torch.float32).contiguous()
         if x.dim() != 2 or x.shape[1] != self.d:
             raise ValueError(f"train: expected [n,{self.d}], got {tuple(x.shape)}")
         n = x.shape[0]
         if n < self.nlist:
             raise ValueError(f"train: {n} training vectors for {self.nlist} cells")
+        if self.d % 4:
+            raise ValueError("train: d must be a multiple of 4")
         g = torch.Generator(device="cpu").manual_seed(self.seed)
         perm = torch.randperm(n, generator=g)[: self.nlist].to(self.device)
-        c = x[perm].clone()
-        c = c / c.norm(dim=1, keepdim=True).clamp_min(1e-20)
+        st = _lib.stream_ptr()
+        c = self._gather_rows(x, perm)
+        _lib.check(lib.wise_ivf_normalize_rows(c.data_ptr(), self.nlist, self.d, c.data_ptr(), st), "wise_ivf_normalize_rows")
+        sums = torch.empty(self.nlist, self.d, dtype=torch.float32, device=self.device)
         for _ in range(self.niter):
             a = self._assign(x, c)
-            sums = torch.zeros(self.nlist, self.d, dtype=torch.float32, device=self.device).index_add_(0, a, x)
-            counts = torch.bincount(a, minlength=self.nlist)
-            empty = (counts == 0).nonzero().flatten()
-            if empty.numel():
-                # re-seed every empty cell with a slightly perturbed copy of the fullest cells' centroids
-                donors = torch.argsort(counts, descending=True)[: empty.numel()]
-                sums[empty] = sums[donors] * (1.0 + 1e-3 * torch.sign(sums[donors]))
-            c = sums / sums.norm(dim=1, keepdim=True).clamp_min(1e-20)   # spherical: unit centroids
+            order, list_off, counts = self._group(a)
+            _lib.check(lib.wise_ivf_list_sums(x.data_ptr(), order.data_ptr(), list_off.data_ptr(), self.nlist, self.d,
+                                              sums.data_ptr(), st), "wise_ivf_list_sums")
+            cnt = counts.cpu().numpy()                       # nlist numbers: which cells are empty is decided on the host
+            empty = np.flatnonzero(cnt == 0)
+            if empty.size:
+                # re-seed every empty cell with a slightly perturbed copy of the fullest cells' sums (ties: the lower cell first)
+                donors = np.argsort(-cnt, kind="stable")[: empty.size]
+                e_d = torch.from_numpy(empty.astype(np.int64)).to(self.device)
+                d_d = torch.from_numpy(donors.astype(np.int64)).to(self.device)
+                _lib.check(lib.wise_ivf_reseed(sums.data_ptr(), e_d.data_ptr(), d_d.data_ptr(), int(empty.size), self.d, st),
+                           "wise_ivf_reseed")
+            _lib.check(lib.wise_ivf_normalize_rows(sums.data_ptr(), self.nlist, self.d, c.data_ptr(), st),
+                       "wise_ivf_normalize_rows")    # spherical: unit centroids
         self.centroids = c.contiguous()
         self._quantizer = FlatIPIndex(self.d, device=str(self.device)).adopt(self.centroids, None, id_base=0)
         self.is_trained = True
@@ -133,8 +164,8 @@ class IVFFlatIPIndex:
             raise ValueError(f"add_with_ids: expected [n,{self.d}], got {tuple(x.shape)}")
         if ids.shape != (x.shape[0],):
             raise ValueError("add_with_ids: ids must have one entry per row")
-        x = x.to(self.device, torch.float32)
-        ids = ids.to(self.device, torch.int64)
+        x = x.to(self.device, torch.float32).contiguous()
+        ids = ids.to(self.device, torch.int64).contiguous()
         self._pending.append((x, ids, self._assign(x, self.centroids)))
         self._n += x.shape[0]
 
@@ -149,19 +180,23 @@ class IVFFlatIPIndex:
 
     def _finalize(self):
         if self._pending:
+            lib = _lib.lib()
+            st = _lib.stream_ptr()
             xs = ([self._X] if self._X is not None and self._X.shape[0] else []) + [p[0] for p in self._pending]
             iss = ([self._ids] if self._ids is not None and self._ids.shape[0] else []) + [p[1] for p in self._pending]
             old_assign = []
             if self._X is not None and self._X.shape[0]:
-                sizes = self._list_off[1:] - self._list_off[:-1]
-                old_assign = [torch.repeat_interleave(torch.arange(self.nlist, device=self.device), sizes)]
-            a = torch.cat(old_assign + [p[2] for p in self._pending])
-            order = torch.argsort(a, stable=True)    # rows of a list keep their order of insertion
-            self._X = torch.cat(xs)[order].contiguous()
-            self._ids = torch.cat(iss)[order].contiguous()
-            counts = torch.bincount(a, minlength=self.nlist)
-            self._list_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=self.device),
-                                        torch.cumsum(counts, 0)]).contiguous()
+                oa = torch.empty(self._X.shape[0], dtype=torch.int64, device=self.device)     # the rows already grouped: list c, list_off[c] .. [c + 1]
+                _lib.check(lib.wise_ivf_expand_lists(self._list_off.data_ptr(), self.nlist, oa.data_ptr(), st), "wise_ivf_expand_lists")
+                old_assign = [oa]
+            a = torch.cat(old_assign + [p[2] for p in self._pending]).contiguous()
+            order, list_off, _ = self._group(a)          # stable: rows of a list keep their order of insertion
+            allx, allids = torch.cat(xs).contiguous(), torch.cat(iss).contiguous()
+            self._X = self._gather_rows(allx, order)
+            ids = torch.empty_like(allids)
+            _lib.check(lib.wise_ivf_gather_i64(allids.data_ptr(), order.data_ptr(), order.shape[0], ids.data_ptr(), st), "wise_ivf_gather_i64")
+            self._ids = ids
+            self._list_off = list_off
             self._pending = []
         if self._X is None:
             self._X = torch.empty(0, self.d, dtype=torch.float32, device=self.device)
