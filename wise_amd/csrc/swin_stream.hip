@@ -93,11 +93,18 @@ __global__ __launch_bounds__(128 * NWIN, 1) void swin_qkv_attn_kernel(const floa
 
     const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)ws, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)bq, 0, 3 * C * 4, 0x00020000);   // reads past the end return 0
+    // piece k (k < PW: one 1-KiB fragment; k == PW: the step's biases) of step t's request
+    auto request_piece = [&](int t, int k) {
+        if (k < PW) {
+            const int u = (k * WAVES + wave) % NF;
+            dma16(rS, (t % 3) * STEP + u * 1024, lane * 16, t * STEP + u * 1024);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(uintptr_t)(RB + (t % 3) * BSL + wave * 256), 4, lane * 4, t * 192, 0, 0);
+        }
+    };
     auto request = [&](int t) {
-        const unsigned slot = (t % 3) * STEP;
 #pragma unroll
-        for (int k = 0; k < PW; ++k) { const int u = (k * WAVES + wave) % NF; dma16(rS, slot + u * 1024, lane * 16, t * STEP + u * 1024); }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(uintptr_t)(RB + (t % 3) * BSL + wave * 256), 4, lane * 4, t * 192, 0, 0);
+        for (int k = 0; k <= PW; ++k) request_piece(t, k);
     };
 
     // ---- prologue: gather, LayerNorm, operand fragments: lane (l15, g) holds LN(x)[row][32 ks + 8 g .. + 7]
@@ -271,8 +278,8 @@ __global__ __launch_bounds__(128 * NWIN, 1) void swin_qkv_attn_kernel(const floa
         const int pair = s / 3, typ = s - pair * 3;
         const bool attn = typ == 0 && s > 0;                      // the previous pair's attention rides in this step (its k / v images are complete)
         if (typ == 2) bias_request(pair);                         // used by the attention of `pair` in the next iteration
-        if (s + 2 < NSTEP) request(s + 2);                        // (behind the attention's own loads and stores: the counted wait below
-                                                                  //  leaves exactly this request in flight)
+        const bool req = s + 2 < NSTEP;                           // step s + 2's request rides between this step's MFMAs, a piece at a time
+                                                                  // (a burst of PW + 1 LDS-DMA instructions costs a lone wave ~100 cycles each)
         // ---- the step's 48 columns: tiles [16 j ..][rows] over K = C, fragments through a ring of registers
         const unsigned sb = (s % 3) * STEP;
         const lds_cptr base = (lds_cptr)(uintptr_t)(sb + lane * 16);
@@ -290,6 +297,9 @@ __global__ __launch_bounds__(128 * NWIN, 1) void swin_qkv_attn_kernel(const floa
                     if constexpr (ks == 0) mfma_zero_ba(a1[i][j], wr[f % D], af[i][0]);
                     else mfma_ba(a1[i][j], wr[f % D], af[i][ks]);
                 });
+                if constexpr (f % (NF / (PW + 1)) == 0 && f / (NF / (PW + 1)) <= PW) {
+                    if (req) request_piece(s + 2, f / (NF / (PW + 1)));
+                }
                 if constexpr ((f + 1) % (NF / 4) == 0 && (f + 1) / (NF / 4) <= 4) {
                     constexpr int piece = (f + 1) / (NF / 4) - 1;
                     if (attn) attention_piece(pair - 1, std::integral_constant<int, piece / 2>{}, std::integral_constant<int, piece % 2>{});
