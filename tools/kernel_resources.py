@@ -32,9 +32,8 @@ def code_objects(so: Path):
     return out
 
 
-def main():
-    want = sys.argv[1:]
-    so = ROOT / "wise_amd" / "lib" / "libwise_hip.so"
+def kernel_rows(so: Path = ROOT / "wise_amd" / "lib" / "libwise_hip.so"):
+    """[(demangled name, agprs, registers, sgprs, scratch bytes, vgpr spills, sgpr spills)] of every gfx950 kernel in the library"""
     rows = []
     with tempfile.TemporaryDirectory() as td:
         for n, co in enumerate(code_objects(so)):
@@ -43,15 +42,23 @@ def main():
             notes = subprocess.run([str(LLVM / "llvm-readelf"), "--notes", str(f)], capture_output=True, text=True).stdout
             for ent in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
                 get = lambda k: (re.search(rf"\.{k}:\s+(\S+)", ent) or [None, "?"])[1]
-                rows.append((get("name"), "a" + ent.split()[0], get("vgpr_count"), get("sgpr_count"), get("private_segment_fixed_size"),
-                             get("vgpr_spill_count"), get("sgpr_spill_count"), get("group_segment_fixed_size")))
+                rows.append((get("name"), ent.split()[0], get("vgpr_count"), get("sgpr_count"), get("private_segment_fixed_size"),
+                             get("vgpr_spill_count"), get("sgpr_spill_count")))
     names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.split("\n")
-    for (mangled, agpr, vgpr, sgpr, scratch, vsp, ssp, lds), name in zip(rows, names):
+    out = []
+    for (mangled, agpr, vgpr, sgpr, scratch, vsp, ssp), name in zip(rows, names):
         short = re.sub(r"\(.*", "", name.replace("void wise::", "").replace("void ", ""))
+        out.append((short, agpr, vgpr, sgpr, scratch, vsp, ssp))
+    return out
+
+
+def main():
+    want = sys.argv[1:]
+    for short, agpr, vgpr, sgpr, scratch, vsp, ssp in kernel_rows():
         if want and not any(w in short for w in want):
             continue
         flag = "  <-- SCRATCH / SPILLS" if scratch not in ("0", "?") or vsp not in ("0", "?") else ""
-        print(f"{short:70s} {agpr:>5s} vgpr {vgpr:>3s} sgpr {sgpr:>3s} scratch {scratch:>5s} vspill {vsp:>3s} sspill {ssp:>3s}{flag}")
+        print(f"{short:70s} {'a' + agpr:>5s} vgpr {vgpr:>3s} sgpr {sgpr:>3s} scratch {scratch:>5s} vspill {vsp:>3s} sspill {ssp:>3s}{flag}")
 
 
 if __name__ == "__main__":

@@ -56,6 +56,10 @@ constexpr int chunk_at(int m, int nm, int nch) {
     return -1;
 }
 
+// (An s_nop 1 in front of every MFMA statement — swin_stream.hip's guard against a compiler register copy placed right before a
+//  statement it does not know to be an MFMA — was measured on the 8-wave form: 97.5 -> 106 us per launch, the LDS-bound loop does
+//  not hide it.  These kernels instead stay inside their half of the register file: tests/test_kernel_resources_cpu.py holds them to
+//  their accumulators in the accumulator file and no scratch, tests/test_gpu_mlp_stream.py to the float64 reference.)
 // phase-1 accumulators in the accumulator file (two waves per SIMD with two row tiles each: 128 + 128 registers per wave, and
 // the arithmetic needs the VGPR half): the GELU's first stage copies a tile out (the compiler's own v_accvgpr_read)
 __device__ __forceinline__ void mfma16a_zero(f32x4& acc, const bf16x8& a, const bf16x8& b) {
