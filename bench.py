@@ -305,6 +305,9 @@ def main():
         **traffic_fields("gemm_bf16_kernel"),
         "end_to_end_tflops": round(frames_per_s / world * spec.flops_per_frame() / 1e12, 2),
         "end_to_end_frac": round(frames_per_s / world * spec.flops_per_frame() / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "note": ("with layernorm_fold the family's launches also carry the blocks' LayerNorm work (row statistics, the hi + lo "
+                 "split of the residual stream) and the 24 LayerNorm launches per forward are gone: `frac` is not comparable with "
+                 "the unfolded tower's (0.34-0.365 in round 3) — `end_to_end_frac` is (0.336 -> 0.353)") if eng.spec.ln_fold else "",
     }
 
     if args.roofline_only:
